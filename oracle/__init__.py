@@ -1,0 +1,15 @@
+"""CPU oracle for the Exposure filter-stack hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``exposure_amd/`` imports this
+package; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and there only as the checker / the timed CPU path.
+
+PARITY UNPINNED: the reference (``/root/reference``, TF-1 graph code) ships no
+tests, golden vectors or fixtures, and cannot be imported in this image (no
+tensorflow / cv2; ``util.py:658`` is a SyntaxError on Python >= 3.7).  The
+restatement is therefore pinned by (i) closed-form identities of the reference
+code, (ii) hand-computed points, (iii) float64 finite differences, and (iv)
+agreement of two independently written restatements (``filters_np`` with
+hand-derived backward, ``filters_torch`` with autograd) -- see
+``tests/test_oracle_*.py`` and DESIGN.md section 3.
+"""

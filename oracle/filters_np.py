@@ -1,0 +1,460 @@
+"""NumPy restatement of the reference's per-pixel filters (forward AND backward).
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``); PARITY UNPINNED by the
+reference (it has no tests) -- pinned by identities / known answers / finite
+differences in ``tests/test_oracle_filters.py``.
+
+Every function cites the reference lines it follows (paths relative to
+``/root/reference``).  Images are NHWC ``(N, H, W, 3)``.  Arithmetic runs in the
+dtype of ``img`` promoted to at least float32 (pass float64 arrays for the
+"exact" oracle, float32 arrays to mimic the reference's TF float32 graph
+op-for-op).
+
+Two parameter conventions are provided:
+
+* reference-shaped parameters, exactly what ``filter_param_regressor`` returns
+  in the reference (``E,G: (N,1)``; ``W: (N,3)``; ``S+,Ct,BW: (N,1)``;
+  ``T: (N,1,1,1,8)``; ``C: (N,1,1,3,8)``);
+* *packed* parameters ``(N, P)`` float32, the C-ABI layout
+  (``include/exposure_hip.h``): ``P = 1,1,3,1,8,1,1,24`` for filter ids
+  ``0..7 = E,G,W,S+,T,Ct,BW,C`` (order of ``cfg.filters``,
+  ``config_example.py:22-25``); Color packs ``channel*8 + knot``.
+
+The backward functions are hand-derived (they are what the HIP kernels
+implement); ``oracle/filters_torch.py`` obtains the same gradients from
+autograd on an op-by-op transcription, and the tests require both to agree.
+TF gradient conventions encoded here: ``tf.maximum(x, c)`` / ``tf.minimum(x,
+c)`` pass the gradient to ``x`` on equality, ``tf.clip_by_value`` passes on
+``lo <= x <= hi`` (both inclusive), ``abs'(0) = 0``, and TF-1.x registers
+``RGBToHSV``/``HSVToRGB`` as not differentiable (``hsv_grad_mode=0``).
+"""
+import math
+
+import numpy as np
+
+# cfg.filters order, config_example.py:22-25
+FILTER_NAMES = ('E', 'G', 'W', 'S+', 'T', 'Ct', 'BW', 'C')
+FILTER_ID = {n: i for i, n in enumerate(FILTER_NAMES)}
+NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24)
+CURVE_STEPS = 8  # cfg.curve_steps, config_example.py:27
+LUM_W = (0.27, 0.67, 0.06)  # util.py:271-274
+
+DEFAULT_CFG = dict(
+    curve_steps=8,
+    gamma_range=3,
+    exposure_range=3.5,
+    color_curve_range=(0.90, 1.10),
+    tone_curve_range=(0.5, 2),
+)
+
+
+def _ft(a):
+  a = np.asarray(a)
+  return a.dtype if a.dtype in (np.float32, np.float64) else np.dtype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# helpers: util.py:271-308
+# ---------------------------------------------------------------------------
+def rgb2lum(image):
+  """util.py:271-274 -- keeps a trailing singleton channel."""
+  dt = _ft(image)
+  lum = dt.type(0.27) * image[..., 0] + dt.type(0.67) * image[..., 1] + dt.type(
+      0.06) * image[..., 2]
+  return lum[..., None]
+
+
+def tanh01(x):
+  """util.py:277-278."""
+  dt = _ft(x)
+  return np.tanh(x) * dt.type(0.5) + dt.type(0.5)
+
+
+def tanh_range(l, r, initial=None):
+  """util.py:281-294."""
+
+  def activation(x):
+    dt = _ft(x)
+    if initial is not None:
+      bias = math.atanh(2 * (initial - l) / (r - l) - 1)
+    else:
+      bias = 0
+    return tanh01(x + dt.type(bias)) * dt.type(r - l) + dt.type(l)
+
+  return activation
+
+
+def lerp(a, b, l):
+  """util.py:307-308."""
+  return (1 - l) * a + l * b
+
+
+def sigmoid(x):
+  return 1.0 / (1.0 + np.exp(-x))
+
+
+# ---------------------------------------------------------------------------
+# regressors (reference-shaped outputs)
+# ---------------------------------------------------------------------------
+def exposure_regressor(f, cfg=DEFAULT_CFG):
+  """filters.py:177-179."""
+  return tanh_range(-cfg['exposure_range'], cfg['exposure_range'], initial=0)(f)
+
+
+def gamma_regressor(f, cfg=DEFAULT_CFG):
+  """filters.py:201-203."""
+  lg = np.log(cfg['gamma_range'])
+  return np.exp(tanh_range(-lg, lg)(f))
+
+
+def wb_regressor(f, cfg=DEFAULT_CFG):
+  """filters.py:224-235."""
+  dt = _ft(f)
+  mask = np.array((0, 1, 1), dtype=dt).reshape(1, 3)
+  f = f * mask
+  s = np.exp(tanh_range(-0.5, 0.5)(f))
+  s = s * (dt.type(1.0) / (dt.type(1e-5) + dt.type(0.27) * s[:, 0] + dt.type(0.67) *
+                           s[:, 1] + dt.type(0.06) * s[:, 2]))[:, None]
+  return s
+
+
+def color_regressor(f, cfg=DEFAULT_CFG):
+  """filters.py:256-262 -> (N,1,1,3,8)."""
+  L = cfg['curve_steps']
+  c = np.reshape(f, (-1, 3, L))[:, None, None, :]
+  return tanh_range(*cfg['color_curve_range'], initial=1)(c)
+
+
+def tone_regressor(f, cfg=DEFAULT_CFG):
+  """filters.py:306-310 -> (N,1,1,1,8)."""
+  L = cfg['curve_steps']
+  c = np.reshape(f, (-1, 1, L))[:, None, None, :]
+  return tanh_range(*cfg['tone_curve_range'])(c)
+
+
+def contrast_regressor(f, cfg=DEFAULT_CFG):
+  """filters.py:411-413."""
+  return np.tanh(f)
+
+
+def wnb_regressor(f, cfg=DEFAULT_CFG):
+  """filters.py:435-436."""
+  return sigmoid(f)
+
+
+def satplus_regressor(f, cfg=DEFAULT_CFG):
+  """filters.py:481-482."""
+  return sigmoid(f)
+
+
+REGRESSORS = (exposure_regressor, gamma_regressor, wb_regressor, satplus_regressor,
+              tone_regressor, contrast_regressor, wnb_regressor, color_regressor)
+
+
+# ---------------------------------------------------------------------------
+# TF image ops restated (tensorflow/core/kernels/adjust_hsv / colorspace_op.h;
+# TensorFlow is an un-vendored, unpinned dependency: README.md:25)
+# ---------------------------------------------------------------------------
+def rgb_to_hsv(rgb):
+  """tf.image.rgb_to_hsv as called at filters.py:486."""
+  dt = _ft(rgb)
+  r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+  v = np.maximum(np.maximum(r, g), b)
+  mn = np.minimum(np.minimum(r, g), b)
+  rng = v - mn
+  with np.errstate(divide='ignore', invalid='ignore'):
+    s = np.where(v > 0, rng / np.where(v > 0, v, 1), dt.type(0))
+    norm = dt.type(1.0) / (dt.type(6.0) * np.where(rng > 0, rng, 1))
+    h = np.where(r == v, norm * (g - b),
+                 np.where(g == v, norm * (b - r) + dt.type(2.0 / 6.0),
+                          norm * (r - g) + dt.type(4.0 / 6.0)))
+  h = np.where(rng > 0, h, dt.type(0))
+  h = np.where(h < 0, h + dt.type(1), h)
+  return np.stack([h, s, v], axis=-1)
+
+
+def hsv_to_rgb(hsv):
+  """tf.image.hsv_to_rgb as called at filters.py:492."""
+  dt = _ft(hsv)
+  h, s, v = hsv[..., 0], hsv[..., 1], hsv[..., 2]
+  dh = h * dt.type(6)
+  dr = np.clip(np.abs(dh - dt.type(3)) - dt.type(1), 0, 1)
+  dg = np.clip(dt.type(2) - np.abs(dh - dt.type(2)), 0, 1)
+  db = np.clip(dt.type(2) - np.abs(dh - dt.type(4)), 0, 1)
+  oms = dt.type(1) - s
+  return np.stack([(oms + s * dr) * v, (oms + s * dg) * v, (oms + s * db) * v], axis=-1)
+
+
+# ---------------------------------------------------------------------------
+# process(): forward, reference-shaped params
+# ---------------------------------------------------------------------------
+def exposure_process(img, param):
+  """filters.py:181-182."""
+  dt = _ft(img)
+  return img * np.exp(param[:, None, None, :] * dt.type(np.log(2)))
+
+
+def gamma_process(img, param):
+  """filters.py:205-206."""
+  dt = _ft(img)
+  return np.power(np.maximum(img, dt.type(0.001)), param[:, None, None, :])
+
+
+def wb_process(img, param):
+  """filters.py:237-238."""
+  return img * param[:, None, None, :]
+
+
+def _curve_process(img, param, L):
+  """Shared body of filters.py:264-273 (Color) and 312-322 (Tone)."""
+  dt = _ft(img)
+  curve_sum = np.sum(param, axis=4) + dt.type(1e-30)
+  total = img * 0
+  for i in range(L):
+    total = total + np.clip(img - dt.type(1.0 * i / L), 0, dt.type(1.0 / L)) * param[:, :, :, :, i]
+  total = total * (dt.type(L) / curve_sum)
+  return total
+
+
+def color_process(img, param, L=CURVE_STEPS):
+  """filters.py:264-273; param (N,1,1,3,L)."""
+  return _curve_process(img, param, L)
+
+
+def tone_process(img, param, L=CURVE_STEPS):
+  """filters.py:312-322; param (N,1,1,1,L)."""
+  return _curve_process(img, param, L)
+
+
+def contrast_process(img, param):
+  """filters.py:415-419; param (N,1)."""
+  dt = _ft(img)
+  luminance = np.minimum(np.maximum(rgb2lum(img), dt.type(0.0)), dt.type(1.0))
+  contrast_lum = -np.cos(dt.type(math.pi) * luminance) * dt.type(0.5) + dt.type(0.5)
+  contrast_image = img / (luminance + dt.type(1e-6)) * contrast_lum
+  return lerp(img, contrast_image, param[:, :, None, None])
+
+
+def wnb_process(img, param):
+  """filters.py:438-440; param (N,1)."""
+  luminance = rgb2lum(img)
+  return lerp(img, luminance, param[:, :, None, None])
+
+
+def satplus_full_color(img):
+  """filters.py:485-492: returns (clamped img, full_color)."""
+  dt = _ft(img)
+  img = np.minimum(img, dt.type(1.0))
+  hsv = rgb_to_hsv(img)
+  s = hsv[..., 1:2]
+  v = hsv[..., 2:3]
+  enhanced_s = s + (1 - s) * (dt.type(0.5) - np.abs(dt.type(0.5) - v)) * dt.type(0.8)
+  hsv1 = np.concatenate([hsv[..., 0:1], enhanced_s, hsv[..., 2:]], axis=3)
+  return img, hsv_to_rgb(hsv1)
+
+
+def satplus_process(img, param):
+  """filters.py:484-498; param (N,1).  NB the blend uses the CLAMPED image
+  (``img`` is reassigned at filters.py:485)."""
+  img, full_color = satplus_full_color(img)
+  param = param[:, :, None, None]
+  return img * (1.0 - param) + full_color * param
+
+
+PROCESS = (exposure_process, gamma_process, wb_process, satplus_process, tone_process,
+           contrast_process, wnb_process, color_process)
+
+
+# ---------------------------------------------------------------------------
+# packed <-> reference-shaped parameters
+# ---------------------------------------------------------------------------
+def unpack_params(fid, packed):
+  packed = np.asarray(packed)
+  n = packed.shape[0]
+  assert packed.shape == (n, NUM_PARAMS[fid]), (packed.shape, fid)
+  if fid == FILTER_ID['T']:
+    return packed.reshape(n, 1, 1, 1, CURVE_STEPS)
+  if fid == FILTER_ID['C']:
+    return packed.reshape(n, 1, 1, 3, CURVE_STEPS)
+  return packed
+
+
+def pack_params(fid, param):
+  param = np.asarray(param)
+  return param.reshape(param.shape[0], NUM_PARAMS[fid])
+
+
+def regress_packed(fid, features, cfg=DEFAULT_CFG):
+  """features (N,P) raw FC outputs -> packed params (N,P)."""
+  return pack_params(fid, REGRESSORS[fid](np.asarray(features), cfg))
+
+
+def process_packed(fid, img, packed):
+  return PROCESS[fid](img, unpack_params(fid, np.asarray(packed, dtype=_ft(img))))
+
+
+# ---------------------------------------------------------------------------
+# backward (hand-derived); all take packed params and return (dx, dpacked)
+# ---------------------------------------------------------------------------
+def _sum_hwc(a):
+  return a.reshape(a.shape[0], -1).sum(axis=1)
+
+
+def exposure_backward(img, p, dy):
+  s = np.exp(p[:, None, None, :] * np.log(2))
+  y = img * s
+  return dy * s, (np.log(2) * _sum_hwc(dy * y))[:, None]
+
+
+def gamma_backward(img, p, dy):
+  g = p[:, None, None, :]
+  xm = np.maximum(img, 0.001)
+  y = np.power(xm, g)
+  dx = dy * g * np.power(xm, g - 1) * (img >= 0.001)
+  return dx, _sum_hwc(dy * y * np.log(xm))[:, None]
+
+
+def wb_backward(img, p, dy):
+  return dy * p[:, None, None, :], (dy * img).sum(axis=(1, 2))
+
+
+def _curve_backward(img, k, dy, L):
+  """k: (N,1,1,Cc,L) with Cc in {1,3}."""
+  S = k.sum(axis=4) + 1e-30  # (N,1,1,Cc)
+  T = img * 0
+  slope = img * 0
+  clips = []
+  for i in range(L):
+    t = img - 1.0 * i / L
+    c = np.clip(t, 0, 1.0 / L)
+    clips.append(c)
+    T = T + c * k[..., i]
+    slope = slope + k[..., i] * ((t >= 0) & (t <= 1.0 / L))
+  y = T * (L / S)
+  dx = dy * (L / S) * slope
+  dk = np.stack([dy * ((L / S) * clips[i] - y / S) for i in range(L)], axis=-1)  # (N,H,W,3,L)
+  return dx, dk
+
+
+def tone_backward(img, p, dy, L=CURVE_STEPS):
+  k = p.reshape(-1, 1, 1, 1, L)
+  dx, dk = _curve_backward(img, k, dy, L)
+  return dx, dk.sum(axis=(1, 2, 3))
+
+
+def color_backward(img, p, dy, L=CURVE_STEPS):
+  k = p.reshape(-1, 1, 1, 3, L)
+  dx, dk = _curve_backward(img, k, dy, L)
+  return dx, dk.sum(axis=(1, 2)).reshape(-1, 3 * L)
+
+
+def contrast_backward(img, p, dy):
+  pp = p[:, :, None, None]
+  w = np.array(LUM_W, dtype=img.dtype)
+  lraw = rgb2lum(img)
+  l = np.minimum(np.maximum(lraw, 0.0), 1.0)
+  m = ((lraw >= 0.0) & (lraw <= 1.0)).astype(img.dtype)
+  eps = 1e-6
+  cl = -np.cos(math.pi * l) * 0.5 + 0.5
+  dcl = 0.5 * math.pi * np.sin(math.pi * l)
+  ratio = cl / (l + eps)
+  ci = img * ratio
+  G = dcl / (l + eps) - cl / (l + eps)**2
+  dot = (dy * img).sum(axis=3, keepdims=True)
+  dx = (1 - pp) * dy + pp * (dy * ratio + w * (m * G * dot))
+  return dx, _sum_hwc(dy * (ci - img))[:, None]
+
+
+def wnb_backward(img, p, dy):
+  pp = p[:, :, None, None]
+  w = np.array(LUM_W, dtype=img.dtype)
+  lum = rgb2lum(img)
+  dx = (1 - pp) * dy + pp * w * dy.sum(axis=3, keepdims=True)
+  return dx, _sum_hwc(dy * (lum - img))[:, None]
+
+
+def _satplus_full_grad(xc, dyfull):
+  """d(full_color)/d(xc) applied to dyfull, analytic (hsv_grad_mode=1).
+
+  Uses the hue-free identity full_c = v(1-s') + (s' v / rng)(xc_c - mn) that
+  holds for rng > 0 (hue only encodes (xc_c - mn)/rng).  Returns 0 gradient
+  through full_color where rng == 0 (hue is a constant 0 there).
+  """
+  v = xc.max(axis=3, keepdims=True)
+  mn = xc.min(axis=3, keepdims=True)
+  rng = v - mn
+  n, h, w_, _ = xc.shape
+  # one-hot of arg max / arg min following TF tie order is irrelevant a.e.;
+  # use first-occurrence (ties have measure zero and are excluded in tests).
+  amax = np.eye(3, dtype=xc.dtype)[xc.argmax(axis=3)]
+  amin = np.eye(3, dtype=xc.dtype)[xc.argmin(axis=3)]
+  ok = (rng > 0) & (v > 0)
+  rs = np.where(ok, rng, 1.0)
+  vs = np.where(ok, v, 1.0)
+  s = rs / vs
+  tri = 0.5 - np.abs(0.5 - vs)
+  dtri_dv = np.sign(0.5 - vs)  # d/dv (0.5 - |0.5 - v|) = sign(0.5 - v)
+  sp = s + (1 - s) * tri * 0.8
+  # ds/dxc = (d rng)/v - rng/v^2 dv = (amax-amin)/v - rng/v^2 amax
+  ds = (amax - amin) / vs - (rs / vs**2) * amax
+  dsp = ds * (1 - tri * 0.8) + (1 - s) * 0.8 * dtri_dv * amax
+  d = (xc - mn) / rs  # (N,H,W,3)
+  # full_c = v*(1 - sp) + sp*v*d_c
+  # dfull_c/dx_j = amax_j*(1-sp) - v*dsp_j + dsp_j*v*d_c + sp*amax_j*d_c + sp*v*dd_c/dx_j
+  # dd_c/dx_j = (delta_cj - amin_j)/rng - (xc_c - mn)/rng^2 * (amax_j - amin_j)
+  gsum = dyfull.sum(axis=3, keepdims=True)
+  gd = (dyfull * d).sum(axis=3, keepdims=True)
+  out = amax * (1 - sp) * gsum - vs * dsp * gsum + dsp * vs * gd + sp * amax * gd
+  out = out + sp * vs * (dyfull / rs - amin * gsum / rs - (amax - amin) * gd / rs)
+  return np.where(ok, out, 0.0)
+
+
+def satplus_backward(img, p, dy, hsv_grad_mode=0):
+  pp = p[:, :, None, None]
+  xc, full = satplus_full_color(img)
+  mask = (img <= 1.0)
+  dxc = dy * (1 - pp)
+  if hsv_grad_mode == 1:
+    dxc = dxc + _satplus_full_grad(xc, dy * pp)
+  dx = dxc * mask
+  return dx, _sum_hwc(dy * (full - xc))[:, None]
+
+
+def backward_packed(fid, img, packed, dy, hsv_grad_mode=0):
+  """Gradient of sum(y*dy) w.r.t. (img, packed params). float64 recommended."""
+  img = np.asarray(img)
+  p = np.asarray(packed, dtype=img.dtype)
+  dy = np.asarray(dy, dtype=img.dtype)
+  name = FILTER_NAMES[fid]
+  if name == 'E':
+    return exposure_backward(img, p, dy)
+  if name == 'G':
+    return gamma_backward(img, p, dy)
+  if name == 'W':
+    return wb_backward(img, p, dy)
+  if name == 'S+':
+    return satplus_backward(img, p, dy, hsv_grad_mode)
+  if name == 'T':
+    return tone_backward(img, p, dy)
+  if name == 'Ct':
+    return contrast_backward(img, p, dy)
+  if name == 'BW':
+    return wnb_backward(img, p, dy)
+  if name == 'C':
+    return color_backward(img, p, dy)
+  raise ValueError(fid)
+
+
+# ---------------------------------------------------------------------------
+# Filter.apply with specified_parameter (filters.py:62-99, masking off)
+# ---------------------------------------------------------------------------
+def apply_specified(fid, img, packed, high_res=None):
+  """lerp(img, process(img, p), mask) with mask == ones(1,1,1,1)
+  (filters.py:111-113, 88) == 0*img + 1*process."""
+  dt = _ft(img)
+  mask = np.ones((1, 1, 1, 1), dtype=dt)
+  low = lerp(img, process_packed(fid, img, packed), mask)
+  high = None
+  if high_res is not None:
+    high = lerp(high_res, process_packed(fid, high_res, packed), mask)
+  return low, high
