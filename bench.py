@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""Headline benchmark: Mpixels/s through the 8-step filter chain, forward + backward.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch: the 8 filters of cfg.filters
+(E,G,W,S+,T,Ct,BW,C; /root/reference/config_example.py:22-25) applied sequentially, one HIP
+kernel per filter step forward and one backward (dx + per-image parameter gradients), on a
+64x512x512x3 fp16 NHWC batch already resident in HBM.  Multi-GPU: images are independent, so
+ranks hold disjoint replicas of the batch shape (weak scaling, no data-path collective).
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the
+dominant kernel (HIP-event timed, algorithmic bytes: 12 B/px fwd, 18 B/px bwd at fp16) and
+`cpu_baseline` (the torch-CPU fp32 op-by-op restatement, oracle/filters_torch.py, timed on the
+host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from exposure_amd import _cabi, synthetic  # noqa: E402
+
+FILTER_NAMES = synthetic.FILTER_NAMES
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--shape', default='C', help='A|B|C (synthetic.SHAPES) or N,H,W')
+  ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
+  ap.add_argument('--kernel-reps', type=int, default=20, help='launches per kernel for the roofline timing')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-per-kernel', action='store_true')
+  ap.add_argument('--seed', type=int, default=1234)
+  return ap.parse_args()
+
+
+def make_device_case(shape, dtype, dev, seed):
+  """Same distributions as synthetic.make_case, generated on the device for the big shapes."""
+  g = torch.Generator(device=dev).manual_seed(seed)
+  x = torch.rand(shape, device=dev, generator=g, dtype=torch.float32)
+  x = (x**2.2) * (1.0 / 0.99**2.2)
+  dy = torch.randn(shape, device=dev, generator=g, dtype=torch.float32)
+  rng = np.random.default_rng(seed)
+  params = [torch.from_numpy(synthetic.make_params(rng, fid, shape[0])).to(dev) for fid in range(8)]
+  return x.to(dtype), dy.to(dtype), params
+
+
+class Chain:
+  """Buffers + one-call-per-direction launch of the 8-step chain (expo_chain_fwd / expo_chain_bwd)."""
+
+  def __init__(self, shape, dtype, dev, seed):
+    self.ids = list(range(8))
+    x, dy, self.params = make_device_case(shape, dtype, dev, seed)
+    self.acts = [x] + [torch.empty_like(x) for _ in range(8)]
+    # gradients ping-pong between two buffers; grads[8] = upstream dy
+    ga, gb = torch.empty_like(x), torch.empty_like(x)
+    self.grads = [ga if (i % 2 == 0) else gb for i in range(8)] + [dy]
+    self.dparams = [torch.empty_like(p) for p in self.params]
+
+  def step(self):
+    _cabi.chain_fwd(self.ids, self.acts, self.params)
+    _cabi.chain_bwd(self.ids, self.acts, self.grads, self.params, self.dparams)
+
+
+def time_kernels(chain, reps):
+  """Average duration (ms) of each of the 16 kernels, HIP events on the launch stream."""
+  out = {}
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  for i in range(8):
+    x, y, p = chain.acts[i], chain.acts[i + 1], chain.params[i]
+    for _ in range(3):
+      _cabi.filter_fwd(i, x, y, p)
+    ev0.record()
+    for _ in range(reps):
+      _cabi.filter_fwd(i, x, y, p)
+    ev1.record()
+    torch.cuda.synchronize()
+    out['fwd_' + FILTER_NAMES[i]] = ev0.elapsed_time(ev1) / reps
+  for i in range(8):
+    x, dy, dx, p, dp = chain.acts[i], chain.grads[i + 1], chain.grads[i], chain.params[i], chain.dparams[i]
+    for _ in range(3):
+      _cabi.filter_bwd(i, x, dy, dx, p, dp)
+    ev0.record()
+    for _ in range(reps):
+      _cabi.filter_bwd(i, x, dy, dx, p, dp)
+    ev1.record()
+    torch.cuda.synchronize()
+    out['bwd_' + FILTER_NAMES[i]] = ev0.elapsed_time(ev1) / reps  # includes the tiny dparams memset
+  return out
+
+
+def cpu_baseline():
+  """torch-CPU fp32 op-by-op restatement (oracle/filters_torch.py), all host threads, on a bounded
+  sample: BASELINE shape B (16x512x512x3), best of 3 after 1 warm-up."""
+  from oracle import filters_torch as ft
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  shape = synthetic.SHAPES['B']
+  x, dy, params = synthetic.make_case(1234, shape, np.float16)
+  tx = torch.from_numpy(x.astype(np.float32))
+  tdy = torch.from_numpy(dy.astype(np.float32))
+  tp = [torch.from_numpy(p) for p in params]
+  best = float('inf')
+  for it in range(4):
+    t0 = time.perf_counter()
+    ft.chain_fwd_bwd(tx, tp, tdy)
+    dt = time.perf_counter() - t0
+    if it > 0:
+      best = min(best, dt)
+  px = shape[0] * shape[1] * shape[2]
+  model = ''
+  try:
+    for line in open('/proc/cpuinfo'):
+      if line.startswith('model name'):
+        model = line.split(':', 1)[1].strip()
+        break
+  except OSError:
+    pass
+  return {
+      'value': px / best / 1e6,
+      'unit': 'Mpixels/s',
+      'cores': cores,
+      'kind': 'port',
+      'sample': 'CPU restatement (torch fp32, %d threads, %s): 8-step chain fwd+bwd on 16x512x512x3, best of 3' %
+                (cores, model or 'unknown CPU'),
+  }
+
+
+def load_traffic(kernel):
+  """Per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+  path = os.path.join(ROOT, 'profiles', 'traffic.json')
+  try:
+    return json.load(open(path)).get(kernel)
+  except (OSError, ValueError):
+    return None
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group('nccl', device_id=dev)
+  if args.gpus != world and rank == 0:
+    print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+
+  shape = synthetic.SHAPES[args.shape] if args.shape in synthetic.SHAPES else tuple(
+      int(v) for v in args.shape.split(',')) + (3,)
+  dtype = torch.float16 if args.dtype == 'f16' else torch.float32
+  esz = 2 if args.dtype == 'f16' else 4
+  chain = Chain(shape, dtype, dev, args.seed + rank)
+  px = shape[0] * shape[1] * shape[2]
+
+  def barrier():
+    if dist is not None:
+      dist.barrier()
+
+  for _ in range(args.warmup):
+    chain.step()
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    chain.step()
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  ms_per_step = elapsed / args.steps * 1e3
+  value = world * px / (elapsed / args.steps) / 1e6
+
+  result = {
+      'metric': 'Mpixels/s through 8-step filter chain fwd+bwd',
+      'value': value,
+      'unit': 'Mpixels/s',
+      'n_gpus': world,
+      'steps': args.steps,
+      'warmup': args.warmup,
+      'ms_per_step': ms_per_step,
+      'higher_is_better': True,
+      'scaling': 'weak',
+      'vs_baseline': None,
+      'dtype': args.dtype,
+      'data': 'synthetic',
+      'config': {
+          'workload': '8-step filter chain (E,G,W,S+,T,Ct,BW,C) fwd+bwd, %dx%dx%dx3 %s NHWC per GPU, one HIP '
+                      'kernel per filter step and direction' % (shape[0], shape[1], shape[2], args.dtype),
+          'batch_per_gpu': shape[0],
+          'height': shape[1],
+          'width': shape[2],
+          'parallelism': 'image-sharded replicas x%d (no data-path collective)' % world,
+          'chain_algorithmic_GBps': 8 * 5 * 3 * esz * px / (elapsed / args.steps) / 1e9 * 1.0,
+      },
+  }
+
+  if rank == 0 and not args.no_per_kernel:
+    per = time_kernels(chain, args.kernel_reps)
+    dom = max(per, key=per.get)
+    bpp = (2 if dom.startswith('fwd') else 3) * 3 * esz  # algorithmic bytes per pixel per launch
+    achieved = bpp * px / (per[dom] * 1e-3) / 1e9
+    result['roofline'] = {
+        'bound': 'hbm',
+        'kernel': dom,
+        'achieved': achieved,
+        'peak': HBM_PEAK_GBPS,
+        'unit': 'GB/s',
+        'frac': achieved / HBM_PEAK_GBPS,
+        'traffic': load_traffic(dom),
+        'avg_launch_ms': per[dom],
+        'algorithmic_bytes_per_launch': bpp * px,
+    }
+    result['per_kernel'] = {
+        k: {
+            'ms': v,
+            'GBps': (2 if k.startswith('fwd') else 3) * 3 * esz * px / (v * 1e-3) / 1e9
+        } for k, v in per.items()
+    }
+  barrier()
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    result['cpu_baseline'] = cpu_baseline()
+  if rank == 0:
+    print(json.dumps(result))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

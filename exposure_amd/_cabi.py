@@ -1,0 +1,237 @@
+"""ctypes binding of ``libexposure_hip.so`` (C-ABI: ``include/exposure_hip.h``).
+
+This is the ONLY way the package reaches the filter maths: there is no CPU or
+eager-PyTorch fallback.  If the library is missing, fails to load, or a tensor is
+not on a ROCm device, the call raises -- loudly -- instead of computing elsewhere.
+
+PyTorch is used for plumbing only: device memory (``tensor.data_ptr()``) and the
+current HIP stream (``torch.cuda.current_stream().cuda_stream``).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libexposure_hip.so')
+
+EXPO_ABI_VERSION = 1
+EXPO_F16, EXPO_F32 = 0, 1
+EXPO_MAX_PARAMS = 24
+NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24)
+
+# every symbol include/exposure_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+SIGNATURES = {
+    'expo_version': (_i, []),
+    'expo_last_error': (ctypes.c_char_p, []),
+    'expo_num_filter_params': (_i, [_i]),
+    'expo_filter_fwd': (_i, [_i, _vp, _vp, _fp, _i, _i, _i, _i, _vp]),
+    'expo_filter_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    'expo_filter_dispatch_fwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    'expo_filter_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
+                            _vp]),
+    'expo_chain_bwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp]),
+    'expo_critic_stats': (_i, [_vp, _fp, _i, _i, _i, _i, _vp]),
+    'expo_overexposure_penalty': (_i, [_vp, _fp, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+class ExposureHipError(RuntimeError):
+  pass
+
+
+def load():
+  """Load (once) and return the ctypes library; raises if it is not built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise ExposureHipError(
+        'exposure_amd: %s not found -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+        '(or exposure_amd/csrc/build.sh). There is no CPU fallback.' % LIB_PATH)
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name)  # AttributeError if the symbol is missing
+    fn.restype = res
+    fn.argtypes = args
+  ver = lib.expo_version()
+  if ver != EXPO_ABI_VERSION:
+    raise ExposureHipError('exposure_amd: ABI version mismatch (library %d, binding %d)' % (ver, EXPO_ABI_VERSION))
+  _lib = lib
+  return lib
+
+
+def _check(rc, what):
+  if rc != 0:
+    msg = load().expo_last_error()
+    raise ExposureHipError('%s failed (code %d): %s' % (what, rc, (msg or b'').decode()))
+
+
+def _dtype_code(t):
+  if t.dtype == torch.float16:
+    return EXPO_F16
+  if t.dtype == torch.float32:
+    return EXPO_F32
+  raise ExposureHipError('exposure_amd: image dtype must be float16 or float32, got %s' % t.dtype)
+
+
+def _img(t, name):
+  if not isinstance(t, torch.Tensor) or not t.is_cuda:
+    raise ExposureHipError('exposure_amd: %s must be a tensor on a ROCm device (HIP path only, no CPU fallback)' %
+                           name)
+  if t.dim() != 4 or t.shape[3] != 3:
+    raise ExposureHipError('exposure_amd: %s must be NHWC with C == 3, got %s' % (name, tuple(t.shape)))
+  if not t.is_contiguous():
+    raise ExposureHipError('exposure_amd: %s must be contiguous NHWC' % name)
+  return t
+
+
+def _f32(t, name, shape):
+  if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+    raise ExposureHipError('exposure_amd: %s must be a contiguous float32 device tensor of shape %s, got %s %s' %
+                           (name, tuple(shape), t.dtype, tuple(t.shape)))
+  return t
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+  return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def num_filter_params(fid):
+  return load().expo_num_filter_params(fid)
+
+
+def filter_fwd(fid, x, y, params):
+  lib = load()
+  _img(x, 'x'), _img(y, 'y')
+  n, h, w, _ = x.shape
+  assert y.shape == x.shape and y.dtype == x.dtype
+  _f32(params, 'params', (n, NUM_PARAMS[fid]))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_filter_fwd(fid, _ptr(x), _ptr(y), _ptr(params), n, h, w, _dtype_code(x), _stream()),
+           'expo_filter_fwd')
+
+
+def filter_bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0):
+  lib = load()
+  _img(x, 'x'), _img(dy, 'dy')
+  n, h, w, _ = x.shape
+  assert dy.shape == x.shape and dy.dtype == x.dtype
+  if dx is not None:
+    _img(dx, 'dx')
+    assert dx.shape == x.shape and dx.dtype == x.dtype
+  _f32(params, 'params', (n, NUM_PARAMS[fid]))
+  _f32(dparams, 'dparams', (n, NUM_PARAMS[fid]))
+  with torch.cuda.device(x.device):
+    _check(
+        lib.expo_filter_bwd(fid, _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams), n, h, w,
+                            _dtype_code(x), hsv_grad_mode, _stream()), 'expo_filter_bwd')
+
+
+def _ids(ids, n):
+  if not ids.is_cuda or ids.dtype != torch.int32 or tuple(ids.shape) != (n,) or not ids.is_contiguous():
+    raise ExposureHipError('exposure_amd: filter_ids must be a contiguous int32 device tensor of shape (%d,)' % n)
+  return ids
+
+
+def dispatch_fwd(ids, x, y, params, penalty=None):
+  lib = load()
+  _img(x, 'x'), _img(y, 'y')
+  n, h, w, _ = x.shape
+  _ids(ids, n)
+  _f32(params, 'params', (n, EXPO_MAX_PARAMS))
+  if penalty is not None:
+    _f32(penalty, 'penalty', (n,))
+  with torch.cuda.device(x.device):
+    _check(
+        lib.expo_filter_dispatch_fwd(_ptr(ids), _ptr(x), _ptr(y), _ptr(params), _ptr(penalty), n, h, w,
+                                     _dtype_code(x), _stream()), 'expo_filter_dispatch_fwd')
+
+
+def dispatch_bwd(ids, x, dy, dx, params, dparams, dpenalty=None, hsv_grad_mode=0):
+  lib = load()
+  _img(x, 'x'), _img(dy, 'dy')
+  n, h, w, _ = x.shape
+  _ids(ids, n)
+  if dx is not None:
+    _img(dx, 'dx')
+  _f32(params, 'params', (n, EXPO_MAX_PARAMS))
+  _f32(dparams, 'dparams', (n, EXPO_MAX_PARAMS))
+  if dpenalty is not None:
+    _f32(dpenalty, 'dpenalty', (n,))
+  with torch.cuda.device(x.device):
+    _check(
+        lib.expo_filter_dispatch_bwd(_ptr(ids), _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams),
+                                     _ptr(dpenalty), n, h, w, _dtype_code(x), hsv_grad_mode, _stream()),
+        'expo_filter_dispatch_bwd')
+
+
+def _ptr_array(tensors):
+  arr = (ctypes.c_void_p * len(tensors))()
+  for i, t in enumerate(tensors):
+    arr[i] = t.data_ptr()
+  return arr
+
+
+def chain_fwd(filter_ids, acts, params):
+  """acts: list of steps+1 image tensors (acts[0] input); params: list of (N,P_i) float32."""
+  lib = load()
+  steps = len(filter_ids)
+  assert len(acts) == steps + 1 and len(params) == steps
+  n, h, w, _ = acts[0].shape
+  for a in acts:
+    _img(a, 'act')
+    assert a.shape == acts[0].shape and a.dtype == acts[0].dtype
+  for fid, p in zip(filter_ids, params):
+    _f32(p, 'params', (n, NUM_PARAMS[fid]))
+  ids = (ctypes.c_int * steps)(*filter_ids)
+  with torch.cuda.device(acts[0].device):
+    _check(lib.expo_chain_fwd(ids, steps, _ptr_array(acts), _ptr_array(params), n, h, w, _dtype_code(acts[0]),
+                              _stream()), 'expo_chain_fwd')
+
+
+def chain_bwd(filter_ids, acts, grads, params, dparams, hsv_grad_mode=0):
+  lib = load()
+  steps = len(filter_ids)
+  assert len(acts) == steps + 1 and len(grads) == steps + 1 and len(params) == steps and len(dparams) == steps
+  n, h, w, _ = acts[0].shape
+  for a in list(acts) + list(grads):
+    _img(a, 'act/grad')
+    assert a.shape == acts[0].shape and a.dtype == acts[0].dtype
+  for fid, p, dp in zip(filter_ids, params, dparams):
+    _f32(p, 'params', (n, NUM_PARAMS[fid]))
+    _f32(dp, 'dparams', (n, NUM_PARAMS[fid]))
+  ids = (ctypes.c_int * steps)(*filter_ids)
+  with torch.cuda.device(acts[0].device):
+    _check(
+        lib.expo_chain_bwd(ids, steps, _ptr_array(acts), _ptr_array(grads), _ptr_array(params),
+                           _ptr_array(dparams), n, h, w, _dtype_code(acts[0]), hsv_grad_mode, _stream()),
+        'expo_chain_bwd')
+
+
+def critic_stats(x, stats):
+  lib = load()
+  _img(x, 'x')
+  n, h, w, _ = x.shape
+  _f32(stats, 'stats', (n, 3))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_critic_stats(_ptr(x), _ptr(stats), n, h, w, _dtype_code(x), _stream()), 'expo_critic_stats')
+
+
+def overexposure_penalty(y, penalty):
+  lib = load()
+  _img(y, 'y')
+  n, h, w, _ = y.shape
+  _f32(penalty, 'penalty', (n,))
+  with torch.cuda.device(y.device):
+    _check(lib.expo_overexposure_penalty(_ptr(y), _ptr(penalty), n, h, w, _dtype_code(y), _stream()),
+           'expo_overexposure_penalty')

@@ -1,0 +1,632 @@
+// exposure_hip.hip -- gfx950 kernels + C-ABI (include/exposure_hip.h) for Exposure's
+// differentiable per-pixel filter stack (reference: /root/reference/filters.py).
+//
+// Kernel plan (HBM-bound pixel maps; no contraction => no MFMA here):
+//   filter_fwd_kernel<F,T>   one pass:  read x (6 B/px fp16), write y (6 B/px)
+//   filter_bwd_kernel<F,T>   one pass:  read x, dy, write dx (18 B/px); y is recomputed;
+//                            per-image parameter gradients: per-thread fp32 partials ->
+//                            wave shuffle reduce -> LDS across the 4 waves -> one atomic
+//                            per (block, parameter)
+//   dispatch_{fwd,bwd}       same bodies behind a block-uniform switch on filter_ids[n]
+//                            (the reference's one-hot select, agent.py:119-125) with the
+//                            over-exposure penalty (agent.py:249-251) fused in
+//   stats / penalty          per-image reductions (critics.py:48-62, agent.py:249-251)
+// Grid: blockIdx.y = image (so parameters are block-uniform -> SGPRs), blockIdx.x =
+// chunk of the image; each thread walks 48-byte pixel groups with a block stride.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <type_traits>
+
+#include "../../include/exposure_hip.h"
+#include "filter_math.h"
+#include "pixel_io.h"
+
+namespace expo {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// Block-reduce NACC accumulators, finish them to NOUT outputs, add atomically to out[].
+template <int NACC, int NOUT, class Finish>
+__device__ __forceinline__ void block_reduce_atomic(float* acc, float* __restrict__ out, Finish fin) {
+  __shared__ float red[kWaves][NACC];
+  __shared__ float tot[NACC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) {
+    const float s = wave_sum(acc[j]);
+    if (lane == 0) red[wv][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kWaves; ++k) s += red[k][threadIdx.x];
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NOUT) atomicAdd(out + threadIdx.x, fin(tot, threadIdx.x));
+}
+
+// --------------------------------------------------------------------------- forward
+template <class F, typename T, bool VEC, bool NT, bool PEN>
+__device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict__ yi,
+                                         const float* __restrict__ prm, float* pen_out,
+                                         int hw, int groups, float inv_count) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const typename F::Prm q = F::load(prm);
+  float pen = 0.f;
+  const int stride = gridDim.x * kThreads;
+  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+    float v[PPL * 3];
+    if constexpr (VEC) {
+      unpack<T>(load_raw<NT>(xi, g), v);
+    } else {
+      load_slow<T>(xi, g, hw, v);
+    }
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      float y[3];
+      F::fwd(q, v + 3 * k, y);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v[3 * k + c] = y[c];
+        if constexpr (PEN) {
+          const bool live = VEC || (g * PPL + k < hw);
+          const float o = fmaxf(y[c] - 1.0f, 0.0f);
+          if (live) pen = fmaf(o, o, pen);
+        }
+      }
+    }
+    if constexpr (VEC) {
+      store_raw<NT>(yi, g, pack<T>(v));
+    } else {
+      store_slow<T>(yi, g, hw, v);
+    }
+  }
+  if constexpr (PEN) {
+    float a[1] = {pen};
+    block_reduce_atomic<1, 1>(a, pen_out, [=](const float* t, int) { return t[0] * inv_count; });
+  }
+}
+
+template <class F, typename T, bool VEC, bool NT>
+__global__ __launch_bounds__(kThreads) void filter_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                              const float* __restrict__ params,
+                                                              int hw, int groups) {
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  fwd_body<F, T, VEC, NT, false>(x + off, y + off, params + n * F::NP, nullptr, hw, groups, 0.f);
+}
+
+// -------------------------------------------------------------------------- backward
+template <class F, typename T, bool VEC, bool NT, bool HAS_DX, bool PEN, int MODE>
+__device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __restrict__ dyi,
+                                         T* __restrict__ dxi, const float* __restrict__ prm,
+                                         float* __restrict__ dprm, int hw, int groups, float pen_scale) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const typename F::Prm q = F::load(prm);
+  // per-image curve LUT (Tone / Color backward) staged in LDS once per block
+  __shared__ __attribute__((aligned(16))) float lut[F::kLutFloats > 0 ? F::kLutFloats : 4];
+  if constexpr (F::kLutFloats > 0) {
+    F::stage(prm, lut);
+    __syncthreads();
+  }
+  float acc[F::NACC];
+#pragma unroll
+  for (int j = 0; j < F::NACC; ++j) acc[j] = 0.f;
+  const int stride = gridDim.x * kThreads;
+  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+    float v[PPL * 3], d[PPL * 3];
+    if constexpr (VEC) {
+      const RawGroup rx = load_raw<NT>(xi, g);
+      const RawGroup rd = load_raw<NT>(dyi, g);
+      unpack<T>(rx, v);
+      unpack<T>(rd, d);
+    } else {
+      load_slow<T>(xi, g, hw, v);
+      load_slow<T>(dyi, g, hw, d);
+    }
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      float dx[3];
+      if constexpr (PEN) {
+        // fused over-exposure penalty: dy += 2 max(y-1,0) * dpen / (H W 3)
+        float y[3];
+        F::fwd(q, v + 3 * k, y);
+        const bool live = VEC || (g * PPL + k < hw);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          if (live) d[3 * k + c] = fmaf(fmaxf(y[c] - 1.0f, 0.0f), pen_scale, d[3 * k + c]);
+      }
+      F::bwd(q, lut, v + 3 * k, d + 3 * k, dx, acc, MODE);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d[3 * k + c] = dx[c];
+    }
+    if constexpr (HAS_DX) {
+      if constexpr (VEC) {
+        store_raw<NT>(dxi, g, pack<T>(d));
+      } else {
+        store_slow<T>(dxi, g, hw, d);
+      }
+    }
+  }
+  block_reduce_atomic<F::NACC, F::NP>(acc, dprm, [=](const float* t, int j) { return F::finish_one(prm, t, j); });
+}
+
+template <class F, typename T, bool VEC, bool NT, bool HAS_DX, int MODE>
+__global__ __launch_bounds__(kThreads) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                              T* __restrict__ dx,
+                                                              const float* __restrict__ params,
+                                                              float* __restrict__ dparams, int hw,
+                                                              int groups) {
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  bwd_body<F, T, VEC, NT, HAS_DX, false, MODE>(x + off, dy + off, HAS_DX ? dx + off : nullptr,
+                                               params + n * F::NP, dparams + n * F::NP, hw, groups, 0.f);
+}
+
+// --------------------------------------------------- per-image dispatch (one-hot select)
+template <typename T, bool VEC>
+__device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  float z[PPL * 3];
+#pragma unroll
+  for (int j = 0; j < PPL * 3; ++j) z[j] = 0.f;
+  const int stride = gridDim.x * kThreads;
+  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+    if constexpr (VEC) store_raw<false>(yi, g, pack<T>(z));
+    else store_slow<T>(yi, g, hw, z);
+  }
+}
+
+// SET is a bit mask of the filter ids this launch handles (bit 8 = id -1).  The dispatch is
+// issued as two launches -- light filters and the register-heavy curve filters -- so each gets
+// its own VGPR budget / occupancy; blocks whose image selected a filter outside SET exit at once.
+constexpr int kSetLight = 0x100 | 0x6F;  // -1, E, G, W, S+, Ct, BW
+constexpr int kSetCurves = 0x90;         // T, C
+
+template <typename T, bool VEC, bool PEN, int SET>
+__global__ __launch_bounds__(kThreads) void dispatch_fwd_kernel(const int32_t* __restrict__ ids,
+                                                                const T* __restrict__ x, T* __restrict__ y,
+                                                                const float* __restrict__ params,
+                                                                float* __restrict__ penalty, int hw, int groups,
+                                                                float inv_count) {
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  const float* prm = params + n * EXPO_MAX_PARAMS;
+  float* pen = PEN ? penalty + n : nullptr;
+  const int id = ids[n];  // block-uniform
+#define EXPO_CASE(ID, F)                                                                              \
+  case ID:                                                                                            \
+    if constexpr ((SET >> ID) & 1) fwd_body<F, T, VEC, false, PEN>(x + off, y + off, prm, pen, hw, groups, inv_count); \
+    break;
+  switch (id) {
+    EXPO_CASE(0, ExposureF)
+    EXPO_CASE(1, GammaF)
+    EXPO_CASE(2, WhiteBalanceF)
+    EXPO_CASE(3, SatPlusF)
+    EXPO_CASE(4, ToneF)
+    EXPO_CASE(5, ContrastF)
+    EXPO_CASE(6, WnbF)
+    EXPO_CASE(7, ColorF)
+    default:  // id -1: all-zero one-hot
+      if constexpr ((SET >> 8) & 1) zero_image<T, VEC>(y + off, hw, groups);
+      break;
+  }
+#undef EXPO_CASE
+}
+
+template <typename T, bool VEC, bool HAS_DX, bool PEN, int MODE, int SET>
+__global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* __restrict__ ids,
+                                                                const T* __restrict__ x, const T* __restrict__ dy,
+                                                                T* __restrict__ dx, const float* __restrict__ params,
+                                                                float* __restrict__ dparams,
+                                                                const float* __restrict__ dpenalty, int hw,
+                                                                int groups, float inv_count) {
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  const float* prm = params + n * EXPO_MAX_PARAMS;
+  float* dprm = dparams + n * EXPO_MAX_PARAMS;
+  const float ps = PEN ? 2.0f * inv_count * dpenalty[n] : 0.f;
+  T* dxi = HAS_DX ? dx + off : nullptr;
+  const int id = ids[n];
+#define EXPO_CASE(ID, F)                                                                                  \
+  case ID:                                                                                                \
+    if constexpr ((SET >> ID) & 1)                                                                        \
+      bwd_body<F, T, VEC, false, HAS_DX, PEN, MODE>(x + off, dy + off, dxi, prm, dprm, hw, groups, ps);   \
+    break;
+  switch (id) {
+    EXPO_CASE(0, ExposureF)
+    EXPO_CASE(1, GammaF)
+    EXPO_CASE(2, WhiteBalanceF)
+    EXPO_CASE(3, SatPlusF)
+    EXPO_CASE(4, ToneF)
+    EXPO_CASE(5, ContrastF)
+    EXPO_CASE(6, WnbF)
+    EXPO_CASE(7, ColorF)
+    default:
+      if constexpr (HAS_DX && ((SET >> 8) & 1)) zero_image<T, VEC>(dxi, hw, groups);
+      break;
+  }
+#undef EXPO_CASE
+}
+
+// ------------------------------------------------------------- per-image reductions
+// critics.py:48-62.  Raw sums {sum(l-1/2), sum (l-1/2)^2, sum sat} are accumulated
+// (shifted to tame the E[l^2]-E[l]^2 cancellation) and finished by stats_finish_kernel.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x, float* __restrict__ sums,
+                                                         int hw, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y;
+  const T* xi = x + size_t(n) * hw * 3;
+  float acc[3] = {0.f, 0.f, 0.f};
+  const int stride = gridDim.x * kThreads;
+  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+    float v[PPL * 3];
+    if constexpr (VEC) unpack<T>(load_raw<false>(xi, g), v);
+    else load_slow<T>(xi, g, hw, v);
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      if (VEC || (g * PPL + k < hw)) {
+        const float* p = v + 3 * k;
+        // critics.py:48-49: r*.27 + g*.67 + b*.06 + 1e-5
+        const float l = ((p[0] * kLumR + p[1] * kLumG) + p[2] * kLumB + 1e-5f) - 0.5f;
+        acc[0] += l;
+        acc[1] = fmaf(l, l, acc[1]);
+        const float c0 = clamp01x(p[0], 0.f, 1.f), c1 = clamp01x(p[1], 0.f, 1.f), c2 = clamp01x(p[2], 0.f, 1.f);
+        const float mx = fmaxf(fmaxf(c0, c1), c2), mn = fminf(fminf(c0, c1), c2);
+        acc[2] += (mx - mn) / (fminf(mx + mn, 2.0f - mx - mn) + 1e-2f);
+      }
+    }
+  }
+  block_reduce_atomic<3, 3>(acc, sums + n * 3, [](const float* t, int j) { return t[j]; });
+}
+
+__global__ void stats_finish_kernel(float* __restrict__ stats, int n, float inv_hw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float m = stats[i * 3 + 0] * inv_hw, m2 = stats[i * 3 + 1] * inv_hw;
+  stats[i * 3 + 0] = m + 0.5f;
+  stats[i * 3 + 1] = m2 - m * m;  // tf.nn.moments: population variance
+  stats[i * 3 + 2] = stats[i * 3 + 2] * inv_hw;
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__ y, float* __restrict__ pen,
+                                                           int hw, int groups, float inv_count) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y;
+  const T* yi = y + size_t(n) * hw * 3;
+  float acc[1] = {0.f};
+  const int stride = gridDim.x * kThreads;
+  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+    float v[PPL * 3];
+    if constexpr (VEC) unpack<T>(load_raw<false>(yi, g), v);
+    else load_slow<T>(yi, g, hw, v);
+#pragma unroll
+    for (int j = 0; j < PPL * 3; ++j) {
+      const float o = fmaxf(v[j] - 1.0f, 0.0f);  // padding lanes hold 0 -> contribute 0
+      acc[0] = fmaf(o, o, acc[0]);
+    }
+  }
+  block_reduce_atomic<1, 1>(acc, pen + n, [=](const float* t, int) { return t[0] * inv_count; });
+}
+
+// ==================================================================== host side
+thread_local std::string g_err;
+
+static int fail(int code, const char* what) {
+  g_err = what;
+  return code;
+}
+static int fail_hip(hipError_t e, const char* where) {
+  g_err = std::string(where) + ": " + hipGetErrorString(e);
+  return EXPO_E_HIP;
+}
+#define HIP_TRY(expr, where)                         \
+  do {                                               \
+    hipError_t e_ = (expr);                          \
+    if (e_ != hipSuccess) return fail_hip(e_, where); \
+  } while (0)
+
+static const int kNumParams[EXPO_NUM_FILTERS] = {1, 1, 3, 1, 8, 1, 1, 24};
+
+struct Geom {
+  int hw, groups, blocks_x;
+  bool vec;
+};
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// groups of 48 bytes per image; blocks per image chosen so the whole grid is >= ~1024
+// blocks when the problem allows and each thread walks a few groups (amortises the
+// reduction epilogue); capped at 2048-ish total blocks (grid-stride the rest).
+template <typename T>
+static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> ptrs) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  Geom g;
+  g.hw = h * w;
+  g.groups = (g.hw + PPL - 1) / PPL;
+  g.vec = (g.hw % PPL) == 0;
+  for (const void* p : ptrs) g.vec = g.vec && (p == nullptr || aligned16(p));
+  const int max_bx = (g.groups + kThreads - 1) / kThreads;
+  int bx = (g.groups + kThreads * 4 - 1) / (kThreads * 4);  // ~4 groups per thread
+  const long want = 1024;
+  if (long(bx) * n < want) bx = int((want + n - 1) / n);
+  if (bx > max_bx) bx = max_bx;
+  if (bx < 1) bx = 1;
+  g.blocks_x = bx;
+  return g;
+}
+
+static int check_common(int n, int h, int w, int dtype) {
+  if (n < 0 || h < 1 || w < 1) return fail(EXPO_E_BADARG, "n >= 0, h >= 1, w >= 1 required");
+  if (n > 65535) return fail(EXPO_E_BADARG, "n > 65535 not supported (grid.y)");
+  if (long(h) * long(w) > (1L << 28)) return fail(EXPO_E_BADARG, "h*w too large");
+  if (dtype != EXPO_F16 && dtype != EXPO_F32) return fail(EXPO_E_BADDTYPE, "dtype must be EXPO_F16 or EXPO_F32");
+  return EXPO_OK;
+}
+
+template <class F, typename T>
+static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, y});
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  if (g.vec)
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, false>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+  else
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, false, false>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+  HIP_TRY(hipGetLastError(), "filter_fwd launch");
+  return EXPO_OK;
+}
+
+template <class F, typename T>
+static int launch_bwd(const void* x, const void* dy, void* dx, const float* params, float* dparams, int n,
+                      int h, int w, int mode, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * F::NP, s), "dparams memset");
+#define EXPO_L(VEC, HAS_DX, MODE)                                                                        \
+  hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, false, HAS_DX, MODE>), grid, block, 0, s, (const T*)x, \
+                     (const T*)dy, (T*)dx, params, dparams, g.hw, g.groups)
+  // only SaturationPlus has a mode-dependent backward
+  const bool m1 = std::is_same<F, SatPlusF>::value && mode == 1;
+  const int key = (g.vec ? 4 : 0) | (dx ? 2 : 0) | (m1 ? 1 : 0);
+  switch (key) {
+    case 7: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(true, true, 1); break;
+    case 6: EXPO_L(true, true, 0); break;
+    case 5: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(true, false, 1); break;
+    case 4: EXPO_L(true, false, 0); break;
+    case 3: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(false, true, 1); break;
+    case 2: EXPO_L(false, true, 0); break;
+    case 1: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(false, false, 1); break;
+    default: EXPO_L(false, false, 0); break;
+  }
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "filter_bwd launch");
+  return EXPO_OK;
+}
+
+template <typename T>
+static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int h, int w, hipStream_t s) {
+  switch (id) {
+    case 0: return launch_fwd<ExposureF, T>(x, y, p, n, h, w, s);
+    case 1: return launch_fwd<GammaF, T>(x, y, p, n, h, w, s);
+    case 2: return launch_fwd<WhiteBalanceF, T>(x, y, p, n, h, w, s);
+    case 3: return launch_fwd<SatPlusF, T>(x, y, p, n, h, w, s);
+    case 4: return launch_fwd<ToneF, T>(x, y, p, n, h, w, s);
+    case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s);
+    case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s);
+    case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s);
+  }
+  return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+}
+
+template <typename T>
+static int bwd_by_id(int id, const void* x, const void* dy, void* dx, const float* p, float* dp, int n, int h,
+                     int w, int mode, hipStream_t s) {
+  switch (id) {
+    case 0: return launch_bwd<ExposureF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
+    case 1: return launch_bwd<GammaF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
+    case 2: return launch_bwd<WhiteBalanceF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
+    case 3: return launch_bwd<SatPlusF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
+    case 4: return launch_bwd<ToneF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
+    case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
+    case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
+    case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
+  }
+  return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+}
+
+template <typename T>
+static int dispatch_fwd_t(const int32_t* ids, const void* x, void* y, const float* params, float* penalty, int n,
+                          int h, int w, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, y});
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  const float inv_count = 1.0f / (float(g.hw) * 3.0f);
+  if (penalty) HIP_TRY(hipMemsetAsync(penalty, 0, sizeof(float) * size_t(n), s), "penalty memset");
+#define EXPO_L(VEC, PEN)                                                                                 \
+  do {                                                                                                   \
+    hipLaunchKernelGGL((dispatch_fwd_kernel<T, VEC, PEN, kSetLight>), grid, block, 0, s, ids,            \
+                       (const T*)x, (T*)y, params, penalty, g.hw, g.groups, inv_count);                  \
+    hipLaunchKernelGGL((dispatch_fwd_kernel<T, VEC, PEN, kSetCurves>), grid, block, 0, s, ids,           \
+                       (const T*)x, (T*)y, params, penalty, g.hw, g.groups, inv_count);                  \
+  } while (0)
+  if (g.vec) {
+    if (penalty) EXPO_L(true, true); else EXPO_L(true, false);
+  } else {
+    if (penalty) EXPO_L(false, true); else EXPO_L(false, false);
+  }
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "dispatch_fwd launch");
+  return EXPO_OK;
+}
+
+template <typename T>
+static int dispatch_bwd_t(const int32_t* ids, const void* x, const void* dy, void* dx, const float* params,
+                          float* dparams, const float* dpenalty, int n, int h, int w, int mode, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  const float inv_count = 1.0f / (float(g.hw) * 3.0f);
+  HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * EXPO_MAX_PARAMS, s), "dparams memset");
+#define EXPO_L2(VEC, HAS_DX, PEN, MODE, SET)                                                              \
+  hipLaunchKernelGGL((dispatch_bwd_kernel<T, VEC, HAS_DX, PEN, MODE, SET>), grid, block, 0, s, ids,       \
+                     (const T*)x, (const T*)dy, (T*)dx, params, dparams, dpenalty, g.hw, g.groups, inv_count)
+#define EXPO_L(VEC, HAS_DX, PEN)                                                                          \
+  do {                                                                                                    \
+    if (mode == 1) EXPO_L2(VEC, HAS_DX, PEN, 1, kSetLight); else EXPO_L2(VEC, HAS_DX, PEN, 0, kSetLight); \
+    EXPO_L2(VEC, HAS_DX, PEN, 0, kSetCurves);                                                             \
+  } while (0)
+  const int key = (g.vec ? 4 : 0) | (dx ? 2 : 0) | (dpenalty ? 1 : 0);
+  switch (key) {
+    case 7: EXPO_L(true, true, true); break;
+    case 6: EXPO_L(true, true, false); break;
+    case 5: EXPO_L(true, false, true); break;
+    case 4: EXPO_L(true, false, false); break;
+    case 3: EXPO_L(false, true, true); break;
+    case 2: EXPO_L(false, true, false); break;
+    case 1: EXPO_L(false, false, true); break;
+    default: EXPO_L(false, false, false); break;
+  }
+#undef EXPO_L
+#undef EXPO_L2
+  HIP_TRY(hipGetLastError(), "dispatch_bwd launch");
+  return EXPO_OK;
+}
+
+template <typename T>
+static int stats_t(const void* x, float* stats, int n, int h, int w, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x});
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  HIP_TRY(hipMemsetAsync(stats, 0, sizeof(float) * size_t(n) * 3, s), "stats memset");
+  if (g.vec) hipLaunchKernelGGL((stats_kernel<T, true>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
+  else hipLaunchKernelGGL((stats_kernel<T, false>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
+  HIP_TRY(hipGetLastError(), "stats launch");
+  hipLaunchKernelGGL(stats_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, s, stats, n, 1.0f / float(g.hw));
+  HIP_TRY(hipGetLastError(), "stats_finish launch");
+  return EXPO_OK;
+}
+
+template <typename T>
+static int penalty_t(const void* y, float* pen, int n, int h, int w, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {y});
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  HIP_TRY(hipMemsetAsync(pen, 0, sizeof(float) * size_t(n), s), "penalty memset");
+  const float inv_count = 1.0f / (float(g.hw) * 3.0f);
+  if (g.vec) hipLaunchKernelGGL((penalty_kernel<T, true>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
+  else hipLaunchKernelGGL((penalty_kernel<T, false>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
+  HIP_TRY(hipGetLastError(), "penalty launch");
+  return EXPO_OK;
+}
+
+}  // namespace expo
+
+// ======================================================================== C-ABI
+using namespace expo;
+
+extern "C" {
+
+int expo_version(void) { return EXPO_ABI_VERSION; }
+
+const char* expo_last_error(void) { return g_err.c_str(); }
+
+int expo_num_filter_params(int filter_id) {
+  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return -1;
+  return kNumParams[filter_id];
+}
+
+int expo_filter_fwd(int filter_id, const void* x, void* y, const float* params, int n, int h, int w, int dtype,
+                    void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+  if (n == 0) return EXPO_OK;
+  if (!x || !y || !params) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? fwd_by_id<half_t>(filter_id, x, y, params, n, h, w, s)
+                           : fwd_by_id<float>(filter_id, x, y, params, n, h, w, s);
+}
+
+int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx, const float* params, float* dparams,
+                    int n, int h, int w, int dtype, int hsv_grad_mode, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+  if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
+  if (n == 0) return EXPO_OK;
+  if (!x || !dy || !params || !dparams) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? bwd_by_id<half_t>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s)
+                           : bwd_by_id<float>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s);
+}
+
+int expo_filter_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y, const float* params,
+                             float* penalty, int n, int h, int w, int dtype, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!filter_ids || !x || !y || !params) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? dispatch_fwd_t<half_t>(filter_ids, x, y, params, penalty, n, h, w, s)
+                           : dispatch_fwd_t<float>(filter_ids, x, y, params, penalty, n, h, w, s);
+}
+
+int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const void* dy, void* dx,
+                             const float* params, float* dparams, const float* dpenalty, int n, int h, int w,
+                             int dtype, int hsv_grad_mode, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
+  if (n == 0) return EXPO_OK;
+  if (!filter_ids || !x || !dy || !params || !dparams) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16
+             ? dispatch_bwd_t<half_t>(filter_ids, x, dy, dx, params, dparams, dpenalty, n, h, w, hsv_grad_mode, s)
+             : dispatch_bwd_t<float>(filter_ids, x, dy, dx, params, dparams, dpenalty, n, h, w, hsv_grad_mode, s);
+}
+
+int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const float* const* params, int n, int h,
+                   int w, int dtype, void* stream) {
+  if (steps < 0 || !filter_ids || !acts || !params) return fail(EXPO_E_BADARG, "bad chain arguments");
+  for (int i = 0; i < steps; ++i) {
+    const int rc = expo_filter_fwd(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, dtype, stream);
+    if (rc) return rc;
+  }
+  return EXPO_OK;
+}
+
+int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* const* grads,
+                   const float* const* params, float* const* dparams, int n, int h, int w, int dtype,
+                   int hsv_grad_mode, void* stream) {
+  if (steps < 0 || !filter_ids || !acts || !grads || !params || !dparams)
+    return fail(EXPO_E_BADARG, "bad chain arguments");
+  for (int i = steps - 1; i >= 0; --i) {
+    const int rc = expo_filter_bwd(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], dparams[i], n, h,
+                                   w, dtype, hsv_grad_mode, stream);
+    if (rc) return rc;
+  }
+  return EXPO_OK;
+}
+
+int expo_critic_stats(const void* x, float* stats, int n, int h, int w, int dtype, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!x || !stats) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? stats_t<half_t>(x, stats, n, h, w, s) : stats_t<float>(x, stats, n, h, w, s);
+}
+
+int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w, int dtype, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!y || !penalty) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? penalty_t<half_t>(y, penalty, n, h, w, s) : penalty_t<float>(y, penalty, n, h, w, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// filter_math.h -- per-pixel maths of the eight Exposure filters, forward and backward,
+// written for gfx950 wave64 VALU (fp32 arithmetic, hardware transcendentals).
+//
+// Each functor restates one `process()` of /root/reference/filters.py and the gradient
+// TF-1 derives for it (tie conventions: SURVEY.md section 8a; oracle: oracle/filters_np.py).
+//
+//   NP    packed parameters per image (C-ABI layout, include/exposure_hip.h)
+//   NACC  per-thread fp32 accumulators the backward keeps; they are *linear* in the
+//         per-pixel contributions, so block sums can be finished (finish_one) and added
+//         atomically across blocks.
+//   Prm   per-image derived constants; loaded through a block-uniform pointer, so the
+//         compiler keeps them in SGPRs (scalar loads) -- no LDS staging is needed for
+//         wave-uniform data on CDNA.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace expo {
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// v_sin_f32 / v_cos_f32 take their argument in revolutions (x * 2*pi radians)
+__device__ __forceinline__ float sin_rev(float x) { return __builtin_amdgcn_sinf(x); }
+__device__ __forceinline__ float cos_rev(float x) { return __builtin_amdgcn_cosf(x); }
+__device__ __forceinline__ float clamp01x(float x, float lo, float hi) {
+  return __builtin_amdgcn_fmed3f(x, lo, hi);
+}
+
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kLumR = 0.27f, kLumG = 0.67f, kLumB = 0.06f;  // util.py:271-274
+constexpr int kCurveSteps = 8;                                 // config_example.py:27
+struct alignas(16) float4_lut { float x, y, z, w; };
+
+// util.py:271-274 -- same association order as the reference: (.27 r + .67 g) + .06 b
+__device__ __forceinline__ float lum3(const float x[3]) {
+  return (kLumR * x[0] + kLumG * x[1]) + kLumB * x[2];
+}
+
+// ---------------------------------------------------------------------------------
+// 0  ExposureFilter   filters.py:181-182   y = x * exp(p ln2)
+// ---------------------------------------------------------------------------------
+struct ExposureF {
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
+  struct Prm { float s; };
+  __device__ static Prm load(const float* __restrict__ p) { return {exp2f(p[0])}; }
+  __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = x[c] * q.s;
+  }
+  __device__ static void bwd(const Prm& q, const float*, const float x[3], const float dy[3], float dx[3],
+                             float acc[NACC], int) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dx[c] = dy[c] * q.s;
+      acc[0] = fmaf(dy[c], x[c], acc[0]);
+    }
+  }
+  // dp = ln2 * sum dy*y = ln2 * s * sum dy*x
+  __device__ static float finish_one(const float* __restrict__ p, const float* a, int) { return kLn2 * exp2f(p[0]) * a[0]; }
+};
+
+// ---------------------------------------------------------------------------------
+// 1  GammaFilter   filters.py:205-206   y = pow(max(x, 0.001), g)
+// ---------------------------------------------------------------------------------
+struct GammaF {
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
+  struct Prm { float g; };
+  __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
+  __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = fast_exp2(q.g * fast_log2(fmaxf(x[c], 0.001f)));
+  }
+  __device__ static void bwd(const Prm& q, const float*, const float x[3], const float dy[3], float dx[3],
+                             float acc[NACC], int) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xm = fmaxf(x[c], 0.001f);
+      const float lg = fast_log2(xm);
+      const float y = fast_exp2(q.g * lg);
+      const float t = dy[c] * y;
+      // tf.maximum passes the gradient to x on equality (x >= 0.001)
+      dx[c] = (x[c] >= 0.001f) ? t * q.g * fast_rcp(xm) : 0.0f;
+      acc[0] = fmaf(t, lg, acc[0]);
+    }
+  }
+  __device__ static float finish_one(const float* __restrict__, const float* a, int) { return kLn2 * a[0]; }
+};
+
+// ---------------------------------------------------------------------------------
+// 2  ImprovedWhiteBalanceFilter   filters.py:237-238   y_c = x_c * s_c
+// ---------------------------------------------------------------------------------
+struct WhiteBalanceF {
+  static constexpr int NP = 3, NACC = 3, kLutFloats = 0;
+  struct Prm { float s[3]; };
+  __device__ static Prm load(const float* __restrict__ p) { return {{p[0], p[1], p[2]}}; }
+  __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = x[c] * q.s[c];
+  }
+  __device__ static void bwd(const Prm& q, const float*, const float x[3], const float dy[3], float dx[3],
+                             float acc[NACC], int) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dx[c] = dy[c] * q.s[c];
+      acc[c] = fmaf(dy[c], x[c], acc[c]);
+    }
+  }
+  __device__ static float finish_one(const float* __restrict__, const float* a, int j) { return a[j]; }
+};
+
+// ---------------------------------------------------------------------------------
+// 3  SaturationPlusFilter   filters.py:484-498
+//    xc = min(x,1); (h,s,v) = rgb_to_hsv(xc); s' = s + (1-s)(.5-|.5-v|).8;
+//    full = hsv_to_rgb(h,s',v); y = xc(1-p) + full p
+//    The hue is never materialised: for rng = v - min > 0 the HSV->RGB ramp values are
+//    d_c = (xc_c - min)/rng (hue only encodes the position of the middle channel), and
+//    for rng == 0 TF's hue is 0, i.e. d = (1,0,0).  full_c = ((1-s') + s' d_c) v.
+// ---------------------------------------------------------------------------------
+struct SatPlusF {
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
+  struct Prm { float p; };
+  __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
+
+  struct Hsv { float xc[3], v, mn, rng, s, sp, d[3]; };
+  __device__ static Hsv analyse(const float x[3]) {
+    Hsv a;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.xc[c] = fminf(x[c], 1.0f);
+    a.v = fmaxf(fmaxf(a.xc[0], a.xc[1]), a.xc[2]);
+    a.mn = fminf(fminf(a.xc[0], a.xc[1]), a.xc[2]);
+    a.rng = a.v - a.mn;
+    a.s = (a.v > 0.0f) ? a.rng * fast_rcp(a.v) : 0.0f;
+    const float tri = 0.5f - fabsf(0.5f - a.v);
+    a.sp = a.s + (1.0f - a.s) * tri * 0.8f;
+    const bool col = a.rng > 0.0f;
+    const float ir = col ? fast_rcp(a.rng) : 0.0f;
+    a.d[0] = col ? (a.xc[0] - a.mn) * ir : 1.0f;
+    a.d[1] = (a.xc[1] - a.mn) * ir;
+    a.d[2] = (a.xc[2] - a.mn) * ir;
+    return a;
+  }
+  __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
+    const Hsv a = analyse(x);
+    const float oms = 1.0f - a.sp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float full = (oms + a.sp * a.d[c]) * a.v;
+      y[c] = a.xc[c] * (1.0f - q.p) + full * q.p;
+    }
+  }
+  __device__ static void bwd(const Prm& q, const float*, const float x[3], const float dy[3], float dx[3],
+                             float acc[NACC], int mode) {
+    const Hsv a = analyse(x);
+    const float oms = 1.0f - a.sp;
+    float gfull[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float full = (oms + a.sp * a.d[c]) * a.v;
+      acc[0] = fmaf(dy[c], full - a.xc[c], acc[0]);
+      gfull[c] = dy[c] * q.p;
+    }
+    float dxc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dxc[c] = dy[c] * (1.0f - q.p);
+    if (mode == 1 && a.rng > 0.0f && a.v > 0.0f) {
+      // analytic d full / d xc (oracle/filters_np.py::_satplus_full_grad)
+      int imax = 0, imin = 0;
+      if (a.xc[1] > a.xc[imax]) imax = 1;
+      if (a.xc[2] > a.xc[imax]) imax = 2;
+      if (a.xc[1] < a.xc[imin]) imin = 1;
+      if (a.xc[2] < a.xc[imin]) imin = 2;
+      const float iv = 1.0f / a.v, ir = 1.0f / a.rng;
+      const float tri = 0.5f - fabsf(0.5f - a.v);
+      const float dtri = (0.5f - a.v) > 0.f ? 1.f : ((0.5f - a.v) < 0.f ? -1.f : 0.f);
+      const float gsum = gfull[0] + gfull[1] + gfull[2];
+      const float gd = gfull[0] * a.d[0] + gfull[1] * a.d[1] + gfull[2] * a.d[2];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float amax = (j == imax) ? 1.f : 0.f, amin = (j == imin) ? 1.f : 0.f;
+        const float ds = (amax - amin) * iv - a.rng * iv * iv * amax;
+        const float dsp = ds * (1.0f - tri * 0.8f) + (1.0f - a.s) * 0.8f * dtri * amax;
+        float o = amax * oms * gsum - a.v * dsp * gsum + dsp * a.v * gd + a.sp * amax * gd;
+        o += a.sp * a.v * ir * (gfull[j] - amin * gsum - (amax - amin) * gd);
+        dxc[j] += o;
+      }
+    }
+    // tf.minimum(img, 1.0) passes the gradient on x <= 1
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dx[c] = (x[c] <= 1.0f) ? dxc[c] : 0.0f;
+  }
+  __device__ static float finish_one(const float* __restrict__, const float* a, int) { return a[0]; }
+};
+
+// ---------------------------------------------------------------------------------
+// 4 / 7  ToneFilter (filters.py:312-322) and ColorFilter (filters.py:264-273):
+//    y = (L/S) sum_i clip(x - i/L, 0, 1/L) k_i,  S = sum_i k_i + 1e-30, L = 8.
+//    Tone shares one curve over the channels (NC = 1), Color has one per channel.
+//
+//    Forward: with E_i = clamp(x, 0, i/L) (E_0 = 0) the clips telescope,
+//      clip_i = E_{i+1} - E_i  =>  T = sum_i k_i clip_i = sum_{i=1..L} E_i (k_{i-1} - k_i),  k_L := 0
+//    i.e. 8 v_min + 8 v_fma per element with the knot differences in SGPRs.
+//
+//    Backward: per-curve LUT staged in LDS, entry j = {k_j, k_{j+1}, P_j = sum_{i<j} k_i / L}:
+//      j = clamp(ceil(L x) - 1, 0, L-1)      (x in (j/L, (j+1)/L] -> segment j)
+//      T = P_j + (clamp(x,0,1) - j/L) k_j
+//      dT/dx = [0 <= x <= 1] k_j + [L x integer, 1 <= L x <= L-1] k_{j+1}
+//    (tf.clip_by_value passes the gradient on BOTH inclusive bounds, so exactly on a
+//    knot the two neighbouring segments both contribute -- SURVEY.md section 8a-6).
+//    Accumulators per curve: Q_i = sum dy E_i (i = 1..L), B = sum dy y;
+//      sum dy clip_i = Q_{i+1} - Q_i,   dk_i = (L/S)(Q_{i+1} - Q_i) - B/S.
+// ---------------------------------------------------------------------------------
+template <int NC>
+struct CurveF {
+  static constexpr int L = kCurveSteps;
+  static constexpr int NP = NC * L, NACC = NC * (L + 1);
+  static constexpr int kLutFloats = NC * L * 4;
+  struct Prm { float delta[NC][L]; float scale[NC]; };  // delta[c][i-1] = k_{i-1} - k_i
+  __device__ static Prm load(const float* __restrict__ p) {
+    Prm q;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float S = 0.f;
+#pragma unroll
+      for (int i = 0; i < L; ++i) {
+        const float k = p[c * L + i];
+        q.delta[c][i] = k - ((i + 1 < L) ? p[c * L + i + 1] : 0.0f);
+        S += k;
+      }
+      S += 1e-30f;
+      q.scale[c] = float(L) / S;
+    }
+    return q;
+  }
+  // LDS LUT for the backward; call with all threads of the block, then __syncthreads().
+  __device__ static void stage(const float* __restrict__ p, float* lut) {
+    const int t = threadIdx.x;
+    if (t < NC * L) {
+      const int c = t / L, j = t % L;
+      float P = 0.f;
+      for (int i = 0; i < j; ++i) P += p[c * L + i];
+      lut[t * 4 + 0] = p[c * L + j];
+      lut[t * 4 + 1] = (j + 1 < L) ? p[c * L + j + 1] : 0.0f;
+      lut[t * 4 + 2] = P * (1.0f / L);
+      lut[t * 4 + 3] = 0.0f;
+    }
+  }
+  __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int cc = (NC == 1) ? 0 : c;
+      const float xc = clamp01x(x[c], 0.0f, 1.0f);
+      float t = xc * q.delta[cc][L - 1];  // E_L = clamp(x,0,1)
+#pragma unroll
+      for (int i = 1; i < L; ++i) t = fmaf(fminf(xc, float(i) / L), q.delta[cc][i - 1], t);
+      y[c] = t * q.scale[cc];
+    }
+  }
+  __device__ static void bwd(const Prm& q, const float* lut, const float x[3], const float dy[3],
+                             float dx[3], float acc[NACC], int) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int cc = (NC == 1) ? 0 : c;
+      const float xv = x[c], g = dy[c];
+      const float xc = clamp01x(xv, 0.0f, 1.0f);
+      const float u = xv * float(L);  // exact
+      const float cu = ceilf(u);
+      const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
+      const float4_lut e = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
+      const float t = fmaf(fmaf(jf, -1.0f / L, xc), e.x, e.z);
+      const float y = t * q.scale[cc];
+      const bool inside = (xv >= 0.0f) && (xv <= 1.0f);
+      const bool knot = (cu == u) && (u >= 1.0f) && (u <= float(L - 1));
+      const float slope = (inside ? e.x : 0.0f) + (knot ? e.y : 0.0f);
+      dx[c] = g * q.scale[cc] * slope;
+      float* a = acc + cc * (L + 1);
+#pragma unroll
+      for (int i = 1; i < L; ++i) a[i - 1] = fmaf(g, fminf(xc, float(i) / L), a[i - 1]);
+      a[L - 1] = fmaf(g, xc, a[L - 1]);
+      a[L] = fmaf(g, y, a[L]);
+    }
+  }
+  // a[] per curve: Q_1..Q_L, B.  dk_i = scale (Q_{i+1} - Q_i) - B / S,  Q_0 = 0
+  __device__ static float finish_one(const float* __restrict__ p, const float* a, int j) {
+    const int c = j / L, i = j % L;
+    float S = 0.f;
+    for (int t = 0; t < L; ++t) S += p[c * L + t];
+    S += 1e-30f;
+    const float* ac = a + c * (L + 1);
+    const float qi = (i == 0) ? 0.0f : ac[i - 1];
+    return (float(L) / S) * (ac[i] - qi) - ac[L] / S;
+  }
+};
+using ToneF = CurveF<1>;
+using ColorF = CurveF<3>;
+
+// ---------------------------------------------------------------------------------
+// 5  ContrastFilter   filters.py:415-419
+//    l = clip(lum(x),0,1); cl = -cos(pi l)/2 + 1/2 = sin^2(pi l / 2) (no cancellation);
+//    ci = x/(l+1e-6)*cl; y = (1-p) x + p ci
+// ---------------------------------------------------------------------------------
+struct ContrastF {
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
+  struct Prm { float p; };
+  __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
+  __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
+    const float l = clamp01x(lum3(x), 0.0f, 1.0f);
+    const float sh = sin_rev(l * 0.25f);
+    const float ratio = sh * sh * fast_rcp(l + 1e-6f);
+    const float f = (1.0f - q.p) + q.p * ratio;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = x[c] * f;
+  }
+  __device__ static void bwd(const Prm& q, const float*, const float x[3], const float dy[3], float dx[3],
+                             float acc[NACC], int) {
+    const float lraw = lum3(x);
+    const float l = clamp01x(lraw, 0.0f, 1.0f);
+    const float sh = sin_rev(l * 0.25f), ch = cos_rev(l * 0.25f);
+    const float cl = sh * sh;
+    const float dcl = kPi * sh * ch;  // 0.5 pi sin(pi l)
+    const float inv = fast_rcp(l + 1e-6f);
+    const float ratio = cl * inv;
+    const float G = (dcl - ratio) * inv;  // d/dl [cl/(l+eps)]
+    const float dot = dy[0] * x[0] + dy[1] * x[1] + dy[2] * x[2];
+    // maximum(.,0) / minimum(.,1) pass the gradient on 0 <= lum <= 1 (inclusive)
+    const float common = (lraw >= 0.0f && lraw <= 1.0f) ? q.p * G * dot : 0.0f;
+    const float f = (1.0f - q.p) + q.p * ratio;
+    dx[0] = fmaf(dy[0], f, kLumR * common);
+    dx[1] = fmaf(dy[1], f, kLumG * common);
+    dx[2] = fmaf(dy[2], f, kLumB * common);
+    acc[0] = fmaf(dot, ratio - 1.0f, acc[0]);  // sum_c dy_c (ci_c - x_c)
+  }
+  __device__ static float finish_one(const float* __restrict__, const float* a, int) { return a[0]; }
+};
+
+// ---------------------------------------------------------------------------------
+// 6  WNBFilter   filters.py:438-440   y_c = (1-p) x_c + p lum(x)
+// ---------------------------------------------------------------------------------
+struct WnbF {
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
+  struct Prm { float p; };
+  __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
+  __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
+    const float pl = q.p * lum3(x);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = fmaf(1.0f - q.p, x[c], pl);
+  }
+  __device__ static void bwd(const Prm& q, const float*, const float x[3], const float dy[3], float dx[3],
+                             float acc[NACC], int) {
+    const float l = lum3(x);
+    const float sdy = dy[0] + dy[1] + dy[2];
+    const float dot = dy[0] * x[0] + dy[1] * x[1] + dy[2] * x[2];
+    const float ps = q.p * sdy;
+    dx[0] = fmaf(1.0f - q.p, dy[0], kLumR * ps);
+    dx[1] = fmaf(1.0f - q.p, dy[1], kLumG * ps);
+    dx[2] = fmaf(1.0f - q.p, dy[2], kLumB * ps);
+    acc[0] += l * sdy - dot;  // sum_c dy_c (lum - x_c)
+  }
+  __device__ static float finish_one(const float* __restrict__, const float* a, int) { return a[0]; }
+};
+
+}  // namespace expo

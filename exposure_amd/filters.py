@@ -1,0 +1,344 @@
+"""The reference's ``Filter`` plugin protocol on PyTorch-ROCm, backed by the HIP library.
+
+Mirrors ``/root/reference/filters.py`` class-for-class: same class names, method names,
+arguments, parameter tensor shapes and return triple, so a torch restatement of
+``agent_generator`` can run ``filter.apply(net, filter_features, high_res=high_res)``
+(``agent.py:67-68``) unchanged.  What differs is where the work happens:
+
+* ``process(img, param)`` does not compose elementwise tensor ops; it makes ONE call into
+  ``libexposure_hip.so`` (``expo_filter_fwd``), and its autograd backward makes one call
+  (``expo_filter_bwd``) that returns the image gradient and the per-image parameter
+  gradients in a single pass.  There is no CPU / eager fallback: a CPU tensor raises.
+* parameter regression (two tiny FCs + range squashing, ``filters.py:28-44`` and the
+  per-class ``filter_param_regressor``) stays in torch -- it is (N x 4096) GEMM work that
+  hipBLASLt handles, not pixel work.
+
+Images are NHWC (as in the reference), float16 or float32, on a ROCm device.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _cabi
+from .util import lrelu, tanh_range
+
+FILTER_SHORT_NAMES = ('E', 'G', 'W', 'S+', 'T', 'Ct', 'BW', 'C')
+
+
+class _PixelFilterFunction(torch.autograd.Function):
+  """y = process_<fid>(img, packed) through the C-ABI; backward = expo_filter_bwd."""
+
+  @staticmethod
+  def forward(ctx, img, packed, fid, hsv_grad_mode):
+    img = img.contiguous()
+    packed = packed.contiguous().float()
+    y = torch.empty_like(img)
+    _cabi.filter_fwd(fid, img, y, packed)
+    ctx.save_for_backward(img, packed)
+    ctx.fid = fid
+    ctx.hsv_grad_mode = hsv_grad_mode
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    img, packed = ctx.saved_tensors
+    dy = dy.contiguous().to(img.dtype)
+    dx = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+    dparams = torch.empty_like(packed)
+    _cabi.filter_bwd(ctx.fid, img, dy, dx, packed, dparams, ctx.hsv_grad_mode)
+    return dx, dparams, None, None
+
+
+def pixel_filter(fid, img, packed, hsv_grad_mode=0):
+  """Functional entry: filter ``fid`` (0..7, ``cfg.filters`` order) with packed (N,P) params."""
+  return _PixelFilterFunction.apply(img, packed, fid, hsv_grad_mode)
+
+
+def _shape_hwc(net):
+  shape = tuple(net.shape) if hasattr(net, 'shape') else tuple(net)
+  return tuple(int(s) for s in shape[1:])
+
+
+class Filter(nn.Module):
+  """filters.py:9-167.  ``net`` is an NHWC tensor (or its shape); ``cfg`` the config Dict."""
+
+  filter_id = None
+
+  def __init__(self, net, cfg):
+    super().__init__()
+    self.cfg = cfg
+    self.height, self.width, self.channels = _shape_hwc(net)
+    # Specified in child classes
+    self.num_filter_parameters = None
+    self.short_name = None
+    self.filter_parameters = None
+    self.fc1 = None
+    self.fc2 = None
+
+  def _build_regressor(self):
+    """The two FCs of extract_parameters (filters.py:28-42), Xavier-initialised."""
+    in_dim = self.cfg.feature_extractor_dims
+    out_dim = self.get_num_filter_parameters() + self.get_num_mask_parameters()
+    self.fc1 = nn.Linear(in_dim, self.cfg.fc1_size)
+    self.fc2 = nn.Linear(self.cfg.fc1_size, out_dim)
+    for fc in (self.fc1, self.fc2):
+      nn.init.xavier_uniform_(fc.weight)
+      nn.init.zeros_(fc.bias)
+
+  def get_short_name(self):
+    assert self.short_name
+    return self.short_name
+
+  def get_num_filter_parameters(self):
+    assert self.num_filter_parameters
+    return self.num_filter_parameters
+
+  def extract_parameters(self, features):
+    """filters.py:28-44."""
+    features = lrelu(self.fc1(features))
+    features = self.fc2(features)
+    p = self.get_num_filter_parameters()
+    return features[:, :p], features[:, p:]
+
+  # Should be implemented in child classes
+  def filter_param_regressor(self, features):
+    assert False
+
+  def pack(self, param):
+    """reference-shaped parameter tensor -> (N, P) float32 C-ABI layout."""
+    return param.reshape(param.shape[0], self.get_num_filter_parameters())
+
+  # Process the whole image, without masking
+  def process(self, img, param):
+    hsv_mode = int(self.cfg.get('hsv_grad_mode', 0)) if hasattr(self.cfg, 'get') else 0
+    return pixel_filter(self.filter_id, img, self.pack(param), hsv_mode)
+
+  def debug_info_batched(self):
+    return False
+
+  def no_high_res(self):
+    return False
+
+  # Apply the whole filter with masking
+  def apply(self, img, img_features=None, specified_parameter=None, high_res=None):
+    """filters.py:62-99 -> (low_res_output, high_res_output or None, debug_info)."""
+    assert (img_features is None) ^ (specified_parameter is None)
+    if img_features is not None:
+      filter_features, mask_parameters = self.extract_parameters(img_features)
+      filter_parameters = self.filter_param_regressor(filter_features)
+    else:
+      assert not self.use_masking()
+      filter_parameters = specified_parameter
+      mask_parameters = torch.zeros((1, self.get_num_mask_parameters()), dtype=torch.float32,
+                                    device=img.device)
+    debug_info = {}
+    # We only debug the first image of this batch
+    if self.debug_info_batched():
+      debug_info['filter_parameters'] = filter_parameters
+    else:
+      debug_info['filter_parameters'] = filter_parameters[0]
+    self.mask_parameters = mask_parameters
+    self.mask = self.get_mask(img, mask_parameters)
+    debug_info['mask'] = self.mask[0]
+    # lerp(img, process(img, p), ones(1,1,1,1)) == process(img, p): the constant-one mask of the
+    # shipped configs (cfg.masking = False) is folded away instead of spending two more passes.
+    low_res_output = self.process(img, filter_parameters)
+    if high_res is not None:
+      if self.no_high_res():
+        high_res_output = high_res
+      else:
+        self.high_res_mask = self.get_mask(high_res, mask_parameters)
+        high_res_output = self.process(high_res, filter_parameters)
+    else:
+      high_res_output = None
+    return low_res_output, high_res_output, debug_info
+
+  # nn.Module.apply(fn) is shadowed by the reference's method name on purpose; keep access to it.
+  module_apply = nn.Module.apply
+
+  def use_masking(self):
+    return self.cfg.masking
+
+  def get_num_mask_parameters(self):
+    return 6
+
+  def get_mask(self, img, mask_parameters):
+    """filters.py:110-148.  Only the masking-disabled branch is in scope."""
+    if not self.use_masking():
+      return torch.ones((1, 1, 1, 1), dtype=torch.float32, device=img.device)
+    raise NotImplementedError('cfg.masking=True is outside the hot-path scope (SURVEY.md section 8f-3)')
+
+  def visualize_filter(self, debug_info, canvas):
+    raise NotImplementedError('cv2 drawing is out of scope')
+
+  def visualize_mask(self, debug_info, res):
+    raise NotImplementedError('cv2 drawing is out of scope')
+
+
+class ExposureFilter(Filter):
+  """filters.py:170-182."""
+  filter_id = 0
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.short_name = 'E'
+    self.num_filter_parameters = 1
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    return tanh_range(-self.cfg.exposure_range, self.cfg.exposure_range, initial=0)(features)
+
+
+class GammaFilter(Filter):
+  """filters.py:194-206."""
+  filter_id = 1
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.short_name = 'G'
+    self.num_filter_parameters = 1
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    log_gamma_range = math.log(self.cfg.gamma_range)
+    return torch.exp(tanh_range(-log_gamma_range, log_gamma_range)(features))
+
+
+class ImprovedWhiteBalanceFilter(Filter):
+  """filters.py:215-238."""
+  filter_id = 2
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.short_name = 'W'
+    self.channels = 3
+    self.num_filter_parameters = self.channels
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    log_wb_range = 0.5
+    mask = torch.tensor([[0.0, 1.0, 1.0]], dtype=features.dtype, device=features.device)
+    features = features * mask
+    color_scaling = torch.exp(tanh_range(-log_wb_range, log_wb_range)(features))
+    # normalize by luminance
+    color_scaling = color_scaling * (1.0 / (1e-5 + 0.27 * color_scaling[:, 0] + 0.67 * color_scaling[:, 1] +
+                                            0.06 * color_scaling[:, 2]))[:, None]
+    return color_scaling
+
+
+class ColorFilter(Filter):
+  """filters.py:247-273 (north_star calls it ColorCurveFilter)."""
+  filter_id = 7
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.curve_steps = cfg.curve_steps
+    assert cfg.curve_steps == 8, 'the HIP curve kernels are built for cfg.curve_steps == 8'
+    self.short_name = 'C'
+    self.num_filter_parameters = self.channels * cfg.curve_steps
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    color_curve = features.reshape(-1, self.channels, self.cfg.curve_steps)[:, None, None, :]
+    return tanh_range(*self.cfg.color_curve_range, initial=1)(color_curve)
+
+
+ColorCurveFilter = ColorFilter
+
+
+class ToneFilter(Filter):
+  """filters.py:298-322."""
+  filter_id = 4
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.curve_steps = cfg.curve_steps
+    assert cfg.curve_steps == 8, 'the HIP curve kernels are built for cfg.curve_steps == 8'
+    self.short_name = 'T'
+    self.num_filter_parameters = cfg.curve_steps
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    tone_curve = features.reshape(-1, 1, self.cfg.curve_steps)[:, None, None, :]
+    return tanh_range(*self.cfg.tone_curve_range)(tone_curve)
+
+
+class ContrastFilter(Filter):
+  """filters.py:404-419."""
+  filter_id = 5
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.short_name = 'Ct'
+    self.num_filter_parameters = 1
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    return torch.tanh(features)
+
+
+class WNBFilter(Filter):
+  """filters.py:428-440."""
+  filter_id = 6
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.short_name = 'BW'
+    self.num_filter_parameters = 1
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    return torch.sigmoid(features)
+
+
+class SaturationPlusFilter(Filter):
+  """filters.py:474-498."""
+  filter_id = 3
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.short_name = 'S+'
+    self.num_filter_parameters = 1
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    return torch.sigmoid(features)
+
+
+ALL_FILTERS = (ExposureFilter, GammaFilter, ImprovedWhiteBalanceFilter, SaturationPlusFilter, ToneFilter,
+               ContrastFilter, WNBFilter, ColorFilter)
+
+
+class _DispatchFunction(torch.autograd.Function):
+  """Per-image filter choice + fused over-exposure penalty (expo_filter_dispatch_fwd/bwd)."""
+
+  @staticmethod
+  def forward(ctx, img, params24, filter_ids, hsv_grad_mode):
+    img = img.contiguous()
+    params24 = params24.contiguous().float()
+    filter_ids = filter_ids.contiguous().to(torch.int32)
+    y = torch.empty_like(img)
+    penalty = torch.empty((img.shape[0],), dtype=torch.float32, device=img.device)
+    _cabi.dispatch_fwd(filter_ids, img, y, params24, penalty)
+    ctx.save_for_backward(img, params24, filter_ids)
+    ctx.hsv_grad_mode = hsv_grad_mode
+    return y, penalty
+
+  @staticmethod
+  def backward(ctx, dy, dpenalty):
+    img, params24, filter_ids = ctx.saved_tensors
+    dy = dy.contiguous().to(img.dtype)
+    dpenalty = dpenalty.contiguous().float()
+    dx = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+    dparams = torch.empty_like(params24)
+    _cabi.dispatch_bwd(filter_ids, img, dy, dx, params24, dparams, dpenalty, ctx.hsv_grad_mode)
+    return dx, dparams, None, None
+
+
+def dispatch_filters(img, params24, filter_ids, hsv_grad_mode=0):
+  """One launch pair instead of "run all 8 filters, stack, one-hot, reduce_sum" (agent.py:58-77,
+  119-125).  params24: (N, 24) float32, row n = packed params of filter ``filter_ids[n]`` in its
+  first P slots.  Returns (y, overexposure_penalty[N]) -- the latter is agent.py:249-251's
+  ``reduce_mean(maximum(net - 1, 0)**2, axis=(1,2,3))``."""
+  return _DispatchFunction.apply(img, params24, filter_ids, hsv_grad_mode)

@@ -1,0 +1,77 @@
+"""Host-side helpers mirrored from the reference's ``util.py`` (torch, any device).
+
+These are the tiny scalar / activation helpers the regressors and the convnets use
+(``/root/reference/util.py:13-16, 31-36, 40-72, 225-229, 271-294, 307-308``); the per-pixel
+image maths itself lives in the HIP library, not here.
+"""
+import math
+
+import torch
+
+# util.py:13-16
+STATE_REWARD_DIM = 0
+STATE_STOPPED_DIM = 1
+STATE_STEP_DIM = 2
+STATE_DROPOUT_BEGIN = 3
+
+
+class Dict(dict):
+  """Attribute-style dict used for ``cfg`` (util.py:40-72)."""
+
+  def __getattr__(self, key):
+    try:
+      return self[key]
+    except KeyError as e:
+      raise AttributeError(key) from e
+
+  def __setattr__(self, key, value):
+    self[key] = value
+
+  def __delattr__(self, key):
+    del self[key]
+
+
+def lrelu(x, leak=0.2):
+  """util.py:225-229 -- written as f1*x + f2*|x| so it stays twice differentiable a.e.
+  (needed by the WGAN-GP double backward through the critic)."""
+  f1 = 0.5 * (1 + leak)
+  f2 = 0.5 * (1 - leak)
+  return f1 * x + f2 * torch.abs(x)
+
+
+def rgb2lum(image):
+  """util.py:271-274 (NHWC)."""
+  lum = 0.27 * image[:, :, :, 0] + 0.67 * image[:, :, :, 1] + 0.06 * image[:, :, :, 2]
+  return lum[:, :, :, None]
+
+
+def tanh01(x):
+  """util.py:277-278."""
+  return torch.tanh(x) * 0.5 + 0.5
+
+
+def tanh_range(l, r, initial=None):
+  """util.py:281-294."""
+
+  def activation(x):
+    if initial is not None:
+      bias = math.atanh(2 * (initial - l) / (r - l) - 1)
+    else:
+      bias = 0
+    return tanh01(x + bias) * (r - l) + l
+
+  return activation
+
+
+def lerp(a, b, l):
+  """util.py:307-308."""
+  return (1 - l) * a + l * b
+
+
+def enrich_image_input(cfg, net, states):
+  """util.py:31-36: broadcast the state vector to H x W planes and append as channels (NHWC)."""
+  if cfg.img_include_states:
+    n, h, w, _ = net.shape
+    planes = states[:, None, None, :].to(net.dtype).expand(n, h, w, states.shape[1])
+    net = torch.cat([net, planes], dim=3)
+  return net

@@ -1,0 +1,169 @@
+/*
+ * exposure_hip.h -- C-ABI of libexposure_hip.so: the MI355X (gfx950) implementation
+ * of Exposure's differentiable per-pixel filter stack.
+ *
+ * The reference (yuanming-hu/exposure, TF-1 Python) has NO FFI for this path: the
+ * filters are Python classes composed of TF elementwise ops.  This header is the
+ * boundary a native replacement of that path binds; each entry point cites the
+ * reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - Images are contiguous NHWC, C = 3, dtype EXPO_F16 (default) or EXPO_F32.
+ *   - Every pointer is a caller-owned DEVICE pointer that must stay valid until the
+ *     work enqueued on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream) has completed.  No allocation, no ownership transfer, no host sync.
+ *   - Stateless and re-entrant; ordering only through `stream`.
+ *   - Filter ids follow cfg.filters (config_example.py:22-25):
+ *       0 E  ExposureFilter              P = 1   params[n][0] = EV stops
+ *       1 G  GammaFilter                 P = 1   gamma
+ *       2 W  ImprovedWhiteBalanceFilter  P = 3   per-channel scale
+ *       3 S+ SaturationPlusFilter        P = 1   blend in [0,1]
+ *       4 T  ToneFilter                  P = 8   curve slopes k_0..k_7
+ *       5 Ct ContrastFilter              P = 1   blend in [-1,1]
+ *       6 BW WNBFilter                   P = 1   blend in [0,1]
+ *       7 C  ColorFilter                 P = 24  k[channel*8 + knot]
+ *     `params` are the outputs of Filter.filter_param_regressor (filters.py:177-179,
+ *     201-203, 224-235, 481-482, 306-310, 411-413, 435-436, 256-262) flattened to
+ *     float32 [N][P].
+ *   - All functions return EXPO_OK (0) or a negative EXPO_E_* code; the message of
+ *     the last failure on the calling thread is available from expo_last_error().
+ */
+#ifndef EXPOSURE_HIP_H_
+#define EXPOSURE_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXPO_ABI_VERSION 1
+
+#define EXPO_OK 0
+#define EXPO_E_BADARG (-1)
+#define EXPO_E_BADDTYPE (-2)
+#define EXPO_E_HIP (-3)
+
+#define EXPO_F16 0
+#define EXPO_F32 1
+
+#define EXPO_NUM_FILTERS 8
+#define EXPO_MAX_PARAMS 24
+
+#define EXPO_FILTER_EXPOSURE 0
+#define EXPO_FILTER_GAMMA 1
+#define EXPO_FILTER_WB 2
+#define EXPO_FILTER_SATPLUS 3
+#define EXPO_FILTER_TONE 4
+#define EXPO_FILTER_CONTRAST 5
+#define EXPO_FILTER_WNB 6
+#define EXPO_FILTER_COLOR 7
+
+/* hsv_grad_mode for SaturationPlus backward: 0 = TF-1.x faithful (RGBToHSV / HSVToRGB
+ * are registered NotDifferentiable, so no gradient flows through full_color);
+ * 1 = analytic gradient through the HSV round trip. */
+#define EXPO_HSV_GRAD_TF1 0
+#define EXPO_HSV_GRAD_ANALYTIC 1
+
+/* Library / ABI version (EXPO_ABI_VERSION of the built library). */
+int expo_version(void);
+
+/* Message of the last error raised on the calling thread ("" if none). */
+const char* expo_last_error(void);
+
+/* Replaces Filter.get_num_filter_parameters() (filters.py:24-26); -1 on bad id. */
+int expo_num_filter_params(int filter_id);
+
+/*
+ * y = <Filter>.process(x, params)      replaces filters.py:181-182 (E), 205-206 (G),
+ * 237-238 (W), 484-498 (S+), 312-322 (T), 415-419 (Ct), 438-440 (BW), 264-273 (C).
+ * With cfg.masking = False (config_example.py:36) this is also Filter.apply's
+ * lerp(img, process(img, p), ones) (filters.py:88, 111-113).
+ * x, y: [N][H][W][3] of dtype; y may alias x.  params: float32 [N][P].
+ * Any H, W >= 1 (the same parameters may be applied to the 64x64 proxy and to the
+ * full-resolution image: filters.py:89-96).
+ */
+int expo_filter_fwd(int filter_id, const void* x, void* y, const float* params,
+                    int n, int h, int w, int dtype, void* stream);
+
+/*
+ * Backward of expo_filter_fwd: what tf.gradients produces for process() in the
+ * reference graph (net.py:222-251 via ly.optimize_loss).
+ *   dx      [N][H][W][3] dtype, may be NULL (parameter gradient only), may alias dy.
+ *   dparams float32 [N][P], OVERWRITTEN with sum_{h,w,c} dy * d y/d param.
+ * y is recomputed from x (never read).
+ */
+int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx,
+                    const float* params, float* dparams, int n, int h, int w,
+                    int dtype, int hsv_grad_mode, void* stream);
+
+/*
+ * Per-image filter choice == the reference's "compute all 8 filters, stack, multiply
+ * by one_hot(selected_filter_id), reduce_sum" (agent.py:58-77, 119-125) without the
+ * 7 discarded outputs.  filter_ids: int32 [N] in [-1, 7]; -1 (pdf_sample with noise
+ * 0, pdf_sample_layer.py:5-10) selects nothing: y = 0, all gradients 0.
+ * params / dparams: float32 [N][EXPO_MAX_PARAMS]; row n holds the P values of filter
+ * filter_ids[n] in its first P slots (remaining slots ignored / written as 0).
+ * penalty (nullable): float32 [N], overwritten with mean_{h,w,c} max(y - 1, 0)^2,
+ * the over-exposure term of agent.py:249-251, fused into the same pass.
+ */
+int expo_filter_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y,
+                             const float* params, float* penalty, int n, int h, int w,
+                             int dtype, void* stream);
+
+/*
+ * Backward of expo_filter_dispatch_fwd.  dpenalty (nullable): float32 [N], upstream
+ * gradient of the fused penalty; its contribution 2*max(y-1,0)/(H*W*3)*dpenalty[n]
+ * is added to dy before back-propagating through the selected filter.
+ */
+int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const void* dy,
+                             void* dx, const float* params, float* dparams,
+                             const float* dpenalty, int n, int h, int w, int dtype,
+                             int hsv_grad_mode, void* stream);
+
+/*
+ * The benchmark construct of SURVEY.md section 8(d): `steps` filters applied
+ * sequentially, one kernel per step, enqueued by a single call.
+ *   filter_ids  host int [steps]
+ *   acts        host array of steps+1 device image pointers: acts[0] = input,
+ *               acts[i+1] = output of step i (kept: the backward reads them)
+ *   params      host array of `steps` device pointers, float32 [N][P_i]
+ */
+int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts,
+                   const float* const* params, int n, int h, int w, int dtype,
+                   void* stream);
+
+/*
+ * Backward of expo_chain_fwd.
+ *   grads    host array of steps+1 device image pointers: grads[steps] = upstream
+ *            dy (read), grads[i] = gradient w.r.t. acts[i] (written).  Entries may
+ *            ping-pong between two buffers as long as grads[i] != grads[i+1] is not
+ *            required (dx may alias dy).
+ *   dparams  host array of `steps` device pointers, float32 [N][P_i], overwritten.
+ */
+int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts,
+                   void* const* grads, const float* const* params,
+                   float* const* dparams, int n, int h, int w, int dtype,
+                   int hsv_grad_mode, void* stream);
+
+/*
+ * Per-image statistics the critic appends as constant feature planes
+ * (critics.py:48-62): stats[n] = { mean(lum), variance(lum), mean(sat) } with
+ * lum = .27R + .67G + .06B + 1e-5 and
+ * sat = (max - min) / (min(max + min, 2 - max - min) + 1e-2) on the [0,1]-clipped image.
+ * stats: float32 [N][3], overwritten.
+ */
+int expo_critic_stats(const void* x, float* stats, int n, int h, int w, int dtype,
+                      void* stream);
+
+/*
+ * mean_{h,w,c} max(y - 1, 0)^2 per image (agent.py:249-251). penalty: float32 [N].
+ */
+int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w,
+                              int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXPOSURE_HIP_H_ */

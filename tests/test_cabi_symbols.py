@@ -1,0 +1,69 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/exposure_hip.h declares;
+argument validation (no compute without a GPU); product path refuses CPU tensors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from exposure_amd import _cabi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+  txt = open(os.path.join(ROOT, 'include', 'exposure_hip.h')).read()
+  txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+  return sorted(set(re.findall(r'\b(expo_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_header_and_binding_agree():
+  assert header_symbols() == sorted(_cabi.SIGNATURES)
+
+
+def test_library_exports_every_symbol():
+  lib = ctypes.CDLL(_cabi.LIB_PATH)
+  for name in header_symbols():
+    assert hasattr(lib, name), name
+
+
+def test_version_and_param_counts():
+  lib = _cabi.load()
+  assert lib.expo_version() == _cabi.EXPO_ABI_VERSION
+  assert [lib.expo_num_filter_params(i) for i in range(8)] == list(_cabi.NUM_PARAMS)
+  assert lib.expo_num_filter_params(-1) == -1 and lib.expo_num_filter_params(8) == -1
+
+
+def test_argument_validation_without_gpu():
+  lib = _cabi.load()
+  assert lib.expo_filter_fwd(9, None, None, None, 1, 1, 1, 0, None) == -1
+  assert b'filter_id' in lib.expo_last_error()
+  assert lib.expo_filter_fwd(0, None, None, None, 1, 1, 1, 7, None) == -2
+  assert lib.expo_filter_fwd(0, None, None, None, 1, 0, 1, 0, None) == -1
+  assert lib.expo_filter_fwd(0, None, None, None, 1, 1, 1, 0, None) == -1  # null pointers
+  assert lib.expo_filter_fwd(0, None, None, None, 0, 1, 1, 0, None) == 0  # empty batch is a no-op
+  assert lib.expo_filter_bwd(0, None, None, None, None, None, 1, 1, 1, 0, 5, None) == -1  # bad hsv mode
+  assert lib.expo_critic_stats(None, None, 0, 4, 4, 0, None) == 0
+  assert lib.expo_chain_fwd(None, 1, None, None, 1, 1, 1, 0, None) == -1
+
+
+def test_product_path_refuses_cpu_tensors():
+  from exposure_amd import filters
+  from exposure_amd.config import make_cfg
+  cfg = make_cfg()
+  f = filters.ExposureFilter((1, 4, 4, 3), cfg)
+  img = torch.rand(2, 4, 4, 3)
+  with pytest.raises(_cabi.ExposureHipError, match='no CPU fallback'):
+    f.process(img, torch.zeros(2, 1))
+  with pytest.raises(_cabi.ExposureHipError):
+    f.apply(img, specified_parameter=torch.zeros(2, 1))
+
+
+def test_no_oracle_import_in_product():
+  pkg = os.path.join(ROOT, 'exposure_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for fn in files:
+      if fn.endswith(('.py', '.hip', '.h')):
+        src = open(os.path.join(dirpath, fn)).read()
+        assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), fn

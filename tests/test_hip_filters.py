@@ -1,0 +1,251 @@
+"""GPU parity: every HIP filter kernel (through the C-ABI) vs the float64 oracle on the same
+fp16/fp32-quantised inputs; edge cases; size-independent properties at full size."""
+import numpy as np
+import pytest
+import torch
+
+from exposure_amd import _cabi, filters, synthetic
+from exposure_amd.config import make_cfg
+from oracle import filters_np as fnp
+from tests._tol import assert_image_close, assert_param_grad_close
+
+pytestmark = pytest.mark.gpu
+
+NP_DT = {torch.float16: np.float16, torch.float32: np.float32}
+
+
+def run_fwd_bwd(fid, x, dy, p, dtype, dev, mode=0, need_dx=True):
+  tx = torch.from_numpy(x).to(dev).to(dtype)
+  tdy = torch.from_numpy(dy).to(dev).to(dtype)
+  tp = torch.from_numpy(p).to(dev)
+  y = torch.empty_like(tx)
+  _cabi.filter_fwd(fid, tx, y, tp)
+  dx = torch.empty_like(tx) if need_dx else None
+  dp = torch.full_like(tp, 7.0)  # must be overwritten
+  _cabi.filter_bwd(fid, tx, tdy, dx, tp, dp, mode)
+  torch.cuda.synchronize()
+  return (y.float().cpu().numpy(), dx.float().cpu().numpy() if need_dx else None, dp.cpu().numpy())
+
+
+def oracle(fid, x, dy, p, mode=0):
+  x64, dy64, p64 = x.astype(np.float64), dy.astype(np.float64), p.astype(np.float64)
+  y = fnp.process_packed(fid, x64, p64)
+  dx, dp = fnp.backward_packed(fid, x64, p64, dy64, hsv_grad_mode=mode)
+  return y, dx, dp
+
+
+def grad_scale(fid, x, dy, p):
+  """sum over pixels of |dy| * O(1) sensitivity: bound for accumulated fp32 rounding."""
+  n = x.shape[0]
+  s = np.abs(dy.astype(np.float64)).reshape(n, -1).sum(axis=1, keepdims=True)
+  return np.broadcast_to(s, p.shape) * (4.0 if fid in (0, 1) else 1.0)
+
+
+@pytest.mark.parametrize('fid', range(8))
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [(4, 64, 64, 3), (3, 16, 24, 3)])
+def test_filter_matches_oracle(fid, dtype, shape, gpu_device):
+  x, dy, params = synthetic.make_case(1000 + fid, shape, NP_DT[dtype])
+  p = params[fid]
+  y, dx, dp = run_fwd_bwd(fid, x, dy, p, dtype, gpu_device)
+  ry, rdx, rdp = oracle(fid, x, dy, p)
+  assert_image_close(y, ry, NP_DT[dtype], 'y fid %d' % fid)
+  assert_image_close(dx, rdx, NP_DT[dtype], 'dx fid %d' % fid)
+  assert_param_grad_close(dp, rdp, grad_scale(fid, x, dy, p), 'dparams fid %d' % fid)
+
+
+@pytest.mark.parametrize('fid', range(8))
+@pytest.mark.parametrize('shape', [(2, 5, 7, 3), (1, 1, 1, 3), (3, 1, 9, 3), (2, 33, 3, 3)])
+def test_ragged_shapes_take_elementwise_path(fid, shape, gpu_device):
+  x, dy, params = synthetic.make_case(2000 + fid, shape, np.float16)
+  y, dx, dp = run_fwd_bwd(fid, x, dy, params[fid], torch.float16, gpu_device)
+  ry, rdx, rdp = oracle(fid, x, dy, params[fid])
+  assert_image_close(y, ry, np.float16, 'y')
+  assert_image_close(dx, rdx, np.float16, 'dx')
+  assert_param_grad_close(dp, rdp, grad_scale(fid, x, dy, params[fid]), 'dp')
+
+
+def test_unaligned_base_pointer(gpu_device):
+  # a view whose data_ptr is 2-byte aligned only -> must fall back to the element path
+  x, dy, params = synthetic.make_case(31, (2, 8, 8, 3), np.float16)
+  big = torch.zeros(2 * 8 * 8 * 3 + 1, dtype=torch.float16, device=gpu_device)
+  tx = big[1:].view(2, 8, 8, 3)
+  tx.copy_(torch.from_numpy(x))
+  y = torch.empty_like(torch.from_numpy(x)).to(gpu_device)
+  tp = torch.from_numpy(params[4]).to(gpu_device)
+  _cabi.filter_fwd(4, tx, y, tp)
+  ry, _, _ = oracle(4, x, dy, params[4])
+  assert_image_close(y.float().cpu().numpy(), ry, np.float16)
+
+
+@pytest.mark.parametrize('fid', range(8))
+def test_dx_optional_and_in_place(fid, gpu_device):
+  x, dy, params = synthetic.make_case(3000 + fid, (2, 16, 16, 3), np.float16)
+  _, _, dp_ref = run_fwd_bwd(fid, x, dy, params[fid], torch.float16, gpu_device)
+  _, none_dx, dp = run_fwd_bwd(fid, x, dy, params[fid], torch.float16, gpu_device, need_dx=False)
+  assert none_dx is None
+  np.testing.assert_allclose(dp, dp_ref, rtol=1e-5, atol=1e-5)
+  # y may alias x, dx may alias dy
+  tx = torch.from_numpy(x).to(gpu_device)
+  tdy = torch.from_numpy(dy).to(gpu_device)
+  tp = torch.from_numpy(params[fid]).to(gpu_device)
+  y = torch.empty_like(tx)
+  _cabi.filter_fwd(fid, tx, y, tp)
+  dx = torch.empty_like(tx)
+  dpp = torch.empty_like(tp)
+  _cabi.filter_bwd(fid, tx, tdy, dx, tp, dpp)
+  _cabi.filter_bwd(fid, tx, tdy, tdy, tp, dpp)
+  assert torch.equal(tdy, dx)
+  _cabi.filter_fwd(fid, tx, tx, tp)
+  assert torch.equal(tx, y)
+
+
+def test_known_answers_on_device(gpu_device):
+  dev = gpu_device
+  x = torch.full((1, 8, 8, 3), 0.25, dtype=torch.float32, device=dev)
+  y = torch.empty_like(x)
+  one = torch.ones((1, 1), device=dev)
+  _cabi.filter_fwd(0, x, y, one)
+  assert torch.allclose(y, torch.full_like(y, 0.5), atol=1e-6)
+  _cabi.filter_fwd(1, x, y, one * 0.5)
+  assert torch.allclose(y, torch.full_like(y, 0.5), atol=1e-6)
+  k = torch.tensor([[2.0, 1, 1, 1, 1, 1, 1, 1]], device=dev)
+  _cabi.filter_fwd(4, x * 0.5, y, k)
+  assert torch.allclose(y, torch.full_like(y, 8 / 9 * 0.25), atol=1e-6)
+  _cabi.filter_fwd(6, x, y, one * 0)  # WNB p = 0 -> identity
+  assert torch.equal(y, x)
+  _cabi.filter_fwd(5, x, y, one * 0)  # contrast p = 0 -> identity
+  assert torch.allclose(y, x, atol=1e-7)
+  grey = torch.full((1, 8, 8, 3), 0.5, dtype=torch.float32, device=dev)
+  _cabi.filter_fwd(3, grey, y, one)  # S+ p = 1 on grey: TF hue 0 -> (v, v(1-s'), v(1-s')), s' = .4
+  exp = torch.tensor([0.5, 0.3, 0.3], device=dev).expand_as(y)
+  assert torch.allclose(y, exp, atol=1e-6)
+
+
+def test_gradient_ties_follow_tf(gpu_device):
+  dev = gpu_device
+  # tone: x exactly on knots -> both neighbouring segments contribute (inclusive clip gradient)
+  k = torch.arange(1, 9, dtype=torch.float32, device=dev).reshape(1, 8)
+  vals = [0.25, 0.0, 1.0, 0.125, 0.875, 1.5, -0.5, 0.3]
+  x = torch.tensor(vals, dtype=torch.float32, device=dev).repeat_interleave(3).reshape(1, 1, 8, 3).contiguous()
+  dy = torch.ones_like(x)
+  dx = torch.empty_like(x)
+  dk = torch.empty_like(k)
+  _cabi.filter_bwd(4, x, dy, dx, k, dk)
+  rdx, rdk = fnp.backward_packed(4, x.cpu().numpy().astype(np.float64), k.cpu().numpy().astype(np.float64),
+                                 dy.cpu().numpy().astype(np.float64))
+  np.testing.assert_allclose(dx.cpu().numpy(), rdx, rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(dk.cpu().numpy(), rdk, rtol=1e-4, atol=1e-5)
+  # gamma: x == 0.001 passes, below blocks; S+: x == 1 passes, above blocks
+  x = torch.tensor([0.001, 0.0005, 0.5] * 8, dtype=torch.float32, device=dev).reshape(1, 1, 8, 3).contiguous()
+  g = torch.full((1, 1), 2.0, device=dev)
+  _cabi.filter_bwd(1, x, torch.ones_like(x), dx, g, torch.empty_like(g))
+  rdx, _ = fnp.backward_packed(1, x.cpu().numpy().astype(np.float64), np.array([[2.0]]), np.ones((1, 1, 8, 3)))
+  np.testing.assert_allclose(dx.cpu().numpy(), rdx, rtol=1e-5, atol=1e-9)
+  x = torch.tensor([1.0, 1.5, 0.2] * 8, dtype=torch.float32, device=dev).reshape(1, 1, 8, 3).contiguous()
+  p = torch.full((1, 1), 0.25, device=dev)
+  _cabi.filter_bwd(3, x, torch.ones_like(x), dx, p, torch.empty_like(p))
+  np.testing.assert_allclose(dx.cpu().numpy()[0, 0, 0], [0.75, 0.0, 0.75], rtol=1e-6)
+
+
+def test_satplus_analytic_mode(gpu_device):
+  x, dy, params = synthetic.make_case(77, (2, 32, 32, 3), np.float32)
+  y, dx, dp = run_fwd_bwd(3, x, dy, params[3], torch.float32, gpu_device, mode=1)
+  ry, rdx, rdp = oracle(3, x, dy, params[3], mode=1)
+  # the analytic HSV gradient has 1/rng and 1/v factors: compare with a relative bound
+  err = np.abs(dx - rdx)
+  assert (err <= 1e-3 + 1e-3 * np.abs(rdx)).all(), err.max()
+  assert_param_grad_close(dp, rdp, grad_scale(3, x, dy, params[3]))
+
+
+def test_autograd_function_matches_oracle(gpu_device):
+  cfg = make_cfg()
+  x, dy, params = synthetic.make_case(55, (2, 16, 16, 3), np.float32)
+  for fid, cls in enumerate(cfg.filters):
+    f = cls((2, 16, 16, 3), cfg).to(gpu_device)
+    assert f.filter_id == fid
+    tx = torch.from_numpy(x).to(gpu_device).requires_grad_(True)
+    ref_shaped = torch.from_numpy(fnp.unpack_params(fid, params[fid])).to(gpu_device).requires_grad_(True)
+    low, high, info = f.apply(tx, specified_parameter=ref_shaped)
+    assert high is None and 'filter_parameters' in info and 'mask' in info
+    low.backward(torch.from_numpy(dy).to(gpu_device))
+    ry, rdx, rdp = oracle(fid, x, dy, params[fid])
+    assert_image_close(low.detach().cpu().numpy(), ry, np.float32)
+    assert_image_close(tx.grad.cpu().numpy(), rdx, np.float32)
+    assert_param_grad_close(ref_shaped.grad.reshape(2, -1).cpu().numpy(), rdp, grad_scale(fid, x, dy, params[fid]))
+
+
+def test_high_res_uses_same_parameters(gpu_device):
+  cfg = make_cfg()
+  f = filters.ToneFilter((1, 64, 64, 3), cfg).to(gpu_device)
+  lo, _, p = synthetic.make_case(8, (2, 64, 64, 3), np.float16)
+  hi, _, _ = synthetic.make_case(9, (2, 96, 128, 3), np.float16)
+  feats = torch.randn(2, cfg.feature_extractor_dims, device=gpu_device)
+  low, high, info = f.apply(torch.from_numpy(lo).to(gpu_device), img_features=feats,
+                            high_res=torch.from_numpy(hi).to(gpu_device))
+  prm = f.filter_param_regressor(f.extract_parameters(feats)[0]).detach()
+  assert prm.shape == (2, 1, 1, 1, 8)
+  packed = prm.reshape(2, 8).cpu().numpy()
+  assert_image_close(low.float().cpu().numpy(), fnp.process_packed(4, lo.astype(np.float64), packed), np.float16)
+  assert_image_close(high.float().cpu().numpy(), fnp.process_packed(4, hi.astype(np.float64), packed), np.float16)
+
+
+def test_chain_matches_stepwise_oracle(gpu_device):
+  """Config 2 of BASELINE.json: full 8-filter chain fwd+bwd at 64x64x64x3 fp16, per-step check
+  (each step's oracle input is the previous fp16 GPU output, so the bound stays per-pixel)."""
+  shape = synthetic.SHAPES['A']
+  x, dy, params = synthetic.make_case(1234, shape, np.float16)
+  dev = gpu_device
+  acts = [torch.from_numpy(x).to(dev)] + [torch.empty(shape, dtype=torch.float16, device=dev) for _ in range(8)]
+  prm = [torch.from_numpy(p).to(dev) for p in params]
+  _cabi.chain_fwd(list(range(8)), acts, prm)
+  grads = [torch.empty(shape, dtype=torch.float16, device=dev) for _ in range(8)] + [torch.from_numpy(dy).to(dev)]
+  dprm = [torch.empty_like(p) for p in prm]
+  _cabi.chain_bwd(list(range(8)), acts, grads, prm, dprm)
+  torch.cuda.synchronize()
+  for i in range(8):
+    xin = acts[i].cpu().numpy()
+    gin = grads[i + 1].cpu().numpy()
+    ry, rdx, rdp = oracle(i, xin, gin, params[i])
+    assert_image_close(acts[i + 1].float().cpu().numpy(), ry, np.float16, 'chain y step %d' % i)
+    assert_image_close(grads[i].float().cpu().numpy(), rdx, np.float16, 'chain dx step %d' % i)
+    assert_param_grad_close(dprm[i].cpu().numpy(), rdp, grad_scale(i, xin, gin, params[i]), 'chain dp step %d' % i)
+
+
+def test_full_size_properties(gpu_device):
+  """BASELINE config 5 size (16x512x512x3 fp16): size-independent properties instead of a full
+  oracle run -- identities, linearity of the backward in dy, determinism of y."""
+  shape = synthetic.SHAPES['B']
+  dev = gpu_device
+  g = torch.Generator(device=dev).manual_seed(5)
+  x = (torch.rand(shape, device=dev, generator=g)**2.2 * 1.02).half()
+  dy = torch.randn(shape, device=dev, generator=g).half()
+  n = shape[0]
+  y = torch.empty_like(x)
+  # identities
+  _cabi.filter_fwd(0, x, y, torch.zeros(n, 1, device=dev))
+  assert torch.equal(y, x)
+  _cabi.filter_fwd(6, x, y, torch.zeros(n, 1, device=dev))
+  assert torch.equal(y, x)
+  _cabi.filter_fwd(4, x, y, torch.full((n, 8), 1.3, device=dev))
+  assert (y.float() - x.float().clamp(0, 1)).abs().max() <= 2.0**-11
+  _cabi.filter_fwd(7, x, y, torch.full((n, 24), 0.97, device=dev))
+  assert (y.float() - x.float().clamp(0, 1)).abs().max() <= 2.0**-11
+  _cabi.filter_fwd(3, x, y, torch.zeros(n, 1, device=dev))
+  assert torch.equal(y, x.clamp(max=1.0))
+  # backward is linear in dy: bwd(2 dy) == 2 bwd(dy) exactly (power-of-two scaling)
+  for fid in range(8):
+    p = torch.from_numpy(synthetic.make_params(np.random.default_rng(fid), fid, n)).to(dev)
+    dx1, dx2 = torch.empty_like(x), torch.empty_like(x)
+    dp1, dp2 = torch.empty_like(p), torch.empty_like(p)
+    _cabi.filter_bwd(fid, x, dy, dx1, p, dp1)
+    _cabi.filter_bwd(fid, x, dy * 2, dx2, p, dp2)
+    assert torch.equal(dx1 * 2, dx2), fid
+    scale = dp1.abs().max().item() + 1.0
+    assert (dp2 - 2 * dp1).abs().max().item() <= 2e-3 * scale, fid  # atomics reorder fp32 sums
+    # sampled oracle check on one image row
+    xi = x[:1, :4].cpu().numpy()
+    yi = torch.empty_like(x[:1, :4])
+    _cabi.filter_fwd(fid, x[:1, :4].contiguous(), yi, p[:1].contiguous())
+    assert_image_close(yi.float().cpu().numpy(), fnp.process_packed(fid, xi.astype(np.float64), p[:1].cpu().numpy()),
+                       np.float16)
