@@ -104,24 +104,30 @@ def time_kernels(chain, reps):
 
 
 def cpu_baseline():
-  """torch-CPU fp32 op-by-op restatement (oracle/filters_torch.py), all host threads, on a bounded
-  sample: BASELINE shape B (16x512x512x3), best of 3 after 1 warm-up."""
+  """torch-CPU fp32 op-by-op restatement (oracle/filters_torch.py) timed on the host cores on a
+  bounded sample (4x512x512x3 = 1 Mpixel per pass).  torch's intra-op pool does not scale to every
+  core of a big host for this op mix, so a few thread counts are tried (1 warm-up + best of 2 each)
+  and the best is reported together with the thread count that produced it."""
   from oracle import filters_torch as ft
-  cores = os.cpu_count() or 1
-  torch.set_num_threads(cores)
-  shape = synthetic.SHAPES['B']
+  ncpu = os.cpu_count() or 1
+  shape = (4, 512, 512, 3)
   x, dy, params = synthetic.make_case(1234, shape, np.float16)
   tx = torch.from_numpy(x.astype(np.float32))
   tdy = torch.from_numpy(dy.astype(np.float32))
   tp = [torch.from_numpy(p) for p in params]
-  best = float('inf')
-  for it in range(4):
-    t0 = time.perf_counter()
-    ft.chain_fwd_bwd(tx, tp, tdy)
-    dt = time.perf_counter() - t0
-    if it > 0:
-      best = min(best, dt)
   px = shape[0] * shape[1] * shape[2]
+  best, best_threads = float('inf'), 1
+  t_start = time.perf_counter()
+  for threads in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)}):
+    torch.set_num_threads(threads)
+    for it in range(3):
+      t0 = time.perf_counter()
+      ft.chain_fwd_bwd(tx, tp, tdy)
+      dt = time.perf_counter() - t0
+      if it > 0 and dt < best:
+        best, best_threads = dt, threads
+    if time.perf_counter() - t_start > 25.0:
+      break
   model = ''
   try:
     for line in open('/proc/cpuinfo'):
@@ -133,10 +139,11 @@ def cpu_baseline():
   return {
       'value': px / best / 1e6,
       'unit': 'Mpixels/s',
-      'cores': cores,
+      'cores': best_threads,
       'kind': 'port',
-      'sample': 'CPU restatement (torch fp32, %d threads, %s): 8-step chain fwd+bwd on 16x512x512x3, best of 3' %
-                (cores, model or 'unknown CPU'),
+      'sample': 'CPU restatement (torch fp32 op-by-op, best of {8,16,32,64} threads = %d, host %s with %d '
+                'logical CPUs): 8-step chain fwd+bwd on 4x512x512x3, best of 2 after 1 warm-up' %
+                (best_threads, model or 'unknown CPU', ncpu),
   }
 
 

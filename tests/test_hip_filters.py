@@ -186,8 +186,8 @@ def test_high_res_uses_same_parameters(gpu_device):
   prm = f.filter_param_regressor(f.extract_parameters(feats)[0]).detach()
   assert prm.shape == (2, 1, 1, 1, 8)
   packed = prm.reshape(2, 8).cpu().numpy()
-  assert_image_close(low.float().cpu().numpy(), fnp.process_packed(4, lo.astype(np.float64), packed), np.float16)
-  assert_image_close(high.float().cpu().numpy(), fnp.process_packed(4, hi.astype(np.float64), packed), np.float16)
+  assert_image_close(low.detach().float().cpu().numpy(), fnp.process_packed(4, lo.astype(np.float64), packed), np.float16)
+  assert_image_close(high.detach().float().cpu().numpy(), fnp.process_packed(4, hi.astype(np.float64), packed), np.float16)
 
 
 def test_chain_matches_stepwise_oracle(gpu_device):
@@ -233,14 +233,15 @@ def test_full_size_properties(gpu_device):
   assert (y.float() - x.float().clamp(0, 1)).abs().max() <= 2.0**-11
   _cabi.filter_fwd(3, x, y, torch.zeros(n, 1, device=dev))
   assert torch.equal(y, x.clamp(max=1.0))
-  # backward is linear in dy: bwd(2 dy) == 2 bwd(dy) exactly (power-of-two scaling)
+  # backward is linear in dy: bwd(2 dy) == 2 bwd(dy) (power-of-two scaling is exact in fp32; only
+  # results that land in the fp16 subnormal range may round differently, by <= 1 subnormal ulp)
   for fid in range(8):
     p = torch.from_numpy(synthetic.make_params(np.random.default_rng(fid), fid, n)).to(dev)
     dx1, dx2 = torch.empty_like(x), torch.empty_like(x)
     dp1, dp2 = torch.empty_like(p), torch.empty_like(p)
     _cabi.filter_bwd(fid, x, dy, dx1, p, dp1)
     _cabi.filter_bwd(fid, x, dy * 2, dx2, p, dp2)
-    assert torch.equal(dx1 * 2, dx2), fid
+    assert (dx1.float() * 2 - dx2.float()).abs().max().item() <= 2.0**-23, fid
     scale = dp1.abs().max().item() + 1.0
     assert (dp2 - 2 * dp1).abs().max().item() <= 2e-3 * scale, fid  # atomics reorder fp32 sums
     # sampled oracle check on one image row
