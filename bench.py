@@ -69,7 +69,12 @@ class Chain:
     # gradients ping-pong between two buffers; grads[8] = upstream dy
     ga, gb = torch.empty_like(x), torch.empty_like(x)
     self.grads = [ga if (i % 2 == 0) else gb for i in range(8)] + [dy]
-    self.dparams = [torch.empty_like(p) for p in self.params]
+    # per-step parameter gradients carved from one flat buffer -> a single zero-fill per backward
+    flat = torch.empty(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+    self.dparams, off = [], 0
+    for p in self.params:
+      self.dparams.append(flat[off:off + p.numel()].view_as(p))
+      off += p.numel()
 
   def step(self):
     _cabi.chain_fwd(self.ids, self.acts, self.params)

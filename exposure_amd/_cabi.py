@@ -13,7 +13,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libexposure_hip.so')
+# EXPO_HIP_LIB selects an alternative build of the SAME library (kernel-variant A/B runs); it is
+# never a non-HIP implementation.
+LIB_PATH = os.environ.get('EXPO_HIP_LIB') or os.path.join(_HERE, 'libexposure_hip.so')
 
 EXPO_ABI_VERSION = 1
 EXPO_F16, EXPO_F32 = 0, 1

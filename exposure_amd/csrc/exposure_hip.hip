@@ -16,12 +16,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <type_traits>
 
 #include "../../include/exposure_hip.h"
 #include "filter_math.h"
 #include "pixel_io.h"
+
+#ifndef EXPO_CURVE_PREFETCH
+#define EXPO_CURVE_PREFETCH 1
+#endif
 
 namespace expo {
 
@@ -65,13 +70,8 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   const typename F::Prm q = F::load(prm);
   float pen = 0.f;
   const int stride = gridDim.x * kThreads;
-  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
-    float v[PPL * 3];
-    if constexpr (VEC) {
-      unpack<T>(load_raw<NT>(xi, g), v);
-    } else {
-      load_slow<T>(xi, g, hw, v);
-    }
+  // per-group work, shared by the prefetching (VEC) and the element-wise loop
+  auto compute = [&](float* v, int g) {
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       float y[3];
@@ -80,15 +80,22 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
       for (int c = 0; c < 3; ++c) {
         v[3 * k + c] = y[c];
         if constexpr (PEN) {
-          const bool live = VEC || (g * PPL + k < hw);
+          // padding pixels are x = 0, and f(0) <= 1 for every filter, so they add nothing
           const float o = fmaxf(y[c] - 1.0f, 0.0f);
-          if (live) pen = fmaf(o, o, pen);
+          pen = fmaf(o, o, pen);
         }
       }
     }
-    if constexpr (VEC) {
-      store_raw<NT>(yi, g, pack<T>(v));
-    } else {
+  };
+  if constexpr (VEC) {
+    const T* const ins[1] = {xi};
+    stream_groups<T, 1, true, EXPO_PREFETCH != 0>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                  [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3];
+      load_slow<T>(xi, g, hw, v);
+      compute(v, g);
       store_slow<T>(yi, g, hw, v);
     }
   }
@@ -124,17 +131,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
 #pragma unroll
   for (int j = 0; j < F::NACC; ++j) acc[j] = 0.f;
   const int stride = gridDim.x * kThreads;
-  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
-    float v[PPL * 3], d[PPL * 3];
-    if constexpr (VEC) {
-      const RawGroup rx = load_raw<NT>(xi, g);
-      const RawGroup rd = load_raw<NT>(dyi, g);
-      unpack<T>(rx, v);
-      unpack<T>(rd, d);
-    } else {
-      load_slow<T>(xi, g, hw, v);
-      load_slow<T>(dyi, g, hw, d);
-    }
+  auto compute = [&](float* v, float* d, int g) {
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       float dx[3];
@@ -142,28 +139,33 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
         // fused over-exposure penalty: dy += 2 max(y-1,0) * dpen / (H W 3)
         float y[3];
         F::fwd(q, v + 3 * k, y);
-        const bool live = VEC || (g * PPL + k < hw);
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          if (live) d[3 * k + c] = fmaf(fmaxf(y[c] - 1.0f, 0.0f), pen_scale, d[3 * k + c]);
+        for (int c = 0; c < 3; ++c)  // padding pixels: y = f(0) <= 1 -> no contribution
+          d[3 * k + c] = fmaf(fmaxf(y[c] - 1.0f, 0.0f), pen_scale, d[3 * k + c]);
       }
       F::bwd(q, lut, v + 3 * k, d + 3 * k, dx, acc, MODE);
 #pragma unroll
       for (int c = 0; c < 3; ++c) d[3 * k + c] = dx[c];
     }
-    if constexpr (HAS_DX) {
-      if constexpr (VEC) {
-        store_raw<NT>(dxi, g, pack<T>(d));
-      } else {
-        store_slow<T>(dxi, g, hw, d);
-      }
+  };
+  if constexpr (VEC) {
+    const T* const ins[2] = {xi, dyi};
+    stream_groups<T, 2, HAS_DX, (F::kLutFloats > 0 ? EXPO_CURVE_PREFETCH : EXPO_PREFETCH) != 0>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                    [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3], d[PPL * 3];
+      load_slow<T>(xi, g, hw, v);
+      load_slow<T>(dyi, g, hw, d);
+      compute(v, d, g);
+      if constexpr (HAS_DX) store_slow<T>(dxi, g, hw, d);
     }
   }
   block_reduce_atomic<F::NACC, F::NP>(acc, dprm, [=](const float* t, int j) { return F::finish_one(prm, t, j); });
 }
 
 template <class F, typename T, bool VEC, bool NT, bool HAS_DX, int MODE>
-__global__ __launch_bounds__(kThreads) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(kThreads, F::kMinWaves) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                               T* __restrict__ dx,
                                                               const float* __restrict__ params,
                                                               float* __restrict__ dparams, int hw,
@@ -182,9 +184,13 @@ __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int group
 #pragma unroll
   for (int j = 0; j < PPL * 3; ++j) z[j] = 0.f;
   const int stride = gridDim.x * kThreads;
-  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
-    if constexpr (VEC) store_raw<false>(yi, g, pack<T>(z));
-    else store_slow<T>(yi, g, hw, z);
+  if constexpr (VEC) {
+    const RawGroup rz = pack<T>(z);
+    const __amdgpu_buffer_rsrc_t ry = make_image_rsrc(yi, hw);
+    for (int gw = blockIdx.x * kThreads + (threadIdx.x & ~63); gw * PPL < hw; gw += stride)
+      store_raw(ry, chunk_byte_offset<T>(gw, threadIdx.x & 63), rz);
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) store_slow<T>(yi, g, hw, z);
   }
 }
 
@@ -271,13 +277,10 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
   const T* xi = x + size_t(n) * hw * 3;
   float acc[3] = {0.f, 0.f, 0.f};
   const int stride = gridDim.x * kThreads;
-  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
-    float v[PPL * 3];
-    if constexpr (VEC) unpack<T>(load_raw<false>(xi, g), v);
-    else load_slow<T>(xi, g, hw, v);
+  auto compute = [&](const float* v, int g) {
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-      if (VEC || (g * PPL + k < hw)) {
+      if (live_pixel<T, VEC>(g, k, threadIdx.x & 63, hw)) {
         const float* p = v + 3 * k;
         // critics.py:48-49: r*.27 + g*.67 + b*.06 + 1e-5
         const float l = ((p[0] * kLumR + p[1] * kLumG) + p[2] * kLumB + 1e-5f) - 0.5f;
@@ -287,6 +290,17 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
         const float mx = fmaxf(fmaxf(c0, c1), c2), mn = fminf(fminf(c0, c1), c2);
         acc[2] += (mx - mn) / (fminf(mx + mn, 2.0f - mx - mn) + 1e-2f);
       }
+    }
+  };
+  if constexpr (VEC) {
+    const T* const ins[1] = {xi};
+    stream_groups<T, 1, false, true>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                      [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3];
+      load_slow<T>(xi, g, hw, v);
+      compute(v, g);
     }
   }
   block_reduce_atomic<3, 3>(acc, sums + n * 3, [](const float* t, int j) { return t[j]; });
@@ -309,19 +323,37 @@ __global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__
   const T* yi = y + size_t(n) * hw * 3;
   float acc[1] = {0.f};
   const int stride = gridDim.x * kThreads;
-  for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
-    float v[PPL * 3];
-    if constexpr (VEC) unpack<T>(load_raw<false>(yi, g), v);
-    else load_slow<T>(yi, g, hw, v);
+  auto compute = [&](const float* v) {
 #pragma unroll
     for (int j = 0; j < PPL * 3; ++j) {
       const float o = fmaxf(v[j] - 1.0f, 0.0f);  // padding lanes hold 0 -> contribute 0
       acc[0] = fmaf(o, o, acc[0]);
     }
+  };
+  if constexpr (VEC) {
+    const T* const ins[1] = {yi};
+    stream_groups<T, 1, false, true>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                      [&](float (&v)[1][PPL * 3], int) { compute(v[0]); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3];
+      load_slow<T>(yi, g, hw, v);
+      compute(v);
+    }
   }
   block_reduce_atomic<1, 1>(acc, pen + n, [=](const float* t, int) { return t[0] * inv_count; });
 }
 
+#ifdef EXPO_PROBE
+// register-pressure probe builds (tools/probe.sh): instantiate a few kernels, skip the host side
+template __global__ void filter_bwd_kernel<ToneF, half_t, true, false, true, 0>(const half_t*, const half_t*, half_t*,
+                                                                                const float*, float*, int, int);
+template __global__ void filter_bwd_kernel<ColorF, half_t, true, false, true, 0>(const half_t*, const half_t*, half_t*,
+                                                                                 const float*, float*, int, int);
+template __global__ void filter_bwd_kernel<WnbF, half_t, true, false, true, 0>(const half_t*, const half_t*, half_t*,
+                                                                               const float*, float*, int, int);
+}  // namespace expo
+#else
 // ==================================================================== host side
 thread_local std::string g_err;
 
@@ -346,7 +378,12 @@ struct Geom {
   bool vec;
 };
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  const int x = atoi(v);
+  return x > 0 ? x : dflt;
+}
 
 // groups of 48 bytes per image; blocks per image chosen so the whole grid is >= ~1024
 // blocks when the problem allows and each thread walks a few groups (amortises the
@@ -357,10 +394,11 @@ static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
   Geom g;
   g.hw = h * w;
   g.groups = (g.hw + PPL - 1) / PPL;
-  g.vec = (g.hw % PPL) == 0;
-  for (const void* p : ptrs) g.vec = g.vec && (p == nullptr || aligned16(p));
+  g.vec = (g.hw % VecTraits<T>::PPV) == 0;  // dwordx3 path: whole 12-byte vectors, 4-byte aligned
+  for (const void* p : ptrs) g.vec = g.vec && (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 3) == 0);
   const int max_bx = (g.groups + kThreads - 1) / kThreads;
-  int bx = (g.groups + kThreads * 4 - 1) / (kThreads * 4);  // ~4 groups per thread
+  static const int gpt = env_int("EXPO_GROUPS_PER_THREAD", 4);  // groups each thread walks
+  int bx = (g.groups + kThreads * gpt - 1) / (kThreads * gpt);
   const long want = 1024;
   if (long(bx) * n < want) bx = int((want + n - 1) / n);
   if (bx > max_bx) bx = max_bx;
@@ -391,10 +429,10 @@ static int launch_fwd(const void* x, void* y, const float* params, int n, int h,
 
 template <class F, typename T>
 static int launch_bwd(const void* x, const void* dy, void* dx, const float* params, float* dparams, int n,
-                      int h, int w, int mode, hipStream_t s) {
+                      int h, int w, int mode, hipStream_t s, bool zeroed) {
   const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * F::NP, s), "dparams memset");
+  if (!zeroed) HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * F::NP, s), "dparams memset");
 #define EXPO_L(VEC, HAS_DX, MODE)                                                                        \
   hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, false, HAS_DX, MODE>), grid, block, 0, s, (const T*)x, \
                      (const T*)dy, (T*)dx, params, dparams, g.hw, g.groups)
@@ -433,16 +471,16 @@ static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int 
 
 template <typename T>
 static int bwd_by_id(int id, const void* x, const void* dy, void* dx, const float* p, float* dp, int n, int h,
-                     int w, int mode, hipStream_t s) {
+                     int w, int mode, hipStream_t s, bool zeroed = false) {
   switch (id) {
-    case 0: return launch_bwd<ExposureF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
-    case 1: return launch_bwd<GammaF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
-    case 2: return launch_bwd<WhiteBalanceF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
-    case 3: return launch_bwd<SatPlusF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
-    case 4: return launch_bwd<ToneF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
-    case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
-    case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
-    case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, dp, n, h, w, mode, s);
+    case 0: return launch_bwd<ExposureF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
+    case 1: return launch_bwd<GammaF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
+    case 2: return launch_bwd<WhiteBalanceF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
+    case 3: return launch_bwd<SatPlusF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
+    case 4: return launch_bwd<ToneF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
+    case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
+    case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
+    case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
   }
   return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
 }
@@ -605,9 +643,28 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
                    int hsv_grad_mode, void* stream) {
   if (steps < 0 || !filter_ids || !acts || !grads || !params || !dparams)
     return fail(EXPO_E_BADARG, "bad chain arguments");
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
+  if (n == 0 || steps == 0) return EXPO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // If the caller laid the per-step dparams blocks out back to back (in either order), zero them
+  // with ONE fill instead of one per step (each fill is a ~3-5 us launch on the critical path).
+  bool contiguous = true;
+  size_t total = 0;
+  for (int i = 0; i < steps; ++i) {
+    if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+    if (!dparams[i]) return fail(EXPO_E_BADARG, "null pointer");
+    if (i > 0 && dparams[i] != dparams[i - 1] + size_t(n) * kNumParams[filter_ids[i - 1]]) contiguous = false;
+    total += size_t(n) * kNumParams[filter_ids[i]];
+  }
+  if (contiguous) HIP_TRY(hipMemsetAsync(dparams[0], 0, sizeof(float) * total, s), "dparams memset");
   for (int i = steps - 1; i >= 0; --i) {
-    const int rc = expo_filter_bwd(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], dparams[i], n, h,
-                                   w, dtype, hsv_grad_mode, stream);
+    if (!acts[i] || !grads[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
+    const int rc = dtype == EXPO_F16
+                       ? bwd_by_id<half_t>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], dparams[i], n,
+                                           h, w, hsv_grad_mode, s, contiguous)
+                       : bwd_by_id<float>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], dparams[i], n,
+                                          h, w, hsv_grad_mode, s, contiguous);
     if (rc) return rc;
   }
   return EXPO_OK;
@@ -630,3 +687,4 @@ int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w
 }
 
 }  // extern "C"
+#endif  // EXPO_PROBE

@@ -1,11 +1,10 @@
 // pixel_io.h -- NHWC pixel-group loads/stores for gfx950.
 //
 // A lane owns whole pixels (the coupled filters S+, Ct, BW need R,G,B of a pixel in one
-// lane).  One "group" is 48 contiguous bytes = three 16-byte accesses per lane:
+// lane).  One "group" is the work of one thread iteration: 48 bytes =
 //   fp16: 8 pixels (24 halves)      fp32: 4 pixels (12 floats)
-// so every global access is a dwordx4 and a wave covers 3 KiB contiguous per group-row.
-// Images whose pixel count is not a multiple of the group size (or whose base is not
-// 16-byte aligned) take the element-wise path (VEC = false), which is slow but exact.
+// and a wave iteration covers 3 KiB of contiguous image.  Images the vector path cannot take
+// (odd fp16 pixel counts, unaligned bases) use the element-wise path (VEC = false): slow, exact.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -13,86 +12,172 @@
 namespace expo {
 
 typedef _Float16 half_t;
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-typedef float float4_t __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 template <typename T> struct PixTraits;
 template <> struct PixTraits<half_t> { static constexpr int PPL = 8; };
 template <> struct PixTraits<float> { static constexpr int PPL = 4; };
 
-template <bool NT>
-__device__ __forceinline__ u32x4_t ld16(const u32x4_t* p) {
-  if constexpr (NT) return __builtin_nontemporal_load(p);
-  else return *p;
-}
-template <bool NT>
-__device__ __forceinline__ void st16(u32x4_t* p, u32x4_t v) {
-  if constexpr (NT) __builtin_nontemporal_store(v, p);
-  else *p = v;
+// ---------------------------------------------------------------------------------------
+// Vector path: dwordx3 buffer accesses.  12 bytes = 2 fp16 pixels = 1 fp32 pixel, so lane i of a
+// wave touches bytes [12 i, 12 i + 12) of a 768-byte row: every access is fully coalesced
+// (consecutive lanes -> consecutive addresses) AND pixel-aligned (a lane owns whole pixels, which
+// the coupled filters S+ / Ct / BW need) with no LDS transpose.  A thread iteration is four such
+// rows (8 fp16 / 4 fp32 pixels per lane, 3 KiB per wave); the four rows share ONE 32-bit byte
+// offset VGPR and differ only in the instruction's immediate offset (0/768/1536/2304).
+//
+// Each image is addressed through a raw buffer resource (SRD in SGPRs, num_records = image bytes):
+// the hardware bounds check returns 0 for loads and drops stores past the end of the image, so the
+// image's partial last chunk runs the same branch-free code as every other chunk.
+//
+// (The first design read 48 contiguous bytes per lane as three global_load_dwordx4: its 48-byte
+// lane stride touches every cache line from three instructions and measured 15-20 % below the
+// coalesced pattern -- tools/membench.hip copy48 vs copy12/copy16, profiles/r01_*_membench.txt.)
+// Requirements: fp16: H*W even and a 4-byte aligned base; fp32: always (4-byte aligned).
+// ---------------------------------------------------------------------------------------
+#ifndef EXPO_PREFETCH
+#define EXPO_PREFETCH 1
+#endif
+
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+
+template <typename T> struct VecTraits;
+template <> struct VecTraits<half_t> { static constexpr int PPV = 2; };  // pixels per 12-byte vector
+template <> struct VecTraits<float> { static constexpr int PPV = 1; };
+
+struct RawGroup { u32x3_t q[4]; };
+
+// gfx9-family raw buffer descriptor word 3 (DATA_FORMAT = 32-bit); stride 0 = raw, bounds-checked
+constexpr int kBufferRsrcFlags = 0x00020000;
+
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_image_rsrc(const T* img, int hw) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(img), 0, hw * 3 * int(sizeof(T)), kBufferRsrcFlags);
 }
 
-// raw 48-byte group held in registers between the load issue and its first use
-struct RawGroup { u32x4_t q[3]; };
+// byte offset of this lane's first vector in the wave chunk that starts at group gw
+template <typename T>
+__device__ __forceinline__ int chunk_byte_offset(int gw, int lane) {
+  constexpr int PPL = PixTraits<T>::PPL, PPV = VecTraits<T>::PPV;
+  return (gw * (PPL / PPV) + lane) * 12;
+}
 
-template <bool NT>
-__device__ __forceinline__ RawGroup load_raw(const void* img, int g) {
-  const u32x4_t* p = reinterpret_cast<const u32x4_t*>(img) + size_t(g) * 3;
+__device__ __forceinline__ RawGroup load_raw(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
   RawGroup r;
-  r.q[0] = ld16<NT>(p);
-  r.q[1] = ld16<NT>(p + 1);
-  r.q[2] = ld16<NT>(p + 2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r.q[j] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, byte_off + j * 768, 0, 0);
   return r;
+}
+__device__ __forceinline__ void store_raw(__amdgpu_buffer_rsrc_t rsrc, int byte_off, const RawGroup& r) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b96(r.q[j], rsrc, byte_off + j * 768, 0, 0);
 }
 
 template <typename T> __device__ __forceinline__ void unpack(const RawGroup& r, float* out);
 template <> __device__ __forceinline__ void unpack<half_t>(const RawGroup& r, float* out) {
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const half8_t h = __builtin_bit_cast(half8_t, r.q[j]);
+  for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) out[j * 8 + e] = float(h[e]);
+    for (int e = 0; e < 3; ++e) {
+      // NB: bit_cast of a vector-element lvalue reads element 0 (clang quirk) -> copy to a scalar
+      const uint32_t w = r.q[j][e];
+      const half2_t h = __builtin_bit_cast(half2_t, w);
+      out[j * 6 + e * 2] = float(h[0]);
+      out[j * 6 + e * 2 + 1] = float(h[1]);
+    }
   }
 }
 template <> __device__ __forceinline__ void unpack<float>(const RawGroup& r, float* out) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const float4_t f = __builtin_bit_cast(float4_t, r.q[j]);
+  for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) out[j * 4 + e] = f[e];
+    for (int e = 0; e < 3; ++e) {
+      const uint32_t w = r.q[j][e];
+      out[j * 3 + e] = __builtin_bit_cast(float, w);
+    }
   }
 }
-
 template <typename T> __device__ __forceinline__ RawGroup pack(const float* in);
 template <> __device__ __forceinline__ RawGroup pack<half_t>(const float* in) {
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
   RawGroup r;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    half8_t h;
+  for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = half_t(in[j * 8 + e]);  // round-to-nearest-even
-    r.q[j] = __builtin_bit_cast(u32x4_t, h);
+    for (int e = 0; e < 3; ++e) {
+      half2_t h;
+      h[0] = half_t(in[j * 6 + e * 2]);  // round-to-nearest-even
+      h[1] = half_t(in[j * 6 + e * 2 + 1]);
+      r.q[j][e] = __builtin_bit_cast(uint32_t, h);
+    }
   }
   return r;
 }
 template <> __device__ __forceinline__ RawGroup pack<float>(const float* in) {
   RawGroup r;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    float4_t f;
+  for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) f[e] = in[j * 4 + e];
-    r.q[j] = __builtin_bit_cast(u32x4_t, f);
+    for (int e = 0; e < 3; ++e) r.q[j][e] = __builtin_bit_cast(uint32_t, in[j * 3 + e]);
   }
   return r;
 }
 
-template <bool NT>
-__device__ __forceinline__ void store_raw(void* img, int g, const RawGroup& r) {
-  u32x4_t* p = reinterpret_cast<u32x4_t*>(img) + size_t(g) * 3;
-  st16<NT>(p, r.q[0]);
-  st16<NT>(p + 1, r.q[1]);
-  st16<NT>(p + 2, r.q[2]);
+// Streaming driver of the vector path.  Each wave walks 3 KiB chunks of one image with a block
+// stride; NIN input streams (x, or x and dy) are unpacked to fp32, fn(v, g) transforms them in
+// place, and the LAST stream is written back when HAS_OUT.  With PF the next chunk's loads are in
+// flight while the current one computes (software prefetch; costs 12 VGPRs per stream).
+template <typename T, int NIN, bool HAS_OUT, bool PF, class Fn>
+__device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out, int hw, int first_gw,
+                                              int stride, Fn&& fn) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int lane = threadIdx.x & 63;
+  __amdgpu_buffer_rsrc_t rin[NIN];
+#pragma unroll
+  for (int s = 0; s < NIN; ++s) rin[s] = make_image_rsrc(in[s], hw);
+  __amdgpu_buffer_rsrc_t rout = rin[0];
+  if constexpr (HAS_OUT) rout = make_image_rsrc(out, hw);
+  int gw = first_gw;  // wave-uniform
+  if (gw * PPL >= hw) return;
+  RawGroup cur[NIN];
+#pragma unroll
+  for (int s = 0; s < NIN; ++s) cur[s] = load_raw(rin[s], chunk_byte_offset<T>(gw, lane));
+  while (true) {
+    const int gn = gw + stride;
+    const bool more = gn * PPL < hw;  // wave-uniform
+    RawGroup nxt[NIN];
+#pragma unroll
+    for (int s = 0; s < NIN; ++s) nxt[s] = cur[s];
+    if (PF && more) {
+#pragma unroll
+      for (int s = 0; s < NIN; ++s) nxt[s] = load_raw(rin[s], chunk_byte_offset<T>(gn, lane));
+    }
+    float v[NIN][PPL * 3];
+#pragma unroll
+    for (int s = 0; s < NIN; ++s) unpack<T>(cur[s], v[s]);
+    fn(v, gw + lane);
+    if constexpr (HAS_OUT) store_raw(rout, chunk_byte_offset<T>(gw, lane), pack<T>(v[NIN - 1]));
+    if (!PF && more) {
+#pragma unroll
+      for (int s = 0; s < NIN; ++s) nxt[s] = load_raw(rin[s], chunk_byte_offset<T>(gn, lane));
+    }
+    if (!more) break;
+    gw = gn;
+#pragma unroll
+    for (int s = 0; s < NIN; ++s) cur[s] = nxt[s];
+  }
+}
+
+// Is pixel slot k of the group a real pixel?  (group index g = wave base + lane)
+template <typename T, bool VEC>
+__device__ __forceinline__ bool live_pixel(int g, int k, int lane, int hw) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  if constexpr (VEC) {
+    constexpr int PPV = VecTraits<T>::PPV;
+    const int gw = g - lane;
+    return gw * PPL + (k / PPV) * 64 * PPV + lane * PPV + (k % PPV) < hw;
+  }
+  return g * PPL + k < hw;
 }
 
 // element-wise (ragged / unaligned) path: group g covers pixels [g*PPL, g*PPL+PPL) ∩ [0,hw)

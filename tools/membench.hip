@@ -73,6 +73,87 @@ __global__ __launch_bounds__(256) void rrw48(const u32x4* __restrict__ a, const 
   }
 }
 
+// Coalesced global accesses + wave-private LDS transpose to the 48-byte-per-lane pixel-group
+// register layout and back (the data path proposed for the filter kernels).
+template <bool DMA>
+__global__ __launch_bounds__(256) void copy16lds(const u32x4* __restrict__ a, u32x4* __restrict__ b, size_t nchunks) {
+  __shared__ u32x4 smem[4][192];  // 3 KiB per wave
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  u32x4* sm = smem[wave];
+  for (size_t ch = size_t(blockIdx.x) * 4 + wave; ch < nchunks; ch += size_t(gridDim.x) * 4) {
+    const u32x4* src = a + ch * 192;
+    if constexpr (DMA) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(sm + j * 64), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      u32x4 v0 = src[lane], v1 = src[64 + lane], v2 = src[128 + lane];
+      sm[lane] = v0; sm[64 + lane] = v1; sm[128 + lane] = v2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 r0 = sm[3 * lane], r1 = sm[3 * lane + 1], r2 = sm[3 * lane + 2];
+    r0.x ^= 1u; r1.y ^= 1u; r2.z ^= 1u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    sm[3 * lane] = r0; sm[3 * lane + 1] = r1; sm[3 * lane + 2] = r2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 c0 = sm[lane], c1 = sm[64 + lane], c2 = sm[128 + lane];
+    u32x4* dst = b + ch * 192;
+    dst[lane] = c0; dst[64 + lane] = c1; dst[128 + lane] = c2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// dwordx3 accesses: lane i -> bytes [12 i, 12 i + 12) of each 768-byte wave row; fully coalesced AND
+// pixel-aligned (12 B = 2 fp16 pixels = 1 fp32 pixel).  J rows per thread per iteration.
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+template <int J>
+__global__ __launch_bounds__(256) void copy12(const uint32_t* __restrict__ a, uint32_t* __restrict__ b, size_t nrows) {
+  // a "row" = 64 lanes x 12 B = 768 B; each wave handles J consecutive rows per iteration
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (size_t r = (size_t(blockIdx.x) * 4 + wave) * J; r < nrows; r += size_t(gridDim.x) * 4 * J) {
+    u32x3 v[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if (r + j < nrows) v[j] = *reinterpret_cast<const u32x3*>(a + (r + j) * 192 + lane * 3);
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if (r + j < nrows) { v[j].x ^= 1u; *reinterpret_cast<u32x3*>(b + (r + j) * 192 + lane * 3) = v[j]; }
+  }
+}
+template <int J>
+__global__ __launch_bounds__(256) void rrw12(const uint32_t* __restrict__ a, const uint32_t* __restrict__ c,
+                                             uint32_t* __restrict__ b, size_t nrows) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (size_t r = (size_t(blockIdx.x) * 4 + wave) * J; r < nrows; r += size_t(gridDim.x) * 4 * J) {
+    u32x3 v[J], w[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if (r + j < nrows) {
+        v[j] = *reinterpret_cast<const u32x3*>(a + (r + j) * 192 + lane * 3);
+        w[j] = *reinterpret_cast<const u32x3*>(c + (r + j) * 192 + lane * 3);
+      }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+      if (r + j < nrows) *reinterpret_cast<u32x3*>(b + (r + j) * 192 + lane * 3) = v[j] ^ w[j];
+  }
+}
+
+// coalesced read x, read dy, write dx (no transpose): ceiling for a channel-phase backward
+__global__ __launch_bounds__(256) void rrw16(const u32x4* __restrict__ a, const u32x4* __restrict__ c,
+                                             u32x4* __restrict__ b, size_t n16) {
+  const size_t stride = size_t(gridDim.x) * 256;
+  for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n16; i += stride) {
+    u32x4 v = a[i], w = c[i];
+    b[i] = v ^ w;
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = (argc > 1 ? atol(argv[1]) : 96) * (1ul << 20);  // per buffer
   const int nbuf = argc > 2 ? atoi(argv[2]) : 9;
@@ -82,7 +163,7 @@ int main(int argc, char** argv) {
   const size_t n16 = bytes / 16, ngroups = bytes / 48;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int grids[] = {1024, 2048, 4096, 8192, 16384};
+  const int grids[] = {2048, 8192, 32768};
   printf("buffer %zu MiB x %d, %d reps\n", bytes >> 20, nbuf, reps);
   for (int grid : grids) {
     auto run = [&](const char* name, int streams, auto launch) {
@@ -100,6 +181,12 @@ int main(int argc, char** argv) {
     run("copy48nt", 2, [&](int i) { copy48<true, 1><<<grid, 256>>>(buf[i % nbuf], buf[(i + 1) % nbuf], ngroups); });
     run("copy48u2", 2, [&](int i) { copy48<false, 2><<<grid, 256>>>(buf[i % nbuf], buf[(i + 1) % nbuf], ngroups); });
     run("rrw48", 3, [&](int i) { rrw48<false><<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], ngroups); });
+    run("copy16lds", 2, [&](int i) { copy16lds<false><<<grid, 256>>>(buf[i % nbuf], buf[(i + 1) % nbuf], bytes / 3072); });
+    run("copy16dma", 2, [&](int i) { copy16lds<true><<<grid, 256>>>(buf[i % nbuf], buf[(i + 1) % nbuf], bytes / 3072); });
+    run("rrw16", 3, [&](int i) { rrw16<<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], n16); });
+    run("copy12x4", 2, [&](int i) { copy12<4><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768); });
+    run("copy12x8", 2, [&](int i) { copy12<8><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768); });
+    run("rrw12x4", 3, [&](int i) { rrw12<4><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (const uint32_t*)buf[(i + 4) % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768); });
     run("rrw48nt", 3, [&](int i) { rrw48<true><<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], ngroups); });
   }
   return 0;
