@@ -389,7 +389,7 @@ static int env_int(const char* name, int dflt) {
 // blocks when the problem allows and each thread walks a few groups (amortises the
 // reduction epilogue); capped at 2048-ish total blocks (grid-stride the rest).
 template <typename T>
-static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> ptrs) {
+static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> ptrs, bool reduces = true) {
   constexpr int PPL = PixTraits<T>::PPL;
   Geom g;
   g.hw = h * w;
@@ -397,7 +397,11 @@ static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
   g.vec = (g.hw % VecTraits<T>::PPV) == 0;  // dwordx3 path: whole 12-byte vectors, 4-byte aligned
   for (const void* p : ptrs) g.vec = g.vec && (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 3) == 0);
   const int max_bx = (g.groups + kThreads - 1) / kThreads;
-  static const int gpt = env_int("EXPO_GROUPS_PER_THREAD", 4);  // groups each thread walks
+  // groups each thread walks: kernels with a reduction epilogue (atomics per block) want fewer,
+  // fatter blocks; pure maps (forward) stream best with many blocks (tools/membench.hip)
+  static const int gpt_red = env_int("EXPO_BWD_GROUPS_PER_THREAD", 4);
+  static const int gpt_map = env_int("EXPO_FWD_GROUPS_PER_THREAD", 2);
+  const int gpt = reduces ? gpt_red : gpt_map;
   int bx = (g.groups + kThreads * gpt - 1) / (kThreads * gpt);
   const long want = 1024;
   if (long(bx) * n < want) bx = int((want + n - 1) / n);
@@ -417,7 +421,7 @@ static int check_common(int n, int h, int w, int dtype) {
 
 template <class F, typename T>
 static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s) {
-  const Geom g = make_geom<T>(n, h, w, {x, y});
+  const Geom g = make_geom<T>(n, h, w, {x, y}, false);
   const dim3 grid(g.blocks_x, n), block(kThreads);
   if (g.vec)
     hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, false>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);

@@ -274,8 +274,10 @@ struct CurveF {
       const float4_lut e = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
       const float t = fmaf(fmaf(jf, -1.0f / L, xc), e.x, e.z);
       const float y = t * q.scale[cc];
-      const bool inside = (xv >= 0.0f) && (xv <= 1.0f);
-      const bool knot = (cu == u) && (u >= 1.0f) && (u <= float(L - 1));
+      // inside: 0 <= x <= 1  <=>  clamp(x) == x.   knot: L x is an integer in [1, L-1]; the test
+      // (cu - 1 == jf) accepts L x in [1, L] and the LUT's k_L := 0 makes L x == L contribute 0.
+      const bool inside = (xc == xv);
+      const bool knot = (cu == u) && (cu - 1.0f == jf);
       const float slope = (inside ? e.x : 0.0f) + (knot ? e.y : 0.0f);
       dx[c] = g * q.scale[cc] * slope;
       float* a = acc + cc * (L + 1);
