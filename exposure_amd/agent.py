@@ -1,0 +1,204 @@
+"""Policy network of the retouching agent (``/root/reference/agent.py``) on PyTorch-ROCm.
+
+``feature_extractor`` (agent.py:11-37) and ``agent_generator`` (agent.py:41-260) keep their
+reference names, arguments and return structure.  What changes is the image path:
+
+* the reference applies ALL filters to the same input, stacks the 8 results and multiplies by
+  ``one_hot(selected_filter_id)`` (agent.py:58-77, 119-125) -- 8 full-image passes of which 7
+  are discarded.  The selector's pdf does not depend on the filter outputs, so here the action
+  is sampled first and ONE fused HIP launch pair (``expo_filter_dispatch_fwd``) applies, per
+  image, only the selected filter -- and accumulates the over-exposure penalty
+  (agent.py:249-251) in the same pass.  Gradients are identical: the one-hot product zeroes
+  every non-selected filter's image and parameter gradients in the reference too.
+* the convolutions / FCs are MIOpen / hipBLASLt GEMMs (MFMA) through torch; tensors stay NHWC
+  (``channels_last``) end to end so no layout change sits between the filter kernels and conv1.
+
+Stochastic inputs are explicit so runs are reproducible and parity-testable: ``z[:, 0]`` is
+the selection noise (agent.py:47) and ``dropout_masks`` (two (N, 4096) 0/1 tensors) replace the
+always-on ``tf.nn.dropout`` of agent.py:36 (pass ``None`` to draw them).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import filters as F
+from .util import (STATE_DROPOUT_BEGIN, STATE_REWARD_DIM, STATE_STEP_DIM, STATE_STOPPED_DIM,
+                   enrich_image_input, lrelu)
+
+
+def _xavier_conv(conv):
+  nn.init.xavier_uniform_(conv.weight)
+  nn.init.zeros_(conv.bias)
+
+
+class FeatureExtractor(nn.Module):
+  """agent.py:11-37: ``x - 0.5``; conv4x4/s2 (SAME) + lrelu until 4x4; flatten (H,W,C order);
+  dropout(keep_prob) ALWAYS on.  Input NHWC (N, S, S, C_in)."""
+
+  def __init__(self, in_channels, output_dim, cfg, size=None):
+    super().__init__()
+    size = int(size or cfg.source_img_size)
+    min_feature_map_size = 4
+    assert output_dim % (min_feature_map_size**2) == 0, 'output dim=%d' % output_dim
+    self.output_dim = output_dim
+    self.keep_prob = float(cfg.dropout_keep_prob)
+    channels = cfg.base_channels
+    layers = []
+    size //= 2
+    layers.append(nn.Conv2d(in_channels, channels, kernel_size=4, stride=2, padding=1))
+    prev = channels
+    while size > min_feature_map_size:
+      if size == min_feature_map_size * 2:
+        channels = output_dim // (min_feature_map_size**2)
+      else:
+        channels *= 2
+      assert size % 2 == 0
+      size //= 2
+      layers.append(nn.Conv2d(prev, channels, kernel_size=4, stride=2, padding=1))
+      prev = channels
+    self.convs = nn.ModuleList(layers)
+    for c in self.convs:
+      _xavier_conv(c)
+    self.to(memory_format=torch.channels_last)
+
+  def forward(self, net_nhwc, dropout_mask=None):
+    # NHWC storage viewed as NCHW/channels_last: no copy, MIOpen picks its NHWC kernels
+    net = (net_nhwc.float() - 0.5).permute(0, 3, 1, 2)
+    for conv in self.convs:
+      net = lrelu(conv(net))
+    net = net.permute(0, 2, 3, 1).reshape(net.shape[0], self.output_dim)  # TF reshape order (H,W,C)
+    if dropout_mask is None:
+      dropout_mask = (torch.rand_like(net) < self.keep_prob).to(net.dtype)
+    # tf.nn.dropout: x / keep_prob * mask
+    return net * dropout_mask * (1.0 / self.keep_prob)
+
+
+def feature_extractor(net, output_dim, cfg, module, dropout_mask=None):
+  """Functional spelling of agent.py:11 for callers that hold the module."""
+  assert module.output_dim == output_dim
+  return module(net, dropout_mask)
+
+
+def pdf_sample(pdf, uniform_noise):
+  """pdf_sample_layer.py:5-10 (bit-identical integer result for identical pdf / noise)."""
+  pdf = pdf / (pdf.sum(dim=1, keepdim=True) + 1e-36)
+  cdf = torch.cumsum(pdf, dim=1) - pdf  # exclusive
+  return ((cdf < uniform_noise).sum(dim=1) - 1).to(torch.int32)
+
+
+class Agent(nn.Module):
+  """``agent_generator`` (agent.py:41-260) as a module.  ``forward`` mirrors its signature:
+  ``inp = (net, z, states)``, ``is_train`` (0/1), ``progress`` (float), optional ``high_res``."""
+
+  def __init__(self, cfg, img_shape=None):
+    super().__init__()
+    self.cfg = cfg
+    s = cfg.source_img_size
+    img_shape = img_shape or (1, s, s, cfg.real_img_channels)
+    self.filters = nn.ModuleList([x(img_shape, cfg) for x in cfg.filters])  # agent.py:45
+    in_ch = cfg.real_img_channels + (cfg.num_state_dim if cfg.img_include_states else 0)
+    assert cfg.shared_feature_extractor, 'only the shared feature extractor of the shipped configs is built'
+    self.filter_features = FeatureExtractor(in_ch, cfg.feature_extractor_dims, cfg)
+    self.selector_features = FeatureExtractor(in_ch, cfg.feature_extractor_dims, cfg)
+    self.selector_fc1 = nn.Linear(cfg.feature_extractor_dims, cfg.fc1_size)
+    self.selector_fc2 = nn.Linear(cfg.fc1_size, len(cfg.filters))
+    for fc in (self.selector_fc1, self.selector_fc2):
+      nn.init.xavier_uniform_(fc.weight)
+      nn.init.zeros_(fc.bias)
+
+  def regress_all(self, filter_features):
+    """Per-filter FC heads + range squashing -> list of reference-shaped parameter tensors."""
+    out = []
+    for filt in self.filters:
+      f, _mask_params = filt.extract_parameters(filter_features)
+      out.append(filt.filter_param_regressor(f))
+    return out
+
+  def action_pdf(self, selector_features):
+    """agent.py:87-107 -> (pdf, entropy)."""
+    cfg = self.cfg
+    h = lrelu(self.selector_fc1(selector_features))
+    pdf = torch.softmax(self.selector_fc2(h), dim=1) + 1e-37
+    pdf = pdf * (1 - cfg.exploration) + cfg.exploration * 1.0 / len(self.filters)
+    pdf = pdf / (pdf.sum(dim=1, keepdim=True) + 1e-30)
+    entropy = (-pdf * torch.log(pdf)).sum(dim=1)[:, None]
+    return pdf, entropy
+
+  def forward(self, inp, is_train, progress, cfg=None, high_res=None, dropout_masks=None):
+    cfg = cfg or self.cfg
+    net, z, states = inp
+    n = net.shape[0]
+    k = len(self.filters)
+    selection_noise = z[:, 0:1]
+    masks = dropout_masks or (None, None)
+
+    enriched = enrich_image_input(cfg, net.float(), states)
+    filter_features = self.filter_features(enriched, masks[0])
+    params = self.regress_all(filter_features)  # 8 x reference-shaped
+
+    selector_features = self.selector_features(enriched, masks[1])
+    pdf, entropy = self.action_pdf(selector_features)
+    random_filter_id = pdf_sample(pdf, selection_noise)
+    max_filter_id = torch.argmax(pdf, dim=1).to(torch.int32)
+    is_train = int(is_train)
+    selected_filter_id = is_train * random_filter_id + (1 - is_train) * max_filter_id
+    filter_one_hot = (selected_filter_id[:, None] == torch.arange(k, device=net.device)[None, :]).to(pdf.dtype)
+    surrogate = (filter_one_hot * torch.log(pdf + 1e-10)).sum(dim=1, keepdim=True)
+
+    # one-hot gather of the selected filter's packed parameters -> (N, 24); same gradient
+    # routing as the reference's one-hot product over the stacked images
+    params24 = net.new_zeros((n, F._cabi.EXPO_MAX_PARAMS), dtype=torch.float32)
+    for j, (filt, p) in enumerate(zip(self.filters, params)):
+      pj = filt.pack(p).float()
+      params24 = params24 + torch.nn.functional.pad(pj, (0, F._cabi.EXPO_MAX_PARAMS - pj.shape[1])) * \
+          filter_one_hot[:, j:j + 1]
+    hsv_mode = int(cfg.get('hsv_grad_mode', 0))
+    out, overexposure = F.dispatch_filters(net, params24, selected_filter_id, hsv_mode)
+    high_res_output = None
+    if high_res is not None:
+      high_res_output, _ = F.dispatch_filters(high_res, params24, selected_filter_id, hsv_mode)
+
+    debug_info = {
+        'state': states,
+        'selected_filter_id': selected_filter_id[0],
+        'filter_debug_info': [{'filter_parameters': p[0]} for p in params],
+        'pdf': pdf[0],
+        # batched extras (not in the reference dict; used by tests / the eval loop)
+        'selected_filter_ids': selected_filter_id,
+        'pdf_batch': pdf,
+        'params24': params24,
+    }
+
+    # Calculate new states (agent.py:207-238)
+    is_last_step = (torch.abs(states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1] + 1 - cfg.test_steps) < 1e-4).to(
+        states.dtype)
+    submitted = is_last_step
+    new_states = [None for _ in range(STATE_DROPOUT_BEGIN + 1)]
+    new_states[STATE_REWARD_DIM] = submitted
+    new_states[STATE_STOPPED_DIM] = submitted
+    new_states[STATE_STEP_DIM] = (states[:, STATE_STEP_DIM] + 1)[:, None]
+    filter_usage = states[:, STATE_STEP_DIM + 1:]
+    early_stop_penalty = (1 - is_last_step) * submitted * cfg.early_stop_penalty
+    usage_penalty = (filter_usage * filter_one_hot).sum(dim=1, keepdim=True)
+    new_states[STATE_STEP_DIM + 1] = torch.maximum(filter_usage, filter_one_hot)
+    new_states = torch.cat(new_states, dim=1)
+
+    if cfg.clamp:
+      raise NotImplementedError('cfg.clamp=True is not used by the shipped configs (config_example.py:39)')
+
+    entropy_penalty = (1.0 - progress) * cfg.exploration_penalty * (-entropy + math.log(k))
+    # Will be subtracted from the reward (agent.py:247-252)
+    penalty = overexposure[:, None] + entropy_penalty + usage_penalty * cfg.filter_usage_penalty + \
+        early_stop_penalty
+
+    if high_res is None:
+      return (out, new_states, surrogate, penalty), debug_info, None
+    return (out, new_states, high_res_output), debug_info, None
+
+
+def agent_generator(inp, is_train, progress, cfg, high_res=None, alex_in=None, module=None, dropout_masks=None):
+  """agent.py:41 signature; ``module`` is the :class:`Agent` holding the weights (the reference
+  keeps them in the TF variable scope 'generator')."""
+  assert module is not None, 'pass the Agent module that owns the generator weights'
+  return module(inp, is_train, progress, cfg=cfg, high_res=high_res, dropout_masks=dropout_masks)

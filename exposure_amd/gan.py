@@ -1,0 +1,141 @@
+"""One training iteration of the reference's GAN trainer (``/root/reference/net.py:92-251``):
+the callers of the filter hot path.  Losses, stop-gradients, optimiser settings and learning
+rate schedules follow the reference line by line; the filter work inside ``Agent`` runs in the
+HIP library.
+
+``GAN.generator_step`` == one ``sess.run([opt_g, opt_v, ...])`` (net.py:325-335);
+``GAN.critic_step`` == one ``sess.run(opt_c)`` (net.py:358-365).  With a process group the
+gradients are all-reduced in flat buckets (``exposure_amd.dist``) before the optimiser steps.
+"""
+import torch
+from torch import nn
+
+from . import dist as xdist
+from .agent import Agent
+from .critics import Critic
+from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
+
+
+class GAN(nn.Module):
+
+  def __init__(self, cfg, device=None, process_group=None):
+    super().__init__()
+    self.cfg = cfg
+    self.generator = Agent(cfg)
+    self.critic = Critic(cfg, num_state_dim=0)
+    self.value = Critic(cfg, num_state_dim=cfg.num_state_dim)
+    if device is not None:
+      self.to(device)
+    adam = dict(betas=(cfg.adam_beta1, cfg.adam_beta2), eps=1e-8)  # config_example.py:158
+    self.opt_g = torch.optim.Adam(self.generator.parameters(), lr=cfg.lr_g(0), **adam)
+    self.opt_v = torch.optim.Adam(self.value.parameters(), lr=cfg.value_lr_mul * cfg.lr_g(0), **adam)
+    self.opt_c = torch.optim.Adam(self.critic.parameters(), lr=cfg.lr_c(0), **adam)
+    self.process_group = process_group
+    self.world_size = xdist.world_size(process_group)
+    self.buckets = {
+        'g': xdist.GradBucket(self.generator.parameters()),
+        'v': xdist.GradBucket(self.value.parameters()),
+        'c': xdist.GradBucket(self.critic.parameters()),
+    }
+    # ExponentialMovingAverage(decay=0.99, zero_debias=True) of c_average (net.py:107-108, 165-168)
+    self.c_average_biased = 0.0
+    self.c_average_steps = 0
+
+  # -- learning rates (config_example.py:134-158; net.py:222-251)
+  def set_lrs(self, it, zero_g=False):
+    lr_g = 0.0 if zero_g else self.cfg.lr_g(it)  # net.py:327-328: lr_g = 0 at iter 0
+    for g in self.opt_g.param_groups:
+      g['lr'] = lr_g
+    for g in self.opt_v.param_groups:
+      g['lr'] = self.cfg.value_lr_mul * lr_g
+    for g in self.opt_c.param_groups:
+      g['lr'] = self.cfg.lr_c(it)
+
+  def generator_losses(self, fake_input, z, states, progress, is_train=1, dropout_masks=None):
+    """net.py:56-165 (WGAN branch, use_TD, use_penalty)."""
+    cfg = self.cfg
+    (fake_output, new_states, surrogate, penalty), debug, _ = self.generator(
+        (fake_input, z, states), is_train=is_train, progress=progress, dropout_masks=dropout_masks)
+    fake_logit = self.critic(fake_output)
+    with torch.no_grad():
+      fake_input_logit = self.critic(fake_input)
+    old_value = self.value(fake_input, states)
+    new_value = self.value(fake_output, new_states)
+    stopped = new_states[:, STATE_STOPPED_DIM:STATE_STOPPED_DIM + 1]
+    clear_final = (new_states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1] > cfg.maximum_trajectory_length).float()
+    new_value = new_value * (1.0 - clear_final)
+    raw_reward = (cfg.all_reward + (1 - cfg.all_reward) * stopped) * (fake_logit - fake_input_logit) * \
+        cfg.critic_logit_multiplier
+    reward = raw_reward - penalty if cfg.use_penalty else raw_reward
+    q_value = reward + (1.0 - stopped) * cfg.discount_factor * new_value
+    advantage = q_value.detach() - old_value
+    v_loss = (advantage**2).mean()
+    routine_loss = -q_value * cfg.parameter_lr_mul
+    g_loss = (routine_loss + surrogate * (-advantage).detach()).mean()
+    return dict(g_loss=g_loss, v_loss=v_loss, fake_output=fake_output, new_states=new_states, reward=reward,
+                q_value=q_value, fake_logit=fake_logit, debug=debug)
+
+  def generator_step(self, fake_input, z, states, progress, it=1, dropout_masks=None):
+    """opt_g on g_loss w.r.t. theta_g and opt_v on v_loss w.r.t. theta_v (net.py:222-241)."""
+    self.set_lrs(it, zero_g=(it == 0))
+    out = self.generator_losses(fake_input, z, states, progress, 1, dropout_masks)
+    self.opt_g.zero_grad(set_to_none=True)
+    self.opt_v.zero_grad(set_to_none=True)
+    gp = list(self.generator.parameters())
+    vp = list(self.value.parameters())
+    # theta_g sees only g_loss; theta_v sees only v_loss (optimize_loss variables= lists)
+    g_grads = torch.autograd.grad(out['g_loss'], gp, retain_graph=True, allow_unused=True)
+    v_grads = torch.autograd.grad(out['v_loss'], vp, allow_unused=True)
+    for p, g in zip(gp, g_grads):
+      p.grad = g if g is not None else torch.zeros_like(p)
+    for p, g in zip(vp, v_grads):
+      p.grad = g if g is not None else torch.zeros_like(p)
+    if self.world_size > 1:
+      # losses are means over the GLOBAL batch: average the per-rank (local-mean) gradients
+      hg = self.buckets['g'].all_reduce_mean(self.process_group, async_op=True)
+      hv = self.buckets['v'].all_reduce_mean(self.process_group, async_op=True)
+      hg.wait_and_scatter()
+      hv.wait_and_scatter()
+    self.opt_g.step()
+    self.opt_v.step()
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items() if k != 'debug'}
+
+  def critic_losses(self, real_data, fake_input, z, states, progress, alpha=None, dropout_masks=None):
+    """net.py:126-194: c_loss = mean(fake - real) + lambda * mean(max(||grad||-1, 0)^2)."""
+    cfg = self.cfg
+    with torch.no_grad():
+      (fake_output, _, _, _), _, _ = self.generator((fake_input, z, states), is_train=1, progress=progress,
+                                                   dropout_masks=dropout_masks)
+    fake_output = fake_output.float()
+    real_data = real_data.float()
+    real_logit = self.critic(real_data)
+    fake_logit = self.critic(fake_output)
+    c_loss = (fake_logit - real_logit).mean()
+    if alpha is None:
+      alpha = torch.rand((real_data.shape[0], 1, 1, 1), device=real_data.device)
+    interpolated = (real_data + alpha * (fake_output - real_data)).requires_grad_(True)
+    inte_logit = self.critic(interpolated)
+    gradients, = torch.autograd.grad(inte_logit.sum(), interpolated, create_graph=True)
+    gradient_norm = torch.sqrt(1e-6 + (gradients**2).sum(dim=(1, 2, 3)))
+    gradient_penalty = cfg.gradient_penalty_lambda * (torch.clamp_min(gradient_norm - 1.0, 0.0)**2).mean()
+    total = c_loss + gradient_penalty if cfg.gradient_penalty_lambda > 0 else c_loss
+    c_average = ((fake_logit + real_logit).mean() * 0.5).detach()
+    return dict(c_loss=total, emd=-c_loss.detach(), gradient_norm=gradient_norm.mean().detach(),
+                gradient_penalty=gradient_penalty.detach(), c_average=c_average)
+
+  def critic_step(self, real_data, fake_input, z, states, progress, it=1, alpha=None, dropout_masks=None):
+    self.set_lrs(it)
+    out = self.critic_losses(real_data, fake_input, z, states, progress, alpha, dropout_masks)
+    self.opt_c.zero_grad(set_to_none=True)
+    out['c_loss'].backward()
+    if self.world_size > 1:
+      self.buckets['c'].all_reduce_mean(self.process_group, async_op=True).wait_and_scatter()
+      ca = out['c_average'].clone()
+      xdist.all_reduce_mean_(ca, self.process_group)
+      out['c_average'] = ca
+    self.opt_c.step()
+    # update_average (net.py:165-168, 267-268): debiased EMA of the logit centre
+    self.c_average_steps += 1
+    self.c_average_biased = 0.99 * self.c_average_biased + 0.01 * float(out['c_average'])
+    out['c_average_smoothed'] = self.c_average_biased / (1.0 - 0.99**self.c_average_steps)
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}

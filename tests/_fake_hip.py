@@ -1,0 +1,75 @@
+"""TEST-ONLY stand-in for the C-ABI binding so host logic (agent step, GAN step, gloo data
+parallelism) can be exercised in this GPU-less container.  It patches the *python binding*
+functions of ``exposure_amd._cabi`` with oracle-backed CPU implementations via
+``unittest.mock``; the product package has no knowledge of it and no fallback of its own."""
+import contextlib
+from unittest import mock
+
+import numpy as np
+import torch
+
+from oracle import agent_np
+from oracle import filters_torch as ft
+
+NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24)
+
+
+def _fwd(fid, x, y, params):
+  y.copy_(ft.process_packed(fid, x.double(), params.double()).to(y.dtype))
+
+
+def _bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0):
+  with torch.enable_grad():  # called from inside autograd.Function.backward (grad mode off)
+    gx, gp = ft.backward_packed(fid, x.double(), params.double(), dy.double(), hsv_grad_mode)
+  if dx is not None:
+    dx.copy_(gx.to(dx.dtype))
+  dparams.copy_(gp.float())
+
+
+def _dispatch_fwd(ids, x, y, params, penalty=None):
+  for n in range(x.shape[0]):
+    fid = int(ids[n])
+    if fid < 0:
+      y[n].zero_()
+    else:
+      p = params[n:n + 1, :NUM_PARAMS[fid]].contiguous()
+      y[n:n + 1].copy_(ft.process_packed(fid, x[n:n + 1].double(), p.double()).to(y.dtype))
+  if penalty is not None:
+    penalty.copy_(((y.double() - 1).clamp_min(0)**2).mean(dim=(1, 2, 3)).float())
+
+
+def _dispatch_bwd(ids, x, dy, dx, params, dparams, dpenalty=None, hsv_grad_mode=0):
+  dparams.zero_()
+  cnt = x.shape[1] * x.shape[2] * 3
+  for n in range(x.shape[0]):
+    fid = int(ids[n])
+    if fid < 0:
+      if dx is not None:
+        dx[n].zero_()
+      continue
+    p = params[n:n + 1, :NUM_PARAMS[fid]].contiguous().double()
+    xi = x[n:n + 1].double()
+    g = dy[n:n + 1].double()
+    if dpenalty is not None:
+      yi = ft.process_packed(fid, xi, p)
+      g = g + 2.0 * (yi - 1).clamp_min(0) * float(dpenalty[n]) / cnt
+    with torch.enable_grad():
+      gx, gp = ft.backward_packed(fid, xi, p, g, hsv_grad_mode)
+    if dx is not None:
+      dx[n:n + 1].copy_(gx.to(dx.dtype))
+    dparams[n, :NUM_PARAMS[fid]] = gp[0].float()
+
+
+def _stats(x, stats):
+  stats.copy_(torch.from_numpy(agent_np.critic_stats(x.double().numpy())).float())
+
+
+def _penalty(y, pen):
+  pen.copy_(torch.from_numpy(agent_np.overexposure_penalty(y.double().numpy())).float())
+
+
+@contextlib.contextmanager
+def fake_hip():
+  with mock.patch.multiple('exposure_amd._cabi', filter_fwd=_fwd, filter_bwd=_bwd, dispatch_fwd=_dispatch_fwd,
+                           dispatch_bwd=_dispatch_bwd, critic_stats=_stats, overexposure_penalty=_penalty):
+    yield

@@ -1,0 +1,148 @@
+"""CPU tests of the host logic around the filter path (agent step, losses) with the C-ABI binding
+mocked by the oracle (tests/_fake_hip.py).  Integer outputs must be bit-identical to the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from exposure_amd import agent as xagent
+from exposure_amd.config import make_cfg
+from exposure_amd.gan import GAN
+from oracle import agent_np
+from oracle import filters_np as fnp
+from tests._fake_hip import fake_hip
+
+
+def test_pdf_sample_known_answers():
+  # pdf_sample_layer.py:55-78: pdf ~ (2,4,8) -> u in (0,1/7] -> 0, (1/7,3/7] -> 1, else 2
+  pdf = np.tile(np.array([[2.0, 4.0, 8.0]], dtype=np.float32), (7, 1))
+  u = np.array([[0.0], [0.05], [1 / 7 - 1e-4], [1 / 7 + 1e-4], [0.4], [0.43], [0.99]], dtype=np.float32)
+  want = np.array([-1, 0, 0, 1, 1, 2, 2], dtype=np.int32)
+  assert np.array_equal(agent_np.pdf_sample(pdf, u), want)
+  got = xagent.pdf_sample(torch.from_numpy(pdf), torch.from_numpy(u))
+  assert got.dtype == torch.int32 and np.array_equal(got.numpy(), want)
+  # empirical frequencies 1/7, 2/7, 4/7
+  rng = np.random.default_rng(0)
+  uu = rng.random((70000, 1), dtype=np.float32)
+  ids = agent_np.pdf_sample(np.tile(pdf[:1], (70000, 1)), uu)
+  freq = np.bincount(ids, minlength=3) / 70000.0
+  assert np.abs(freq - np.array([1, 2, 4]) / 7).max() < 0.01
+
+
+def make_inputs(n=6, seed=0, s=64):
+  rng = np.random.default_rng(seed)
+  img = (rng.random((n, s, s, 3), dtype=np.float32)**2.2).astype(np.float32)
+  states = np.zeros((n, 11), dtype=np.float32)
+  states[:, 2] = rng.integers(0, 5, n)  # step
+  states[:, 3:] = (rng.random((n, 8)) < 0.3)
+  z = rng.random((n, 131), dtype=np.float32)
+  masks = [(rng.random((n, 4096)) < 0.5).astype(np.float32) for _ in range(2)]
+  return img, states, z, masks
+
+
+@pytest.mark.parametrize('is_train', [0, 1])
+def test_agent_step_matches_oracle(is_train):
+  torch.manual_seed(0)
+  cfg = make_cfg()
+  ag = xagent.Agent(cfg)
+  img, states, z, masks = make_inputs()
+  z[0, 0] = 0.0  # noise 0 -> id -1 (all-zero one-hot) when sampling
+  t = lambda a: torch.from_numpy(a)
+  with fake_hip():
+    (out, new_states, surrogate, penalty), dbg, _ = ag((t(img), t(z), t(states)), is_train=is_train, progress=0.25,
+                                                      dropout_masks=[t(m) for m in masks])
+  # oracle from the SAME torch-computed logits / params (the nets are torch plumbing)
+  pdf = dbg['pdf_batch'].detach().numpy()
+  ids = dbg['selected_filter_ids'].numpy()
+  assert ids.dtype == np.int32
+  # recompute the selection from the selector logits with the numpy restatement
+  with torch.no_grad():
+    enriched = xagent.enrich_image_input(cfg, t(img), t(states))
+    sel = ag.selector_features(enriched, t(masks[1]))
+    logits = ag.selector_fc2(xagent.lrelu(ag.selector_fc1(sel))).numpy()
+    feats = ag.filter_features(enriched, t(masks[0]))
+    params = [f.pack(p).numpy() for f, p in zip(ag.filters, ag.regress_all(feats))]
+  o_pdf, o_ent, o_ids, o_onehot, o_sur = agent_np.action_selection(logits.astype(np.float64), z[:, 0:1].astype(np.float64),
+                                                                    is_train)
+  assert np.array_equal(ids, o_ids), (ids, o_ids)
+  if is_train:
+    assert ids[0] == -1
+  np.testing.assert_allclose(pdf, o_pdf, rtol=1e-5)
+  np.testing.assert_allclose(surrogate.detach().numpy(), o_sur, rtol=1e-4, atol=1e-6)
+  o_img = agent_np.apply_all_and_select(img.astype(np.float64), [p.astype(np.float64) for p in params], o_onehot)
+  np.testing.assert_allclose(out.detach().numpy(), o_img, rtol=1e-5, atol=1e-6)
+  o_states, o_usage, o_last, o_sub = agent_np.new_states(states.astype(np.float64), o_onehot)
+  assert np.array_equal(new_states.numpy(), o_states.astype(np.float32))
+  o_pen = agent_np.penalty(o_img, o_ent, o_usage, o_last, o_sub, 0.25)
+  np.testing.assert_allclose(penalty.detach().numpy(), o_pen, rtol=1e-4, atol=1e-6)
+
+
+def test_states_after_five_steps():
+  torch.manual_seed(1)
+  cfg = make_cfg()
+  ag = xagent.Agent(cfg)
+  img, states, z, _ = make_inputs(n=3, seed=2)
+  states[:] = 0
+  t = torch.from_numpy
+  cur, st = t(img), t(states)
+  used = np.zeros((3, 8))
+  with fake_hip(), torch.no_grad():
+    for k in range(5):
+      (cur, st, _, _), dbg, _ = ag((cur, t(z), st), is_train=0, progress=0.0)
+      used[np.arange(3), dbg['selected_filter_ids'].numpy()] = 1
+      done = float(k + 1 == cfg.test_steps)
+      assert np.array_equal(st[:, :3].numpy(), np.tile([[done, done, k + 1]], (3, 1)).astype(np.float32))
+      assert np.array_equal(st[:, 3:].numpy(), used.astype(np.float32))
+
+
+def test_high_res_path_uses_low_res_parameters():
+  torch.manual_seed(2)
+  cfg = make_cfg()
+  ag = xagent.Agent(cfg)
+  img, states, z, masks = make_inputs(n=2, seed=3)
+  hi = (np.random.default_rng(5).random((2, 96, 80, 3), dtype=np.float32)**2.2)
+  t = torch.from_numpy
+  with fake_hip(), torch.no_grad():
+    (low, new_states, high), dbg, _ = ag((t(img), t(z), t(states)), is_train=0, progress=0.0, high_res=t(hi),
+                                         dropout_masks=[t(m) for m in masks])
+  ids = dbg['selected_filter_ids'].numpy()
+  p24 = dbg['params24'].numpy()
+  for n in range(2):
+    fid = int(ids[n])
+    p = p24[n:n + 1, :fnp.NUM_PARAMS[fid]].astype(np.float64)
+    np.testing.assert_allclose(high[n:n + 1].numpy(), fnp.process_packed(fid, hi[n:n + 1].astype(np.float64), p),
+                               rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(low[n:n + 1].numpy(), fnp.process_packed(fid, img[n:n + 1].astype(np.float64), p),
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_gan_steps_run_and_update_only_their_parameters():
+  torch.manual_seed(3)
+  cfg = make_cfg()
+  gan = GAN(cfg)
+  img, states, z, masks = make_inputs(n=4, seed=4)
+  real = (np.random.default_rng(6).random((4, 64, 64, 3), dtype=np.float32))
+  t = torch.from_numpy
+  snap = lambda m: [p.detach().clone() for p in m.parameters()]
+  g0, v0, c0 = snap(gan.generator), snap(gan.value), snap(gan.critic)
+  with fake_hip():
+    out = gan.generator_step(t(img), t(z), t(states), progress=0.1, it=5, dropout_masks=[t(m) for m in masks])
+  assert np.isfinite(float(out['g_loss'])) and np.isfinite(float(out['v_loss']))
+  changed = lambda a, m: any(not torch.equal(x, y) for x, y in zip(a, m.parameters()))
+  assert changed(g0, gan.generator) and changed(v0, gan.value) and not changed(c0, gan.critic)
+  g1, v1 = snap(gan.generator), snap(gan.value)
+  with fake_hip():
+    out = gan.critic_step(t(real), t(img), t(z), t(states), progress=0.1, it=5)
+  assert np.isfinite(float(out['c_loss'])) and float(out['gradient_norm']) > 0
+  assert changed(c0, gan.critic) and not changed(g1, gan.generator) and not changed(v1, gan.value)
+  # iteration 0 runs the generator with lr_g = 0 (net.py:327-328)
+  g2 = snap(gan.generator)
+  with fake_hip():
+    gan.generator_step(t(img), t(z), t(states), progress=0.0, it=0)
+  assert not changed(g2, gan.generator)
+
+
+def test_lr_schedules():
+  cfg = make_cfg()
+  assert cfg.lr_g(0) == pytest.approx(0.3 * 5e-5)
+  assert cfg.lr_c(20000) == pytest.approx(5e-5 * 0.1**3)
+  assert cfg.lr_g(10000) == pytest.approx(0.3 * 5e-5 * 0.1**1.5)

@@ -1,0 +1,104 @@
+"""world_size-2 gloo test of the image-sharded data-parallel step: two CPU processes, each with
+half of the global minibatch, must end at the same weights as one process with the whole batch
+(losses are global-batch means; gradients are bucket-all-reduced).  The C-ABI binding is mocked by
+the oracle (tests/_fake_hip.py) because there is no GPU here."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _inputs(n=4, s=64):
+  rng = np.random.default_rng(0)
+  t = torch.from_numpy
+  img = t((rng.random((n, s, s, 3), dtype=np.float32)**2.2).astype(np.float32))
+  real = t(rng.random((n, s, s, 3), dtype=np.float32))
+  states = torch.zeros(n, 11)
+  states[:, 2] = t(rng.integers(0, 4, n).astype(np.float32))
+  z = t(rng.random((n, 131), dtype=np.float32))
+  masks = [t((rng.random((n, 4096)) < 0.5).astype(np.float32)) for _ in range(2)]
+  alpha = t(rng.random((n, 1, 1, 1), dtype=np.float32))
+  return img, real, states, z, masks, alpha
+
+
+def _run_steps(gan, img, real, states, z, masks, alpha):
+  from tests._fake_hip import fake_hip
+  with fake_hip():
+    g = gan.generator_step(img, z, states, progress=0.1, it=7, dropout_masks=masks)
+    c = gan.critic_step(real, img, z, states, progress=0.1, it=7, alpha=alpha, dropout_masks=masks)
+  return g, c
+
+
+def _worker(rank, world, port, out_dir):
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.set_num_threads(2)
+  from exposure_amd import dist as xdist
+  from exposure_amd.config import make_cfg
+  from exposure_amd.gan import GAN
+  torch.manual_seed(123)  # identical initial weights on every rank
+  gan = GAN(make_cfg())
+  img, real, states, z, masks, alpha = _inputs()
+  sh = xdist.shard
+  _run_steps(gan, sh(img), sh(real), sh(states), sh(z), [sh(m) for m in masks], sh(alpha))
+  torch.save({'params': [p.detach().clone() for p in gan.parameters()],
+              'grads': [p.grad.detach().clone() for p in gan.parameters()]}, os.path.join(out_dir, 'rank%d.pt' % rank))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_matches_single_process(tmp_path):
+  from exposure_amd.config import make_cfg
+  from exposure_amd.gan import GAN
+  torch.manual_seed(123)
+  ref = GAN(make_cfg())
+  _run_steps(ref, *_inputs())
+  port = _free_port()
+  mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
+  r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
+  for a, b in zip(r0['params'], r1['params']):
+    assert torch.equal(a, b)  # ranks stay in lock-step
+  # all-reduced mean gradients == full-batch gradients
+  for g, p in zip(r0['grads'], ref.parameters()):
+    scale = float(p.grad.abs().max()) + 1e-12
+    assert float((g - p.grad).abs().max()) <= 2e-4 * scale + 1e-9
+  # weights: Adam normalises each element's first step to ~lr, so a near-zero gradient whose sign
+  # differs by rounding can move a weight by up to 2 lr (lr_v = 10 lr_g ~ 1.5e-4)
+  worst = 0.0
+  for a, p in zip(r0['params'], ref.parameters()):
+    worst = max(worst, float((a - p.detach()).abs().max()))
+  assert worst < 3e-4, worst
+
+
+def test_shard_helpers_single_process():
+  from exposure_amd import dist as xdist
+  t = torch.arange(8)
+  assert xdist.world_size() == 1 and xdist.rank() == 0
+  assert torch.equal(xdist.shard(t), t)
+  b = xdist.GradBucket([torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2, 2))])
+  for p in b.params:
+    p.grad = torch.full_like(p, 2.0)
+  b.all_reduce_mean(None)
+  assert all(torch.equal(p.grad, torch.full_like(p, 2.0)) for p in b.params)
+  g1 = xdist.per_image_generator(1, 5, 'cpu')
+  g2 = xdist.per_image_generator(1, 5, 'cpu')
+  assert torch.equal(torch.rand(4, generator=g1), torch.rand(4, generator=g2))

@@ -1,0 +1,173 @@
+"""GPU parity of the fused per-image dispatch (one-hot select + over-exposure penalty), the
+per-image reductions, and the agent / GAN step running on the real HIP library."""
+import numpy as np
+import pytest
+import torch
+
+from exposure_amd import _cabi, agent as xagent, critics, filters, synthetic
+from exposure_amd.config import make_cfg
+from exposure_amd.gan import GAN
+from oracle import agent_np
+from oracle import filters_np as fnp
+from tests._tol import assert_image_close, assert_param_grad_close
+
+pytestmark = pytest.mark.gpu
+NP_DT = {torch.float16: np.float16, torch.float32: np.float32}
+
+
+def dispatch_case(seed, shape, np_dt):
+  rng = np.random.default_rng(seed)
+  n = shape[0]
+  x = synthetic.make_images(rng, shape, np_dt)
+  x *= np_dt(1.6)  # more over-exposed pixels so the penalty is exercised
+  dy = synthetic.make_grad(rng, shape, np_dt)
+  ids = rng.integers(-1, 8, n).astype(np.int32)
+  ids[:9] = np.arange(-1, 8)[:min(9, n)]  # every branch at least once
+  p24 = np.zeros((n, 24), dtype=np.float32)
+  for i, fid in enumerate(ids):
+    if fid >= 0:
+      p24[i, :fnp.NUM_PARAMS[fid]] = synthetic.make_params(rng, int(fid), 1)[0]
+  dpen = rng.standard_normal(n).astype(np.float32) * 50.0
+  return x, dy, ids, p24, dpen
+
+
+def dispatch_oracle(x, dy, ids, p24, dpen):
+  n = x.shape[0]
+  x64, dy64 = x.astype(np.float64), dy.astype(np.float64)
+  y = np.zeros_like(x64)
+  dx = np.zeros_like(x64)
+  dp = np.zeros((n, 24))
+  cnt = x.shape[1] * x.shape[2] * 3
+  for i, fid in enumerate(ids):
+    if fid < 0:
+      continue
+    p = p24[i:i + 1, :fnp.NUM_PARAMS[fid]].astype(np.float64)
+    y[i:i + 1] = fnp.process_packed(int(fid), x64[i:i + 1], p)
+    g = dy64[i:i + 1] + (2.0 * np.maximum(y[i:i + 1] - 1, 0) * dpen[i] / cnt if dpen is not None else 0.0)
+    gx, gp = fnp.backward_packed(int(fid), x64[i:i + 1], p, g)
+    dx[i:i + 1] = gx
+    dp[i, :fnp.NUM_PARAMS[fid]] = gp[0]
+  return y, agent_np.overexposure_penalty(y), dx, dp
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [(12, 64, 64, 3), (10, 9, 7, 3)])
+@pytest.mark.parametrize('with_pen', [True, False])
+def test_dispatch_matches_oracle(dtype, shape, with_pen, gpu_device):
+  dev = gpu_device
+  x, dy, ids, p24, dpen = dispatch_case(17, shape, NP_DT[dtype])
+  tx, tdy = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+  tid, tp = torch.from_numpy(ids).to(dev), torch.from_numpy(p24).to(dev)
+  y = torch.empty_like(tx)
+  pen = torch.full((shape[0],), -3.0, device=dev) if with_pen else None
+  _cabi.dispatch_fwd(tid, tx, y, tp, pen)
+  dx = torch.empty_like(tx)
+  dp = torch.full_like(tp, 9.0)
+  tdpen = torch.from_numpy(dpen).to(dev) if with_pen else None
+  _cabi.dispatch_bwd(tid, tx, tdy, dx, tp, dp, tdpen)
+  ry, rpen, rdx, rdp = dispatch_oracle(x, dy, ids, p24, dpen if with_pen else None)
+  assert_image_close(y.float().cpu().numpy(), ry, NP_DT[dtype], 'dispatch y')
+  assert_image_close(dx.float().cpu().numpy(), rdx, NP_DT[dtype], 'dispatch dx')
+  scale = np.abs(dy.astype(np.float64)).reshape(shape[0], -1).sum(axis=1, keepdims=True) * 4 + 50.0
+  assert_param_grad_close(dp.cpu().numpy(), rdp, np.broadcast_to(scale, rdp.shape), 'dispatch dparams')
+  if with_pen:
+    np.testing.assert_allclose(pen.cpu().numpy(), rpen, rtol=2e-4, atol=1e-7)
+  # id -1: y == 0, dx == 0, dparams == 0
+  sel = ids < 0
+  assert sel.any()
+  assert float(y[torch.from_numpy(sel).to(dev)].abs().max()) == 0.0
+  assert float(dp[torch.from_numpy(sel).to(dev)].abs().max()) == 0.0
+
+
+def test_dispatch_autograd_matches_per_filter(gpu_device):
+  dev = gpu_device
+  x, dy, ids, p24, _ = dispatch_case(23, (9, 32, 32, 3), np.float32)
+  tx = torch.from_numpy(x).to(dev).requires_grad_(True)
+  tp = torch.from_numpy(p24).to(dev).requires_grad_(True)
+  y, pen = filters.dispatch_filters(tx, tp, torch.from_numpy(ids).to(dev))
+  w = torch.linspace(-1, 1, 9, device=dev)
+  ((y * torch.from_numpy(dy).to(dev)).sum() + (pen * w).sum()).backward()
+  ry, rpen, rdx, rdp = dispatch_oracle(x, dy, ids, p24, w.cpu().numpy())
+  assert_image_close(tx.grad.cpu().numpy(), rdx, np.float32)
+  np.testing.assert_allclose(pen.detach().cpu().numpy(), rpen, rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [(5, 64, 64, 3), (3, 7, 5, 3), (2, 512, 512, 3)])
+def test_critic_stats_and_penalty(dtype, shape, gpu_device):
+  dev = gpu_device
+  rng = np.random.default_rng(3)
+  x = (synthetic.make_images(rng, shape, NP_DT[dtype]) * NP_DT[dtype](1.5))
+  tx = torch.from_numpy(x).to(dev)
+  stats = critics.critic_stats(tx)
+  ref = agent_np.critic_stats(x.astype(np.float64))
+  np.testing.assert_allclose(stats.cpu().numpy(), ref, rtol=2e-4, atol=2e-6)
+  # the differentiable torch statistics the critic uses in training agree too
+  np.testing.assert_allclose(critics.stat_features(tx).cpu().numpy(), ref, rtol=2e-4, atol=2e-6)
+  pen = torch.empty(shape[0], device=dev)
+  _cabi.overexposure_penalty(tx, pen)
+  np.testing.assert_allclose(pen.cpu().numpy(), agent_np.overexposure_penalty(x.astype(np.float64)), rtol=2e-4,
+                             atol=1e-8)
+
+
+def test_agent_step_on_gpu_matches_oracle(gpu_device):
+  dev = gpu_device
+  torch.manual_seed(0)
+  cfg = make_cfg()
+  ag = xagent.Agent(cfg).to(dev)
+  rng = np.random.default_rng(1)
+  n = 16
+  img = synthetic.make_images(rng, (n, 64, 64, 3), np.float16)
+  states = np.zeros((n, 11), dtype=np.float32)
+  states[:, 2] = rng.integers(0, 5, n)
+  states[:, 3:] = rng.random((n, 8)) < 0.3
+  z = rng.random((n, 131), dtype=np.float32)
+  z[0, 0] = 0.0
+  masks = [torch.from_numpy((rng.random((n, 4096)) < 0.5).astype(np.float32)).to(dev) for _ in range(2)]
+  t = lambda a: torch.from_numpy(a).to(dev)
+  (out, new_states, surrogate, penalty), dbg, _ = ag((t(img), t(z), t(states)), is_train=1, progress=0.3,
+                                                    dropout_masks=masks)
+  ids = dbg['selected_filter_ids'].cpu().numpy()
+  pdf = dbg['pdf_batch'].detach().cpu().numpy().astype(np.float64)
+  # integer outputs: bit-identical to the numpy restatement fed the same pdf and noise
+  o_ids = agent_np.pdf_sample(pdf.astype(np.float32), z[:, 0:1])
+  assert np.array_equal(ids, o_ids) and ids[0] == -1
+  onehot = (ids[:, None] == np.arange(8)[None, :]).astype(np.float64)
+  p24 = dbg['params24'].detach().cpu().numpy()
+  params = [p24[:, :fnp.NUM_PARAMS[f]].astype(np.float64) for f in range(8)]
+  ref_img = np.zeros((n, 64, 64, 3))
+  for i in range(n):
+    if ids[i] >= 0:
+      ref_img[i:i + 1] = fnp.process_packed(int(ids[i]), img[i:i + 1].astype(np.float64), params[ids[i]][i:i + 1])
+  assert out.dtype == torch.float16
+  assert_image_close(out.float().cpu().numpy(), ref_img, np.float16, 'agent out')
+  o_states, o_usage, o_last, o_sub = agent_np.new_states(states.astype(np.float64), onehot)
+  assert np.array_equal(new_states.cpu().numpy(), o_states.astype(np.float32))
+  ent = -(pdf * np.log(pdf)).sum(axis=1, keepdims=True)
+  # the fused penalty is computed on the fp32 filter output before the fp16 rounding
+  o_pen = agent_np.penalty(ref_img, ent, o_usage, o_last, o_sub, 0.3)
+  np.testing.assert_allclose(penalty.detach().cpu().numpy(), o_pen, rtol=1e-3, atol=1e-5)
+
+
+def test_gan_steps_on_gpu(gpu_device):
+  dev = gpu_device
+  torch.manual_seed(0)
+  cfg = make_cfg()
+  gan = GAN(cfg, device=dev)
+  rng = np.random.default_rng(2)
+  n = cfg.batch_size
+  t = lambda a: torch.from_numpy(a).to(dev)
+  img = t(synthetic.make_images(rng, (n, 64, 64, 3), np.float16))
+  real = t(synthetic.make_images(rng, (n, 64, 64, 3), np.float16))
+  states = torch.zeros(n, 11, device=dev)
+  z = t(rng.random((n, 131), dtype=np.float32))
+  c0 = [p.detach().clone() for p in gan.critic.parameters()]
+  g0 = [p.detach().clone() for p in gan.generator.parameters()]
+  out = gan.generator_step(img, z, states, progress=0.1, it=3)
+  assert torch.isfinite(out['g_loss']) and torch.isfinite(out['v_loss'])
+  assert out['fake_output'].dtype == torch.float16 and out['fake_output'].shape == img.shape
+  assert any(not torch.equal(a, b) for a, b in zip(g0, gan.generator.parameters()))
+  assert all(torch.equal(a, b) for a, b in zip(c0, gan.critic.parameters()))
+  out = gan.critic_step(real, img, z, states, progress=0.1, it=3)
+  assert torch.isfinite(out['c_loss']) and float(out['gradient_norm']) > 0
+  assert any(not torch.equal(a, b) for a, b in zip(c0, gan.critic.parameters()))
