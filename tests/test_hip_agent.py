@@ -140,7 +140,7 @@ def test_agent_step_on_gpu_matches_oracle(gpu_device):
     if ids[i] >= 0:
       ref_img[i:i + 1] = fnp.process_packed(int(ids[i]), img[i:i + 1].astype(np.float64), params[ids[i]][i:i + 1])
   assert out.dtype == torch.float16
-  assert_image_close(out.float().cpu().numpy(), ref_img, np.float16, 'agent out')
+  assert_image_close(out.detach().float().cpu().numpy(), ref_img, np.float16, 'agent out')
   o_states, o_usage, o_last, o_sub = agent_np.new_states(states.astype(np.float64), onehot)
   assert np.array_equal(new_states.cpu().numpy(), o_states.astype(np.float32))
   ent = -(pdf * np.log(pdf)).sum(axis=1, keepdims=True)
