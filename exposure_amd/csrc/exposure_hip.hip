@@ -33,10 +33,43 @@ namespace expo {
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 
-__device__ __forceinline__ float wave_sum(float v) {
+// Wave-level "reduce-scatter" butterfly for N accumulators: at each xor step a lane keeps half of
+// its values and adds the partner's copy of that half, so the 6 steps cost ~N shuffles in total
+// (27 -> 14+7+4+2+1+1 = 29) instead of 6 N.  On return lane l holds, in acc[0], the wave total of
+// accumulator index reduce_index<N>(l) (valid if < N); lanes l and l^1 hold the same value.
+template <int N, int M>
+__device__ __forceinline__ void reduce_scatter_step(float* acc, int lane) {
+  constexpr int H = (N + 1) / 2;
+  const bool upper = (lane & M) != 0;
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  for (int j = 0; j < H; ++j) {
+    const float lo = acc[j];
+    const float hi = (j + H < N) ? acc[j + H] : 0.0f;
+    const float keep = upper ? hi : lo;
+    const float send = upper ? lo : hi;
+    acc[j] = keep + __shfl_xor(send, M, 64);
+  }
+}
+template <int N>
+__device__ __forceinline__ int wave_reduce_scatter(float* acc, int lane) {
+  constexpr int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
+  static_assert(n5 == 1, "at most 32 accumulators");
+  if constexpr (N > 1) reduce_scatter_step<N, 32>(acc, lane); else acc[0] += __shfl_xor(acc[0], 32, 64);
+  if constexpr (n1 > 1) reduce_scatter_step<n1, 16>(acc, lane); else acc[0] += __shfl_xor(acc[0], 16, 64);
+  if constexpr (n2 > 1) reduce_scatter_step<n2, 8>(acc, lane); else acc[0] += __shfl_xor(acc[0], 8, 64);
+  if constexpr (n3 > 1) reduce_scatter_step<n3, 4>(acc, lane); else acc[0] += __shfl_xor(acc[0], 4, 64);
+  if constexpr (n4 > 1) reduce_scatter_step<n4, 2>(acc, lane); else acc[0] += __shfl_xor(acc[0], 2, 64);
+  acc[0] += __shfl_xor(acc[0], 1, 64);
+  // Which accumulator does this lane's surviving slot 0 hold?  Walk the halvings backwards; a slot
+  // that was padding at any level (odd split) is invalid (-1).
+  int l = 0;
+  bool ok = true;
+  if constexpr (n4 > 1) { l += (lane & 2) ? n5 : 0; ok = ok && l < n4; }
+  if constexpr (n3 > 1) { l += (lane & 4) ? n4 : 0; ok = ok && l < n3; }
+  if constexpr (n2 > 1) { l += (lane & 8) ? n3 : 0; ok = ok && l < n2; }
+  if constexpr (n1 > 1) { l += (lane & 16) ? n2 : 0; ok = ok && l < n1; }
+  if constexpr (N > 1) { l += (lane & 32) ? n1 : 0; ok = ok && l < N; }
+  return ok ? l : -1;
 }
 
 // Block-reduce NACC accumulators, finish them to NOUT outputs, add atomically to out[].
@@ -45,11 +78,8 @@ __device__ __forceinline__ void block_reduce_atomic(float* acc, float* __restric
   __shared__ float red[kWaves][NACC];
   __shared__ float tot[NACC];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < NACC; ++j) {
-    const float s = wave_sum(acc[j]);
-    if (lane == 0) red[wv][j] = s;
-  }
+  const int idx = wave_reduce_scatter<NACC>(acc, lane);
+  if ((lane & 1) == 0 && idx >= 0) red[wv][idx] = acc[0];
   __syncthreads();
   if (threadIdx.x < NACC) {
     float s = 0.f;
@@ -132,20 +162,28 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   for (int j = 0; j < F::NACC; ++j) acc[j] = 0.f;
   const int stride = gridDim.x * kThreads;
   auto compute = [&](float* v, float* d, int g) {
+    if constexpr (PEN) {
+      // fused over-exposure penalty: dy += 2 max(y-1,0) * dpen / (H W 3)
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) {
-      float dx[3];
-      if constexpr (PEN) {
-        // fused over-exposure penalty: dy += 2 max(y-1,0) * dpen / (H W 3)
+      for (int k = 0; k < PPL; ++k) {
         float y[3];
         F::fwd(q, v + 3 * k, y);
 #pragma unroll
         for (int c = 0; c < 3; ++c)  // padding pixels: y = f(0) <= 1 -> no contribution
           d[3 * k + c] = fmaf(fmaxf(y[c] - 1.0f, 0.0f), pen_scale, d[3 * k + c]);
       }
-      F::bwd(q, lut, v + 3 * k, d + 3 * k, dx, acc, MODE);
+    }
+    if constexpr (F::kHasGroupBwd) {
+      // with the fused penalty dy is no longer an fp16 value -> use the generic fp32 accumulation
+      F::template bwd_group<PPL, std::is_same<T, half_t>::value && !PEN>(q, lut, v, d, acc);
+    } else {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) d[3 * k + c] = dx[c];
+      for (int k = 0; k < PPL; ++k) {
+        float dx[3];
+        F::bwd(q, lut, v + 3 * k, d + 3 * k, dx, acc, MODE);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[3 * k + c] = dx[c];
+      }
     }
   };
   if constexpr (VEC) {

@@ -42,6 +42,7 @@ __device__ __forceinline__ float lum3(const float x[3]) {
 // ---------------------------------------------------------------------------------
 struct ExposureF {
   static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr bool kHasGroupBwd = false;
   struct Prm { float s; };
   __device__ static Prm load(const float* __restrict__ p) { return {exp2f(p[0])}; }
   __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
@@ -65,6 +66,7 @@ struct ExposureF {
 // ---------------------------------------------------------------------------------
 struct GammaF {
   static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr bool kHasGroupBwd = false;
   struct Prm { float g; };
   __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
   __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
@@ -92,6 +94,7 @@ struct GammaF {
 // ---------------------------------------------------------------------------------
 struct WhiteBalanceF {
   static constexpr int NP = 3, NACC = 3, kLutFloats = 0, kMinWaves = 1;
+  static constexpr bool kHasGroupBwd = false;
   struct Prm { float s[3]; };
   __device__ static Prm load(const float* __restrict__ p) { return {{p[0], p[1], p[2]}}; }
   __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
@@ -119,6 +122,7 @@ struct WhiteBalanceF {
 // ---------------------------------------------------------------------------------
 struct SatPlusF {
   static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr bool kHasGroupBwd = false;
   struct Prm { float p; };
   __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
 
@@ -273,7 +277,6 @@ struct CurveF {
       const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
       const float4_lut e = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
       const float t = fmaf(fmaf(jf, -1.0f / L, xc), e.x, e.z);
-      const float y = t * q.scale[cc];
       // inside: 0 <= x <= 1  <=>  clamp(x) == x.   knot: L x is an integer in [1, L-1]; the test
       // (cu - 1 == jf) accepts L x in [1, L] and the LUT's k_L := 0 makes L x == L contribute 0.
       const bool inside = (xc == xv);
@@ -284,18 +287,74 @@ struct CurveF {
 #pragma unroll
       for (int i = 1; i < L; ++i) a[i - 1] = fmaf(g, fminf(xc, float(i) / L), a[i - 1]);
       a[L - 1] = fmaf(g, xc, a[L - 1]);
-      a[L] = fmaf(g, y, a[L]);
+      a[L] = fmaf(g, t, a[L]);
     }
   }
-  // a[] per curve: Q_1..Q_L, B.  dk_i = scale (Q_{i+1} - Q_i) - B / S,  Q_0 = 0
+  // Group backward (PPL pixels at once).  F16X: the inputs are exactly representable in fp16
+  // (fp16 storage), so the eight accumulator updates Q_i += dy * min(x^, i/8) of TWO pixels run
+  // as one v_pk_min_f16 + one v_dot2c_f32_f16 (fp16 x fp16 products are exact in fp32): 17 VALU
+  // per element pair instead of 32.  Everything else (LUT, dx, B) stays fp32 per element.
+  static constexpr bool kHasGroupBwd = true;
+  template <int PPL, bool F16X>
+  __device__ static void bwd_group(const Prm& q, const float* lut, const float* x, float* d, float acc[NACC]) {
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    static_assert(PPL % 2 == 0, "pixels are processed in pairs");
+#pragma unroll
+    for (int k = 0; k < PPL; k += 2) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int cc = (NC == 1) ? 0 : c;
+        float* a = acc + cc * (L + 1);
+        const float xA = x[3 * k + c], xB = x[3 * k + 3 + c];
+        const float gA = d[3 * k + c], gB = d[3 * k + 3 + c];
+        if constexpr (F16X) {
+          const half2_t x2 = {_Float16(xA), _Float16(xB)};  // exact: values came from fp16 storage
+          const half2_t g2 = {_Float16(gA), _Float16(gB)};
+          const half2_t z2 = {_Float16(0.f), _Float16(0.f)};
+          const half2_t xp = __builtin_elementwise_max(x2, z2);
+#pragma unroll
+          for (int i = 1; i <= L; ++i) {
+            const half2_t t2 = {_Float16(float(i) / L), _Float16(float(i) / L)};
+            a[i - 1] = __builtin_amdgcn_fdot2(g2, __builtin_elementwise_min(xp, t2), a[i - 1], false);
+          }
+        } else {
+          const float xcA = clamp01x(xA, 0.0f, 1.0f), xcB = clamp01x(xB, 0.0f, 1.0f);
+#pragma unroll
+          for (int i = 1; i < L; ++i) {
+            a[i - 1] = fmaf(gA, fminf(xcA, float(i) / L), a[i - 1]);
+            a[i - 1] = fmaf(gB, fminf(xcB, float(i) / L), a[i - 1]);
+          }
+          a[L - 1] = fmaf(gA, xcA, a[L - 1]);
+          a[L - 1] = fmaf(gB, xcB, a[L - 1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float xv = e ? xB : xA, g = e ? gB : gA;
+          const float xc = clamp01x(xv, 0.0f, 1.0f);
+          const float u = xv * float(L);  // exact
+          const float cu = ceilf(u);
+          const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
+          const float4_lut en = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
+          const float t = fmaf(fmaf(jf, -1.0f / L, xc), en.x, en.z);
+          const bool inside = (xc == xv);
+          const bool knot = (cu == u) && (cu - 1.0f == jf);
+          const float slope = (inside ? en.x : 0.0f) + (knot ? en.y : 0.0f);
+          a[L] = fmaf(g, t, a[L]);  // sum dy * T  (B = scale * this)
+          d[3 * (k + e) + c] = g * q.scale[cc] * slope;
+        }
+      }
+    }
+  }
+  // a[] per curve: Q_1..Q_L, sum dy*T.  dk_i = scale (Q_{i+1} - Q_i) - scale * a[L] / S,  Q_0 = 0
   __device__ static float finish_one(const float* __restrict__ p, const float* a, int j) {
     const int c = j / L, i = j % L;
     float S = 0.f;
     for (int t = 0; t < L; ++t) S += p[c * L + t];
     S += 1e-30f;
+    const float scale = float(L) / S;
     const float* ac = a + c * (L + 1);
     const float qi = (i == 0) ? 0.0f : ac[i - 1];
-    return (float(L) / S) * (ac[i] - qi) - ac[L] / S;
+    return scale * (ac[i] - qi) - scale * ac[L] / S;
   }
 };
 using ToneF = CurveF<1>;
@@ -308,6 +367,7 @@ using ColorF = CurveF<3>;
 // ---------------------------------------------------------------------------------
 struct ContrastF {
   static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr bool kHasGroupBwd = false;
   struct Prm { float p; };
   __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
   __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
@@ -345,6 +405,7 @@ struct ContrastF {
 // ---------------------------------------------------------------------------------
 struct WnbF {
   static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr bool kHasGroupBwd = false;
   struct Prm { float p; };
   __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
   __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
