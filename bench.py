@@ -45,6 +45,9 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-per-kernel', action='store_true')
   ap.add_argument('--seed', type=int, default=1234)
+  ap.add_argument('--workload', default='chain', choices=['chain', 'train'],
+                  help="chain: the headline filter-chain metric; train: one reference training iteration "
+                  "(1 generator/value step + cfg.citers critic steps, net.py:307-365) on 64 images per GPU")
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                   help='replay the 17 launches of a step from one hipGraph (auto: on for launch-bound small shapes)')
   return ap.parse_args()
@@ -184,6 +187,75 @@ def load_traffic(kernel):
     return None
 
 
+def run_train(args, world, rank, dev, dist):
+  """BASELINE configs 3/4: agent rollout step + policy CNN + WGAN-GP critic, batch 64 per GPU,
+  random-init weights, synthetic FiveK-shaped inputs, gradients all-reduced over RCCL."""
+  from exposure_amd.config import make_cfg
+  from exposure_amd.gan import GAN
+  cfg = make_cfg()
+  torch.manual_seed(args.seed)  # identical initial weights on every rank
+  gan = GAN(cfg, device=dev)
+  n = cfg.batch_size
+  g = torch.Generator(device=dev).manual_seed(args.seed + 1 + rank)
+  img = ((torch.rand((n, 64, 64, 3), device=dev, generator=g)**2.2) * (1.0 / 0.99**2.2)).half()
+  real = torch.rand((n, 64, 64, 3), device=dev, generator=g).half()
+  states = torch.zeros((n, cfg.num_state_dim), device=dev)
+  z = torch.rand((n, cfg.z_dim), device=dev, generator=g)
+
+  def iteration(it):
+    out = gan.generator_step(img, z, states, progress=0.1, it=it)
+    for _ in range(cfg.citers):
+      gan.critic_step(real, img, z, states, progress=0.1, it=it)
+    return out
+
+  def barrier():
+    if dist is not None:
+      dist.barrier()
+
+  for i in range(args.warmup):
+    iteration(i + 1)
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    iteration(i + 1)
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  if rank == 0:
+    ms = elapsed / args.steps * 1e3
+    print(json.dumps({
+        'metric': 'generator-step images/s (1 G/V step + %d critic steps per iteration)' % cfg.citers,
+        'value': world * n / (elapsed / args.steps),
+        'unit': 'images/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': ms,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f16 images / f32 nets',
+        'data': 'synthetic',
+        'config': {
+            'workload': 'reference training iteration (net.py:307-365): agent rollout step, policy CNN, value net, '
+                        'WGAN-GP critic; batch %d x 64x64x3 per GPU; random-init weights' % n,
+            'global_batch': world * n,
+            'parallelism': 'dp%d image-sharded, 3 flat gradient buckets over RCCL' % world,
+            'reference_note': 'README.md:43: ~0.30 s/iteration on a GTX 1080 Ti (whole run ~100 min / 20000 it)',
+        },
+    }))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
   args = parse()
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -199,6 +271,8 @@ def main():
     dist.init_process_group('nccl', device_id=dev)
   if args.gpus != world and rank == 0:
     print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+  if args.workload == 'train':
+    return run_train(args, world, rank, dev, dist)
 
   shape = synthetic.SHAPES[args.shape] if args.shape in synthetic.SHAPES else tuple(
       int(v) for v in args.shape.split(',')) + (3,)

@@ -106,6 +106,9 @@ class Agent(nn.Module):
     for fc in (self.selector_fc1, self.selector_fc2):
       nn.init.xavier_uniform_(fc.weight)
       nn.init.zeros_(fc.bias)
+    # position in cfg.filters -> C-ABI filter id (they differ when cfg.filters is a subset/reorder)
+    self.register_buffer('abi_filter_ids', torch.tensor([f.filter_id for f in self.filters], dtype=torch.int32),
+                         persistent=False)
 
   def regress_all(self, filter_features):
     """Per-filter FC heads + range squashing -> list of reference-shaped parameter tensors."""
@@ -154,10 +157,12 @@ class Agent(nn.Module):
       params24 = params24 + torch.nn.functional.pad(pj, (0, F._cabi.EXPO_MAX_PARAMS - pj.shape[1])) * \
           filter_one_hot[:, j:j + 1]
     hsv_mode = int(cfg.get('hsv_grad_mode', 0))
-    out, overexposure = F.dispatch_filters(net, params24, selected_filter_id, hsv_mode)
+    abi_ids = torch.where(selected_filter_id >= 0, self.abi_filter_ids[selected_filter_id.clamp_min(0).long()],
+                          torch.full_like(selected_filter_id, -1))
+    out, overexposure = F.dispatch_filters(net, params24, abi_ids, hsv_mode)
     high_res_output = None
     if high_res is not None:
-      high_res_output, _ = F.dispatch_filters(high_res, params24, selected_filter_id, hsv_mode)
+      high_res_output, _ = F.dispatch_filters(high_res, params24, abi_ids, hsv_mode)
 
     debug_info = {
         'state': states,
@@ -166,6 +171,7 @@ class Agent(nn.Module):
         'pdf': pdf[0],
         # batched extras (not in the reference dict; used by tests / the eval loop)
         'selected_filter_ids': selected_filter_id,
+        'abi_filter_ids': abi_ids,
         'pdf_batch': pdf,
         'params24': params24,
     }

@@ -1,0 +1,63 @@
+"""High-resolution inference loop (``/root/reference/net.py:711-821``, ``evaluate.py:8-31``).
+
+Per image: a 64x64 proxy is made from the full-resolution picture (``net.py:779``: bilinear resize
+of the centre crop), and for ``cfg.test_steps`` (= 5) steps the agent regresses parameters and picks
+a filter on the PROXY while the same per-image parameters are applied to BOTH the proxy and the
+full-resolution tensor (``filters.py:88-96``; ``agent.py:124-129``), feeding both outputs back
+(``net.py:796-821``).  ``is_train = 0`` -> the action is ``argmax(pdf)`` (``agent.py:114-116``);
+dropout stays on, as in the reference (``agent.py:36``), unless masks are passed.
+
+Image decoding (16-bit TIFF / ProPhoto linearisation, ``util.py:311-323, 495-501``) and the PNG /
+pickle outputs of ``net.py:825-877`` are file I/O, out of scope: this function works on tensors.
+"""
+import torch
+
+from .util import STATE_STOPPED_DIM
+
+
+def linearize_ProPhotoRGB(pp_rgb):
+  """util.py:495-501 as used by net.py:733 (``reverse=False``): gamma 1.8 decode."""
+  return pp_rgb**1.8
+
+
+def get_image_center(image):
+  """util.py:160-167: the largest centred square (NHWC)."""
+  h, w = image.shape[1], image.shape[2]
+  if h > w:
+    o = (h - w) // 2
+    return image[:, o:o + w]
+  o = (w - h) // 2
+  return image[:, :, o:o + h]
+
+
+def make_low_res(high_res, size):
+  """net.py:779: cv2.resize(get_image_center(hi), (size, size)) -- bilinear, half-pixel centres."""
+  c = get_image_center(high_res).permute(0, 3, 1, 2).float()
+  low = torch.nn.functional.interpolate(c, size=(size, size), mode='bilinear', align_corners=False,
+                                        antialias=False)
+  return low.permute(0, 2, 3, 1).contiguous().to(high_res.dtype)
+
+
+@torch.no_grad()
+def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trace=False):
+  """Run the 5-step retouching loop.  ``high_res``: NHWC device tensor (fp16/fp32), linear RGB.
+  Returns (retouched_high_res, retouched_low_res, states[, trace of selected filter ids])."""
+  cfg = agent.cfg
+  steps = steps or cfg.test_steps
+  n = high_res.shape[0]
+  dev = high_res.device
+  low = make_low_res(high_res, cfg.source_img_size)
+  states = torch.zeros((n, cfg.num_state_dim), dtype=torch.float32, device=dev)  # get_initial_states
+  if z is None:
+    z = torch.rand((n, cfg.z_dim), device=dev)
+  trace = []
+  hi = high_res.contiguous()
+  for i in range(steps):
+    masks = dropout_masks[i] if dropout_masks is not None else None
+    (low, states, hi), dbg, _ = agent((low, z, states), is_train=0, progress=0.0, high_res=hi, dropout_masks=masks)
+    trace.append(dbg['selected_filter_ids'].clone())
+    if bool((states[:, STATE_STOPPED_DIM] > 0).all()):
+      break
+  if return_trace:
+    return hi, low, states, torch.stack(trace, dim=1)
+  return hi, low, states

@@ -146,3 +146,36 @@ def test_lr_schedules():
   assert cfg.lr_g(0) == pytest.approx(0.3 * 5e-5)
   assert cfg.lr_c(20000) == pytest.approx(5e-5 * 0.1**3)
   assert cfg.lr_g(10000) == pytest.approx(0.3 * 5e-5 * 0.1**1.5)
+
+
+def test_evaluate_loop_two_filter_config():
+  """BASELINE config 1 plumbing: cfg.filters = [Exposure, Gamma], one image, 5 steps, CPU-only."""
+  from exposure_amd import evaluate, filters
+  torch.manual_seed(4)
+  cfg = make_cfg(filters=[filters.GammaFilter, filters.ExposureFilter])  # reordered on purpose
+  assert cfg.num_state_dim == 5
+  ag = xagent.Agent(cfg)
+  assert ag.abi_filter_ids.tolist() == [1, 0]
+  hi = torch.from_numpy((np.random.default_rng(7).random((1, 96, 128, 3), dtype=np.float32)**2.2))
+  masks = [[(torch.rand(1, 4096) < 0.5).float() for _ in range(2)] for _ in range(5)]
+  z = torch.rand(1, cfg.z_dim)
+  with fake_hip():
+    out_hi, out_lo, states, trace = evaluate.retouch(ag, hi, z=z, dropout_masks=masks, return_trace=True)
+  assert out_hi.shape == hi.shape and out_lo.shape == (1, 64, 64, 3)
+  assert trace.shape == (1, 5)
+  assert states[0, :3].tolist() == [1.0, 1.0, 5.0]
+  # replay the trace with the oracle: parameters come from the low-res proxy, applied to high-res
+  lo = evaluate.make_low_res(hi, 64)
+  st = torch.zeros(1, 5)
+  ref_hi = hi.numpy().astype(np.float64)
+  with fake_hip(), torch.no_grad():
+    for i in range(5):
+      (lo2, st2, _), dbg, _ = ag((lo, z, st), is_train=0, progress=0.0, high_res=torch.from_numpy(ref_hi).float(),
+                                 dropout_masks=masks[i])
+      j = int(dbg['selected_filter_ids'][0])
+      assert j == int(trace[0, i])
+      fid = int(ag.abi_filter_ids[j])
+      p = dbg['params24'][:, :fnp.NUM_PARAMS[fid]].numpy().astype(np.float64)
+      ref_hi = fnp.process_packed(fid, ref_hi, p)
+      lo, st = lo2, st2
+  np.testing.assert_allclose(out_hi.numpy(), ref_hi, rtol=2e-5, atol=2e-6)
