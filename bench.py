@@ -45,6 +45,8 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-per-kernel', action='store_true')
   ap.add_argument('--seed', type=int, default=1234)
+  ap.add_argument('--order', default='0,1,2,3,4,5,6,7', help='filter ids of the chain steps (experiments only; the '
+                  'metric is defined on the cfg.filters order 0..7)')
   ap.add_argument('--workload', default='chain', choices=['chain', 'train'],
                   help="chain: the headline filter-chain metric; train: one reference training iteration "
                   "(1 generator/value step + cfg.citers critic steps, net.py:307-365) on 64 images per GPU")
@@ -67,9 +69,10 @@ def make_device_case(shape, dtype, dev, seed):
 class Chain:
   """Buffers + one-call-per-direction launch of the 8-step chain (expo_chain_fwd / expo_chain_bwd)."""
 
-  def __init__(self, shape, dtype, dev, seed):
-    self.ids = list(range(8))
-    x, dy, self.params = make_device_case(shape, dtype, dev, seed)
+  def __init__(self, shape, dtype, dev, seed, ids=None):
+    self.ids = list(ids) if ids is not None else list(range(8))
+    x, dy, params = make_device_case(shape, dtype, dev, seed)
+    self.params = [params[i] for i in self.ids]
     self.acts = [x] + [torch.empty_like(x) for _ in range(8)]
     # gradients ping-pong between two buffers; grads[8] = upstream dy
     ga, gb = torch.empty_like(x), torch.empty_like(x)
@@ -108,29 +111,36 @@ class Chain:
 
 
 def time_kernels(chain, reps):
-  """Average duration (ms) of each of the 16 kernels, HIP events on the launch stream."""
+  """Average duration (ms) of each of the 16 kernels measured IN the chain sequence (so every
+  kernel sees the cache state it sees in the timed region: each step writes a fresh 96 MiB tensor),
+  with a HIP event pair around every launch on the launch stream.  These agree with the
+  per-kernel averages of `rocprofv3 --kernel-trace --stats` for the same command."""
+  ids = chain.ids
+  nsteps = len(ids)
+  names = ['fwd_' + FILTER_NAMES[i] for i in ids] + ['bwd_' + FILTER_NAMES[i] for i in reversed(ids)]
+  ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in names]
+        for _ in range(reps)]
+  for r in range(-2, reps):  # two untimed passes first
+    k = 0
+    for i in range(nsteps):
+      if r >= 0:
+        ev[r][k][0].record()
+      _cabi.filter_fwd(ids[i], chain.acts[i], chain.acts[i + 1], chain.params[i])
+      if r >= 0:
+        ev[r][k][1].record()
+      k += 1
+    for i in reversed(range(nsteps)):
+      if r >= 0:
+        ev[r][k][0].record()
+      _cabi.filter_bwd(ids[i], chain.acts[i], chain.grads[i + 1], chain.grads[i], chain.params[i], chain.dparams[i],
+                       accumulate=True)  # kernel only: the chain zero-fills all dparams once per step
+      if r >= 0:
+        ev[r][k][1].record()
+      k += 1
+  torch.cuda.synchronize()
   out = {}
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  for i in range(8):
-    x, y, p = chain.acts[i], chain.acts[i + 1], chain.params[i]
-    for _ in range(3):
-      _cabi.filter_fwd(i, x, y, p)
-    ev0.record()
-    for _ in range(reps):
-      _cabi.filter_fwd(i, x, y, p)
-    ev1.record()
-    torch.cuda.synchronize()
-    out['fwd_' + FILTER_NAMES[i]] = ev0.elapsed_time(ev1) / reps
-  for i in range(8):
-    x, dy, dx, p, dp = chain.acts[i], chain.grads[i + 1], chain.grads[i], chain.params[i], chain.dparams[i]
-    for _ in range(3):
-      _cabi.filter_bwd(i, x, dy, dx, p, dp)
-    ev0.record()
-    for _ in range(reps):
-      _cabi.filter_bwd(i, x, dy, dx, p, dp)
-    ev1.record()
-    torch.cuda.synchronize()
-    out['bwd_' + FILTER_NAMES[i]] = ev0.elapsed_time(ev1) / reps  # includes the tiny dparams memset
+  for k, name in enumerate(names):
+    out[name] = sum(ev[r][k][0].elapsed_time(ev[r][k][1]) for r in range(reps)) / reps
   return out
 
 
@@ -278,7 +288,7 @@ def main():
       int(v) for v in args.shape.split(',')) + (3,)
   dtype = torch.float16 if args.dtype == 'f16' else torch.float32
   esz = 2 if args.dtype == 'f16' else 4
-  chain = Chain(shape, dtype, dev, args.seed + rank)
+  chain = Chain(shape, dtype, dev, args.seed + rank, [int(v) for v in args.order.split(',')])
   px = shape[0] * shape[1] * shape[2]
   use_graph = args.graph == 'on' or (args.graph == 'auto' and px * 3 * esz < (32 << 20))
   if use_graph:

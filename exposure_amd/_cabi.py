@@ -30,6 +30,7 @@ SIGNATURES = {
     'expo_num_filter_params': (_i, [_i]),
     'expo_filter_fwd': (_i, [_i, _vp, _vp, _fp, _i, _i, _i, _i, _vp]),
     'expo_filter_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    'expo_filter_bwd_accumulate': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     'expo_filter_dispatch_fwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
     'expo_filter_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
@@ -123,7 +124,7 @@ def filter_fwd(fid, x, y, params):
            'expo_filter_fwd')
 
 
-def filter_bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0):
+def filter_bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0, accumulate=False):
   lib = load()
   _img(x, 'x'), _img(dy, 'dy')
   n, h, w, _ = x.shape
@@ -133,10 +134,10 @@ def filter_bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0):
     assert dx.shape == x.shape and dx.dtype == x.dtype
   _f32(params, 'params', (n, NUM_PARAMS[fid]))
   _f32(dparams, 'dparams', (n, NUM_PARAMS[fid]))
+  fn = lib.expo_filter_bwd_accumulate if accumulate else lib.expo_filter_bwd
   with torch.cuda.device(x.device):
-    _check(
-        lib.expo_filter_bwd(fid, _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams), n, h, w,
-                            _dtype_code(x), hsv_grad_mode, _stream()), 'expo_filter_bwd')
+    _check(fn(fid, _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams), n, h, w, _dtype_code(x),
+              hsv_grad_mode, _stream()), 'expo_filter_bwd')
 
 
 def _ids(ids, n):

@@ -647,6 +647,19 @@ int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx, cons
                            : bwd_by_id<float>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s);
 }
 
+int expo_filter_bwd_accumulate(int filter_id, const void* x, const void* dy, void* dx, const float* params,
+                               float* dparams, int n, int h, int w, int dtype, int hsv_grad_mode, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+  if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
+  if (n == 0) return EXPO_OK;
+  if (!x || !dy || !params || !dparams) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16
+             ? bwd_by_id<half_t>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s, true)
+             : bwd_by_id<float>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s, true);
+}
+
 int expo_filter_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y, const float* params,
                              float* penalty, int n, int h, int w, int dtype, void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;

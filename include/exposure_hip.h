@@ -99,6 +99,16 @@ int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx,
                     int dtype, int hsv_grad_mode, void* stream);
 
 /*
+ * Same as expo_filter_bwd but dparams is ACCUMULATED into (dparams += ...): no zero-fill is
+ * enqueued, the caller owns the initial value.  This is gradient accumulation over several
+ * backward calls that share a parameter tensor (e.g. the low-resolution and the high-resolution
+ * application of one filter, filters.py:88-96, or micro-batches).
+ */
+int expo_filter_bwd_accumulate(int filter_id, const void* x, const void* dy, void* dx,
+                               const float* params, float* dparams, int n, int h, int w,
+                               int dtype, int hsv_grad_mode, void* stream);
+
+/*
  * Per-image filter choice == the reference's "compute all 8 filters, stack, multiply
  * by one_hot(selected_filter_id), reduce_sum" (agent.py:58-77, 119-125) without the
  * 7 discarded outputs.  filter_ids: int32 [N] in [-1, 7]; -1 (pdf_sample with noise

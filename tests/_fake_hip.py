@@ -18,12 +18,15 @@ def _fwd(fid, x, y, params):
   y.copy_(ft.process_packed(fid, x.double(), params.double()).to(y.dtype))
 
 
-def _bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0):
+def _bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0, accumulate=False):
   with torch.enable_grad():  # called from inside autograd.Function.backward (grad mode off)
     gx, gp = ft.backward_packed(fid, x.double(), params.double(), dy.double(), hsv_grad_mode)
   if dx is not None:
     dx.copy_(gx.to(dx.dtype))
-  dparams.copy_(gp.float())
+  if accumulate:
+    dparams.add_(gp.float())
+  else:
+    dparams.copy_(gp.float())
 
 
 def _dispatch_fwd(ids, x, y, params, penalty=None):

@@ -250,3 +250,17 @@ def test_full_size_properties(gpu_device):
     _cabi.filter_fwd(fid, x[:1, :4].contiguous(), yi, p[:1].contiguous())
     assert_image_close(yi.float().cpu().numpy(), fnp.process_packed(fid, xi.astype(np.float64), p[:1].cpu().numpy()),
                        np.float16)
+
+
+def test_bwd_accumulate(gpu_device):
+  x, dy, params = synthetic.make_case(91, (3, 32, 32, 3), np.float16)
+  dev = gpu_device
+  for fid in (0, 4, 7):
+    tx, tdy, tp = (torch.from_numpy(a).to(dev) for a in (x, dy, params[fid]))
+    dp = torch.empty_like(tp)
+    _cabi.filter_bwd(fid, tx, tdy, None, tp, dp)
+    acc = torch.full_like(tp, 1.5)
+    _cabi.filter_bwd(fid, tx, tdy, None, tp, acc, accumulate=True)
+    _cabi.filter_bwd(fid, tx, tdy, None, tp, acc, accumulate=True)
+    scale = dp.abs().max().item() + 1.0
+    assert (acc - (1.5 + 2 * dp)).abs().max().item() <= 1e-3 * scale
