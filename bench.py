@@ -206,16 +206,23 @@ def run_train(args, world, rank, dev, dist):
   torch.manual_seed(args.seed)  # identical initial weights on every rank
   gan = GAN(cfg, device=dev)
   n = cfg.batch_size
-  g = torch.Generator(device=dev).manual_seed(args.seed + 1 + rank)
-  img = ((torch.rand((n, 64, 64, 3), device=dev, generator=g)**2.2) * (1.0 / 0.99**2.2)).half()
-  real = torch.rand((n, 64, 64, 3), device=dev, generator=g).half()
-  states = torch.zeros((n, cfg.num_state_dim), device=dev)
-  z = torch.rand((n, cfg.z_dim), device=dev, generator=g)
+  from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
+  memory = ReplayMemory(cfg, SyntheticProvider(dev, seed=args.seed + 10 * rank + 1),
+                        SyntheticProvider(dev, gamma=1.0, seed=args.seed + 10 * rank + 2), seed=args.seed + rank)
+  # net.py:320-328: the first iteration rolls the generator with lr_g = 0 until terminated
+  # trajectories exist for the critic to replay (100 steps in the reference; 8 suffice: 5 steps end one)
+  for _ in range(8):
+    feed, feats = memory.get_feed_dict_and_states(n)
+    out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
+    memory.replace_memory(out['fake_output'], out['new_states'], feats)
 
   def iteration(it):
-    out = gan.generator_step(img, z, states, progress=0.1, it=it)
+    feed, feats = memory.get_feed_dict_and_states(n)
+    out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], progress=it / cfg.max_iter_step, it=it)
+    memory.replace_memory(out['fake_output'], out['new_states'], feats)
     for _ in range(cfg.citers):
-      gan.critic_step(real, img, z, states, progress=0.1, it=it)
+      rep = memory.get_replay_feed_dict(n)
+      gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
     return out
 
   def barrier():

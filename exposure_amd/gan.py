@@ -100,13 +100,13 @@ class GAN(nn.Module):
     self.opt_v.step()
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items() if k != 'debug'}
 
-  def critic_losses(self, real_data, fake_input, z, states, progress, alpha=None, dropout_masks=None):
-    """net.py:126-194: c_loss = mean(fake - real) + lambda * mean(max(||grad||-1, 0)^2)."""
+  def critic_losses(self, real_data, fake_output, alpha=None):
+    """net.py:126-194: c_loss = mean(fake - real) + lambda * mean(max(||grad||-1, 0)^2).
+    ``fake_output`` is FED, as in the reference: the critic update runs on terminated images
+    replayed from the memory (``replay_memory.py:168-185`` feeds the ``fake_output`` tensor), the
+    generator is not executed."""
     cfg = self.cfg
-    with torch.no_grad():
-      (fake_output, _, _, _), _, _ = self.generator((fake_input, z, states), is_train=1, progress=progress,
-                                                   dropout_masks=dropout_masks)
-    fake_output = fake_output.float()
+    fake_output = fake_output.detach().float()
     real_data = real_data.float()
     real_logit = self.critic(real_data)
     fake_logit = self.critic(fake_output)
@@ -123,9 +123,9 @@ class GAN(nn.Module):
     return dict(c_loss=total, emd=-c_loss.detach(), gradient_norm=gradient_norm.mean().detach(),
                 gradient_penalty=gradient_penalty.detach(), c_average=c_average)
 
-  def critic_step(self, real_data, fake_input, z, states, progress, it=1, alpha=None, dropout_masks=None):
+  def critic_step(self, real_data, fake_output, it=1, alpha=None):
     self.set_lrs(it)
-    out = self.critic_losses(real_data, fake_input, z, states, progress, alpha, dropout_masks)
+    out = self.critic_losses(real_data, fake_output, alpha)
     self.opt_c.zero_grad(set_to_none=True)
     out['c_loss'].backward()
     if self.world_size > 1:
@@ -139,3 +139,32 @@ class GAN(nn.Module):
     self.c_average_biased = 0.99 * self.c_average_biased + 0.01 * float(out['c_average'])
     out['c_average_smoothed'] = self.c_average_biased / (1.0 - 0.99**self.c_average_steps)
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+  # -- the training loop (net.py:298-403), minus visualisation / checkpoints / TensorBoard
+  def train(self, memory, max_iter_step=None, log_every=0, log=print):
+    cfg = self.cfg
+    max_iter_step = cfg.max_iter_step if max_iter_step is None else max_iter_step
+    history = []
+    for it in range(max_iter_step + 1):
+      progress = float(it) / cfg.max_iter_step
+      if cfg.gan == 'w' and (it < cfg.critic_initialization or it % 500 == 0):
+        citers = 100
+      else:
+        citers = cfg.citers
+      giters = 100 if it == 0 else cfg.giters  # make sure there are terminating states
+      g_out = None
+      for _ in range(giters):
+        feed, features = memory.get_feed_dict_and_states(cfg.batch_size)
+        g_out = self.generator_step(feed['fake_input'], feed['z'], feed['states'], progress, it=it)
+        memory.replace_memory(g_out['fake_output'], g_out['new_states'], features)
+      c_out = None
+      for _ in range(citers):
+        feed = memory.get_replay_feed_dict(cfg.batch_size)
+        c_out = self.critic_step(feed['real_data'], feed['fake_output'], it=it)
+      rec = dict(iter=it, g_loss=float(g_out['g_loss']), v_loss=float(g_out['v_loss']), emd=float(c_out['emd']),
+                 cgn=float(c_out['gradient_norm']))
+      history.append(rec)
+      if log_every and it % log_every == 0:
+        log('it%6d, g_loss=%.2f, v_loss=%.2f, EMD=%.3f, cgn=%.2f  %s' %
+            (it, rec['g_loss'], rec['v_loss'], rec['emd'], rec['cgn'], memory.debug()))
+    return history

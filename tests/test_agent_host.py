@@ -131,7 +131,7 @@ def test_gan_steps_run_and_update_only_their_parameters():
   assert changed(g0, gan.generator) and changed(v0, gan.value) and not changed(c0, gan.critic)
   g1, v1 = snap(gan.generator), snap(gan.value)
   with fake_hip():
-    out = gan.critic_step(t(real), t(img), t(z), t(states), progress=0.1, it=5)
+    out = gan.critic_step(t(real), t(img), it=5)
   assert np.isfinite(float(out['c_loss'])) and float(out['gradient_norm']) > 0
   assert changed(c0, gan.critic) and not changed(g1, gan.generator) and not changed(v1, gan.value)
   # iteration 0 runs the generator with lr_g = 0 (net.py:327-328)

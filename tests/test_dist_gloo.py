@@ -40,7 +40,7 @@ def _run_steps(gan, img, real, states, z, masks, alpha):
   from tests._fake_hip import fake_hip
   with fake_hip():
     g = gan.generator_step(img, z, states, progress=0.1, it=7, dropout_masks=masks)
-    c = gan.critic_step(real, img, z, states, progress=0.1, it=7, alpha=alpha, dropout_masks=masks)
+    c = gan.critic_step(real, g['fake_output'], it=7, alpha=alpha)
   return g, c
 
 

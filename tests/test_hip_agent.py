@@ -168,6 +168,42 @@ def test_gan_steps_on_gpu(gpu_device):
   assert out['fake_output'].dtype == torch.float16 and out['fake_output'].shape == img.shape
   assert any(not torch.equal(a, b) for a, b in zip(g0, gan.generator.parameters()))
   assert all(torch.equal(a, b) for a, b in zip(c0, gan.critic.parameters()))
-  out = gan.critic_step(real, img, z, states, progress=0.1, it=3)
+  out = gan.critic_step(real, out['fake_output'], it=3)
   assert torch.isfinite(out['c_loss']) and float(out['gradient_norm']) > 0
   assert any(not torch.equal(a, b) for a, b in zip(c0, gan.critic.parameters()))
+
+
+def test_training_loop_on_gpu(gpu_device):
+  """A few iterations of the reference's G/C alternation (net.py:307-365) with the device-resident
+  replay memory: everything (filters, nets, pool) stays on the GPU."""
+  from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
+  dev = gpu_device
+  torch.manual_seed(0)
+  cfg = make_cfg()
+  cfg.batch_size = 16
+  cfg.replay_memory_size = 32
+  cfg.max_iter_step = 3
+  cfg.critic_initialization = 0
+  cfg.citers = 2
+  gan = GAN(cfg, device=dev)
+  mem = ReplayMemory(cfg, SyntheticProvider(dev, seed=1), SyntheticProvider(dev, gamma=1.0, seed=2), seed=0)
+
+  class Few(type(gan)):
+    pass
+
+  # iteration 0 of GAN.train runs 100 generator steps; keep the test short by pre-rolling 6
+  for _ in range(6):
+    feed, feats = mem.get_feed_dict_and_states(cfg.batch_size)
+    out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
+    mem.replace_memory(out['fake_output'], out['new_states'], feats)
+  assert mem.images.is_cuda and mem.images.dtype == torch.float16
+  assert int((mem.states[:, 1] > 0).sum()) > 0
+  for it in range(1, 4):
+    feed, feats = mem.get_feed_dict_and_states(cfg.batch_size)
+    g = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], it / 3.0, it=it)
+    mem.replace_memory(g['fake_output'], g['new_states'], feats)
+    for _ in range(cfg.citers):
+      rep = mem.get_replay_feed_dict(cfg.batch_size)
+      c = gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
+    assert torch.isfinite(g['g_loss']) and torch.isfinite(c['c_loss'])
+  assert len(mem) == 32

@@ -1,0 +1,79 @@
+"""Replay memory semantics (replay_memory.py) and a short run of the G/C alternation loop
+(net.py:307-365) on CPU with the C-ABI binding mocked by the oracle."""
+import numpy as np
+import torch
+
+from exposure_amd.config import make_cfg
+from exposure_amd.gan import GAN
+from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
+from tests._fake_hip import fake_hip
+
+
+def make_memory(cfg, seed=0):
+  dev = torch.device('cpu')
+  return ReplayMemory(cfg, SyntheticProvider(dev, dtype=torch.float32, seed=seed),
+                      SyntheticProvider(dev, gamma=1.0, dtype=torch.float32, seed=seed + 1), seed=seed)
+
+
+def test_pool_semantics():
+  cfg = make_cfg()
+  cfg.batch_size = 16
+  cfg.replay_memory_size = 32
+  mem = make_memory(cfg)
+  assert len(mem) == 32 and float(mem.states.abs().max()) == 0.0
+  feed, feats = mem.get_feed_dict_and_states(16)
+  assert feed['fake_input'].shape == (16, 64, 64, 3) and feed['z'].shape == (16, cfg.z_dim)
+  assert len(mem) == 16  # popped
+  # return them: half terminated, a quarter over-length
+  states = feed['states'].clone()
+  states[:8, 1] = 1.0
+  states[:, 2] = 3
+  states[8:12, 2] = 9  # over maximum_trajectory_length -> kept with prob .5
+  mem.replace_memory(feed['fake_input'], states, feats)
+  assert len(mem) == 32
+  n_done = int((mem.states[:, 1] > 0).sum())
+  assert n_done == 8
+  # generator batches never contain terminated records
+  f2, _ = mem.get_feed_dict_and_states(16)
+  assert float(f2['states'][:, 1].max()) == 0.0
+  # critic replay contains ONLY terminated records (with repetition)
+  mem.fill_pool()
+  rep = mem.get_replay_feed_dict(16)
+  assert rep['fake_output'].shape == (16, 64, 64, 3)
+  _, st, _ = mem.replay_fake_batch(16)
+  assert float(st[:, 1].min()) == 1.0
+
+
+def test_training_loop_runs_and_terminates_trajectories():
+  torch.manual_seed(0)
+  cfg = make_cfg()
+  cfg.batch_size = 4
+  cfg.replay_memory_size = 8
+  cfg.max_iter_step = 1000
+  gan = GAN(cfg)
+  mem = make_memory(cfg, seed=3)
+  # shorten the warm-up constants of net.py:314-323 for the test
+  cfg.critic_initialization = 0
+  orig_giters = cfg.giters
+
+  class Short(GAN):
+    pass
+
+  with fake_hip():
+    # iteration 0 runs 100 generator steps with lr_g = 0 so terminated states exist (net.py:320-328);
+    # run a reduced version: call the pieces of train() by hand
+    for _ in range(6):
+      feed, feats = mem.get_feed_dict_and_states(cfg.batch_size)
+      out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
+      mem.replace_memory(out['fake_output'], out['new_states'], feats)
+    assert int((mem.states[:, 1] > 0).sum()) > 0  # step counter reached test_steps for some records
+    hist = []
+    for it in range(1, 3):
+      feed, feats = mem.get_feed_dict_and_states(cfg.batch_size)
+      g = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], it / 1000.0, it=it)
+      mem.replace_memory(g['fake_output'], g['new_states'], feats)
+      rep = mem.get_replay_feed_dict(cfg.batch_size)
+      c = gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
+      hist.append((float(g['g_loss']), float(c['c_loss'])))
+  assert all(np.isfinite(v) for pair in hist for v in pair)
+  assert cfg.giters == orig_giters
