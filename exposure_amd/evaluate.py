@@ -61,3 +61,46 @@ def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trac
   if return_trace:
     return hi, low, states, torch.stack(trace, dim=1)
   return hi, low, states
+
+
+def load_image(path):
+  """net.py:726-747: ``.tif`` -> 16-bit ProPhoto, linearised (x**1.8); anything else readable by
+  PIL -> 8-bit sRGB-ish, ``/255``, ``**2.2``, scaled by ``1 / (2 max)``."""
+  import numpy as np
+  if path.lower().endswith(('.tif', '.tiff')):
+    from .tiff16 import read_tiff16
+    return linearize_ProPhotoRGB(read_tiff16(path))
+  from PIL import Image
+  img = (np.asarray(Image.open(path).convert('RGB'), dtype=np.float32) / 255.0)**2.2
+  return img / (2 * img.max())
+
+
+def main(argv=None):
+  """``python -m exposure_amd.evaluate [--weights w.pt] [--out out.npy] img ...`` -- the tensor part
+  of ``evaluate.py:8-31``: 5 retouching steps per image on the GPU; writes the linear result."""
+  import argparse
+  import numpy as np
+  from .agent import Agent
+  from .config import make_cfg
+  ap = argparse.ArgumentParser()
+  ap.add_argument('images', nargs='+')
+  ap.add_argument('--weights', default=None, help='torch state_dict of exposure_amd.agent.Agent (random init if absent)')
+  ap.add_argument('--out', default=None)
+  ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
+  args = ap.parse_args(argv)
+  dev = torch.device('cuda:0')
+  cfg = make_cfg()
+  agent = Agent(cfg).to(dev)
+  if args.weights:
+    agent.load_state_dict(torch.load(args.weights, map_location=dev))
+  dt = torch.float16 if args.dtype == 'f16' else torch.float32
+  for path in args.images:
+    hi = torch.from_numpy(np.ascontiguousarray(load_image(path))).to(dev).to(dt)[None]
+    out, _low, states, trace = retouch(agent, hi, return_trace=True)
+    names = [agent.filters[int(j)].get_short_name() for j in trace[0]]
+    print('%s: %dx%d  filters: %s' % (path, hi.shape[2], hi.shape[1], ' '.join(names)))
+    np.save(args.out or (path + '.retouched.npy'), out[0].float().cpu().numpy())
+
+
+if __name__ == '__main__':
+  main()
