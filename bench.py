@@ -283,7 +283,7 @@ def main():
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
   dist = None
-  if world > 1:
+  if world > 1 or 'LOCAL_RANK' in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
     import torch.distributed as dist
     dist.init_process_group('nccl', device_id=dev)
   if args.gpus != world and rank == 0:
