@@ -20,10 +20,10 @@ LIB_PATH = os.environ.get('EXPO_HIP_LIB') or os.path.join(_HERE, 'libexposure_hi
 EXPO_ABI_VERSION = 1
 EXPO_F16, EXPO_F32 = 0, 1
 EXPO_MAX_PARAMS = 24
-NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24)
+NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24, 2)  # ids 0..7 = cfg.filters order, 8 = LevelFilter
 
 # every symbol include/exposure_hip.h declares: name -> (restype, argtypes)
-_vp, _i, _fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+_vp, _i, _fp, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 SIGNATURES = {
     'expo_version': (_i, []),
     'expo_last_error': (ctypes.c_char_p, []),
@@ -31,6 +31,8 @@ SIGNATURES = {
     'expo_filter_fwd': (_i, [_i, _vp, _vp, _fp, _i, _i, _i, _i, _vp]),
     'expo_filter_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     'expo_filter_bwd_accumulate': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    'expo_filter_apply_fwd': (_i, [_i, _vp, _vp, _fp, _fp, _f, _f, _i, _i, _i, _i, _vp]),
+    'expo_filter_apply_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _i, _i, _vp]),
     'expo_filter_dispatch_fwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
     'expo_filter_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
@@ -138,6 +140,37 @@ def filter_bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0, accumulate=Fals
   with torch.cuda.device(x.device):
     _check(fn(fid, _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams), n, h, w, _dtype_code(x),
               hsv_grad_mode, _stream()), 'expo_filter_bwd')
+
+
+def apply_fwd(fid, x, y, params, mask_params, maximum_sharpness, minimum_strength):
+  lib = load()
+  _img(x, 'x'), _img(y, 'y')
+  n, h, w, _ = x.shape
+  _f32(params, 'params', (n, NUM_PARAMS[fid]))
+  _f32(mask_params, 'mask_params', (n, 6))
+  with torch.cuda.device(x.device):
+    _check(
+        lib.expo_filter_apply_fwd(fid, _ptr(x), _ptr(y), _ptr(params), _ptr(mask_params), float(maximum_sharpness),
+                                  float(minimum_strength), n, h, w, _dtype_code(x), _stream()),
+        'expo_filter_apply_fwd')
+
+
+def apply_bwd(fid, x, dy, dx, params, dparams, mask_params, dmask_params, maximum_sharpness, minimum_strength,
+              hsv_grad_mode=0):
+  lib = load()
+  _img(x, 'x'), _img(dy, 'dy')
+  n, h, w, _ = x.shape
+  if dx is not None:
+    _img(dx, 'dx')
+  _f32(params, 'params', (n, NUM_PARAMS[fid]))
+  _f32(dparams, 'dparams', (n, NUM_PARAMS[fid]))
+  _f32(mask_params, 'mask_params', (n, 6))
+  _f32(dmask_params, 'dmask_params', (n, 6))
+  with torch.cuda.device(x.device):
+    _check(
+        lib.expo_filter_apply_bwd(fid, _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams), _ptr(mask_params),
+                                  _ptr(dmask_params), float(maximum_sharpness), float(minimum_strength), n, h, w,
+                                  _dtype_code(x), hsv_grad_mode, _stream()), 'expo_filter_apply_bwd')
 
 
 def _ids(ids, n):

@@ -214,6 +214,118 @@ __global__ __launch_bounds__(kThreads, F::kMinWaves) void filter_bwd_kernel(cons
                                                params + n * F::NP, dparams + n * F::NP, hw, groups, 0.f);
 }
 
+// ------------------------------------------------ Filter.apply with a spatial mask (masking on)
+// out = (1 - mask) x + mask process(x), mask per pixel from MaskPrm (filters.py:86-88, 110-148).
+template <class F, typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                             const float* __restrict__ params,
+                                                             const float* __restrict__ mask_params, float sharp,
+                                                             float min_strength, int h, int w, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y, hw = h * w;
+  const size_t off = size_t(n) * hw * 3;
+  const T* xi = x + off;
+  T* yi = y + off;
+  const typename F::Prm q = F::load(params + n * F::NP);
+  const MaskPrm mk = MaskPrm::load(mask_params + n * 6, sharp, min_strength, h, w);
+  const int stride = gridDim.x * kThreads;
+  auto compute = [&](float* v, int g) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      float p[3];
+      F::fwd(q, v + 3 * k, p);
+      const MaskPrm::Eval e = mk.eval(pixel_index<T, VEC>(g, k, lane), v + 3 * k);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[3 * k + c] = fmaf(e.m, p[c] - v[3 * k + c], v[3 * k + c]);
+    }
+  };
+  if constexpr (VEC) {
+    const T* const ins[1] = {xi};
+    stream_groups<T, 1, true, true>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                    [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3];
+      load_slow<T>(xi, g, hw, v);
+      compute(v, g);
+      store_slow<T>(yi, g, hw, v);
+    }
+  }
+}
+
+template <class F, typename T, bool VEC, bool HAS_DX, int MODE>
+__global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                             T* __restrict__ dx, const float* __restrict__ params,
+                                                             float* __restrict__ dparams,
+                                                             const float* __restrict__ mask_params,
+                                                             float* __restrict__ dmask, float sharp,
+                                                             float min_strength, int h, int w, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y, hw = h * w;
+  const size_t off = size_t(n) * hw * 3;
+  const T* xi = x + off;
+  const T* dyi = dy + off;
+  T* dxi = HAS_DX ? dx + off : nullptr;
+  const float* prm = params + n * F::NP;
+  const typename F::Prm q = F::load(prm);
+  const MaskPrm mk = MaskPrm::load(mask_params + n * 6, sharp, min_strength, h, w);
+  __shared__ __attribute__((aligned(16))) float lut[F::kLutFloats > 0 ? F::kLutFloats : 4];
+  if constexpr (F::kLutFloats > 0) {
+    F::stage(prm, lut);
+    __syncthreads();
+  }
+  float acc[F::NACC], macc[6];
+#pragma unroll
+  for (int j = 0; j < F::NACC; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) macc[j] = 0.f;
+  const int stride = gridDim.x * kThreads;
+  auto compute = [&](float* v, float* d, int g) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      const float* xv = v + 3 * k;
+      float* dv = d + 3 * k;
+      float p[3], gp[3], dxf[3];
+      F::fwd(q, xv, p);
+      const MaskPrm::Eval e = mk.eval(pixel_index<T, VEC>(g, k, lane), xv);
+      const float dm = dv[0] * (p[0] - xv[0]) + dv[1] * (p[1] - xv[1]) + dv[2] * (p[2] - xv[2]);
+      const float gsig = dm * mk.S * e.sg * (1.0f - e.sg);  // dL/d(inp)
+      const float graw = gsig * mk.k;                       // dL/d(inp_raw)
+      macc[0] = fmaf(graw, e.gx, macc[0]);
+      macc[1] = fmaf(graw, e.gy, macc[1]);
+      macc[2] = fmaf(graw, e.lumc, macc[2]);
+      macc[3] = fmaf(graw, 2.0f, macc[3]);
+      macc[4] = fmaf(gsig * e.inp_raw, mk.k_over_mp4, macc[4]);
+      macc[5] = fmaf(dm * e.sg, mk.dS, macc[5]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gp[c] = e.m * dv[c];
+      F::bwd(q, lut, xv, gp, dxf, acc, MODE);
+      const float gl = graw * mk.c;  // through lum(x) inside the mask
+      dv[0] = fmaf(1.0f - e.m, dv[0], dxf[0]) + kLumR * gl;
+      dv[1] = fmaf(1.0f - e.m, dv[1], dxf[1]) + kLumG * gl;
+      dv[2] = fmaf(1.0f - e.m, dv[2], dxf[2]) + kLumB * gl;
+    }
+  };
+  if constexpr (VEC) {
+    const T* const ins[2] = {xi, dyi};
+    stream_groups<T, 2, HAS_DX, true>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                      [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3], d[PPL * 3];
+      load_slow<T>(xi, g, hw, v);
+      load_slow<T>(dyi, g, hw, d);
+      compute(v, d, g);
+      if constexpr (HAS_DX) store_slow<T>(dxi, g, hw, d);
+    }
+  }
+  block_reduce_atomic<F::NACC, F::NP>(acc, dparams + n * F::NP, [=](const float* t, int j) { return F::finish_one(prm, t, j); });
+  __syncthreads();
+  block_reduce_atomic<6, 6>(macc, dmask + n * 6, [](const float* t, int j) { return t[j]; });
+}
+
 // --------------------------------------------------- per-image dispatch (one-hot select)
 template <typename T, bool VEC>
 __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int groups) {
@@ -232,10 +344,10 @@ __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int group
   }
 }
 
-// SET is a bit mask of the filter ids this launch handles (bit 8 = id -1).  The dispatch is
+// SET is a bit mask of the filter ids this launch handles (bit 15 = id -1).  The dispatch is
 // issued as two launches -- light filters and the register-heavy curve filters -- so each gets
 // its own VGPR budget / occupancy; blocks whose image selected a filter outside SET exit at once.
-constexpr int kSetLight = 0x100 | 0x6F;  // -1, E, G, W, S+, Ct, BW
+constexpr int kSetLight = 0x8000 | 0x100 | 0x6F;  // -1, E, G, W, S+, Ct, BW, Le
 constexpr int kSetCurves = 0x90;         // T, C
 
 template <typename T, bool VEC, bool PEN, int SET>
@@ -262,8 +374,9 @@ __global__ __launch_bounds__(kThreads) void dispatch_fwd_kernel(const int32_t* _
     EXPO_CASE(5, ContrastF)
     EXPO_CASE(6, WnbF)
     EXPO_CASE(7, ColorF)
+    EXPO_CASE(8, LevelF)
     default:  // id -1: all-zero one-hot
-      if constexpr ((SET >> 8) & 1) zero_image<T, VEC>(y + off, hw, groups);
+      if constexpr ((SET >> 15) & 1) zero_image<T, VEC>(y + off, hw, groups);
       break;
   }
 #undef EXPO_CASE
@@ -297,8 +410,9 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
     EXPO_CASE(5, ContrastF)
     EXPO_CASE(6, WnbF)
     EXPO_CASE(7, ColorF)
+    EXPO_CASE(8, LevelF)
     default:
-      if constexpr (HAS_DX && ((SET >> 8) & 1)) zero_image<T, VEC>(dxi, hw, groups);
+      if constexpr (HAS_DX && ((SET >> 15) & 1)) zero_image<T, VEC>(dxi, hw, groups);
       break;
   }
 #undef EXPO_CASE
@@ -409,7 +523,7 @@ static int fail_hip(hipError_t e, const char* where) {
     if (e_ != hipSuccess) return fail_hip(e_, where); \
   } while (0)
 
-static const int kNumParams[EXPO_NUM_FILTERS] = {1, 1, 3, 1, 8, 1, 1, 24};
+static const int kNumParams[EXPO_NUM_FILTERS] = {1, 1, 3, 1, 8, 1, 1, 24, 2};
 
 struct Geom {
   int hw, groups, blocks_x;
@@ -507,8 +621,9 @@ static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int 
     case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s);
     case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s);
     case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s);
+    case 8: return launch_fwd<LevelF, T>(x, y, p, n, h, w, s);
   }
-  return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+  return fail(EXPO_E_BADARG, "filter_id out of range");
 }
 
 template <typename T>
@@ -523,8 +638,85 @@ static int bwd_by_id(int id, const void* x, const void* dy, void* dx, const floa
     case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
     case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
     case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
+    case 8: return launch_bwd<LevelF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
   }
-  return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+  return fail(EXPO_E_BADARG, "filter_id out of range");
+}
+
+template <class F, typename T>
+static int launch_apply_fwd(const void* x, void* y, const float* params, const float* mp, float sharp, float ms,
+                            int n, int h, int w, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, y}, false);
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  if (g.vec)
+    hipLaunchKernelGGL((apply_fwd_kernel<F, T, true>), grid, block, 0, s, (const T*)x, (T*)y, params, mp, sharp, ms, h, w, g.groups);
+  else
+    hipLaunchKernelGGL((apply_fwd_kernel<F, T, false>), grid, block, 0, s, (const T*)x, (T*)y, params, mp, sharp, ms, h, w, g.groups);
+  HIP_TRY(hipGetLastError(), "apply_fwd launch");
+  return EXPO_OK;
+}
+
+template <class F, typename T>
+static int launch_apply_bwd(const void* x, const void* dy, void* dx, const float* params, float* dparams,
+                            const float* mp, float* dmp, float sharp, float ms, int n, int h, int w, int mode,
+                            hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * F::NP, s), "dparams memset");
+  HIP_TRY(hipMemsetAsync(dmp, 0, sizeof(float) * size_t(n) * 6, s), "dmask memset");
+#define EXPO_L(VEC, HAS_DX, MODE)                                                                          \
+  hipLaunchKernelGGL((apply_bwd_kernel<F, T, VEC, HAS_DX, MODE>), grid, block, 0, s, (const T*)x,          \
+                     (const T*)dy, (T*)dx, params, dparams, mp, dmp, sharp, ms, h, w, g.groups)
+  const bool m1 = std::is_same<F, SatPlusF>::value && mode == 1;
+  const int key = (g.vec ? 4 : 0) | (dx ? 2 : 0) | (m1 ? 1 : 0);
+  switch (key) {
+    case 7: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(true, true, 1); break;
+    case 6: EXPO_L(true, true, 0); break;
+    case 5: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(true, false, 1); break;
+    case 4: EXPO_L(true, false, 0); break;
+    case 3: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(false, true, 1); break;
+    case 2: EXPO_L(false, true, 0); break;
+    case 1: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(false, false, 1); break;
+    default: EXPO_L(false, false, 0); break;
+  }
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "apply_bwd launch");
+  return EXPO_OK;
+}
+
+template <typename T>
+static int apply_fwd_by_id(int id, const void* x, void* y, const float* p, const float* mp, float sharp, float ms,
+                           int n, int h, int w, hipStream_t s) {
+  switch (id) {
+    case 0: return launch_apply_fwd<ExposureF, T>(x, y, p, mp, sharp, ms, n, h, w, s);
+    case 1: return launch_apply_fwd<GammaF, T>(x, y, p, mp, sharp, ms, n, h, w, s);
+    case 2: return launch_apply_fwd<WhiteBalanceF, T>(x, y, p, mp, sharp, ms, n, h, w, s);
+    case 3: return launch_apply_fwd<SatPlusF, T>(x, y, p, mp, sharp, ms, n, h, w, s);
+    case 4: return launch_apply_fwd<ToneF, T>(x, y, p, mp, sharp, ms, n, h, w, s);
+    case 5: return launch_apply_fwd<ContrastF, T>(x, y, p, mp, sharp, ms, n, h, w, s);
+    case 6: return launch_apply_fwd<WnbF, T>(x, y, p, mp, sharp, ms, n, h, w, s);
+    case 7: return launch_apply_fwd<ColorF, T>(x, y, p, mp, sharp, ms, n, h, w, s);
+    case 8: return launch_apply_fwd<LevelF, T>(x, y, p, mp, sharp, ms, n, h, w, s);
+  }
+  return fail(EXPO_E_BADARG, "filter_id out of range");
+}
+
+template <typename T>
+static int apply_bwd_by_id(int id, const void* x, const void* dy, void* dx, const float* p, float* dp,
+                           const float* mp, float* dmp, float sharp, float ms, int n, int h, int w, int mode,
+                           hipStream_t s) {
+  switch (id) {
+    case 0: return launch_apply_bwd<ExposureF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+    case 1: return launch_apply_bwd<GammaF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+    case 2: return launch_apply_bwd<WhiteBalanceF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+    case 3: return launch_apply_bwd<SatPlusF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+    case 4: return launch_apply_bwd<ToneF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+    case 5: return launch_apply_bwd<ContrastF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+    case 6: return launch_apply_bwd<WnbF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+    case 7: return launch_apply_bwd<ColorF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+    case 8: return launch_apply_bwd<LevelF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+  }
+  return fail(EXPO_E_BADARG, "filter_id out of range");
 }
 
 template <typename T>
@@ -627,7 +819,7 @@ int expo_num_filter_params(int filter_id) {
 int expo_filter_fwd(int filter_id, const void* x, void* y, const float* params, int n, int h, int w, int dtype,
                     void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
-  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
   if (n == 0) return EXPO_OK;
   if (!x || !y || !params) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -638,7 +830,7 @@ int expo_filter_fwd(int filter_id, const void* x, void* y, const float* params, 
 int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx, const float* params, float* dparams,
                     int n, int h, int w, int dtype, int hsv_grad_mode, void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
-  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
   if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
   if (n == 0) return EXPO_OK;
   if (!x || !dy || !params || !dparams) return fail(EXPO_E_BADARG, "null pointer");
@@ -650,7 +842,7 @@ int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx, cons
 int expo_filter_bwd_accumulate(int filter_id, const void* x, const void* dy, void* dx, const float* params,
                                float* dparams, int n, int h, int w, int dtype, int hsv_grad_mode, void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
-  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
   if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
   if (n == 0) return EXPO_OK;
   if (!x || !dy || !params || !dparams) return fail(EXPO_E_BADARG, "null pointer");
@@ -658,6 +850,36 @@ int expo_filter_bwd_accumulate(int filter_id, const void* x, const void* dy, voi
   return dtype == EXPO_F16
              ? bwd_by_id<half_t>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s, true)
              : bwd_by_id<float>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s, true);
+}
+
+int expo_filter_apply_fwd(int filter_id, const void* x, void* y, const float* params, const float* mask_params,
+                          float maximum_sharpness, float minimum_strength, int n, int h, int w, int dtype,
+                          void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
+  if (n == 0) return EXPO_OK;
+  if (!x || !y || !params || !mask_params) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? apply_fwd_by_id<half_t>(filter_id, x, y, params, mask_params, maximum_sharpness,
+                                                     minimum_strength, n, h, w, s)
+                           : apply_fwd_by_id<float>(filter_id, x, y, params, mask_params, maximum_sharpness,
+                                                    minimum_strength, n, h, w, s);
+}
+
+int expo_filter_apply_bwd(int filter_id, const void* x, const void* dy, void* dx, const float* params,
+                          float* dparams, const float* mask_params, float* dmask_params, float maximum_sharpness,
+                          float minimum_strength, int n, int h, int w, int dtype, int hsv_grad_mode, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
+  if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
+  if (n == 0) return EXPO_OK;
+  if (!x || !dy || !params || !dparams || !mask_params || !dmask_params) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16
+             ? apply_bwd_by_id<half_t>(filter_id, x, dy, dx, params, dparams, mask_params, dmask_params,
+                                       maximum_sharpness, minimum_strength, n, h, w, hsv_grad_mode, s)
+             : apply_bwd_by_id<float>(filter_id, x, dy, dx, params, dparams, mask_params, dmask_params,
+                                      maximum_sharpness, minimum_strength, n, h, w, hsv_grad_mode, s);
 }
 
 int expo_filter_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y, const float* params,
@@ -707,7 +929,7 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
   bool contiguous = true;
   size_t total = 0;
   for (int i = 0; i < steps; ++i) {
-    if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id must be in [0, 7]");
+    if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
     if (!dparams[i]) return fail(EXPO_E_BADARG, "null pointer");
     if (i > 0 && dparams[i] != dparams[i - 1] + size_t(n) * kNumParams[filter_ids[i - 1]]) contiguous = false;
     total += size_t(n) * kNumParams[filter_ids[i]];

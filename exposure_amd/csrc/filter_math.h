@@ -427,4 +427,79 @@ struct WnbF {
   __device__ static float finish_one(const float* __restrict__, const float* a, int) { return a[0]; }
 };
 
+// ---------------------------------------------------------------------------------
+// 8  LevelFilter   filters.py:449-466 (defined by the reference but not in cfg.filters)
+//    lower = p0, upper = p1 + 1;  y = clip((x - lower) / (upper - lower + 1e-6), 0, 1)
+// ---------------------------------------------------------------------------------
+struct LevelF {
+  static constexpr int NP = 2, NACC = 2, kLutFloats = 0, kMinWaves = 1;
+  static constexpr bool kHasGroupBwd = false;
+  struct Prm { float lower, r; };
+  __device__ static Prm load(const float* __restrict__ p) {
+    return {p[0], 1.0f / ((p[1] + 1.0f) - p[0] + 1e-6f)};
+  }
+  __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = clamp01x((x[c] - q.lower) * q.r, 0.0f, 1.0f);
+  }
+  __device__ static void bwd(const Prm& q, const float*, const float x[3], const float dy[3], float dx[3],
+                             float acc[NACC], int) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float t = (x[c] - q.lower) * q.r;
+      const float g = (t >= 0.0f && t <= 1.0f) ? dy[c] : 0.0f;  // clip_by_value: inclusive both sides
+      dx[c] = g * q.r;
+      acc[0] = fmaf(g, t - 1.0f, acc[0]);
+      acc[1] = fmaf(g, t, acc[1]);
+    }
+  }
+  // d/dlower = r sum g (t-1);  d/dp1 = d/dupper = -r sum g t
+  __device__ static float finish_one(const float* __restrict__ p, const float* a, int j) {
+    const float r = 1.0f / ((p[1] + 1.0f) - p[0] + 1e-6f);
+    return j == 0 ? r * a[0] : -r * a[1];
+  }
+};
+
+// ---------------------------------------------------------------------------------
+// Spatial mask of Filter.apply with cfg.masking = True   filters.py:110-148, 86-88
+//   mp = tanh_range(-5, 5)(mask_parameters)            (done by the caller, differentiably)
+//   inp = gx mp0 + gy mp1 + mp2 (lum(x) - .5) + 2 mp3;  inp *= sharp mp4 / 5
+//   mask = sigmoid(inp) (mp5/5 * .5 + .5)(1 - min_strength) + min_strength
+//   out = (1 - mask) x + mask process(x)
+// gx, gy: the constant grid (row + (se-H)/2)/se - .5, (col + (se-W)/2)/se - .5, se = min(H, W).
+// Backward accumulators (6): d/d mp0..mp5.
+// ---------------------------------------------------------------------------------
+struct MaskPrm {
+  float a, b, c, d2, k, S, ms, k_over_mp4, dS;  // k = sharp mp4/5; S = strength factor; dS = dS/dmp5
+  float inv_se, oi, oj;
+  int w;
+  __device__ static MaskPrm load(const float* __restrict__ mp, float sharp, float min_strength, int h, int w) {
+    MaskPrm m;
+    m.a = mp[0]; m.b = mp[1]; m.c = mp[2]; m.d2 = 2.0f * mp[3];
+    m.k_over_mp4 = sharp / 5.0f;
+    m.k = m.k_over_mp4 * mp[4];
+    m.ms = min_strength;
+    m.dS = (0.5f / 5.0f) * (1.0f - min_strength);
+    m.S = (mp[5] / 5.0f * 0.5f + 0.5f) * (1.0f - min_strength);
+    const int se = h < w ? h : w;
+    m.inv_se = 1.0f / float(se);
+    m.oi = float(se - h) * 0.5f;
+    m.oj = float(se - w) * 0.5f;
+    m.w = w;
+    return m;
+  }
+  struct Eval { float m, sg, inp_raw, gx, gy, lumc; };
+  __device__ Eval eval(int px, const float x[3]) const {
+    Eval e;
+    const int row = px / w, col = px - row * w;
+    e.gx = (float(row) + oi) * inv_se - 0.5f;
+    e.gy = (float(col) + oj) * inv_se - 0.5f;
+    e.lumc = lum3(x) - 0.5f;
+    e.inp_raw = e.gx * a + e.gy * b + c * e.lumc + d2;
+    e.sg = fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * (e.inp_raw * k)));
+    e.m = e.sg * S + ms;
+    return e;
+  }
+};
+
 }  // namespace expo

@@ -180,6 +180,17 @@ __device__ __forceinline__ bool live_pixel(int g, int k, int lane, int hw) {
   return g * PPL + k < hw;
 }
 
+// Linear pixel index (within the image) of pixel slot k of group g.
+template <typename T, bool VEC>
+__device__ __forceinline__ int pixel_index(int g, int k, int lane) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  if constexpr (VEC) {
+    constexpr int PPV = VecTraits<T>::PPV;
+    return (g - lane) * PPL + (k / PPV) * 64 * PPV + lane * PPV + (k % PPV);
+  }
+  return g * PPL + k;
+}
+
 // element-wise (ragged / unaligned) path: group g covers pixels [g*PPL, g*PPL+PPL) ∩ [0,hw)
 template <typename T>
 __device__ __forceinline__ void load_slow(const T* img, int g, int hw, float* out) {

@@ -50,6 +50,32 @@ class _PixelFilterFunction(torch.autograd.Function):
     return dx, dparams, None, None
 
 
+class _MaskedApplyFunction(torch.autograd.Function):
+  """out = lerp(img, process(img, packed), mask(img, mask_params)) -- expo_filter_apply_fwd/bwd."""
+
+  @staticmethod
+  def forward(ctx, img, packed, mask_params, fid, sharp, min_strength, hsv_grad_mode):
+    img = img.contiguous()
+    packed = packed.contiguous().float()
+    mask_params = mask_params.contiguous().float()
+    y = torch.empty_like(img)
+    _cabi.apply_fwd(fid, img, y, packed, mask_params, sharp, min_strength)
+    ctx.save_for_backward(img, packed, mask_params)
+    ctx.args = (fid, sharp, min_strength, hsv_grad_mode)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    img, packed, mask_params = ctx.saved_tensors
+    fid, sharp, min_strength, hsv_grad_mode = ctx.args
+    dy = dy.contiguous().to(img.dtype)
+    dx = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+    dparams = torch.empty_like(packed)
+    dmask = torch.empty_like(mask_params)
+    _cabi.apply_bwd(fid, img, dy, dx, packed, dparams, mask_params, dmask, sharp, min_strength, hsv_grad_mode)
+    return dx, dparams, dmask, None, None, None, None
+
+
 def pixel_filter(fid, img, packed, hsv_grad_mode=0):
   """Functional entry: filter ``fid`` (0..7, ``cfg.filters`` order) with packed (N,P) params."""
   return _PixelFilterFunction.apply(img, packed, fid, hsv_grad_mode)
@@ -139,17 +165,27 @@ class Filter(nn.Module):
     else:
       debug_info['filter_parameters'] = filter_parameters[0]
     self.mask_parameters = mask_parameters
-    self.mask = self.get_mask(img, mask_parameters)
-    debug_info['mask'] = self.mask[0]
-    # lerp(img, process(img, p), ones(1,1,1,1)) == process(img, p): the constant-one mask of the
-    # shipped configs (cfg.masking = False) is folded away instead of spending two more passes.
-    low_res_output = self.process(img, filter_parameters)
+    if not self.use_masking():
+      self.mask = self.get_mask(img, mask_parameters)
+      debug_info['mask'] = self.mask[0]
+      # lerp(img, process(img, p), ones(1,1,1,1)) == process(img, p): the constant-one mask of the
+      # shipped configs (cfg.masking = False) is folded away instead of spending two more passes.
+      apply_one = lambda im: self.process(im, filter_parameters)
+    else:
+      # masking on: mask evaluation, process() and the lerp are ONE kernel (expo_filter_apply_fwd)
+      mp = tanh_range(-5, 5, initial=0)(mask_parameters)  # filters.py:121-123
+      self.mask = self.get_mask(img[:1], mask_parameters[:1])  # debug output (first image) only
+      debug_info['mask'] = self.mask[0]
+      packed = self.pack(filter_parameters)
+      hsv_mode = int(self.cfg.get('hsv_grad_mode', 0))
+      apply_one = lambda im: _MaskedApplyFunction.apply(im, packed, mp, self.filter_id, float(
+          self.cfg.maximum_sharpness), float(self.cfg.minimum_strength), hsv_mode)
+    low_res_output = apply_one(img)
     if high_res is not None:
       if self.no_high_res():
         high_res_output = high_res
       else:
-        self.high_res_mask = self.get_mask(high_res, mask_parameters)
-        high_res_output = self.process(high_res, filter_parameters)
+        high_res_output = apply_one(high_res)
     else:
       high_res_output = None
     return low_res_output, high_res_output, debug_info
@@ -164,10 +200,24 @@ class Filter(nn.Module):
     return 6
 
   def get_mask(self, img, mask_parameters):
-    """filters.py:110-148.  Only the masking-disabled branch is in scope."""
+    """filters.py:110-148 as a tensor.  With masking on, apply() does NOT use this (mask, process
+    and lerp are fused in expo_filter_apply_fwd); it only feeds debug_info['mask'] / visualisers."""
     if not self.use_masking():
       return torch.ones((1, 1, 1, 1), dtype=torch.float32, device=img.device)
-    raise NotImplementedError('cfg.masking=True is outside the hot-path scope (SURVEY.md section 8f-3)')
+    filter_input_range = 5
+    assert mask_parameters.shape[1] == self.get_num_mask_parameters()
+    mp = tanh_range(-filter_input_range, filter_input_range, initial=0)(mask_parameters)
+    h, w = int(img.shape[1]), int(img.shape[2])
+    se = min(h, w)
+    gi = ((torch.arange(h, dtype=torch.float64) + (se - h) / 2.0) / se - 0.5).float().to(img.device)
+    gj = ((torch.arange(w, dtype=torch.float64) + (se - w) / 2.0) / se - 0.5).float().to(img.device)
+    from .util import rgb2lum
+    inp = gi[None, :, None, None] * mp[:, None, None, 0, None] + gj[None, None, :, None] * mp[:, None, None, 1, None] + \
+        mp[:, None, None, 2, None] * (rgb2lum(img.float()) - 0.5) + mp[:, None, None, 3, None] * 2
+    inp = inp * (self.cfg.maximum_sharpness * mp[:, None, None, 4, None] / filter_input_range)
+    mask = torch.sigmoid(inp)
+    return mask * (mp[:, None, None, 5, None] / filter_input_range * 0.5 + 0.5) * \
+        (1 - self.cfg.minimum_strength) + self.cfg.minimum_strength
 
   def visualize_filter(self, debug_info, canvas):
     raise NotImplementedError('cv2 drawing is out of scope')
@@ -290,6 +340,37 @@ class WNBFilter(Filter):
 
   def filter_param_regressor(self, features):
     return torch.sigmoid(features)
+
+
+class LevelFilter(Filter):
+  """filters.py:449-466 (defined by the reference, not part of cfg.filters)."""
+  filter_id = 8
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.short_name = 'Le'
+    self.num_filter_parameters = 2
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    return torch.sigmoid(features)
+
+
+class VignetFilter(Filter):
+  """filters.py:341-401.  In the reference ``process`` is a stub that returns ``img * 0`` and the
+  class is in no config; it is kept here only so the name resolves."""
+  filter_id = None
+
+  def __init__(self, net, cfg):
+    Filter.__init__(self, net, cfg)
+    self.short_name = 'V'
+    self.num_filter_parameters = 1
+
+  def get_num_mask_parameters(self):
+    return 5
+
+  def apply(self, *args, **kwargs):
+    raise NotImplementedError('VignetFilter is a stub in the reference (process returns img * 0) and is unused')
 
 
 class SaturationPlusFilter(Filter):

@@ -13,8 +13,8 @@ import math
 
 import numpy as np
 
-FILTER_NAMES = ('E', 'G', 'W', 'S+', 'T', 'Ct', 'BW', 'C')
-NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24)
+FILTER_NAMES = ('E', 'G', 'W', 'S+', 'T', 'Ct', 'BW', 'C', 'Le')  # 'Le' = LevelFilter (not in cfg.filters)
+NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24, 2)
 
 SHAPES = {
     'A': (64, 64, 64, 3),  # BASELINE config 2
@@ -51,7 +51,7 @@ def regress(fid, f):
   elif name == 'W':
     s = np.exp(_tanh_range(-0.5, 0.5, f * np.array([[0.0, 1.0, 1.0]])))
     p = s / (1e-5 + 0.27 * s[:, 0:1] + 0.67 * s[:, 1:2] + 0.06 * s[:, 2:3])
-  elif name in ('S+', 'BW'):
+  elif name in ('S+', 'BW', 'Le'):
     p = 1.0 / (1.0 + np.exp(-f))
   elif name == 'T':
     p = _tanh_range(0.5, 2.0, f)

@@ -22,6 +22,7 @@
  *       5 Ct ContrastFilter              P = 1   blend in [-1,1]
  *       6 BW WNBFilter                   P = 1   blend in [0,1]
  *       7 C  ColorFilter                 P = 24  k[channel*8 + knot]
+ *       8 Le LevelFilter                 P = 2   lower, upper-1   (not in cfg.filters)
  *     `params` are the outputs of Filter.filter_param_regressor (filters.py:177-179,
  *     201-203, 224-235, 481-482, 306-310, 411-413, 435-436, 256-262) flattened to
  *     float32 [N][P].
@@ -48,7 +49,7 @@ extern "C" {
 #define EXPO_F16 0
 #define EXPO_F32 1
 
-#define EXPO_NUM_FILTERS 8
+#define EXPO_NUM_FILTERS 9
 #define EXPO_MAX_PARAMS 24
 
 #define EXPO_FILTER_EXPOSURE 0
@@ -59,6 +60,7 @@ extern "C" {
 #define EXPO_FILTER_CONTRAST 5
 #define EXPO_FILTER_WNB 6
 #define EXPO_FILTER_COLOR 7
+#define EXPO_FILTER_LEVEL 8 /* LevelFilter (filters.py:449-466): defined by the reference, not in cfg.filters */
 
 /* hsv_grad_mode for SaturationPlus backward: 0 = TF-1.x faithful (RGBToHSV / HSVToRGB
  * are registered NotDifferentiable, so no gradient flows through full_color);
@@ -109,9 +111,29 @@ int expo_filter_bwd_accumulate(int filter_id, const void* x, const void* dy, voi
                                int dtype, int hsv_grad_mode, void* stream);
 
 /*
+ * Filter.apply with the spatial mask enabled (cfg.masking = True; filters.py:62-99, 110-148):
+ *   out = (1 - mask) * x + mask * process(x, params)
+ *   mask = sigmoid((gx*m0 + gy*m1 + m2*(lum(x) - .5) + 2*m3) * maximum_sharpness * m4 / 5)
+ *          * (m5/5 * .5 + .5) * (1 - minimum_strength) + minimum_strength
+ * mask_params: float32 [N][6] = tanh_range(-5, 5)(raw mask parameters) -- the range squashing
+ * (filters.py:121-123) stays with the caller so its gradient is handled by the host autograd.
+ * gx, gy: the constant coordinate grid of filters.py:124-133.  cfg.maximum_sharpness and
+ * cfg.minimum_strength are config_example.py:37-38.
+ */
+int expo_filter_apply_fwd(int filter_id, const void* x, void* y, const float* params,
+                          const float* mask_params, float maximum_sharpness, float minimum_strength,
+                          int n, int h, int w, int dtype, void* stream);
+
+/* Backward of expo_filter_apply_fwd; dparams [N][P] and dmask_params [N][6] are overwritten. */
+int expo_filter_apply_bwd(int filter_id, const void* x, const void* dy, void* dx,
+                          const float* params, float* dparams, const float* mask_params,
+                          float* dmask_params, float maximum_sharpness, float minimum_strength,
+                          int n, int h, int w, int dtype, int hsv_grad_mode, void* stream);
+
+/*
  * Per-image filter choice == the reference's "compute all 8 filters, stack, multiply
  * by one_hot(selected_filter_id), reduce_sum" (agent.py:58-77, 119-125) without the
- * 7 discarded outputs.  filter_ids: int32 [N] in [-1, 7]; -1 (pdf_sample with noise
+ * 7 discarded outputs.  filter_ids: int32 [N] in [-1, 8]; -1 (pdf_sample with noise
  * 0, pdf_sample_layer.py:5-10) selects nothing: y = 0, all gradients 0.
  * params / dparams: float32 [N][EXPO_MAX_PARAMS]; row n holds the P values of filter
  * filter_ids[n] in its first P slots (remaining slots ignored / written as 0).

@@ -33,9 +33,9 @@ import math
 import numpy as np
 
 # cfg.filters order, config_example.py:22-25
-FILTER_NAMES = ('E', 'G', 'W', 'S+', 'T', 'Ct', 'BW', 'C')
+FILTER_NAMES = ('E', 'G', 'W', 'S+', 'T', 'Ct', 'BW', 'C', 'Le')  # 'Le' (LevelFilter) is not in cfg.filters
 FILTER_ID = {n: i for i, n in enumerate(FILTER_NAMES)}
-NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24)
+NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24, 2)
 CURVE_STEPS = 8  # cfg.curve_steps, config_example.py:27
 LUM_W = (0.27, 0.67, 0.06)  # util.py:271-274
 
@@ -147,8 +147,13 @@ def satplus_regressor(f, cfg=DEFAULT_CFG):
   return sigmoid(f)
 
 
+def level_regressor(f, cfg=DEFAULT_CFG):
+  """filters.py:457-458."""
+  return sigmoid(f)
+
+
 REGRESSORS = (exposure_regressor, gamma_regressor, wb_regressor, satplus_regressor,
-              tone_regressor, contrast_regressor, wnb_regressor, color_regressor)
+              tone_regressor, contrast_regressor, wnb_regressor, color_regressor, level_regressor)
 
 
 # ---------------------------------------------------------------------------
@@ -261,8 +266,52 @@ def satplus_process(img, param):
   return img * (1.0 - param) + full_color * param
 
 
+def level_process(img, param):
+  """filters.py:460-466; param (N,2)."""
+  dt = _ft(img)
+  lower = param[:, 0]
+  upper = param[:, 1] + 1
+  lower = lower[:, None, None, None]
+  upper = upper[:, None, None, None]
+  return np.clip((img - lower) / (upper - lower + dt.type(1e-6)), 0.0, 1.0)
+
+
 PROCESS = (exposure_process, gamma_process, wb_process, satplus_process, tone_process,
-           contrast_process, wnb_process, color_process)
+           contrast_process, wnb_process, color_process, level_process)
+
+
+def mask_grid(h, w, dtype=np.float64):
+  """filters.py:124-133: the constant (1,H,W,2) coordinate grid."""
+  se = min(h, w)
+  gi = (np.arange(h, dtype=np.float64) + (se - h) / 2.0) / se - 0.5
+  gj = (np.arange(w, dtype=np.float64) + (se - w) / 2.0) / se - 0.5
+  grid = np.zeros((1, h, w, 2), dtype=np.float32)  # the reference builds it in float32
+  grid[0, :, :, 0] = gi[:, None]
+  grid[0, :, :, 1] = gj[None, :]
+  return grid.astype(dtype)
+
+
+def get_mask(img, mask_parameters, maximum_sharpness=1, minimum_strength=0.3):
+  """filters.py:110-148 with cfg.masking = True; mask_parameters (N,6) RAW (pre tanh_range)."""
+  dt = _ft(img)
+  filter_input_range = 5
+  mp = tanh_range(-filter_input_range, filter_input_range, initial=0)(mask_parameters)
+  grid = mask_grid(img.shape[1], img.shape[2], dt)
+  inp = grid[:, :, :, 0, None] * mp[:, None, None, 0, None] + \
+      grid[:, :, :, 1, None] * mp[:, None, None, 1, None] + \
+      mp[:, None, None, 2, None] * (rgb2lum(img) - dt.type(0.5)) + \
+      mp[:, None, None, 3, None] * 2
+  inp = inp * (maximum_sharpness * mp[:, None, None, 4, None] / filter_input_range)
+  mask = sigmoid(inp)
+  mask = mask * (mp[:, None, None, 5, None] / filter_input_range * dt.type(0.5) + dt.type(0.5)) * \
+      (1 - minimum_strength) + minimum_strength
+  return mask
+
+
+def apply_masked(fid, img, packed, mask_parameters, maximum_sharpness=1, minimum_strength=0.3):
+  """Filter.apply with cfg.masking = True (filters.py:86-88)."""
+  mask = get_mask(img, mask_parameters, maximum_sharpness, minimum_strength)
+  return lerp(img, process_packed(fid, img, packed), mask)
 
 
 # ---------------------------------------------------------------------------
@@ -420,6 +469,18 @@ def satplus_backward(img, p, dy, hsv_grad_mode=0):
   return dx, _sum_hwc(dy * (full - xc))[:, None]
 
 
+def level_backward(img, p, dy):
+  lower = p[:, 0][:, None, None, None]
+  upper = (p[:, 1] + 1)[:, None, None, None]
+  r = 1.0 / (upper - lower + 1e-6)
+  t = (img - lower) * r
+  inside = ((t >= 0.0) & (t <= 1.0)).astype(img.dtype)
+  dx = dy * r * inside
+  dlower = _sum_hwc(dy * inside * r * (t - 1.0))
+  dupper = _sum_hwc(-dy * inside * t * r)
+  return dx, np.stack([dlower, dupper], axis=1)
+
+
 def backward_packed(fid, img, packed, dy, hsv_grad_mode=0):
   """Gradient of sum(y*dy) w.r.t. (img, packed params). float64 recommended."""
   img = np.asarray(img)
@@ -442,6 +503,8 @@ def backward_packed(fid, img, packed, dy, hsv_grad_mode=0):
     return wnb_backward(img, p, dy)
   if name == 'C':
     return color_backward(img, p, dy)
+  if name == 'Le':
+    return level_backward(img, p, dy)
   raise ValueError(fid)
 
 

@@ -19,8 +19,8 @@ import math
 
 import torch
 
-FILTER_NAMES = ('E', 'G', 'W', 'S+', 'T', 'Ct', 'BW', 'C')
-NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24)
+FILTER_NAMES = ('E', 'G', 'W', 'S+', 'T', 'Ct', 'BW', 'C', 'Le')
+NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24, 2)
 CURVE_STEPS = 8
 
 
@@ -140,6 +140,49 @@ def satplus_process(img, param, hsv_grad_mode=0):
   return img * (1.0 - param) + full_color * param
 
 
+def level_process(img, param):
+  """filters.py:460-466."""
+  lower = param[:, 0]
+  upper = param[:, 1] + 1
+  lower = lower[:, None, None, None]
+  upper = upper[:, None, None, None]
+  return torch.clamp((img - lower) / (upper - lower + 1e-6), 0.0, 1.0)
+
+
+def get_mask(img, mask_parameters, maximum_sharpness=1, minimum_strength=0.3):
+  """filters.py:110-148 with cfg.masking = True; mask_parameters RAW (N,6)."""
+  filter_input_range = 5
+  mp = tanh_range(-filter_input_range, filter_input_range, initial=0)(mask_parameters)
+  h, w = img.shape[1], img.shape[2]
+  se = min(h, w)
+  gi = ((torch.arange(h, dtype=torch.float64) + (se - h) / 2.0) / se - 0.5).float().to(img.dtype)
+  gj = ((torch.arange(w, dtype=torch.float64) + (se - w) / 2.0) / se - 0.5).float().to(img.dtype)
+  g0 = gi[None, :, None, None]
+  g1 = gj[None, None, :, None]
+  inp = g0 * mp[:, None, None, 0, None] + g1 * mp[:, None, None, 1, None] + \
+      mp[:, None, None, 2, None] * (rgb2lum(img) - 0.5) + mp[:, None, None, 3, None] * 2
+  inp = inp * (maximum_sharpness * mp[:, None, None, 4, None] / filter_input_range)
+  mask = torch.sigmoid(inp)
+  mask = mask * (mp[:, None, None, 5, None] / filter_input_range * 0.5 + 0.5) * (1 - minimum_strength) + \
+      minimum_strength
+  return mask
+
+
+def apply_masked(fid, img, packed, mask_parameters, maximum_sharpness=1, minimum_strength=0.3, hsv_grad_mode=0):
+  """Filter.apply with cfg.masking = True (filters.py:86-88)."""
+  mask = get_mask(img, mask_parameters, maximum_sharpness, minimum_strength)
+  return lerp(img, process_packed(fid, img, packed, hsv_grad_mode), mask)
+
+
+def apply_masked_backward(fid, img, packed, mask_parameters, dy, maximum_sharpness=1, minimum_strength=0.3,
+                          hsv_grad_mode=0):
+  img = img.detach().clone().requires_grad_(True)
+  packed = packed.detach().clone().requires_grad_(True)
+  mask_parameters = mask_parameters.detach().clone().requires_grad_(True)
+  y = apply_masked(fid, img, packed, mask_parameters, maximum_sharpness, minimum_strength, hsv_grad_mode)
+  return (y.detach(),) + torch.autograd.grad(y, [img, packed, mask_parameters], dy)
+
+
 def unpack_params(fid, packed):
   n = packed.shape[0]
   if FILTER_NAMES[fid] == 'T':
@@ -168,6 +211,8 @@ def process_packed(fid, img, packed, hsv_grad_mode=0):
     return wnb_process(img, p)
   if name == 'C':
     return color_process(img, p)
+  if name == 'Le':
+    return level_process(img, p)
   raise ValueError(fid)
 
 

@@ -31,8 +31,8 @@ def test_library_exports_every_symbol():
 def test_version_and_param_counts():
   lib = _cabi.load()
   assert lib.expo_version() == _cabi.EXPO_ABI_VERSION
-  assert [lib.expo_num_filter_params(i) for i in range(8)] == list(_cabi.NUM_PARAMS)
-  assert lib.expo_num_filter_params(-1) == -1 and lib.expo_num_filter_params(8) == -1
+  assert [lib.expo_num_filter_params(i) for i in range(9)] == list(_cabi.NUM_PARAMS)
+  assert lib.expo_num_filter_params(-1) == -1 and lib.expo_num_filter_params(9) == -1
 
 
 def test_argument_validation_without_gpu():

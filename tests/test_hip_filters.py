@@ -264,3 +264,61 @@ def test_bwd_accumulate(gpu_device):
     _cabi.filter_bwd(fid, tx, tdy, None, tp, acc, accumulate=True)
     scale = dp.abs().max().item() + 1.0
     assert (acc - (1.5 + 2 * dp)).abs().max().item() <= 1e-3 * scale
+
+
+# ------------------------------------------------------------------ LevelFilter + spatial mask
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+def test_level_filter_matches_oracle(dtype, gpu_device):
+  x, dy, _ = synthetic.make_case(401, (3, 32, 48, 3), NP_DT[dtype])
+  p = synthetic.make_params(np.random.default_rng(4), 8, 3)
+  y, dx, dp = run_fwd_bwd(8, x, dy, p, dtype, gpu_device)
+  ry, rdx, rdp = oracle(8, x, dy, p)
+  assert_image_close(y, ry, NP_DT[dtype], 'level y')
+  assert_image_close(dx, rdx, NP_DT[dtype], 'level dx')
+  assert_param_grad_close(dp, rdp, grad_scale(8, x, dy, p) * 2, 'level dp')
+
+
+@pytest.mark.parametrize('fid', range(9))
+@pytest.mark.parametrize('shape', [(3, 64, 64, 3), (2, 17, 23, 3), (2, 40, 24, 3)])
+def test_masked_apply_matches_oracle(fid, shape, gpu_device):
+  """cfg.masking = True path: mask + process + lerp fused in one kernel (filters.py:86-88, 110-148)."""
+  from oracle import filters_torch as ft
+  from exposure_amd.util import tanh_range
+  dev = gpu_device
+  rng = np.random.default_rng(500 + fid)
+  x, dy, _ = synthetic.make_case(600 + fid, shape, np.float32)
+  p = synthetic.make_params(rng, fid, shape[0])
+  raw = rng.standard_normal((shape[0], 6)).astype(np.float32)
+  sharp, ms = 1.0, 0.3
+  ry, rdx, rdp, rdraw = ft.apply_masked_backward(fid, torch.from_numpy(x).double(), torch.from_numpy(p).double(),
+                                                 torch.from_numpy(raw).double(), torch.from_numpy(dy).double(), sharp, ms)
+  tx = torch.from_numpy(x).to(dev).requires_grad_(True)
+  tp = torch.from_numpy(p).to(dev).requires_grad_(True)
+  traw = torch.from_numpy(raw).to(dev).requires_grad_(True)
+  mp = tanh_range(-5, 5, initial=0)(traw)
+  y = filters._MaskedApplyFunction.apply(tx, tp, mp, fid, sharp, ms, 0)
+  y.backward(torch.from_numpy(dy).to(dev))
+  assert_image_close(y.detach().cpu().numpy(), ry.numpy(), np.float32, 'masked y')
+  assert_image_close(tx.grad.cpu().numpy(), rdx.numpy(), np.float32, 'masked dx')
+  scale = np.abs(dy.astype(np.float64)).reshape(shape[0], -1).sum(axis=1, keepdims=True) * 4
+  assert_param_grad_close(tp.grad.cpu().numpy(), rdp.numpy(), np.broadcast_to(scale, p.shape), 'masked dparams')
+  assert_param_grad_close(traw.grad.cpu().numpy(), rdraw.numpy(), np.broadcast_to(scale, raw.shape), 'masked dmask')
+
+
+def test_filter_apply_with_masking_enabled(gpu_device):
+  from oracle import filters_torch as ft
+  dev = gpu_device
+  torch.manual_seed(0)
+  cfg = make_cfg()
+  cfg.masking = True
+  f = filters.ContrastFilter((1, 32, 32, 3), cfg).to(dev)
+  x, _, _ = synthetic.make_case(77, (2, 32, 32, 3), np.float16)
+  hi, _, _ = synthetic.make_case(78, (2, 48, 64, 3), np.float16)
+  feats = torch.randn(2, cfg.feature_extractor_dims, device=dev)
+  low, high, info = f.apply(torch.from_numpy(x).to(dev), img_features=feats, high_res=torch.from_numpy(hi).to(dev))
+  ff, mraw = f.extract_parameters(feats)
+  p = f.filter_param_regressor(ff).detach().cpu().double()
+  for got, src in ((low, x), (high, hi)):
+    ref = ft.apply_masked(5, torch.from_numpy(src).double(), p, mraw.detach().cpu().double(), 1.0, 0.3).numpy()
+    assert_image_close(got.detach().float().cpu().numpy(), ref, np.float16, 'apply(masking)')
+  assert info['mask'].shape == (32, 32, 1)
