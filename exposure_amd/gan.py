@@ -18,9 +18,11 @@ from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
 
 class GAN(nn.Module):
 
-  def __init__(self, cfg, device=None, process_group=None):
+  def __init__(self, cfg, device=None, process_group=None, use_graphs=False):
     super().__init__()
     self.cfg = cfg
+    self.use_graphs = bool(use_graphs)
+    self._graphs = {}
     # MIOpen's default heuristic picks a 2 ms kernel for the double-backward convolutions of the
     # gradient penalty; its benchmark ("find") mode settles on one 2.7x faster (tools/conv_probe.py)
     torch.backends.cudnn.benchmark = True
@@ -30,9 +32,16 @@ class GAN(nn.Module):
     if device is not None:
       self.to(device)
     adam = dict(betas=(cfg.adam_beta1, cfg.adam_beta2), eps=1e-8)  # config_example.py:158
-    self.opt_g = torch.optim.Adam(self.generator.parameters(), lr=cfg.lr_g(0), **adam)
-    self.opt_v = torch.optim.Adam(self.value.parameters(), lr=cfg.value_lr_mul * cfg.lr_g(0), **adam)
-    self.opt_c = torch.optim.Adam(self.critic.parameters(), lr=cfg.lr_c(0), **adam)
+    if self.use_graphs:
+      # hipGraph replay of a whole step: learning rates live in device tensors, Adam is capturable
+      assert device is not None and torch.device(device).type == 'cuda', 'graphs need a ROCm device'
+      adam['capturable'] = True
+      lr = lambda v: torch.tensor(float(v), device=device)
+    else:
+      lr = float
+    self.opt_g = torch.optim.Adam(self.generator.parameters(), lr=lr(cfg.lr_g(0)), **adam)
+    self.opt_v = torch.optim.Adam(self.value.parameters(), lr=lr(cfg.value_lr_mul * cfg.lr_g(0)), **adam)
+    self.opt_c = torch.optim.Adam(self.critic.parameters(), lr=lr(cfg.lr_c(0)), **adam)
     self.process_group = process_group
     self.world_size = xdist.world_size(process_group)
     self.buckets = {
@@ -47,12 +56,17 @@ class GAN(nn.Module):
   # -- learning rates (config_example.py:134-158; net.py:222-251)
   def set_lrs(self, it, zero_g=False):
     lr_g = 0.0 if zero_g else self.cfg.lr_g(it)  # net.py:327-328: lr_g = 0 at iter 0
-    for g in self.opt_g.param_groups:
-      g['lr'] = lr_g
-    for g in self.opt_v.param_groups:
-      g['lr'] = self.cfg.value_lr_mul * lr_g
-    for g in self.opt_c.param_groups:
-      g['lr'] = self.cfg.lr_c(it)
+
+    def put(opt, value):
+      for g in opt.param_groups:
+        if torch.is_tensor(g['lr']):
+          g['lr'].fill_(value)  # in place: the captured graph reads this tensor
+        else:
+          g['lr'] = value
+
+    put(self.opt_g, lr_g)
+    put(self.opt_v, self.cfg.value_lr_mul * lr_g)
+    put(self.opt_c, self.cfg.lr_c(it))
 
   def generator_losses(self, fake_input, z, states, progress, is_train=1, dropout_masks=None):
     """net.py:56-165 (WGAN branch, use_TD, use_penalty)."""
@@ -78,9 +92,7 @@ class GAN(nn.Module):
     return dict(g_loss=g_loss, v_loss=v_loss, fake_output=fake_output, new_states=new_states, reward=reward,
                 q_value=q_value, fake_logit=fake_logit, debug=debug)
 
-  def generator_step(self, fake_input, z, states, progress, it=1, dropout_masks=None):
-    """opt_g on g_loss w.r.t. theta_g and opt_v on v_loss w.r.t. theta_v (net.py:222-241)."""
-    self.set_lrs(it, zero_g=(it == 0))
+  def _generator_body(self, fake_input, z, states, progress, dropout_masks):
     out = self.generator_losses(fake_input, z, states, progress, 1, dropout_masks)
     self.opt_g.zero_grad(set_to_none=True)
     self.opt_v.zero_grad(set_to_none=True)
@@ -101,7 +113,76 @@ class GAN(nn.Module):
       hv.wait_and_scatter()
     self.opt_g.step()
     self.opt_v.step()
-    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items() if k != 'debug'}
+    return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
+
+  def _draw_masks(self, n, device):
+    keep = self.cfg.dropout_keep_prob
+    return [(torch.rand((n, self.cfg.feature_extractor_dims), device=device) < keep).float() for _ in range(2)]
+
+  def generator_step(self, fake_input, z, states, progress, it=1, dropout_masks=None):
+    """opt_g on g_loss w.r.t. theta_g and opt_v on v_loss w.r.t. theta_v (net.py:222-241)."""
+    self.set_lrs(it, zero_g=(it == 0))
+    if self.use_graphs and self.world_size == 1:
+      masks = dropout_masks or self._draw_masks(fake_input.shape[0], fake_input.device)
+      prog = torch.as_tensor(float(progress), device=fake_input.device)
+      return self._replay('g', self._generator_body_graph, (fake_input, z, states, prog, masks[0], masks[1]))
+    return self._generator_body(fake_input, z, states, progress, dropout_masks)
+
+  def _generator_body_graph(self, fake_input, z, states, progress, m0, m1):
+    return self._generator_body(fake_input, z, states, progress, [m0, m1])
+
+  # ---- hipGraph capture / replay of a whole optimisation step --------------------------------
+  def _replay(self, key, body, inputs):
+    """First call per (step kind, input shapes): warm up on a side stream, restore the weights and
+    optimiser state the warm-up touched, capture ``body`` into one hipGraph.  Later calls copy the
+    inputs into the static buffers and replay: ~6 000 eager launches (~10 us of host time each)
+    become one graph launch.  Returned tensors are the graph's static outputs (valid until the
+    next replay of the same graph)."""
+    sig = (key,) + tuple((tuple(t.shape), t.dtype) for t in inputs)
+    entry = self._graphs.get(sig)
+    if entry is None:
+      static_in = [t.clone() for t in inputs]
+      params = list(self.parameters())
+      saved_p = [p.detach().clone() for p in params]
+      saved_o = [opt.state_dict() for opt in (self.opt_g, self.opt_v, self.opt_c)]
+      saved_o = [{'state': {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
+                            for k, st in sd['state'].items()}, 'param_groups': sd['param_groups']} for sd in saved_o]
+      side = torch.cuda.Stream()
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        for _ in range(3):
+          body(*static_in)
+      torch.cuda.current_stream().wait_stream(side)
+      torch.cuda.synchronize()
+
+      def restore():
+        with torch.no_grad():
+          for p, sp in zip(params, saved_p):
+            p.copy_(sp)
+        for opt, sd in zip((self.opt_g, self.opt_v, self.opt_c), saved_o):
+          cur = opt.state_dict()['state']
+          for k, st in sd['state'].items():
+            for kk, vv in st.items():
+              if torch.is_tensor(vv):
+                cur[k][kk].copy_(vv)
+          for k in cur:
+            if k not in sd['state']:  # state created by the warm-up: reset to the fresh-optimizer value
+              for kk, vv in cur[k].items():
+                if torch.is_tensor(vv):
+                  vv.zero_()
+
+      restore()
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(graph):
+        static_out = body(*static_in)
+      restore()  # the capture pass itself does not execute, but keep the state exactly as before
+      entry = (graph, static_in, static_out)
+      self._graphs[sig] = entry
+    graph, static_in, static_out = entry
+    for dst, src in zip(static_in, inputs):
+      dst.copy_(src)
+    graph.replay()
+    return static_out
 
   def critic_losses(self, real_data, fake_output, alpha=None):
     """net.py:126-194: c_loss = mean(fake - real) + lambda * mean(max(||grad||-1, 0)^2).
@@ -126,8 +207,7 @@ class GAN(nn.Module):
     return dict(c_loss=total, emd=-c_loss.detach(), gradient_norm=gradient_norm.mean().detach(),
                 gradient_penalty=gradient_penalty.detach(), c_average=c_average)
 
-  def critic_step(self, real_data, fake_output, it=1, alpha=None):
-    self.set_lrs(it)
+  def _critic_body(self, real_data, fake_output, alpha):
     out = self.critic_losses(real_data, fake_output, alpha)
     self.opt_c.zero_grad(set_to_none=True)
     out['c_loss'].backward()
@@ -137,11 +217,21 @@ class GAN(nn.Module):
       xdist.all_reduce_mean_(ca, self.process_group)
       out['c_average'] = ca
     self.opt_c.step()
-    # update_average (net.py:165-168, 267-268): debiased EMA of the logit centre
+    return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
+
+  def critic_step(self, real_data, fake_output, it=1, alpha=None):
+    self.set_lrs(it)
+    if self.use_graphs and self.world_size == 1:
+      if alpha is None:
+        alpha = torch.rand((real_data.shape[0], 1, 1, 1), device=real_data.device)
+      out = dict(self._replay('c', self._critic_body, (real_data, fake_output, alpha)))
+    else:
+      out = self._critic_body(real_data, fake_output, alpha)
+    # update_average (net.py:165-168, 267-268): debiased EMA of the logit centre, kept on the device
     self.c_average_steps += 1
-    self.c_average_biased = 0.99 * self.c_average_biased + 0.01 * float(out['c_average'])
+    self.c_average_biased = 0.99 * self.c_average_biased + 0.01 * out['c_average']
     out['c_average_smoothed'] = self.c_average_biased / (1.0 - 0.99**self.c_average_steps)
-    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+    return out
 
   # -- the training loop (net.py:298-403), minus visualisation / checkpoints / TensorBoard
   def train(self, memory, max_iter_step=None, log_every=0, log=print):

@@ -32,11 +32,12 @@ class Dict(dict):
 
 
 def lrelu(x, leak=0.2):
-  """util.py:225-229 -- written as f1*x + f2*|x| so it stays twice differentiable a.e.
-  (needed by the WGAN-GP double backward through the critic)."""
-  f1 = 0.5 * (1 + leak)
-  f2 = 0.5 * (1 - leak)
-  return f1 * x + f2 * torch.abs(x)
+  """util.py:225-229: ``f1*x + f2*|x|`` with f1 = (1+leak)/2, f2 = (1-leak)/2, i.e. the leaky ReLU
+  ``x if x > 0 else leak*x``.  Evaluated as ONE fused kernel per direction (``leaky_relu`` has a
+  first and a second derivative in autograd, which the WGAN-GP double backward needs) instead of
+  the four elementwise launches of the literal formula; the two agree to 1 ulp (0.6x + 0.4x vs x)
+  and differ only in the subgradient picked exactly at x == 0 (0.2 here, 0.6 in TF)."""
+  return torch.nn.functional.leaky_relu(x, negative_slope=leak)
 
 
 def rgb2lum(image):

@@ -207,3 +207,32 @@ def test_training_loop_on_gpu(gpu_device):
       c = gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
     assert torch.isfinite(g['g_loss']) and torch.isfinite(c['c_loss'])
   assert len(mem) == 32
+
+
+def test_graphed_steps_match_eager(gpu_device):
+  """hipGraph replay of the generator / critic step == the eager step (same inputs, masks, alpha)."""
+  dev = gpu_device
+  cfg = make_cfg()
+  rng = np.random.default_rng(5)
+  n = 16
+  t = lambda a: torch.from_numpy(a).to(dev)
+  img = t(synthetic.make_images(rng, (n, 64, 64, 3), np.float16))
+  real = t(synthetic.make_images(rng, (n, 64, 64, 3), np.float16))
+  states = torch.zeros(n, 11, device=dev)
+  states[:, 2] = t(rng.integers(0, 4, n).astype(np.float32))
+  z = t(rng.random((n, 131), dtype=np.float32))
+  masks = [t((rng.random((n, 4096)) < 0.5).astype(np.float32)) for _ in range(2)]
+  alpha = t(rng.random((n, 1, 1, 1), dtype=np.float32))
+  results = []
+  for use_graphs in (False, True):
+    torch.manual_seed(11)
+    gan = GAN(cfg, device=dev, use_graphs=use_graphs)
+    for it in (3, 4):  # second call replays the captured graph
+      g = gan.generator_step(img, z, states, progress=0.2, it=it, dropout_masks=masks)
+      fake = g['fake_output'].clone()
+      c = gan.critic_step(real, fake, it=it, alpha=alpha)
+    results.append(([p.detach().clone() for p in gan.parameters()], float(g['g_loss']), float(c['c_loss'])))
+  (pe, ge, ce), (pg, gg, cg) = results
+  assert abs(ge - gg) <= 1e-3 * (1 + abs(ge)) and abs(ce - cg) <= 1e-3 * (1 + abs(ce))
+  worst = max(float((a - b).abs().max()) for a, b in zip(pe, pg))
+  assert worst < 3e-4, worst  # Adam steps are ~lr-sized; see tests/test_dist_gloo.py
