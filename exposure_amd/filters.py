@@ -265,11 +265,13 @@ class ImprovedWhiteBalanceFilter(Filter):
     self.channels = 3
     self.num_filter_parameters = self.channels
     self._build_regressor()
+    # filters.py:226-229: the first feature is masked out (a device buffer: no H2D copy per call,
+    # which would also be illegal inside a hipGraph capture)
+    self.register_buffer('feature_mask', torch.tensor([[0.0, 1.0, 1.0]]), persistent=False)
 
   def filter_param_regressor(self, features):
     log_wb_range = 0.5
-    mask = torch.tensor([[0.0, 1.0, 1.0]], dtype=features.dtype, device=features.device)
-    features = features * mask
+    features = features * self.feature_mask.to(features.dtype)
     color_scaling = torch.exp(tanh_range(-log_wb_range, log_wb_range)(features))
     # normalize by luminance
     color_scaling = color_scaling * (1.0 / (1e-5 + 0.27 * color_scaling[:, 0] + 0.67 * color_scaling[:, 1] +

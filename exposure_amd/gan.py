@@ -133,49 +133,23 @@ class GAN(nn.Module):
 
   # ---- hipGraph capture / replay of a whole optimisation step --------------------------------
   def _replay(self, key, body, inputs):
-    """First call per (step kind, input shapes): warm up on a side stream, restore the weights and
-    optimiser state the warm-up touched, capture ``body`` into one hipGraph.  Later calls copy the
-    inputs into the static buffers and replay: ~6 000 eager launches (~10 us of host time each)
-    become one graph launch.  Returned tensors are the graph's static outputs (valid until the
-    next replay of the same graph)."""
+    """hipGraph execution of one optimisation step.  Per (step kind, input shapes): the FIRST call
+    runs eagerly (it is a normal training step and doubles as the warm-up that lets MIOpen /
+    hipBLASLt pick kernels and allocate workspaces), the SECOND call captures ``body`` into one
+    hipGraph, and from then on the inputs are copied into the static buffers and the graph is
+    replayed: ~6 000 eager launches (~10 us of host time each) become one graph launch.  Returned
+    tensors are the graph's static outputs (valid until the next replay of the same graph)."""
     sig = (key,) + tuple((tuple(t.shape), t.dtype) for t in inputs)
     entry = self._graphs.get(sig)
     if entry is None:
+      self._graphs[sig] = 'warm'
+      return body(*inputs)
+    if entry == 'warm':
       static_in = [t.clone() for t in inputs]
-      params = list(self.parameters())
-      saved_p = [p.detach().clone() for p in params]
-      saved_o = [opt.state_dict() for opt in (self.opt_g, self.opt_v, self.opt_c)]
-      saved_o = [{'state': {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
-                            for k, st in sd['state'].items()}, 'param_groups': sd['param_groups']} for sd in saved_o]
-      side = torch.cuda.Stream()
-      side.wait_stream(torch.cuda.current_stream())
-      with torch.cuda.stream(side):
-        for _ in range(3):
-          body(*static_in)
-      torch.cuda.current_stream().wait_stream(side)
       torch.cuda.synchronize()
-
-      def restore():
-        with torch.no_grad():
-          for p, sp in zip(params, saved_p):
-            p.copy_(sp)
-        for opt, sd in zip((self.opt_g, self.opt_v, self.opt_c), saved_o):
-          cur = opt.state_dict()['state']
-          for k, st in sd['state'].items():
-            for kk, vv in st.items():
-              if torch.is_tensor(vv):
-                cur[k][kk].copy_(vv)
-          for k in cur:
-            if k not in sd['state']:  # state created by the warm-up: reset to the fresh-optimizer value
-              for kk, vv in cur[k].items():
-                if torch.is_tensor(vv):
-                  vv.zero_()
-
-      restore()
       graph = torch.cuda.CUDAGraph()
       with torch.cuda.graph(graph):
         static_out = body(*static_in)
-      restore()  # the capture pass itself does not execute, but keep the state exactly as before
       entry = (graph, static_in, static_out)
       self._graphs[sig] = entry
     graph, static_in, static_out = entry

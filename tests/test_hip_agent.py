@@ -227,7 +227,7 @@ def test_graphed_steps_match_eager(gpu_device):
   for use_graphs in (False, True):
     torch.manual_seed(11)
     gan = GAN(cfg, device=dev, use_graphs=use_graphs)
-    for it in (3, 4):  # second call replays the captured graph
+    for it in (3, 4, 5, 6):  # 1st call eager (warm-up), 2nd captures + replays, then pure replays
       g = gan.generator_step(img, z, states, progress=0.2, it=it, dropout_masks=masks)
       fake = g['fake_output'].clone()
       c = gan.critic_step(real, fake, it=it, alpha=alpha)
