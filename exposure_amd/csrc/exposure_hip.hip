@@ -92,7 +92,7 @@ __device__ __forceinline__ void block_reduce_atomic(float* acc, float* __restric
 }
 
 // --------------------------------------------------------------------------- forward
-template <class F, typename T, bool VEC, bool NT, bool PEN>
+template <class F, typename T, bool VEC, bool PEN>
 __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict__ yi,
                                          const float* __restrict__ prm, float* pen_out,
                                          int hw, int groups, float inv_count) {
@@ -135,17 +135,17 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   }
 }
 
-template <class F, typename T, bool VEC, bool NT>
+template <class F, typename T, bool VEC>
 __global__ __launch_bounds__(kThreads) void filter_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                               const float* __restrict__ params,
                                                               int hw, int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
-  fwd_body<F, T, VEC, NT, false>(x + off, y + off, params + n * F::NP, nullptr, hw, groups, 0.f);
+  fwd_body<F, T, VEC, false>(x + off, y + off, params + n * F::NP, nullptr, hw, groups, 0.f);
 }
 
 // -------------------------------------------------------------------------- backward
-template <class F, typename T, bool VEC, bool NT, bool HAS_DX, bool PEN, int MODE>
+template <class F, typename T, bool VEC, bool HAS_DX, bool PEN, int MODE>
 __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __restrict__ dyi,
                                          T* __restrict__ dxi, const float* __restrict__ prm,
                                          float* __restrict__ dprm, int hw, int groups, float pen_scale) {
@@ -202,15 +202,15 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   block_reduce_atomic<F::NACC, F::NP>(acc, dprm, [=](const float* t, int j) { return F::finish_one(prm, t, j); });
 }
 
-template <class F, typename T, bool VEC, bool NT, bool HAS_DX, int MODE>
-__global__ __launch_bounds__(kThreads, F::kMinWaves) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+template <class F, typename T, bool VEC, bool HAS_DX, int MODE>
+__global__ __launch_bounds__(kThreads) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                               T* __restrict__ dx,
                                                               const float* __restrict__ params,
                                                               float* __restrict__ dparams, int hw,
                                                               int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
-  bwd_body<F, T, VEC, NT, HAS_DX, false, MODE>(x + off, dy + off, HAS_DX ? dx + off : nullptr,
+  bwd_body<F, T, VEC, HAS_DX, false, MODE>(x + off, dy + off, HAS_DX ? dx + off : nullptr,
                                                params + n * F::NP, dparams + n * F::NP, hw, groups, 0.f);
 }
 
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kThreads) void dispatch_fwd_kernel(const int32_t* _
   const int id = ids[n];  // block-uniform
 #define EXPO_CASE(ID, F)                                                                              \
   case ID:                                                                                            \
-    if constexpr ((SET >> ID) & 1) fwd_body<F, T, VEC, false, PEN>(x + off, y + off, prm, pen, hw, groups, inv_count); \
+    if constexpr ((SET >> ID) & 1) fwd_body<F, T, VEC, PEN>(x + off, y + off, prm, pen, hw, groups, inv_count); \
     break;
   switch (id) {
     EXPO_CASE(0, ExposureF)
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
 #define EXPO_CASE(ID, F)                                                                                  \
   case ID:                                                                                                \
     if constexpr ((SET >> ID) & 1)                                                                        \
-      bwd_body<F, T, VEC, false, HAS_DX, PEN, MODE>(x + off, dy + off, dxi, prm, dprm, hw, groups, ps);   \
+      bwd_body<F, T, VEC, HAS_DX, PEN, MODE>(x + off, dy + off, dxi, prm, dprm, hw, groups, ps);   \
     break;
   switch (id) {
     EXPO_CASE(0, ExposureF)
@@ -498,11 +498,11 @@ __global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__
 
 #ifdef EXPO_PROBE
 // register-pressure probe builds (tools/probe.sh): instantiate a few kernels, skip the host side
-template __global__ void filter_bwd_kernel<ToneF, half_t, true, false, true, 0>(const half_t*, const half_t*, half_t*,
+template __global__ void filter_bwd_kernel<ToneF, half_t, true, true, 0>(const half_t*, const half_t*, half_t*,
                                                                                 const float*, float*, int, int);
-template __global__ void filter_bwd_kernel<ColorF, half_t, true, false, true, 0>(const half_t*, const half_t*, half_t*,
+template __global__ void filter_bwd_kernel<ColorF, half_t, true, true, 0>(const half_t*, const half_t*, half_t*,
                                                                                  const float*, float*, int, int);
-template __global__ void filter_bwd_kernel<WnbF, half_t, true, false, true, 0>(const half_t*, const half_t*, half_t*,
+template __global__ void filter_bwd_kernel<WnbF, half_t, true, true, 0>(const half_t*, const half_t*, half_t*,
                                                                                const float*, float*, int, int);
 }  // namespace expo
 #else
@@ -576,9 +576,9 @@ static int launch_fwd(const void* x, void* y, const float* params, int n, int h,
   const Geom g = make_geom<T>(n, h, w, {x, y}, false);
   const dim3 grid(g.blocks_x, n), block(kThreads);
   if (g.vec)
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, false>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
   else
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, false, false>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, false>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
   HIP_TRY(hipGetLastError(), "filter_fwd launch");
   return EXPO_OK;
 }
@@ -590,7 +590,7 @@ static int launch_bwd(const void* x, const void* dy, void* dx, const float* para
   const dim3 grid(g.blocks_x, n), block(kThreads);
   if (!zeroed) HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * F::NP, s), "dparams memset");
 #define EXPO_L(VEC, HAS_DX, MODE)                                                                        \
-  hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, false, HAS_DX, MODE>), grid, block, 0, s, (const T*)x, \
+  hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, HAS_DX, MODE>), grid, block, 0, s, (const T*)x, \
                      (const T*)dy, (T*)dx, params, dparams, g.hw, g.groups)
   // only SaturationPlus has a mode-dependent backward
   const bool m1 = std::is_same<F, SatPlusF>::value && mode == 1;

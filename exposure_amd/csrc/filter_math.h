@@ -41,7 +41,7 @@ __device__ __forceinline__ float lum3(const float x[3]) {
 // 0  ExposureFilter   filters.py:181-182   y = x * exp(p ln2)
 // ---------------------------------------------------------------------------------
 struct ExposureF {
-  static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
   static constexpr bool kHasGroupBwd = false;
   struct Prm { float s; };
   __device__ static Prm load(const float* __restrict__ p) { return {exp2f(p[0])}; }
@@ -65,7 +65,7 @@ struct ExposureF {
 // 1  GammaFilter   filters.py:205-206   y = pow(max(x, 0.001), g)
 // ---------------------------------------------------------------------------------
 struct GammaF {
-  static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
   static constexpr bool kHasGroupBwd = false;
   struct Prm { float g; };
   __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
@@ -93,7 +93,7 @@ struct GammaF {
 // 2  ImprovedWhiteBalanceFilter   filters.py:237-238   y_c = x_c * s_c
 // ---------------------------------------------------------------------------------
 struct WhiteBalanceF {
-  static constexpr int NP = 3, NACC = 3, kLutFloats = 0, kMinWaves = 1;
+  static constexpr int NP = 3, NACC = 3, kLutFloats = 0;
   static constexpr bool kHasGroupBwd = false;
   struct Prm { float s[3]; };
   __device__ static Prm load(const float* __restrict__ p) { return {{p[0], p[1], p[2]}}; }
@@ -121,7 +121,7 @@ struct WhiteBalanceF {
 //    for rng == 0 TF's hue is 0, i.e. d = (1,0,0).  full_c = ((1-s') + s' d_c) v.
 // ---------------------------------------------------------------------------------
 struct SatPlusF {
-  static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
   static constexpr bool kHasGroupBwd = false;
   struct Prm { float p; };
   __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
@@ -219,11 +219,6 @@ struct CurveF {
   static constexpr int L = kCurveSteps;
   static constexpr int NP = NC * L, NACC = NC * (L + 1);
   static constexpr int kLutFloats = NC * L * 4;
-#ifndef EXPO_CURVE_MIN_WAVES
-#define EXPO_CURVE_MIN_WAVES 1
-#endif
-  // optional backward register cap (waves/SIMD); forcing 4 (<= 128 VGPRs) spills, so default 1
-  static constexpr int kMinWaves = EXPO_CURVE_MIN_WAVES;
   struct Prm { float delta[NC][L]; float scale[NC]; };  // delta[c][i-1] = k_{i-1} - k_i
   __device__ static Prm load(const float* __restrict__ p) {
     Prm q;
@@ -366,7 +361,7 @@ using ColorF = CurveF<3>;
 //    ci = x/(l+1e-6)*cl; y = (1-p) x + p ci
 // ---------------------------------------------------------------------------------
 struct ContrastF {
-  static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
   static constexpr bool kHasGroupBwd = false;
   struct Prm { float p; };
   __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
@@ -404,7 +399,7 @@ struct ContrastF {
 // 6  WNBFilter   filters.py:438-440   y_c = (1-p) x_c + p lum(x)
 // ---------------------------------------------------------------------------------
 struct WnbF {
-  static constexpr int NP = 1, NACC = 1, kLutFloats = 0, kMinWaves = 1;
+  static constexpr int NP = 1, NACC = 1, kLutFloats = 0;
   static constexpr bool kHasGroupBwd = false;
   struct Prm { float p; };
   __device__ static Prm load(const float* __restrict__ p) { return {p[0]}; }
@@ -432,7 +427,7 @@ struct WnbF {
 //    lower = p0, upper = p1 + 1;  y = clip((x - lower) / (upper - lower + 1e-6), 0, 1)
 // ---------------------------------------------------------------------------------
 struct LevelF {
-  static constexpr int NP = 2, NACC = 2, kLutFloats = 0, kMinWaves = 1;
+  static constexpr int NP = 2, NACC = 2, kLutFloats = 0;
   static constexpr bool kHasGroupBwd = false;
   struct Prm { float lower, r; };
   __device__ static Prm load(const float* __restrict__ p) {

@@ -322,3 +322,42 @@ def test_filter_apply_with_masking_enabled(gpu_device):
     ref = ft.apply_masked(5, torch.from_numpy(src).double(), p, mraw.detach().cpu().double(), 1.0, 0.3).numpy()
     assert_image_close(got.detach().float().cpu().numpy(), ref, np.float16, 'apply(masking)')
   assert info['mask'].shape == (32, 32, 1)
+
+
+@pytest.mark.parametrize('fid', range(9))
+def test_out_of_range_inputs(fid, gpu_device):
+  """Negative, zero, > 1 and exactly-on-threshold pixels (all the clamps / masks of every filter)."""
+  rng = np.random.default_rng(700 + fid)
+  shape = (2, 24, 16, 3)
+  x = rng.uniform(-0.5, 2.0, shape).astype(np.float32)
+  flat = x.reshape(-1)
+  specials = np.array([0.0, 1.0, 0.001, 0.125, 0.5, 0.875, -0.0, 2.0], dtype=np.float32)
+  flat[::11] = specials[np.arange(flat[::11].size) % specials.size]
+  x[0, 0, :4] = 0.0  # whole black pixels (lum == 0)
+  x[0, 1, :4] = 1.0  # whole white pixels (lum == 1, rng == 0)
+  x[0, 2, :4] = -0.25  # all-negative pixels (S+: v <= 0 -> s = 0)
+  dy = rng.standard_normal(shape).astype(np.float32)
+  p = synthetic.make_params(rng, fid, shape[0])
+  y, dx, dp = run_fwd_bwd(fid, x, dy, p, torch.float32, gpu_device)
+  ry, rdx, rdp = oracle(fid, x, dy, p)
+  assert np.isfinite(y).all() and np.isfinite(dx).all() and np.isfinite(dp).all()
+  assert_image_close(y, ry, np.float32, 'y fid %d' % fid)
+  # contrast: d/dx has a 1/(lum + 1e-6)^2 factor -> compare relative to the gradient's own scale
+  err = np.abs(dx - rdx)
+  assert (err <= 2e-4 + 2e-4 * np.abs(rdx)).all(), (fid, err.max())
+  assert_param_grad_close(dp, rdp, grad_scale(fid, x, dy, p) * 4, 'dp fid %d' % fid)
+
+
+def test_empty_batch_and_error_paths(gpu_device):
+  dev = gpu_device
+  x = torch.empty((0, 8, 8, 3), dtype=torch.float16, device=dev)
+  _cabi.filter_fwd(0, x, torch.empty_like(x), torch.empty((0, 1), device=dev))  # no-op
+  x = torch.zeros((2, 8, 8, 3), dtype=torch.float16, device=dev)
+  with pytest.raises(_cabi.ExposureHipError):
+    _cabi.filter_fwd(0, x, torch.empty_like(x), torch.zeros((2, 3), device=dev))  # wrong P
+  with pytest.raises(_cabi.ExposureHipError):
+    _cabi.filter_fwd(0, x.permute(0, 2, 1, 3), torch.empty_like(x), torch.zeros((2, 1), device=dev))  # not contiguous
+  with pytest.raises(_cabi.ExposureHipError):
+    _cabi.filter_fwd(0, x.double(), torch.empty_like(x).double(), torch.zeros((2, 1), device=dev))  # dtype
+  lib = _cabi.load()
+  assert lib.expo_filter_fwd(0, x.data_ptr(), x.data_ptr(), x.data_ptr(), 70000, 1, 1, 0, None) == -1  # grid.y limit
