@@ -47,7 +47,7 @@ def parse():
   ap.add_argument('--seed', type=int, default=1234)
   ap.add_argument('--order', default='0,1,2,3,4,5,6,7', help='filter ids of the chain steps (experiments only; the '
                   'metric is defined on the cfg.filters order 0..7)')
-  ap.add_argument('--workload', default='chain', choices=['chain', 'train'],
+  ap.add_argument('--workload', default='chain', choices=['chain', 'train', 'infer'],
                   help="chain: the headline filter-chain metric; train: one reference training iteration "
                   "(1 generator/value step + cfg.citers critic steps, net.py:307-365) on 64 images per GPU")
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
@@ -274,6 +274,79 @@ def run_train(args, world, rank, dev, dist):
     dist.destroy_process_group()
 
 
+def run_infer(args, world, rank, dev, dist):
+  """BASELINE config 5: high-resolution inference, 16x512x512x3 fp16, the 8 filters of cfg.filters
+  applied to every image -- (a) one kernel per step (8 reads + 8 writes of the image), (b) the fused
+  multi-step forward (1 read + 1 write).  Forward only."""
+  shape = synthetic.SHAPES[args.shape] if args.shape in synthetic.SHAPES else synthetic.SHAPES['B']
+  if args.shape == 'C' and '--shape' not in sys.argv:
+    shape = synthetic.SHAPES['B']
+  dtype = torch.float16 if args.dtype == 'f16' else torch.float32
+  esz = 2 if args.dtype == 'f16' else 4
+  x, _dy, params = make_device_case(shape, dtype, dev, args.seed + rank)
+  n = shape[0]
+  px = shape[0] * shape[1] * shape[2]
+  ids = torch.arange(8, dtype=torch.int32, device=dev)[None, :].repeat(n, 1).contiguous()
+  p24 = torch.zeros((n, 8, 24), dtype=torch.float32, device=dev)
+  for fid in range(8):
+    p24[:, fid, :params[fid].shape[1]] = params[fid]
+  y = torch.empty_like(x)
+  acts = [x] + [torch.empty_like(x) for _ in range(8)]
+
+  def timed(fn):
+    for _ in range(args.warmup):
+      fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+      dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+      dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+      t = torch.tensor([el], dtype=torch.float64, device=dev)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      el = float(t.item())
+    return el / args.steps
+
+  t_fused = timed(lambda: _cabi.chain_fused_fwd(ids, p24, x, y))
+  t_steps = timed(lambda: _cabi.chain_fwd(list(range(8)), acts, params))
+  same = float((y.float() - acts[8].float()).abs().max())
+  if rank == 0:
+    print(json.dumps({
+        'metric': 'Mpixels/s through 8-step filter chain fwd (high-res inference)',
+        'value': world * px / t_fused / 1e6,
+        'unit': 'Mpixels/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': t_fused * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': args.dtype,
+        'data': 'synthetic',
+        'config': {
+            'workload': 'fused 8-step chain forward (expo_chain_fused_fwd), %dx%dx%dx3 %s per GPU' %
+                        (shape[0], shape[1], shape[2], args.dtype),
+            'algorithmic_GBps_at_96B_per_pixel': 8 * 2 * 3 * esz * px / t_fused / 1e9,
+            'actual_traffic_GBps_at_12B_per_pixel': 2 * 3 * esz * px / t_fused / 1e9,
+            'per_step_kernels_ms': t_steps * 1e3,
+            'per_step_kernels_Mpixels_per_s': world * px / t_steps / 1e6,
+            'speedup_vs_per_step': t_steps / t_fused,
+            'max_abs_diff_fused_vs_per_step': same,
+        },
+    }))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
   args = parse()
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -291,6 +364,8 @@ def main():
     print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
   if args.workload == 'train':
     return run_train(args, world, rank, dev, dist)
+  if args.workload == 'infer':
+    return run_infer(args, world, rank, dev, dist)
 
   shape = synthetic.SHAPES[args.shape] if args.shape in synthetic.SHAPES else tuple(
       int(v) for v in args.shape.split(',')) + (3,)

@@ -39,6 +39,7 @@ SIGNATURES = {
                             _vp]),
     'expo_chain_bwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                             ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp]),
+    'expo_chain_fused_fwd': (_i, [_vp, _fp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'expo_critic_stats': (_i, [_vp, _fp, _i, _i, _i, _i, _vp]),
     'expo_overexposure_penalty': (_i, [_vp, _fp, _i, _i, _i, _i, _vp]),
 }
@@ -252,6 +253,21 @@ def chain_bwd(filter_ids, acts, grads, params, dparams, hsv_grad_mode=0):
         lib.expo_chain_bwd(ids, steps, _ptr_array(acts), _ptr_array(grads), _ptr_array(params),
                            _ptr_array(dparams), n, h, w, _dtype_code(acts[0]), hsv_grad_mode, _stream()),
         'expo_chain_bwd')
+
+
+def chain_fused_fwd(filter_ids, params, x, y):
+  """filter_ids (N, steps) int32, params (N, steps, 24) float32 -> y = all steps applied in registers."""
+  lib = load()
+  _img(x, 'x'), _img(y, 'y')
+  n, h, w, _ = x.shape
+  steps = filter_ids.shape[1]
+  if not filter_ids.is_cuda or filter_ids.dtype != torch.int32 or not filter_ids.is_contiguous() or \
+      tuple(filter_ids.shape) != (n, steps):
+    raise ExposureHipError('exposure_amd: filter_ids must be a contiguous int32 device tensor of shape (N, steps)')
+  _f32(params, 'params', (n, steps, EXPO_MAX_PARAMS))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_chain_fused_fwd(_ptr(filter_ids), _ptr(params), steps, _ptr(x), _ptr(y), n, h, w,
+                                    _dtype_code(x), _stream()), 'expo_chain_fused_fwd')
 
 
 def critic_stats(x, stats):

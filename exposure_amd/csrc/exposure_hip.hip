@@ -418,6 +418,75 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
 #undef EXPO_CASE
 }
 
+// ------------------------------------------------------- fused multi-step forward (inference)
+// The high-resolution inference path (net.py:796-821; BASELINE config 5): the per-step parameters
+// are regressed on the 64x64 proxy only, so by the time the full-resolution image is touched the
+// whole per-image sequence (filter id, parameters) x steps is known.  This kernel applies all
+// `steps` filters to a pixel group while it sits in registers (fp32 between steps -- no fp16
+// rounding of intermediates): ONE read and ONE write of the image instead of one per step.
+// Each wave owns exactly one 3 KiB chunk, so the per-step parameters are fetched once per wave
+// through scalar loads; the step loop is rolled (block-uniform switch per step).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t* __restrict__ ids,
+                                                                   const float* __restrict__ params, int steps,
+                                                                   const T* __restrict__ x, T* __restrict__ y,
+                                                                   int hw, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  const T* xi = x + off;
+  T* yi = y + off;
+  const int32_t* idn = ids + size_t(n) * steps;
+  const float* prn = params + size_t(n) * steps * EXPO_MAX_PARAMS;
+  auto run = [&](float* v) {
+#pragma unroll 1
+    for (int st = 0; st < steps; ++st) {
+      const float* prm = prn + st * EXPO_MAX_PARAMS;
+      const int id = idn[st];  // block-uniform
+#define EXPO_CASE(ID, F)                              \
+  case ID: {                                          \
+    const typename F::Prm q = F::load(prm);           \
+    _Pragma("unroll") for (int k = 0; k < PPL; ++k) { \
+      float o[3];                                     \
+      F::fwd(q, v + 3 * k, o);                        \
+      v[3 * k] = o[0];                                \
+      v[3 * k + 1] = o[1];                            \
+      v[3 * k + 2] = o[2];                            \
+    }                                                 \
+  } break;
+      switch (id) {
+        EXPO_CASE(0, ExposureF)
+        EXPO_CASE(1, GammaF)
+        EXPO_CASE(2, WhiteBalanceF)
+        EXPO_CASE(3, SatPlusF)
+        EXPO_CASE(4, ToneF)
+        EXPO_CASE(5, ContrastF)
+        EXPO_CASE(6, WnbF)
+        EXPO_CASE(7, ColorF)
+        EXPO_CASE(8, LevelF)
+        default:  // id -1: the all-zero one-hot selects nothing -> the image becomes 0
+#pragma unroll
+          for (int j = 0; j < PPL * 3; ++j) v[j] = 0.f;
+          break;
+      }
+#undef EXPO_CASE
+    }
+  };
+  const int stride = gridDim.x * kThreads;
+  if constexpr (VEC) {
+    const T* const ins[1] = {xi};
+    stream_groups<T, 1, true, false>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                     [&](float (&v)[1][PPL * 3], int) { run(v[0]); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3];
+      load_slow<T>(xi, g, hw, v);
+      run(v);
+      store_slow<T>(yi, g, hw, v);
+    }
+  }
+}
+
 // ------------------------------------------------------------- per-image reductions
 // critics.py:48-62.  Raw sums {sum(l-1/2), sum (l-1/2)^2, sum sat} are accumulated
 // (shifted to tame the E[l^2]-E[l]^2 cancellation) and finished by stats_finish_kernel.
@@ -776,6 +845,20 @@ static int dispatch_bwd_t(const int32_t* ids, const void* x, const void* dy, voi
 }
 
 template <typename T>
+static int chain_fused_fwd_t(const int32_t* ids, const float* params, int steps, const void* x, void* y, int n,
+                             int h, int w, hipStream_t s) {
+  Geom g = make_geom<T>(n, h, w, {x, y}, false);
+  g.blocks_x = (g.groups + kThreads - 1) / kThreads;  // one chunk per wave: parameters fetched once
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  if (g.vec)
+    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, true>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
+  else
+    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, false>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
+  HIP_TRY(hipGetLastError(), "chain_fused_fwd launch");
+  return EXPO_OK;
+}
+
+template <typename T>
 static int stats_t(const void* x, float* stats, int n, int h, int w, hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {x});
   const dim3 grid(g.blocks_x, n), block(kThreads);
@@ -945,6 +1028,17 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
     if (rc) return rc;
   }
   return EXPO_OK;
+}
+
+int expo_chain_fused_fwd(const int32_t* filter_ids, const float* params, int steps, const void* x, void* y, int n,
+                         int h, int w, int dtype, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (steps < 0 || steps > 64) return fail(EXPO_E_BADARG, "steps must be in [0, 64]");
+  if (n == 0) return EXPO_OK;
+  if (!x || !y || (steps > 0 && (!filter_ids || !params))) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? chain_fused_fwd_t<half_t>(filter_ids, params, steps, x, y, n, h, w, s)
+                           : chain_fused_fwd_t<float>(filter_ids, params, steps, x, y, n, h, w, s);
 }
 
 int expo_critic_stats(const void* x, float* stats, int n, int h, int w, int dtype, void* stream) {

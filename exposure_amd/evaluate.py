@@ -38,10 +38,26 @@ def make_low_res(high_res, size):
   return low.permute(0, 2, 3, 1).contiguous().to(high_res.dtype)
 
 
+def fused_chain(high_res, filter_ids, params24):
+  """Apply a per-image sequence of filters to the full-resolution image in ONE pass
+  (``expo_chain_fused_fwd``).  filter_ids: (N, steps) int32 C-ABI ids; params24: (N, steps, 24)."""
+  from . import _cabi
+  out = torch.empty_like(high_res)
+  _cabi.chain_fused_fwd(filter_ids.contiguous().to(torch.int32), params24.contiguous().float(),
+                        high_res.contiguous(), out)
+  return out
+
+
 @torch.no_grad()
-def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trace=False):
+def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trace=False, fused=True):
   """Run the 5-step retouching loop.  ``high_res``: NHWC device tensor (fp16/fp32), linear RGB.
-  Returns (retouched_high_res, retouched_low_res, states[, trace of selected filter ids])."""
+  Returns (retouched_high_res, retouched_low_res, states[, trace of selected filter ids]).
+
+  ``fused=True`` (default): the agent steps run on the 64x64 proxy only, recording each step's
+  (filter id, parameters); the full-resolution image is then read once, pushed through all steps
+  in registers and written once.  ``fused=False`` is the reference's schedule (``net.py:796-821``):
+  every step also filters the full-resolution tensor and feeds it back -- identical maths, one
+  fp16 rounding per step, ``steps`` times the HBM traffic."""
   cfg = agent.cfg
   steps = steps or cfg.test_steps
   n = high_res.shape[0]
@@ -50,14 +66,22 @@ def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trac
   states = torch.zeros((n, cfg.num_state_dim), dtype=torch.float32, device=dev)  # get_initial_states
   if z is None:
     z = torch.rand((n, cfg.z_dim), device=dev)
-  trace = []
+  trace, abi_ids, params = [], [], []
   hi = high_res.contiguous()
   for i in range(steps):
     masks = dropout_masks[i] if dropout_masks is not None else None
-    (low, states, hi), dbg, _ = agent((low, z, states), is_train=0, progress=0.0, high_res=hi, dropout_masks=masks)
+    if fused:
+      (low, states, _s, _p), dbg, _ = agent((low, z, states), is_train=0, progress=0.0, dropout_masks=masks)
+      abi_ids.append(dbg['abi_filter_ids'])
+      params.append(dbg['params24'])
+    else:
+      (low, states, hi), dbg, _ = agent((low, z, states), is_train=0, progress=0.0, high_res=hi,
+                                        dropout_masks=masks)
     trace.append(dbg['selected_filter_ids'].clone())
     if bool((states[:, STATE_STOPPED_DIM] > 0).all()):
       break
+  if fused:
+    hi = fused_chain(hi, torch.stack(abi_ids, dim=1), torch.stack(params, dim=1))
   if return_trace:
     return hi, low, states, torch.stack(trace, dim=1)
   return hi, low, states

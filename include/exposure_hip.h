@@ -180,6 +180,18 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts,
                    int hsv_grad_mode, void* stream);
 
 /*
+ * Fused multi-step forward for the high-resolution inference path (net.py:796-821, evaluate.py:8-31):
+ * the agent regresses every step's parameters on the 64x64 proxy, so the per-image sequence
+ * (filter id, parameters) x steps is known before the full-resolution image is touched.  All
+ * `steps` filters are applied while a pixel group sits in registers (fp32 between steps): one
+ * read and one write of the image instead of `steps` of each.
+ *   filter_ids  device int32 [N][steps] in [-1, 8]   (-1: the image becomes 0 from that step on)
+ *   params      device float32 [N][steps][EXPO_MAX_PARAMS], row = packed params of that step's filter
+ */
+int expo_chain_fused_fwd(const int32_t* filter_ids, const float* params, int steps,
+                         const void* x, void* y, int n, int h, int w, int dtype, void* stream);
+
+/*
  * Per-image statistics the critic appends as constant feature planes
  * (critics.py:48-62): stats[n] = { mean(lum), variance(lum), mean(sat) } with
  * lum = .27R + .67G + .06B + 1e-5 and

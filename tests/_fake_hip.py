@@ -11,7 +11,7 @@ import torch
 from oracle import agent_np
 from oracle import filters_torch as ft
 
-NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24)
+NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24, 2)
 
 
 def _fwd(fid, x, y, params):
@@ -63,6 +63,19 @@ def _dispatch_bwd(ids, x, dy, dx, params, dparams, dpenalty=None, hsv_grad_mode=
     dparams[n, :NUM_PARAMS[fid]] = gp[0].float()
 
 
+def _chain_fused_fwd(ids, params, x, y):
+  cur = x.double()
+  for st in range(ids.shape[1]):
+    nxt = torch.zeros_like(cur)
+    for n in range(x.shape[0]):
+      fid = int(ids[n, st])
+      if fid >= 0:
+        p = params[n:n + 1, st, :NUM_PARAMS[fid]].contiguous().double()
+        nxt[n:n + 1] = ft.process_packed(fid, cur[n:n + 1], p)
+    cur = nxt
+  y.copy_(cur.to(y.dtype))
+
+
 def _stats(x, stats):
   stats.copy_(torch.from_numpy(agent_np.critic_stats(x.double().numpy())).float())
 
@@ -74,5 +87,6 @@ def _penalty(y, pen):
 @contextlib.contextmanager
 def fake_hip():
   with mock.patch.multiple('exposure_amd._cabi', filter_fwd=_fwd, filter_bwd=_bwd, dispatch_fwd=_dispatch_fwd,
-                           dispatch_bwd=_dispatch_bwd, critic_stats=_stats, overexposure_penalty=_penalty):
+                           dispatch_bwd=_dispatch_bwd, critic_stats=_stats, overexposure_penalty=_penalty,
+                           chain_fused_fwd=_chain_fused_fwd):
     yield

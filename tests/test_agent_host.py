@@ -161,6 +161,9 @@ def test_evaluate_loop_two_filter_config():
   z = torch.rand(1, cfg.z_dim)
   with fake_hip():
     out_hi, out_lo, states, trace = evaluate.retouch(ag, hi, z=z, dropout_masks=masks, return_trace=True)
+    step_hi, _, _, trace2 = evaluate.retouch(ag, hi, z=z, dropout_masks=masks, return_trace=True, fused=False)
+  assert torch.equal(trace, trace2)
+  np.testing.assert_allclose(out_hi.numpy(), step_hi.numpy(), rtol=2e-5, atol=2e-6)  # fused == stepwise
   assert out_hi.shape == hi.shape and out_lo.shape == (1, 64, 64, 3)
   assert trace.shape == (1, 5)
   assert states[0, :3].tolist() == [1.0, 1.0, 5.0]

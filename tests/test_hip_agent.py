@@ -236,3 +236,46 @@ def test_graphed_steps_match_eager(gpu_device):
   assert abs(ge - gg) <= 1e-3 * (1 + abs(ge)) and abs(ce - cg) <= 1e-3 * (1 + abs(ce))
   worst = max(float((a - b).abs().max()) for a, b in zip(pe, pg))
   assert worst < 3e-4, worst  # Adam steps are ~lr-sized; see tests/test_dist_gloo.py
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [(4, 96, 128, 3), (3, 7, 9, 3)])
+def test_fused_chain_matches_oracle(dtype, shape, gpu_device):
+  """expo_chain_fused_fwd: per-image filter sequences applied in registers == the float64 chain."""
+  dev = gpu_device
+  rng = np.random.default_rng(31)
+  n, steps = shape[0], 8
+  x = synthetic.make_images(rng, shape, NP_DT[dtype])
+  ids = rng.integers(0, 9, (n, steps)).astype(np.int32)
+  ids[0] = np.arange(8)  # the cfg.filters order on image 0
+  ids[1, 3] = -1  # an all-zero one-hot in the middle of image 1's sequence
+  p = np.zeros((n, steps, 24), dtype=np.float32)
+  ref = x.astype(np.float64)
+  for st in range(steps):
+    nxt = np.zeros_like(ref)
+    for i in range(n):
+      fid = int(ids[i, st])
+      if fid >= 0:
+        p[i, st, :fnp.NUM_PARAMS[fid]] = synthetic.make_params(rng, fid, 1)[0]
+        nxt[i:i + 1] = fnp.process_packed(fid, ref[i:i + 1], p[i:i + 1, st, :fnp.NUM_PARAMS[fid]].astype(np.float64))
+    ref = nxt
+  from exposure_amd import evaluate
+  y = evaluate.fused_chain(torch.from_numpy(x).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(p).to(dev))
+  assert_image_close(y.float().cpu().numpy(), ref, NP_DT[dtype], 'fused chain')
+  assert float(y[1].abs().max()) >= 0.0
+
+
+def test_retouch_fused_equals_stepwise_on_gpu(gpu_device):
+  from exposure_amd import evaluate
+  dev = gpu_device
+  torch.manual_seed(3)
+  cfg = make_cfg()
+  ag = xagent.Agent(cfg).to(dev)
+  hi = torch.from_numpy(synthetic.make_images(np.random.default_rng(8), (3, 200, 304, 3), np.float32)).to(dev)
+  z = torch.rand(3, cfg.z_dim, device=dev)
+  masks = [[(torch.rand(3, 4096, device=dev) < 0.5).float() for _ in range(2)] for _ in range(5)]
+  a, la, sa, ta = evaluate.retouch(ag, hi, z=z, dropout_masks=masks, return_trace=True, fused=True)
+  b, lb, sb, tb = evaluate.retouch(ag, hi, z=z, dropout_masks=masks, return_trace=True, fused=False)
+  assert torch.equal(ta, tb) and torch.equal(sa, sb)
+  assert_image_close(a.cpu().numpy(), b.cpu().numpy(), np.float32, 'fused vs stepwise')
+  assert ta.shape == (3, 5) and sa[:, 2].tolist() == [5.0, 5.0, 5.0]
