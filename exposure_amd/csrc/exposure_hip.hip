@@ -439,10 +439,22 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
   const int32_t* idn = ids + size_t(n) * steps;
   const float* prn = params + size_t(n) * steps * EXPO_MAX_PARAMS;
   auto run = [&](float* v) {
+    // software-pipelined parameter fetch: step st+1's id and 24 parameters (wave-uniform -> scalar
+    // loads into SGPRs) are requested before step st computes, hiding the scalar-load latency
+    float cur[EXPO_MAX_PARAMS], nxt[EXPO_MAX_PARAMS];
+    int id = -1, id_next = -1;
+    if (steps > 0) {
+      id = idn[0];
+#pragma unroll
+      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = prn[j];
+    }
 #pragma unroll 1
     for (int st = 0; st < steps; ++st) {
-      const float* prm = prn + st * EXPO_MAX_PARAMS;
-      const int id = idn[st];  // block-uniform
+      const int sn = (st + 1 < steps) ? st + 1 : st;
+      id_next = idn[sn];
+#pragma unroll
+      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) nxt[j] = prn[sn * EXPO_MAX_PARAMS + j];
+      const float* prm = cur;
 #define EXPO_CASE(ID, F)                              \
   case ID: {                                          \
     const typename F::Prm q = F::load(prm);           \
@@ -470,6 +482,9 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
           break;
       }
 #undef EXPO_CASE
+      id = id_next;
+#pragma unroll
+      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = nxt[j];
     }
   };
   const int stride = gridDim.x * kThreads;
