@@ -636,7 +636,7 @@ static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
   // groups each thread walks: kernels with a reduction epilogue (atomics per block) want fewer,
   // fatter blocks; pure maps (forward) stream best with many blocks (tools/membench.hip)
   static const int gpt_red = env_int("EXPO_BWD_GROUPS_PER_THREAD", 4);
-  static const int gpt_map = env_int("EXPO_FWD_GROUPS_PER_THREAD", 2);
+  static const int gpt_map = env_int("EXPO_FWD_GROUPS_PER_THREAD", 1);
   const int gpt = reduces ? gpt_red : gpt_map;
   int bx = (g.groups + kThreads * gpt - 1) / (kThreads * gpt);
   const long want = 1024;

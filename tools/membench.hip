@@ -144,6 +144,39 @@ __global__ __launch_bounds__(256) void rrw12(const uint32_t* __restrict__ a, con
   }
 }
 
+// copy12 through raw buffer resources (the SRD path the filter kernels use), optionally with the
+// fp16 -> fp32 -> fp16 round trip of a real pixel map (WORK) to see what the conversions cost.
+template <int J, bool WORK>
+__global__ __launch_bounds__(256) void copy12buf(const uint32_t* __restrict__ a, uint32_t* __restrict__ b, size_t nrows,
+                                                 int nbytes, float scale) {
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, nbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, nbytes, 0x00020000);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (size_t r = (size_t(blockIdx.x) * 4 + wave) * J; r < nrows; r += size_t(gridDim.x) * 4 * J) {
+    u32x3 v[J];
+    const int off = int(r) * 768 + lane * 12;
+#pragma unroll
+    for (int j = 0; j < J; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b96(ra, off + j * 768, 0, 0);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if constexpr (WORK) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const uint32_t w = v[j][e];
+          half2_t h = __builtin_bit_cast(half2_t, w);
+          h[0] = _Float16(float(h[0]) * scale);
+          h[1] = _Float16(float(h[1]) * scale);
+          v[j][e] = __builtin_bit_cast(uint32_t, h);
+        }
+      } else {
+        v[j].x ^= 1u;
+      }
+      __builtin_amdgcn_raw_buffer_store_b96(v[j], rb, off + j * 768, 0, 0);
+    }
+  }
+}
+
 // coalesced read x, read dy, write dx (no transpose): ceiling for a channel-phase backward
 __global__ __launch_bounds__(256) void rrw16(const u32x4* __restrict__ a, const u32x4* __restrict__ c,
                                              u32x4* __restrict__ b, size_t n16) {
@@ -186,6 +219,8 @@ int main(int argc, char** argv) {
     run("rrw16", 3, [&](int i) { rrw16<<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], n16); });
     run("copy12x4", 2, [&](int i) { copy12<4><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768); });
     run("copy12x8", 2, [&](int i) { copy12<8><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768); });
+    run("c12bufx4", 2, [&](int i) { copy12buf<4, false><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes), 1.0f); });
+    run("c12bufwork", 2, [&](int i) { copy12buf<4, true><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes), 1.0f); });
     run("rrw12x4", 3, [&](int i) { rrw12<4><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (const uint32_t*)buf[(i + 4) % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768); });
     run("rrw48nt", 3, [&](int i) { rrw48<true><<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], ngroups); });
   }
