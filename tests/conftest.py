@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+  # the C-ABI library is git-ignored: (cross-)compile it if this checkout has not been built yet
+  lib = os.path.join(ROOT, 'exposure_amd', 'libexposure_hip.so')
+  if not os.path.exists(lib):
+    import __graft_entry__
+    __graft_entry__.build()
 
 
 def has_gpu():
