@@ -39,7 +39,7 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=5)
-  ap.add_argument('--shape', default='C', help='A|B|C (synthetic.SHAPES) or N,H,W')
+  ap.add_argument('--shape', default=None, help='A|B|C (synthetic.SHAPES) or N,H,W; default C (chain), B (infer)')
   ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
   ap.add_argument('--kernel-reps', type=int, default=20, help='launches per kernel for the roofline timing')
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -53,6 +53,12 @@ def parse():
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                   help='replay the 17 launches of a step from one hipGraph (auto: on for launch-bound small shapes)')
   return ap.parse_args()
+
+
+def parse_shape(name):
+  if name in synthetic.SHAPES:
+    return synthetic.SHAPES[name]
+  return tuple(int(v) for v in name.split(',')) + (3,)
 
 
 def make_device_case(shape, dtype, dev, seed):
@@ -278,9 +284,7 @@ def run_infer(args, world, rank, dev, dist):
   """BASELINE config 5: high-resolution inference, 16x512x512x3 fp16, the 8 filters of cfg.filters
   applied to every image -- (a) one kernel per step (8 reads + 8 writes of the image), (b) the fused
   multi-step forward (1 read + 1 write).  Forward only."""
-  shape = synthetic.SHAPES[args.shape] if args.shape in synthetic.SHAPES else synthetic.SHAPES['B']
-  if args.shape == 'C' and '--shape' not in sys.argv:
-    shape = synthetic.SHAPES['B']
+  shape = parse_shape(args.shape or 'B')
   dtype = torch.float16 if args.dtype == 'f16' else torch.float32
   esz = 2 if args.dtype == 'f16' else 4
   x, _dy, params = make_device_case(shape, dtype, dev, args.seed + rank)
@@ -367,8 +371,7 @@ def main():
   if args.workload == 'infer':
     return run_infer(args, world, rank, dev, dist)
 
-  shape = synthetic.SHAPES[args.shape] if args.shape in synthetic.SHAPES else tuple(
-      int(v) for v in args.shape.split(',')) + (3,)
+  shape = parse_shape(args.shape or 'C')
   dtype = torch.float16 if args.dtype == 'f16' else torch.float32
   esz = 2 if args.dtype == 'f16' else 4
   chain = Chain(shape, dtype, dev, args.seed + rank, [int(v) for v in args.order.split(',')])
