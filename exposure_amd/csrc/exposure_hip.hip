@@ -650,8 +650,10 @@ static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
 static int check_common(int n, int h, int w, int dtype) {
   if (n < 0 || h < 1 || w < 1) return fail(EXPO_E_BADARG, "n >= 0, h >= 1, w >= 1 required");
   if (n > 65535) return fail(EXPO_E_BADARG, "n > 65535 not supported (grid.y)");
-  if (long(h) * long(w) > (1L << 28)) return fail(EXPO_E_BADARG, "h*w too large");
   if (dtype != EXPO_F16 && dtype != EXPO_F32) return fail(EXPO_E_BADDTYPE, "dtype must be EXPO_F16 or EXPO_F32");
+  // one image is addressed through a raw buffer resource with 32-bit byte offsets
+  const long image_bytes = long(h) * long(w) * 3L * (dtype == EXPO_F16 ? 2L : 4L);
+  if (image_bytes > (1L << 31) - 8192) return fail(EXPO_E_BADARG, "one image must be smaller than 2 GiB");
   return EXPO_OK;
 }
 

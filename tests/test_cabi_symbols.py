@@ -45,6 +45,8 @@ def test_argument_validation_without_gpu():
   assert lib.expo_filter_fwd(0, None, None, None, 0, 1, 1, 0, None) == 0  # empty batch is a no-op
   assert lib.expo_filter_bwd(0, None, None, None, None, None, 1, 1, 1, 0, 5, None) == -1  # bad hsv mode
   assert lib.expo_critic_stats(None, None, 0, 4, 4, 0, None) == 0
+  assert lib.expo_filter_fwd(0, None, None, None, 1, 40000, 40000, 0, None) == -1  # image >= 2 GiB
+  assert b'2 GiB' in lib.expo_last_error()
   assert lib.expo_chain_fwd(None, 1, None, None, 1, 1, 1, 0, None) == -1
 
 
