@@ -361,3 +361,26 @@ def test_empty_batch_and_error_paths(gpu_device):
     _cabi.filter_fwd(0, x.double(), torch.empty_like(x).double(), torch.zeros((2, 1), device=dev))  # dtype
   lib = _cabi.load()
   assert lib.expo_filter_fwd(0, x.data_ptr(), x.data_ptr(), x.data_ptr(), 70000, 1, 1, 0, None) == -1  # grid.y limit
+
+
+def test_single_huge_image_offsets(gpu_device):
+  """One 16384 x 16384 fp16 image (1.5 GiB): byte offsets close to the 32-bit limit of the buffer
+  resource.  Checked through identities and a sampled oracle comparison at the far end."""
+  dev = gpu_device
+  h = w = 16384
+  g = torch.Generator(device=dev).manual_seed(1)
+  x = torch.rand((1, h, w, 3), device=dev, generator=g, dtype=torch.float16)
+  y = torch.empty_like(x)
+  _cabi.filter_fwd(0, x, y, torch.zeros((1, 1), device=dev))
+  assert torch.equal(y, x)
+  p = torch.tensor([[1.0]], device=dev)
+  _cabi.filter_fwd(0, x, y, p)
+  tail = slice(h - 2, h)
+  assert torch.equal(y[:, tail], (x[:, tail].float() * 2).half())
+  k = torch.from_numpy(synthetic.make_params(np.random.default_rng(3), 4, 1)).to(dev)
+  _cabi.filter_fwd(4, x, y, k)
+  ref = fnp.process_packed(4, x[:, tail].cpu().numpy().astype(np.float64), k.cpu().numpy().astype(np.float64))
+  assert_image_close(y[:, tail].float().cpu().numpy(), ref, np.float16)
+  dp = torch.empty_like(k)
+  _cabi.filter_bwd(4, x, x, y, k, dp)  # dy := x, dx -> y
+  assert torch.isfinite(dp).all() and torch.isfinite(y[:, tail].float()).all()
