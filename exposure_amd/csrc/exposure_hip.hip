@@ -119,7 +119,7 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, EXPO_PREFETCH != 0>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, true, EXPO_PREFETCH != 0, EXPO_FWD_STORE_POLICY>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                   [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -188,7 +188,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   };
   if constexpr (VEC) {
     const T* const ins[2] = {xi, dyi};
-    stream_groups<T, 2, HAS_DX, (F::kLutFloats > 0 ? EXPO_CURVE_PREFETCH : EXPO_PREFETCH) != 0>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 2, HAS_DX, (F::kLutFloats > 0 ? EXPO_CURVE_PREFETCH : EXPO_PREFETCH) != 0, kStoreCached>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                     [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, true>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                    [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
+    stream_groups<T, 1, true, true, EXPO_FWD_STORE_POLICY>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                                           [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3];
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[2] = {xi, dyi};
-    stream_groups<T, 2, HAS_DX, true>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 2, HAS_DX, true, kStoreCached>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                       [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -338,7 +338,7 @@ __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int group
     const RawGroup rz = pack<T>(z);
     const __amdgpu_buffer_rsrc_t ry = make_image_rsrc(yi, hw);
     for (int gw = blockIdx.x * kThreads + (threadIdx.x & ~63); gw * PPL < hw; gw += stride)
-      store_raw(ry, chunk_byte_offset<T>(gw, threadIdx.x & 63), rz);
+      store_raw<kStoreCached>(ry, chunk_byte_offset<T>(gw, threadIdx.x & 63), rz);
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) store_slow<T>(yi, g, hw, z);
   }
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
   const int stride = gridDim.x * kThreads;
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, false>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, true, false, kStoreCached>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                      [&](float (&v)[1][PPL * 3], int) { run(v[0]); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, false, true>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, false, true, kStoreCached>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                       [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__
   };
   if constexpr (VEC) {
     const T* const ins[1] = {yi};
-    stream_groups<T, 1, false, true>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, false, true, kStoreCached>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                       [&](float (&v)[1][PPL * 3], int) { compute(v[0]); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {

@@ -67,9 +67,23 @@ __device__ __forceinline__ RawGroup load_raw(__amdgpu_buffer_rsrc_t rsrc, int by
   for (int j = 0; j < 4; ++j) r.q[j] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, byte_off + j * 768, 0, 0);
   return r;
 }
+// Cache policy of the output stores (buffer instruction aux bits on gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
+// Measured on the 8-step chain (64x512x512x3 fp16, in-chain HIP-event timings):
+//   cached stores everywhere (default): forward pass 296 us; the first two backward kernels carry
+//     +10..15 us each while the forward's dirty lines drain from the 256 MiB Infinity Cache;
+//   nt stores for the forward outputs only: that backward hangover disappears (-22 us) but every
+//     forward step now re-reads its input from HBM instead of the cache (+19 us): net 0.702 vs
+//     0.705 ms per step, i.e. a wash, with 8 x 96 MiB more HBM reads -> not adopted;
+//   nt stores everywhere: backward kernels lose their cached dy (+9 us each): 0.738 ms.
+constexpr int kStoreCached = 0, kStoreStream = 2;
+#ifndef EXPO_FWD_STORE_POLICY
+#define EXPO_FWD_STORE_POLICY kStoreCached
+#endif
+
+template <int AUX>
 __device__ __forceinline__ void store_raw(__amdgpu_buffer_rsrc_t rsrc, int byte_off, const RawGroup& r) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b96(r.q[j], rsrc, byte_off + j * 768, 0, 0);
+  for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b96(r.q[j], rsrc, byte_off + j * 768, 0, AUX);
 }
 
 template <typename T> __device__ __forceinline__ void unpack(const RawGroup& r, float* out);
@@ -127,7 +141,7 @@ template <> __device__ __forceinline__ RawGroup pack<float>(const float* in) {
 // stride; NIN input streams (x, or x and dy) are unpacked to fp32, fn(v, g) transforms them in
 // place, and the LAST stream is written back when HAS_OUT.  With PF the next chunk's loads are in
 // flight while the current one computes (software prefetch; costs 12 VGPRs per stream).
-template <typename T, int NIN, bool HAS_OUT, bool PF, class Fn>
+template <typename T, int NIN, bool HAS_OUT, bool PF, int STORE_AUX, class Fn>
 __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out, int hw, int first_gw,
                                               int stride, Fn&& fn) {
   constexpr int PPL = PixTraits<T>::PPL;
@@ -156,7 +170,7 @@ __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out,
 #pragma unroll
     for (int s = 0; s < NIN; ++s) unpack<T>(cur[s], v[s]);
     fn(v, gw + lane);
-    if constexpr (HAS_OUT) store_raw(rout, chunk_byte_offset<T>(gw, lane), pack<T>(v[NIN - 1]));
+    if constexpr (HAS_OUT) store_raw<STORE_AUX>(rout, chunk_byte_offset<T>(gw, lane), pack<T>(v[NIN - 1]));
     if (!PF && more) {
 #pragma unroll
       for (int s = 0; s < NIN; ++s) nxt[s] = load_raw(rin[s], chunk_byte_offset<T>(gn, lane));
