@@ -92,7 +92,7 @@ __device__ __forceinline__ void block_reduce_atomic(float* acc, float* __restric
 }
 
 // --------------------------------------------------------------------------- forward
-template <class F, typename T, bool VEC, bool PEN>
+template <class F, typename T, bool VEC, bool PEN, int STORE = kStoreCached>
 __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict__ yi,
                                          const float* __restrict__ prm, float* pen_out,
                                          int hw, int groups, float inv_count) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, EXPO_PREFETCH != 0, EXPO_FWD_STORE_POLICY>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, true, EXPO_PREFETCH != 0, STORE>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                   [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -135,13 +135,13 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   }
 }
 
-template <class F, typename T, bool VEC>
+template <class F, typename T, bool VEC, int STORE>
 __global__ __launch_bounds__(kThreads) void filter_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                               const float* __restrict__ params,
                                                               int hw, int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
-  fwd_body<F, T, VEC, false>(x + off, y + off, params + n * F::NP, nullptr, hw, groups, 0.f);
+  fwd_body<F, T, VEC, false, STORE>(x + off, y + off, params + n * F::NP, nullptr, hw, groups, 0.f);
 }
 
 // -------------------------------------------------------------------------- backward
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, true, EXPO_FWD_STORE_POLICY>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, true, true, kStoreCached>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                                            [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -658,13 +658,18 @@ static int check_common(int n, int h, int w, int dtype) {
 }
 
 template <class F, typename T>
-static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s) {
+static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s,
+                      bool stream_out = false) {
   const Geom g = make_geom<T>(n, h, w, {x, y}, false);
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  if (g.vec)
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+  // stream_out: the output is not re-read by the work that follows (the chain's final activation):
+  // store it with the nt policy so it does not evict / dirty the Infinity Cache (pixel_io.h)
+  if (g.vec && stream_out)
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, kStoreStream>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+  else if (g.vec)
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, kStoreCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
   else
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, false>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, false, kStoreCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
   HIP_TRY(hipGetLastError(), "filter_fwd launch");
   return EXPO_OK;
 }
@@ -697,17 +702,18 @@ static int launch_bwd(const void* x, const void* dy, void* dx, const float* para
 }
 
 template <typename T>
-static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int h, int w, hipStream_t s) {
+static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int h, int w, hipStream_t s,
+                     bool stream_out = false) {
   switch (id) {
-    case 0: return launch_fwd<ExposureF, T>(x, y, p, n, h, w, s);
-    case 1: return launch_fwd<GammaF, T>(x, y, p, n, h, w, s);
-    case 2: return launch_fwd<WhiteBalanceF, T>(x, y, p, n, h, w, s);
-    case 3: return launch_fwd<SatPlusF, T>(x, y, p, n, h, w, s);
-    case 4: return launch_fwd<ToneF, T>(x, y, p, n, h, w, s);
-    case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s);
-    case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s);
-    case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s);
-    case 8: return launch_fwd<LevelF, T>(x, y, p, n, h, w, s);
+    case 0: return launch_fwd<ExposureF, T>(x, y, p, n, h, w, s, stream_out);
+    case 1: return launch_fwd<GammaF, T>(x, y, p, n, h, w, s, stream_out);
+    case 2: return launch_fwd<WhiteBalanceF, T>(x, y, p, n, h, w, s, stream_out);
+    case 3: return launch_fwd<SatPlusF, T>(x, y, p, n, h, w, s, stream_out);
+    case 4: return launch_fwd<ToneF, T>(x, y, p, n, h, w, s, stream_out);
+    case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s, stream_out);
+    case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s, stream_out);
+    case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s, stream_out);
+    case 8: return launch_fwd<LevelF, T>(x, y, p, n, h, w, s, stream_out);
   }
   return fail(EXPO_E_BADARG, "filter_id out of range");
 }
@@ -1008,8 +1014,17 @@ int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const voi
 int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const float* const* params, int n, int h,
                    int w, int dtype, void* stream) {
   if (steps < 0 || !filter_ids || !acts || !params) return fail(EXPO_E_BADARG, "bad chain arguments");
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
   for (int i = 0; i < steps; ++i) {
-    const int rc = expo_filter_fwd(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, dtype, stream);
+    if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
+    if (!acts[i] || !acts[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
+    // acts[1..steps-1] are re-read at once by the next step (and later by the backward); the final
+    // output is not an input of anything this library launches next -> streaming store
+    const bool last = (i == steps - 1);
+    const int rc = dtype == EXPO_F16 ? fwd_by_id<half_t>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, last)
+                                     : fwd_by_id<float>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, last);
     if (rc) return rc;
   }
   return EXPO_OK;

@@ -75,10 +75,8 @@ __device__ __forceinline__ RawGroup load_raw(__amdgpu_buffer_rsrc_t rsrc, int by
 //     forward step now re-reads its input from HBM instead of the cache (+19 us): net 0.702 vs
 //     0.705 ms per step, i.e. a wash, with 8 x 96 MiB more HBM reads -> not adopted;
 //   nt stores everywhere: backward kernels lose their cached dy (+9 us each): 0.738 ms.
+// What IS adopted: expo_chain_fwd streams out only the chain's FINAL activation (nothing re-reads it).
 constexpr int kStoreCached = 0, kStoreStream = 2;
-#ifndef EXPO_FWD_STORE_POLICY
-#define EXPO_FWD_STORE_POLICY kStoreCached
-#endif
 
 template <int AUX>
 __device__ __forceinline__ void store_raw(__amdgpu_buffer_rsrc_t rsrc, int byte_off, const RawGroup& r) {
