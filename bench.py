@@ -131,7 +131,10 @@ def time_kernels(chain, reps):
     for i in range(nsteps):
       if r >= 0:
         ev[r][k][0].record()
-      _cabi.filter_fwd(ids[i], chain.acts[i], chain.acts[i + 1], chain.params[i])
+      if i == nsteps - 1:  # same launch the chain makes: the final activation is stored with the nt policy
+        _cabi.chain_fwd([ids[i]], [chain.acts[i], chain.acts[i + 1]], [chain.params[i]])
+      else:
+        _cabi.filter_fwd(ids[i], chain.acts[i], chain.acts[i + 1], chain.params[i])
       if r >= 0:
         ev[r][k][1].record()
       k += 1
