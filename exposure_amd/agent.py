@@ -10,9 +10,8 @@ reference names, arguments and return structure.  What changes is the image path
   image, only the selected filter -- and accumulates the over-exposure penalty
   (agent.py:249-251) in the same pass.  Gradients are identical: the one-hot product zeroes
   every non-selected filter's image and parameter gradients in the reference too.
-* the convolutions are explicit NHWC im2col + hipBLASLt GEMMs (``exposure_amd/nn.py``) and the FCs
-  plain GEMMs (MFMA) through torch; tensors stay NHWC end to end so no layout change sits between
-  the filter kernels and conv1.
+* the convolutions / FCs are MIOpen / hipBLASLt GEMMs (MFMA) through torch; tensors stay NHWC
+  (``channels_last``) end to end so no layout change sits between the filter kernels and conv1.
 
 Stochastic inputs are explicit so runs are reproducible and parity-testable: ``z[:, 0]`` is
 the selection noise (agent.py:47) and ``dropout_masks`` (two (N, 4096) 0/1 tensors) replace the
@@ -24,9 +23,13 @@ import torch
 from torch import nn
 
 from . import filters as F
-from .nn import Conv4x4S2
 from .util import (STATE_DROPOUT_BEGIN, STATE_REWARD_DIM, STATE_STEP_DIM, STATE_STOPPED_DIM,
                    enrich_image_input, lrelu)
+
+
+def _xavier_conv(conv):
+  nn.init.xavier_uniform_(conv.weight)
+  nn.init.zeros_(conv.bias)
 
 
 class FeatureExtractor(nn.Module):
@@ -43,7 +46,7 @@ class FeatureExtractor(nn.Module):
     channels = cfg.base_channels
     layers = []
     size //= 2
-    layers.append(Conv4x4S2(in_channels, channels))
+    layers.append(nn.Conv2d(in_channels, channels, kernel_size=4, stride=2, padding=1))
     prev = channels
     while size > min_feature_map_size:
       if size == min_feature_map_size * 2:
@@ -52,15 +55,19 @@ class FeatureExtractor(nn.Module):
         channels *= 2
       assert size % 2 == 0
       size //= 2
-      layers.append(Conv4x4S2(prev, channels))
+      layers.append(nn.Conv2d(prev, channels, kernel_size=4, stride=2, padding=1))
       prev = channels
-    self.convs = nn.ModuleList(layers)  # Xavier-uniform weights, zero biases (ly.conv2d defaults)
+    self.convs = nn.ModuleList(layers)
+    for c in self.convs:
+      _xavier_conv(c)
+    self.to(memory_format=torch.channels_last)
 
   def forward(self, net_nhwc, dropout_mask=None):
-    net = net_nhwc.float() - 0.5  # stays NHWC end to end (exposure_amd/nn.py)
+    # NHWC storage viewed as NCHW/channels_last: no copy, MIOpen picks its NHWC kernels
+    net = (net_nhwc.float() - 0.5).permute(0, 3, 1, 2)
     for conv in self.convs:
       net = lrelu(conv(net))
-    net = net.reshape(net.shape[0], self.output_dim)  # TF reshape order (H,W,C)
+    net = net.permute(0, 2, 3, 1).reshape(net.shape[0], self.output_dim)  # TF reshape order (H,W,C)
     if dropout_mask is None:
       dropout_mask = (torch.rand_like(net) < self.keep_prob).to(net.dtype)
     # tf.nn.dropout: x / keep_prob * mask

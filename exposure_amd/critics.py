@@ -13,7 +13,6 @@ import torch
 from torch import nn
 
 from . import _cabi
-from .nn import Conv4x4S2
 from .util import lrelu
 
 
@@ -51,18 +50,19 @@ class Critic(nn.Module):
     in_ch = cfg.real_img_channels + num_state_dim + 3
     channels = cfg.base_channels
     size = cfg.source_img_size // 2
-    convs = [Conv4x4S2(in_ch, channels)]
+    convs = [nn.Conv2d(in_ch, channels, kernel_size=4, stride=2, padding=1)]
     while size > 4:
-      convs.append(Conv4x4S2(channels, channels * 2))
+      convs.append(nn.Conv2d(channels, channels * 2, kernel_size=4, stride=2, padding=1))
       channels *= 2
       size //= 2
     self.convs = nn.ModuleList(convs)
     self.flat = 4 * 4 * channels
     self.fc1 = nn.Linear(self.flat, cfg.fc1_size)
     self.fc2 = nn.Linear(cfg.fc1_size, 1)
-    for m in [self.fc1, self.fc2]:
+    for m in list(self.convs) + [self.fc1, self.fc2]:
       nn.init.xavier_uniform_(m.weight)
       nn.init.zeros_(m.bias)
+    self.to(memory_format=torch.channels_last)
 
   def forward(self, images, states=None):
     images = images.float()
@@ -75,10 +75,10 @@ class Critic(nn.Module):
     n, h, w, _ = images.shape
     planes = states[:, None, None, :].expand(n, h, w, states.shape[1])
     net = torch.cat([images, planes], dim=3)
-    net = net - 0.5  # NHWC end to end (exposure_amd/nn.py)
+    net = (net - 0.5).permute(0, 3, 1, 2)  # NHWC storage, channels_last view
     for conv in self.convs:
       net = lrelu(conv(net))
-    net = net.reshape(n, self.flat)
+    net = net.permute(0, 2, 3, 1).reshape(n, self.flat)
     net = lrelu(self.fc1(net))
     return self.fc2(net)
 

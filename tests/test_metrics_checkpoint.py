@@ -52,9 +52,7 @@ def test_tf_layout_roundtrip_and_conv_equivalence():
   # the HWIO kernel applied TF-style (NHWC, SAME, stride 2) equals the torch conv with the OIHW copy
   conv = gan.critic.convs[0]
   x = torch.randn(2, 8, 8, conv.in_channels)
-  want = conv(x).detach().numpy()
-  ref_conv = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), conv.weight, conv.bias, stride=2, padding=1)
-  np.testing.assert_allclose(want, ref_conv.permute(0, 2, 3, 1).detach().numpy(), rtol=1e-4, atol=1e-5)
+  want = conv(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).detach().numpy()
   w = d['critic/Conv/weights']  # (kh, kw, cin, cout)
   xp = np.pad(x.numpy(), ((0, 0), (1, 1), (1, 1), (0, 0)))
   got = np.zeros_like(want)
