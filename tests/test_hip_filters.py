@@ -384,3 +384,24 @@ def test_single_huge_image_offsets(gpu_device):
   dp = torch.empty_like(k)
   _cabi.filter_bwd(4, x, x, y, k, dp)  # dy := x, dx -> y
   assert torch.isfinite(dp).all() and torch.isfinite(y[:, tail].float()).all()
+
+
+def test_random_shape_sweep(gpu_device):
+  """Seeded sweep over ragged shapes x filters x dtypes: exercises chunk tails of the vector path
+  (H*W even / multiple of 8 / of 512 or not), the element-wise path (odd fp16 pixel counts) and
+  batches with a single image; forward, backward and the dx-less variant against the oracle."""
+  rng = np.random.default_rng(2024)
+  dims = [1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 130]
+  for case in range(72):
+    n = int(rng.integers(1, 5))
+    h, w = int(rng.choice(dims)), int(rng.choice(dims))
+    fid = case % 9
+    dtype = torch.float16 if (case // 9) % 2 == 0 else torch.float32
+    x, dy, _ = synthetic.make_case(5000 + case, (n, h, w, 3), NP_DT[dtype])
+    p = synthetic.make_params(rng, fid, n)
+    y, dx, dp = run_fwd_bwd(fid, x, dy, p, dtype, gpu_device)
+    ry, rdx, rdp = oracle(fid, x, dy, p)
+    tag = 'case %d fid %d %s %dx%dx%d' % (case, fid, dtype, n, h, w)
+    assert_image_close(y, ry, NP_DT[dtype], 'y ' + tag)
+    assert_image_close(dx, rdx, NP_DT[dtype], 'dx ' + tag)
+    assert_param_grad_close(dp, rdp, grad_scale(fid, x, dy, p) * (2 if fid == 8 else 1), 'dp ' + tag)
