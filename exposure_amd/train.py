@@ -1,0 +1,41 @@
+"""``python -m exposure_amd.train [--iters N]`` -- the tensor part of the reference's
+``train.py:9-14`` / ``GAN.train`` (``net.py:298-403``) on synthetic FiveK-shaped data: the G/V and
+critic alternation with the device-resident replay memory, one hipGraph replay per optimisation
+step.  Dataset loading, TensorBoard, PNG dashboards and checkpoints of the reference are out of scope
+(SURVEY.md section 2); ``--save`` writes a plain ``torch.save`` state dict."""
+import argparse
+import time
+
+import torch
+
+from .config import make_cfg
+from .gan import GAN
+from .replay_memory import ReplayMemory, SyntheticProvider
+
+
+def main(argv=None):
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--iters', type=int, default=20, help='training iterations to run (the reference runs 20000)')
+  ap.add_argument('--seed', type=int, default=0)
+  ap.add_argument('--log-every', type=int, default=10)
+  ap.add_argument('--no-graphs', action='store_true')
+  ap.add_argument('--save', default=None)
+  args = ap.parse_args(argv)
+  dev = torch.device('cuda:0')
+  torch.manual_seed(args.seed)
+  cfg = make_cfg()
+  gan = GAN(cfg, device=dev, use_graphs=not args.no_graphs)
+  memory = ReplayMemory(cfg, SyntheticProvider(dev, seed=args.seed + 1), SyntheticProvider(dev, gamma=1.0, seed=args.seed + 2),
+                        seed=args.seed)
+  t0 = time.time()
+  hist = gan.train(memory, max_iter_step=args.iters, log_every=args.log_every)
+  torch.cuda.synchronize()
+  dt = time.time() - t0
+  print('%d iterations in %.1f s (iteration 0 = 100 warm-up generator steps + 100 critic steps, net.py:314-323)' %
+        (len(hist), dt))
+  if args.save:
+    torch.save(gan.state_dict(), args.save)
+
+
+if __name__ == '__main__':
+  main()

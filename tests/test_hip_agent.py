@@ -279,3 +279,10 @@ def test_retouch_fused_equals_stepwise_on_gpu(gpu_device):
   assert torch.equal(ta, tb) and torch.equal(sa, sb)
   assert_image_close(a.cpu().numpy(), b.cpu().numpy(), np.float32, 'fused vs stepwise')
   assert ta.shape == (3, 5) and sa[:, 2].tolist() == [5.0, 5.0, 5.0]
+
+
+def test_train_cli_runs(gpu_device, capsys):
+  from exposure_amd import train
+  train.main(['--iters', '2', '--log-every', '1'])
+  out = capsys.readouterr().out
+  assert 'it     2' in out and 'Replay memory: size 128' in out
