@@ -216,8 +216,10 @@ def run_train(args, world, rank, dev, dist):
   gan = GAN(cfg, device=dev, use_graphs=(world == 1 and args.graph != 'off'))
   n = cfg.batch_size
   from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
-  memory = ReplayMemory(cfg, SyntheticProvider(dev, seed=args.seed + 10 * rank + 1),
-                        SyntheticProvider(dev, gamma=1.0, seed=args.seed + 10 * rank + 2), seed=args.seed + rank)
+  pool_dtype = torch.float16 if args.dtype == 'f16' else torch.float32
+  memory = ReplayMemory(cfg, SyntheticProvider(dev, dtype=pool_dtype, seed=args.seed + 10 * rank + 1),
+                        SyntheticProvider(dev, gamma=1.0, dtype=pool_dtype, seed=args.seed + 10 * rank + 2),
+                        seed=args.seed + rank)
   # net.py:320-328: the first iteration rolls the generator with lr_g = 0 until terminated
   # trajectories exist for the critic to replay (100 steps in the reference; 8 suffice: 5 steps end one)
   for _ in range(8):
@@ -267,7 +269,7 @@ def run_train(args, world, rank, dev, dist):
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f16 images / f32 nets',
+        'dtype': '%s images / f32 nets' % args.dtype,
         'data': 'synthetic',
         'config': {
             'workload': 'reference training iteration (net.py:307-365): agent rollout step, policy CNN, value net, '

@@ -117,9 +117,12 @@ template <> __device__ __forceinline__ RawGroup pack<half_t>(const float* in) {
   for (int j = 0; j < 4; ++j) {
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
+      // round-to-nearest-even, SATURATING at +-65504: five +3.5 EV exposure steps of an untrained
+      // policy exceed the fp16 range, and an inf pixel would poison every later loss (the fp32
+      // reference just carries the large value; fp16 storage carries the largest finite one)
       half2_t h;
-      h[0] = half_t(in[j * 6 + e * 2]);  // round-to-nearest-even
-      h[1] = half_t(in[j * 6 + e * 2 + 1]);
+      h[0] = half_t(__builtin_amdgcn_fmed3f(in[j * 6 + e * 2], -65504.0f, 65504.0f));
+      h[1] = half_t(__builtin_amdgcn_fmed3f(in[j * 6 + e * 2 + 1], -65504.0f, 65504.0f));
       r.q[j][e] = __builtin_bit_cast(uint32_t, h);
     }
   }
@@ -222,7 +225,11 @@ __device__ __forceinline__ void store_slow(T* img, int g, int hw, const float* i
     const int px = g * PPL + k;
     if (px < hw) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) img[size_t(px) * 3 + c] = T(in[k * 3 + c]);
+      for (int c = 0; c < 3; ++c) {
+        float v = in[k * 3 + c];
+        if (sizeof(T) == 2) v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);  // saturate fp16 (see pack)
+        img[size_t(px) * 3 + c] = T(v);
+      }
     }
   }
 }

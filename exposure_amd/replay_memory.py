@@ -16,9 +16,11 @@ from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
 class SyntheticProvider:
   """Stand-in for FiveKDataProvider / ArtistDataProvider (``data_provider.py:59-69`` crop+flip
   augmentation is replaced by drawing FiveK-shaped synthetic tensors): linear-RAW-like images
-  ``U(0,1)**gamma`` of ``size x size x 3``."""
+  ``U(0,1)**gamma`` of ``size x size x 3``.  float32 by default, the reference's dtype for the
+  training pool (``replay_memory.py:16-40``); float16 storage is supported (saturating stores) but an
+  untrained policy can push pixels past the fp16 range within one 5-step trajectory."""
 
-  def __init__(self, device, size=64, gamma=2.2, dtype=torch.float16, seed=0):
+  def __init__(self, device, size=64, gamma=2.2, dtype=torch.float32, seed=0):
     self.device, self.size, self.gamma, self.dtype = device, size, gamma, dtype
     self.gen = torch.Generator(device=device).manual_seed(seed)
     self.count = 0

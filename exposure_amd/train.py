@@ -20,13 +20,15 @@ def main(argv=None):
   ap.add_argument('--log-every', type=int, default=10)
   ap.add_argument('--no-graphs', action='store_true')
   ap.add_argument('--save', default=None)
+  ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'], help='storage type of the image pool')
   args = ap.parse_args(argv)
   dev = torch.device('cuda:0')
   torch.manual_seed(args.seed)
   cfg = make_cfg()
   gan = GAN(cfg, device=dev, use_graphs=not args.no_graphs)
-  memory = ReplayMemory(cfg, SyntheticProvider(dev, seed=args.seed + 1), SyntheticProvider(dev, gamma=1.0, seed=args.seed + 2),
-                        seed=args.seed)
+  dt = torch.float32 if args.dtype == 'f32' else torch.float16
+  memory = ReplayMemory(cfg, SyntheticProvider(dev, dtype=dt, seed=args.seed + 1),
+                        SyntheticProvider(dev, gamma=1.0, dtype=dt, seed=args.seed + 2), seed=args.seed)
   t0 = time.time()
   hist = gan.train(memory, max_iter_step=args.iters, log_every=args.log_every)
   torch.cuda.synchronize()

@@ -186,7 +186,8 @@ def test_training_loop_on_gpu(gpu_device):
   cfg.critic_initialization = 0
   cfg.citers = 2
   gan = GAN(cfg, device=dev)
-  mem = ReplayMemory(cfg, SyntheticProvider(dev, seed=1), SyntheticProvider(dev, gamma=1.0, seed=2), seed=0)
+  mem = ReplayMemory(cfg, SyntheticProvider(dev, dtype=torch.float16, seed=1),
+                     SyntheticProvider(dev, gamma=1.0, dtype=torch.float16, seed=2), seed=0)
 
   class Few(type(gan)):
     pass

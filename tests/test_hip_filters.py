@@ -405,3 +405,15 @@ def test_random_shape_sweep(gpu_device):
     assert_image_close(y, ry, NP_DT[dtype], 'y ' + tag)
     assert_image_close(dx, rdx, NP_DT[dtype], 'dx ' + tag)
     assert_param_grad_close(dp, rdp, grad_scale(fid, x, dy, p) * (2 if fid == 8 else 1), 'dp ' + tag)
+
+
+def test_fp16_stores_saturate(gpu_device):
+  dev = gpu_device
+  x = torch.full((1, 8, 8, 3), 60000.0, dtype=torch.float16, device=dev)
+  y = torch.empty_like(x)
+  _cabi.filter_fwd(0, x, y, torch.full((1, 1), 3.5, device=dev))  # 60000 * 2^3.5 overflows fp16
+  assert torch.isfinite(y).all() and float(y.max()) == 65504.0
+  x5 = torch.full((1, 3, 5, 3), 60000.0, dtype=torch.float16, device=dev)  # odd pixel count: element path
+  y5 = torch.empty_like(x5)
+  _cabi.filter_fwd(0, x5, y5, torch.full((1, 1), 3.5, device=dev))
+  assert float(y5.max()) == 65504.0
