@@ -191,7 +191,9 @@ class Agent(nn.Module):
     new_states = torch.cat(new_states, dim=1)
 
     if cfg.clamp:
-      raise NotImplementedError('cfg.clamp=True is not used by the shipped configs (config_example.py:39)')
+      # agent.py:240-241 (off in the shipped configs): only the proxy image is clipped, exactly as in
+      # the reference -- high_res_output is not.  64x64 images: one tiny torch op, not a kernel.
+      out = torch.clamp(out, 0.0, 5.0)
 
     entropy_penalty = (1.0 - progress) * cfg.exploration_penalty * (-entropy + math.log(k))
     # Will be subtracted from the reward (agent.py:247-252)

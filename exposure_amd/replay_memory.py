@@ -20,14 +20,14 @@ class SyntheticProvider:
   training pool (``replay_memory.py:16-40``); float16 storage is supported (saturating stores) but an
   untrained policy can push pixels past the fp16 range within one 5-step trajectory."""
 
-  def __init__(self, device, size=64, gamma=2.2, dtype=torch.float32, seed=0):
-    self.device, self.size, self.gamma, self.dtype = device, size, gamma, dtype
+  def __init__(self, device, size=64, gamma=2.2, scale=1.0, dtype=torch.float32, seed=0):
+    self.device, self.size, self.gamma, self.scale, self.dtype = device, size, gamma, scale, dtype
     self.gen = torch.Generator(device=device).manual_seed(seed)
     self.count = 0
 
   def get_next_batch(self, batch_size):
     x = torch.rand((batch_size, self.size, self.size, 3), device=self.device, generator=self.gen)
-    x = (x**self.gamma).to(self.dtype)
+    x = ((x**self.gamma) * self.scale).to(self.dtype)
     feat = torch.arange(self.count, self.count + batch_size, device=self.device, dtype=torch.float32)
     self.count += batch_size
     return x, feat

@@ -2,7 +2,14 @@
 ``train.py:9-14`` / ``GAN.train`` (``net.py:298-403``) on synthetic FiveK-shaped data: the G/V and
 critic alternation with the device-resident replay memory, one hipGraph replay per optimisation
 step.  Dataset loading, TensorBoard, PNG dashboards and checkpoints of the reference are out of scope
-(SURVEY.md section 2); ``--save`` writes a plain ``torch.save`` state dict."""
+(SURVEY.md section 2); ``--save`` writes a plain ``torch.save`` state dict.
+
+Note on the numbers it prints: with random-init weights the policy can chain Exposure (x11) and
+Gamma (power 3) steps, so pixel values -- and with them the over-exposure penalty, the critic logits
+and the value targets -- occasionally overflow float32 in the first iterations.  That is the
+reference's arithmetic (``filters.py:181-182, 205-206`` have no clamp; ``cfg.clamp`` is off), not
+a kernel artefact; ``--clamp`` turns on the reference's own ``clip_by_value(net, 0, 5)``
+(``agent.py:240-241``)."""
 import argparse
 import time
 
@@ -20,15 +27,18 @@ def main(argv=None):
   ap.add_argument('--log-every', type=int, default=10)
   ap.add_argument('--no-graphs', action='store_true')
   ap.add_argument('--save', default=None)
+  ap.add_argument('--clamp', action='store_true', help='cfg.clamp = True (agent.py:240-241)')
   ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'], help='storage type of the image pool')
   args = ap.parse_args(argv)
   dev = torch.device('cuda:0')
   torch.manual_seed(args.seed)
   cfg = make_cfg()
+  cfg.clamp = bool(args.clamp)
   gan = GAN(cfg, device=dev, use_graphs=not args.no_graphs)
   dt = torch.float32 if args.dtype == 'f32' else torch.float16
-  memory = ReplayMemory(cfg, SyntheticProvider(dev, dtype=dt, seed=args.seed + 1),
-                        SyntheticProvider(dev, gamma=1.0, dtype=dt, seed=args.seed + 2), seed=args.seed)
+  # toy task with the statistics of the real one: dark linear-RAW-like inputs, brighter targets
+  memory = ReplayMemory(cfg, SyntheticProvider(dev, gamma=2.2, scale=0.35, dtype=dt, seed=args.seed + 1),
+                        SyntheticProvider(dev, gamma=1.2, scale=0.9, dtype=dt, seed=args.seed + 2), seed=args.seed)
   t0 = time.time()
   hist = gan.train(memory, max_iter_step=args.iters, log_every=args.log_every)
   torch.cuda.synchronize()
