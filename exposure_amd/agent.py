@@ -194,6 +194,8 @@ class Agent(nn.Module):
       # agent.py:240-241 (off in the shipped configs): only the proxy image is clipped, exactly as in
       # the reference -- high_res_output is not.  64x64 images: one tiny torch op, not a kernel.
       out = torch.clamp(out, 0.0, 5.0)
+      # the penalty of agent.py:249-251 is taken on the CLIPPED image in the reference
+      overexposure = (torch.clamp_min(out.float() - 1.0, 0.0)**2).mean(dim=(1, 2, 3))
 
     entropy_penalty = (1.0 - progress) * cfg.exploration_penalty * (-entropy + math.log(k))
     # Will be subtracted from the reward (agent.py:247-252)
