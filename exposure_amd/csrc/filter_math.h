@@ -205,7 +205,7 @@ struct SatPlusF {
 //      clip_i = E_{i+1} - E_i  =>  T = sum_i k_i clip_i = sum_{i=1..L} E_i (k_{i-1} - k_i),  k_L := 0
 //    i.e. 8 v_min + 8 v_fma per element with the knot differences in SGPRs.
 //
-//    Backward: per-curve LUT staged in LDS, entry j = {k_j, k_{j+1}, P_j = sum_{i<j} k_i / L}:
+//    Backward: per-curve LUT staged in LDS, entry j = (L/S) {k_j, k_{j+1}, P_j = sum_{i<j} k_i / L}:
 //      j = clamp(ceil(L x) - 1, 0, L-1)      (x in (j/L, (j+1)/L] -> segment j)
 //      T = P_j + (clamp(x,0,1) - j/L) k_j
 //      dT/dx = [0 <= x <= 1] k_j + [L x integer, 1 <= L x <= L-1] k_{j+1}
@@ -241,11 +241,16 @@ struct CurveF {
     const int t = threadIdx.x;
     if (t < NC * L) {
       const int c = t / L, j = t % L;
-      float P = 0.f;
-      for (int i = 0; i < j; ++i) P += p[c * L + i];
-      lut[t * 4 + 0] = p[c * L + j];
-      lut[t * 4 + 1] = (j + 1 < L) ? p[c * L + j + 1] : 0.0f;
-      lut[t * 4 + 2] = P * (1.0f / L);
+      float S = 0.f, P = 0.f;
+      for (int i = 0; i < L; ++i) {
+        S += p[c * L + i];
+        if (i < j) P += p[c * L + i];
+      }
+      S += 1e-30f;
+      const float scale = float(L) / S;  // entries are pre-scaled: y = Ps_j + (x^ - j/L) ks_j
+      lut[t * 4 + 0] = scale * p[c * L + j];
+      lut[t * 4 + 1] = (j + 1 < L) ? scale * p[c * L + j + 1] : 0.0f;
+      lut[t * 4 + 2] = scale * P * (1.0f / L);
       lut[t * 4 + 3] = 0.0f;
     }
   }
@@ -271,18 +276,18 @@ struct CurveF {
       const float cu = ceilf(u);
       const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
       const float4_lut e = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
-      const float t = fmaf(fmaf(jf, -1.0f / L, xc), e.x, e.z);
+      const float y = fmaf(fmaf(jf, -1.0f / L, xc), e.x, e.z);  // LUT entries are pre-scaled by L/S
       // inside: 0 <= x <= 1  <=>  clamp(x) == x.   knot: L x is an integer in [1, L-1]; the test
       // (cu - 1 == jf) accepts L x in [1, L] and the LUT's k_L := 0 makes L x == L contribute 0.
       const bool inside = (xc == xv);
       const bool knot = (cu == u) && (cu - 1.0f == jf);
       const float slope = (inside ? e.x : 0.0f) + (knot ? e.y : 0.0f);
-      dx[c] = g * q.scale[cc] * slope;
+      dx[c] = g * slope;
       float* a = acc + cc * (L + 1);
 #pragma unroll
       for (int i = 1; i < L; ++i) a[i - 1] = fmaf(g, fminf(xc, float(i) / L), a[i - 1]);
       a[L - 1] = fmaf(g, xc, a[L - 1]);
-      a[L] = fmaf(g, t, a[L]);
+      a[L] = fmaf(g, y, a[L]);
     }
   }
   // Group backward (PPL pixels at once).  F16X: the inputs are exactly representable in fp16
@@ -330,17 +335,17 @@ struct CurveF {
           const float cu = ceilf(u);
           const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
           const float4_lut en = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
-          const float t = fmaf(fmaf(jf, -1.0f / L, xc), en.x, en.z);
+          const float y = fmaf(fmaf(jf, -1.0f / L, xc), en.x, en.z);  // pre-scaled LUT: this is y
           const bool inside = (xc == xv);
           const bool knot = (cu == u) && (cu - 1.0f == jf);
           const float slope = (inside ? en.x : 0.0f) + (knot ? en.y : 0.0f);
-          a[L] = fmaf(g, t, a[L]);  // sum dy * T  (B = scale * this)
-          d[3 * (k + e) + c] = g * q.scale[cc] * slope;
+          a[L] = fmaf(g, y, a[L]);  // B = sum dy * y
+          d[3 * (k + e) + c] = g * slope;
         }
       }
     }
   }
-  // a[] per curve: Q_1..Q_L, sum dy*T.  dk_i = scale (Q_{i+1} - Q_i) - scale * a[L] / S,  Q_0 = 0
+  // a[] per curve: Q_1..Q_L, B = sum dy*y.  dk_i = scale (Q_{i+1} - Q_i) - B / S,  Q_0 = 0
   __device__ static float finish_one(const float* __restrict__ p, const float* a, int j) {
     const int c = j / L, i = j % L;
     float S = 0.f;
@@ -349,7 +354,7 @@ struct CurveF {
     const float scale = float(L) / S;
     const float* ac = a + c * (L + 1);
     const float qi = (i == 0) ? 0.0f : ac[i - 1];
-    return scale * (ac[i] - qi) - scale * ac[L] / S;
+    return scale * (ac[i] - qi) - ac[L] / S;
   }
 };
 using ToneF = CurveF<1>;

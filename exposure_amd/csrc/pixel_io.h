@@ -121,8 +121,10 @@ template <> __device__ __forceinline__ RawGroup pack<half_t>(const float* in) {
       // policy exceed the fp16 range, and an inf pixel would poison every later loss (the fp32
       // reference just carries the large value; fp16 storage carries the largest finite one)
       half2_t h;
-      h[0] = half_t(__builtin_amdgcn_fmed3f(in[j * 6 + e * 2], -65504.0f, 65504.0f));
-      h[1] = half_t(__builtin_amdgcn_fmed3f(in[j * 6 + e * 2 + 1], -65504.0f, 65504.0f));
+      h[0] = half_t(in[j * 6 + e * 2]);
+      h[1] = half_t(in[j * 6 + e * 2 + 1]);
+      const half2_t hi = {half_t(65504.0f), half_t(65504.0f)}, lo = {half_t(-65504.0f), half_t(-65504.0f)};
+      h = __builtin_elementwise_max(__builtin_elementwise_min(h, hi), lo);  // +-inf -> +-65504 (packed)
       r.q[j][e] = __builtin_bit_cast(uint32_t, h);
     }
   }
