@@ -349,6 +349,7 @@ __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int group
 // its own VGPR budget / occupancy; blocks whose image selected a filter outside SET exit at once.
 constexpr int kSetLight = 0x8000 | 0x100 | 0x6F;  // -1, E, G, W, S+, Ct, BW, Le
 constexpr int kSetCurves = 0x90;         // T, C
+constexpr int kSetAll = kSetLight | kSetCurves;
 
 template <typename T, bool VEC, bool PEN, int SET>
 __global__ __launch_bounds__(kThreads) void dispatch_fwd_kernel(const int32_t* __restrict__ ids,
@@ -818,13 +819,11 @@ static int dispatch_fwd_t(const int32_t* ids, const void* x, void* y, const floa
   const dim3 grid(g.blocks_x, n), block(kThreads);
   const float inv_count = 1.0f / (float(g.hw) * 3.0f);
   if (penalty) HIP_TRY(hipMemsetAsync(penalty, 0, sizeof(float) * size_t(n), s), "penalty memset");
-#define EXPO_L(VEC, PEN)                                                                                 \
-  do {                                                                                                   \
-    hipLaunchKernelGGL((dispatch_fwd_kernel<T, VEC, PEN, kSetLight>), grid, block, 0, s, ids,            \
-                       (const T*)x, (T*)y, params, penalty, g.hw, g.groups, inv_count);                  \
-    hipLaunchKernelGGL((dispatch_fwd_kernel<T, VEC, PEN, kSetCurves>), grid, block, 0, s, ids,           \
-                       (const T*)x, (T*)y, params, penalty, g.hw, g.groups, inv_count);                  \
-  } while (0)
+  // forward: one launch handles every filter (the heaviest forward body needs ~106 VGPRs, fine for a
+  // streaming kernel); only the backward is split into light / curve launches (124 vs 190 VGPRs)
+#define EXPO_L(VEC, PEN)                                                                             \
+  hipLaunchKernelGGL((dispatch_fwd_kernel<T, VEC, PEN, kSetAll>), grid, block, 0, s, ids, (const T*)x, \
+                     (T*)y, params, penalty, g.hw, g.groups, inv_count)
   if (g.vec) {
     if (penalty) EXPO_L(true, true); else EXPO_L(true, false);
   } else {
