@@ -299,49 +299,53 @@ struct CurveF {
   __device__ static void bwd_group(const Prm& q, const float* lut, const float* x, float* d, float acc[NACC]) {
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     static_assert(PPL % 2 == 0, "pixels are processed in pairs");
+    // Element pairs that share a curve: Tone (one curve for all channels) pairs the two halves of
+    // each raw dword -- elements (2m, 2m+1) -- so the packed operands ARE the loaded registers;
+    // Color pairs channel c of pixel k with channel c of pixel k+1 (a v_perm per operand).
+    constexpr int NPAIR = PPL * 3 / 2;
 #pragma unroll
-    for (int k = 0; k < PPL; k += 2) {
+    for (int m = 0; m < NPAIR; ++m) {
+      const int iA = (NC == 1) ? 2 * m : 3 * (2 * (m / 3)) + (m % 3);
+      const int iB = (NC == 1) ? 2 * m + 1 : iA + 3;
+      const int cc = (NC == 1) ? 0 : (m % 3);
+      float* a = acc + cc * (L + 1);
+      const float xA = x[iA], xB = x[iB];
+      const float gA = d[iA], gB = d[iB];
+      if constexpr (F16X) {
+        const half2_t x2 = {_Float16(xA), _Float16(xB)};  // exact: values came from fp16 storage
+        const half2_t g2 = {_Float16(gA), _Float16(gB)};
+        const half2_t z2 = {_Float16(0.f), _Float16(0.f)};
+        const half2_t xp = __builtin_elementwise_max(x2, z2);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int cc = (NC == 1) ? 0 : c;
-        float* a = acc + cc * (L + 1);
-        const float xA = x[3 * k + c], xB = x[3 * k + 3 + c];
-        const float gA = d[3 * k + c], gB = d[3 * k + 3 + c];
-        if constexpr (F16X) {
-          const half2_t x2 = {_Float16(xA), _Float16(xB)};  // exact: values came from fp16 storage
-          const half2_t g2 = {_Float16(gA), _Float16(gB)};
-          const half2_t z2 = {_Float16(0.f), _Float16(0.f)};
-          const half2_t xp = __builtin_elementwise_max(x2, z2);
-#pragma unroll
-          for (int i = 1; i <= L; ++i) {
-            const half2_t t2 = {_Float16(float(i) / L), _Float16(float(i) / L)};
-            a[i - 1] = __builtin_amdgcn_fdot2(g2, __builtin_elementwise_min(xp, t2), a[i - 1], false);
-          }
-        } else {
-          const float xcA = clamp01x(xA, 0.0f, 1.0f), xcB = clamp01x(xB, 0.0f, 1.0f);
-#pragma unroll
-          for (int i = 1; i < L; ++i) {
-            a[i - 1] = fmaf(gA, fminf(xcA, float(i) / L), a[i - 1]);
-            a[i - 1] = fmaf(gB, fminf(xcB, float(i) / L), a[i - 1]);
-          }
-          a[L - 1] = fmaf(gA, xcA, a[L - 1]);
-          a[L - 1] = fmaf(gB, xcB, a[L - 1]);
+        for (int i = 1; i <= L; ++i) {
+          const half2_t t2 = {_Float16(float(i) / L), _Float16(float(i) / L)};
+          a[i - 1] = __builtin_amdgcn_fdot2(g2, __builtin_elementwise_min(xp, t2), a[i - 1], false);
         }
+      } else {
+        const float xcA = clamp01x(xA, 0.0f, 1.0f), xcB = clamp01x(xB, 0.0f, 1.0f);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float xv = e ? xB : xA, g = e ? gB : gA;
-          const float xc = clamp01x(xv, 0.0f, 1.0f);
-          const float u = xv * float(L);  // exact
-          const float cu = ceilf(u);
-          const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
-          const float4_lut en = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
-          const float y = fmaf(fmaf(jf, -1.0f / L, xc), en.x, en.z);  // pre-scaled LUT: this is y
-          const bool inside = (xc == xv);
-          const bool knot = (cu == u) && (cu - 1.0f == jf);
-          const float slope = (inside ? en.x : 0.0f) + (knot ? en.y : 0.0f);
-          a[L] = fmaf(g, y, a[L]);  // B = sum dy * y
-          d[3 * (k + e) + c] = g * slope;
+        for (int i = 1; i < L; ++i) {
+          a[i - 1] = fmaf(gA, fminf(xcA, float(i) / L), a[i - 1]);
+          a[i - 1] = fmaf(gB, fminf(xcB, float(i) / L), a[i - 1]);
         }
+        a[L - 1] = fmaf(gA, xcA, a[L - 1]);
+        a[L - 1] = fmaf(gB, xcB, a[L - 1]);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int idx = e ? iB : iA;
+        const float xv = e ? xB : xA, g = e ? gB : gA;
+        const float xc = clamp01x(xv, 0.0f, 1.0f);
+        const float u = xv * float(L);  // exact
+        const float cu = ceilf(u);
+        const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
+        const float4_lut en = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
+        const float y = fmaf(fmaf(jf, -1.0f / L, xc), en.x, en.z);  // pre-scaled LUT: this is y
+        const bool inside = (xc == xv);
+        const bool knot = (cu == u) && (cu - 1.0f == jf);
+        const float slope = (inside ? en.x : 0.0f) + (knot ? en.y : 0.0f);
+        a[L] = fmaf(g, y, a[L]);  // B = sum dy * y
+        d[idx] = g * slope;
       }
     }
   }
