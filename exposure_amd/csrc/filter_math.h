@@ -30,7 +30,7 @@ constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kLumR = 0.27f, kLumG = 0.67f, kLumB = 0.06f;  // util.py:271-274
 constexpr int kCurveSteps = 8;                                 // config_example.py:27
-struct alignas(16) float4_lut { float x, y, z, w; };
+struct alignas(8) float2_lut { float x, y; };
 
 // util.py:271-274 -- same association order as the reference: (.27 r + .67 g) + .06 b
 __device__ __forceinline__ float lum3(const float x[3]) {
@@ -205,20 +205,20 @@ struct SatPlusF {
 //      clip_i = E_{i+1} - E_i  =>  T = sum_i k_i clip_i = sum_{i=1..L} E_i (k_{i-1} - k_i),  k_L := 0
 //    i.e. 8 v_min + 8 v_fma per element with the knot differences in SGPRs.
 //
-//    Backward: per-curve LUT staged in LDS, entry j = (L/S) {k_j, k_{j+1}, P_j = sum_{i<j} k_i / L}:
+//    Backward: per-curve LUT staged in LDS, entry j = (L/S) {k_j, k_{j+1}} (the two slopes dx needs):
 //      j = clamp(ceil(L x) - 1, 0, L-1)      (x in (j/L, (j+1)/L] -> segment j)
-//      T = P_j + (clamp(x,0,1) - j/L) k_j
 //      dT/dx = [0 <= x <= 1] k_j + [L x integer, 1 <= L x <= L-1] k_{j+1}
 //    (tf.clip_by_value passes the gradient on BOTH inclusive bounds, so exactly on a
 //    knot the two neighbouring segments both contribute -- SURVEY.md section 8a-6).
-//    Accumulators per curve: Q_i = sum dy E_i (i = 1..L), B = sum dy y;
-//      sum dy clip_i = Q_{i+1} - Q_i,   dk_i = (L/S)(Q_{i+1} - Q_i) - B/S.
+//    Accumulators per curve: Q_i = sum dy E_i (i = 1..L) only.  sum dy clip_i = Q_{i+1} - Q_i, and
+//    B = sum dy y needs no per-element work either: y = (L/S) sum_i E_i (k_{i-1} - k_i), so
+//    B = (L/S) sum_i (k_{i-1} - k_i) Q_i.   dk_i = (L/S)(Q_{i+1} - Q_i) - B/S.
 // ---------------------------------------------------------------------------------
 template <int NC>
 struct CurveF {
   static constexpr int L = kCurveSteps;
-  static constexpr int NP = NC * L, NACC = NC * (L + 1);
-  static constexpr int kLutFloats = NC * L * 4;
+  static constexpr int NP = NC * L, NACC = NC * L;
+  static constexpr int kLutFloats = NC * L * 2;
   struct Prm { float delta[NC][L]; float scale[NC]; };  // delta[c][i-1] = k_{i-1} - k_i
   __device__ static Prm load(const float* __restrict__ p) {
     Prm q;
@@ -241,17 +241,12 @@ struct CurveF {
     const int t = threadIdx.x;
     if (t < NC * L) {
       const int c = t / L, j = t % L;
-      float S = 0.f, P = 0.f;
-      for (int i = 0; i < L; ++i) {
-        S += p[c * L + i];
-        if (i < j) P += p[c * L + i];
-      }
+      float S = 0.f;
+      for (int i = 0; i < L; ++i) S += p[c * L + i];
       S += 1e-30f;
-      const float scale = float(L) / S;  // entries are pre-scaled: y = Ps_j + (x^ - j/L) ks_j
-      lut[t * 4 + 0] = scale * p[c * L + j];
-      lut[t * 4 + 1] = (j + 1 < L) ? scale * p[c * L + j + 1] : 0.0f;
-      lut[t * 4 + 2] = scale * P * (1.0f / L);
-      lut[t * 4 + 3] = 0.0f;
+      const float scale = float(L) / S;  // entries are pre-scaled: dx = dy * (L/S) * slope
+      lut[t * 2 + 0] = scale * p[c * L + j];
+      lut[t * 2 + 1] = (j + 1 < L) ? scale * p[c * L + j + 1] : 0.0f;
     }
   }
   __device__ static void fwd(const Prm& q, const float x[3], float y[3]) {
@@ -272,23 +267,24 @@ struct CurveF {
       const int cc = (NC == 1) ? 0 : c;
       const float xv = x[c], g = dy[c];
       const float xc = clamp01x(xv, 0.0f, 1.0f);
-      const float u = xv * float(L);  // exact
-      const float cu = ceilf(u);
-      const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
-      const float4_lut e = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
-      const float y = fmaf(fmaf(jf, -1.0f / L, xc), e.x, e.z);  // LUT entries are pre-scaled by L/S
-      // inside: 0 <= x <= 1  <=>  clamp(x) == x.   knot: L x is an integer in [1, L-1]; the test
-      // (cu - 1 == jf) accepts L x in [1, L] and the LUT's k_L := 0 makes L x == L contribute 0.
-      const bool inside = (xc == xv);
-      const bool knot = (cu == u) && (cu - 1.0f == jf);
-      const float slope = (inside ? e.x : 0.0f) + (knot ? e.y : 0.0f);
-      dx[c] = g * slope;
-      float* a = acc + cc * (L + 1);
+      dx[c] = g * lut_slope(lut, cc, xv, xc);
+      float* a = acc + cc * L;
 #pragma unroll
       for (int i = 1; i < L; ++i) a[i - 1] = fmaf(g, fminf(xc, float(i) / L), a[i - 1]);
       a[L - 1] = fmaf(g, xc, a[L - 1]);
-      a[L] = fmaf(g, y, a[L]);
     }
+  }
+  // (L/S) dT/dx from the LDS LUT, with TF's inclusive clip gradient (both neighbours on a knot)
+  __device__ static float lut_slope(const float* lut, int cc, float xv, float xc) {
+    const float u = xc * float(L);  // exact; the clamped value indexes the same segment as x
+    const float cu = ceilf(u);
+    const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
+    const float2_lut e = *reinterpret_cast<const float2_lut*>(lut + (cc * L + int(jf)) * 2);
+    // inside: 0 <= x <= 1  <=>  clamp(x) == x.   knot: L x^ is an integer in [1, L-1]; the test
+    // (cu - 1 == jf) accepts [1, L] and the LUT's k_L := 0 makes L x^ == L contribute 0.
+    const bool inside = (xc == xv);
+    const bool knot = (cu == u) && (cu - 1.0f == jf);
+    return inside ? (e.x + (knot ? e.y : 0.0f)) : 0.0f;
   }
   // Group backward (PPL pixels at once).  F16X: the inputs are exactly representable in fp16
   // (fp16 storage), so the eight accumulator updates Q_i += dy * min(x^, i/8) of TWO pixels run
@@ -308,7 +304,7 @@ struct CurveF {
       const int iA = (NC == 1) ? 2 * m : 3 * (2 * (m / 3)) + (m % 3);
       const int iB = (NC == 1) ? 2 * m + 1 : iA + 3;
       const int cc = (NC == 1) ? 0 : (m % 3);
-      float* a = acc + cc * (L + 1);
+      float* a = acc + cc * L;
       const float xA = x[iA], xB = x[iB];
       const float gA = d[iA], gB = d[iB];
       if constexpr (F16X) {
@@ -331,34 +327,24 @@ struct CurveF {
         a[L - 1] = fmaf(gA, xcA, a[L - 1]);
         a[L - 1] = fmaf(gB, xcB, a[L - 1]);
       }
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int idx = e ? iB : iA;
-        const float xv = e ? xB : xA, g = e ? gB : gA;
-        const float xc = clamp01x(xv, 0.0f, 1.0f);
-        const float u = xv * float(L);  // exact
-        const float cu = ceilf(u);
-        const float jf = clamp01x(cu - 1.0f, 0.0f, float(L - 1));
-        const float4_lut en = *reinterpret_cast<const float4_lut*>(lut + (cc * L + int(jf)) * 4);
-        const float y = fmaf(fmaf(jf, -1.0f / L, xc), en.x, en.z);  // pre-scaled LUT: this is y
-        const bool inside = (xc == xv);
-        const bool knot = (cu == u) && (cu - 1.0f == jf);
-        const float slope = (inside ? en.x : 0.0f) + (knot ? en.y : 0.0f);
-        a[L] = fmaf(g, y, a[L]);  // B = sum dy * y
-        d[idx] = g * slope;
-      }
+      d[iA] = gA * lut_slope(lut, cc, xA, clamp01x(xA, 0.0f, 1.0f));
+      d[iB] = gB * lut_slope(lut, cc, xB, clamp01x(xB, 0.0f, 1.0f));
     }
   }
-  // a[] per curve: Q_1..Q_L, B = sum dy*y.  dk_i = scale (Q_{i+1} - Q_i) - B / S,  Q_0 = 0
+  // a[] per curve: Q_1..Q_L.  B = (L/S) sum_m (k_{m-1} - k_m) Q_m;  dk_i = (L/S)(Q_{i+1} - Q_i) - B/S
   __device__ static float finish_one(const float* __restrict__ p, const float* a, int j) {
     const int c = j / L, i = j % L;
-    float S = 0.f;
-    for (int t = 0; t < L; ++t) S += p[c * L + t];
+    const float* k = p + c * L;
+    const float* ac = a + c * L;
+    float S = 0.f, B = 0.f;
+    for (int m = 0; m < L; ++m) {
+      S += k[m];
+      B += (k[m] - ((m + 1 < L) ? k[m + 1] : 0.0f)) * ac[m];  // Q_{m+1} is stored at ac[m]
+    }
     S += 1e-30f;
     const float scale = float(L) / S;
-    const float* ac = a + c * (L + 1);
     const float qi = (i == 0) ? 0.0f : ac[i - 1];
-    return scale * (ac[i] - qi) - ac[L] / S;
+    return scale * (ac[i] - qi) - scale * B / S;
   }
 };
 using ToneF = CurveF<1>;
