@@ -153,8 +153,11 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   const typename F::Prm q = F::load(prm);
   // per-image curve LUT (Tone / Color backward) staged in LDS once per block
   __shared__ __attribute__((aligned(16))) float lut[F::kLutFloats > 0 ? F::kLutFloats : 4];
+  // fp16-exact fast path of the curve filters (bit-pattern LUT + packed accumulators); with the
+  // fused penalty dy is no longer an fp16 value, and the masked path scales it -> generic path there
+  constexpr bool kF16X = std::is_same<T, half_t>::value && !PEN;
   if constexpr (F::kLutFloats > 0) {
-    F::stage(prm, lut);
+    F::template stage_for<kF16X>(prm, lut);
     __syncthreads();
   }
   float acc[F::NACC];
@@ -175,7 +178,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
     }
     if constexpr (F::kHasGroupBwd) {
       // with the fused penalty dy is no longer an fp16 value -> use the generic fp32 accumulation
-      F::template bwd_group<PPL, std::is_same<T, half_t>::value && !PEN>(q, lut, v, d, acc);
+      F::template bwd_group<PPL, kF16X>(q, lut, v, d, acc);
     } else {
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {

@@ -218,7 +218,7 @@ template <int NC>
 struct CurveF {
   static constexpr int L = kCurveSteps;
   static constexpr int NP = NC * L, NACC = NC * L;
-  static constexpr int kLutFloats = NC * L * 2;
+  static constexpr int kLutFloats = NC * 256 * 2;  // fp16 path: 256-entry bit-pattern table per curve
   struct Prm { float delta[NC][L]; float scale[NC]; };  // delta[c][i-1] = k_{i-1} - k_i
   __device__ static Prm load(const float* __restrict__ p) {
     Prm q;
@@ -286,6 +286,45 @@ struct CurveF {
     const bool knot = (cu == u) && (cu - 1.0f == jf);
     return inside ? (e.x + (knot ? e.y : 0.0f)) : 0.0f;
   }
+  // ---- fp16 storage: slope table indexed by the HIGH BYTE of the fp16 bit pattern -------------
+  // Every knot i/8 has a zero low byte (0x3000, 0x3400, 0x3600, 0x3800, 0x3900, 0x3A00, 0x3B00,
+  // 0x3C00), so all fp16 values that share a high byte h and have a NON-zero low byte lie strictly
+  // inside one segment; only the value h<<8 itself can sit on a knot (or be +-0, 1.0).  Entry h =
+  // {slope for low byte != 0, slope for low byte == 0}, both evaluated with TF's inclusive rule on a
+  // representative value -- this also encodes "outside [0,1] -> 0", "-0.0 passes", "1.0 passes".
+  // Per element: byte extract + ds_read_b64 + one select, instead of ceil/clamp/convert/compare chains.
+  __device__ static float slope_rule(const float* __restrict__ k, float scale, float x) {
+    float sl = 0.f;
+    for (int i = 0; i < L; ++i) {
+      const float r = x - float(i) / L;
+      sl += (r >= 0.0f && r <= 1.0f / L) ? k[i] : 0.0f;  // tf.clip_by_value gradient, both bounds inclusive
+    }
+    return scale * sl;
+  }
+  __device__ static void stage16(const float* __restrict__ p, float* lut) {
+    typedef _Float16 half_s;
+    for (int t = threadIdx.x; t < NC * 256; t += blockDim.x) {
+      const int c = t >> 8, h = t & 255;
+      const float* k = p + c * L;
+      float S = 0.f;
+      for (int i = 0; i < L; ++i) S += k[i];
+      S += 1e-30f;
+      const float scale = float(L) / S;
+      const unsigned short b_in = (unsigned short)((h << 8) | 1), b_ex = (unsigned short)(h << 8);
+      const float x_in = float(__builtin_bit_cast(half_s, b_in)), x_ex = float(__builtin_bit_cast(half_s, b_ex));
+      lut[t * 2 + 0] = slope_rule(k, scale, x_in);
+      lut[t * 2 + 1] = slope_rule(k, scale, x_ex);
+    }
+  }
+  __device__ static float slope16(const float* lut, int cc, unsigned short bits) {
+    const float2_lut e = *reinterpret_cast<const float2_lut*>(lut + (cc * 256 + (bits >> 8)) * 2);
+    return (bits & 0xFF) ? e.x : e.y;
+  }
+  template <bool F16X>
+  __device__ static void stage_for(const float* __restrict__ p, float* lut) {
+    if constexpr (F16X) stage16(p, lut); else stage(p, lut);
+  }
+
   // Group backward (PPL pixels at once).  F16X: the inputs are exactly representable in fp16
   // (fp16 storage), so the eight accumulator updates Q_i += dy * min(x^, i/8) of TWO pixels run
   // as one v_pk_min_f16 + one v_dot2c_f32_f16 (fp16 x fp16 products are exact in fp32): 17 VALU
@@ -327,8 +366,13 @@ struct CurveF {
         a[L - 1] = fmaf(gA, xcA, a[L - 1]);
         a[L - 1] = fmaf(gB, xcB, a[L - 1]);
       }
-      d[iA] = gA * lut_slope(lut, cc, xA, clamp01x(xA, 0.0f, 1.0f));
-      d[iB] = gB * lut_slope(lut, cc, xB, clamp01x(xB, 0.0f, 1.0f));
+      if constexpr (F16X) {
+        d[iA] = gA * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xA)));
+        d[iB] = gB * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xB)));
+      } else {
+        d[iA] = gA * lut_slope(lut, cc, xA, clamp01x(xA, 0.0f, 1.0f));
+        d[iB] = gB * lut_slope(lut, cc, xB, clamp01x(xB, 0.0f, 1.0f));
+      }
     }
   }
   // a[] per curve: Q_1..Q_L.  B = (L/S) sum_m (k_{m-1} - k_m) Q_m;  dk_i = (L/S)(Q_{i+1} - Q_i) - B/S
