@@ -92,7 +92,7 @@ __device__ __forceinline__ void block_reduce_atomic(float* acc, float* __restric
 }
 
 // --------------------------------------------------------------------------- forward
-template <class F, typename T, bool VEC, bool PEN, int STORE = kStoreCached>
+template <class F, typename T, bool VEC, bool PEN, class IO = IoCached>
 __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict__ yi,
                                          const float* __restrict__ prm, float* pen_out,
                                          int hw, int groups, float inv_count) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, EXPO_PREFETCH != 0, STORE>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, true, EXPO_PREFETCH != 0, IO>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                   [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -135,17 +135,17 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   }
 }
 
-template <class F, typename T, bool VEC, int STORE>
+template <class F, typename T, bool VEC, class IO>
 __global__ __launch_bounds__(kThreads) void filter_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                               const float* __restrict__ params,
                                                               int hw, int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
-  fwd_body<F, T, VEC, false, STORE>(x + off, y + off, params + n * F::NP, nullptr, hw, groups, 0.f);
+  fwd_body<F, T, VEC, false, IO>(x + off, y + off, params + n * F::NP, nullptr, hw, groups, 0.f);
 }
 
 // -------------------------------------------------------------------------- backward
-template <class F, typename T, bool VEC, bool HAS_DX, bool PEN, int MODE>
+template <class F, typename T, bool VEC, bool HAS_DX, bool PEN, int MODE, class IO = IoCached>
 __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __restrict__ dyi,
                                          T* __restrict__ dxi, const float* __restrict__ prm,
                                          float* __restrict__ dprm, int hw, int groups, float pen_scale) {
@@ -191,7 +191,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   };
   if constexpr (VEC) {
     const T* const ins[2] = {xi, dyi};
-    stream_groups<T, 2, HAS_DX, (F::kLutFloats > 0 ? EXPO_CURVE_PREFETCH : EXPO_PREFETCH) != 0, kStoreCached>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 2, HAS_DX, (F::kLutFloats > 0 ? EXPO_CURVE_PREFETCH : EXPO_PREFETCH) != 0, IO>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                     [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -205,7 +205,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   block_reduce_atomic<F::NACC, F::NP>(acc, dprm, [=](const float* t, int j) { return F::finish_one(prm, t, j); });
 }
 
-template <class F, typename T, bool VEC, bool HAS_DX, int MODE>
+template <class F, typename T, bool VEC, bool HAS_DX, int MODE, class IO>
 __global__ __launch_bounds__(kThreads) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                               T* __restrict__ dx,
                                                               const float* __restrict__ params,
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void filter_bwd_kernel(const T* __restric
                                                               int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
-  bwd_body<F, T, VEC, HAS_DX, false, MODE>(x + off, dy + off, HAS_DX ? dx + off : nullptr,
+  bwd_body<F, T, VEC, HAS_DX, false, MODE, IO>(x + off, dy + off, HAS_DX ? dx + off : nullptr,
                                                params + n * F::NP, dparams + n * F::NP, hw, groups, 0.f);
 }
 
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, true, kStoreCached>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, true, true, IoCached>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                                            [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[2] = {xi, dyi};
-    stream_groups<T, 2, HAS_DX, true, kStoreCached>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 2, HAS_DX, true, IoCached>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                       [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -341,7 +341,7 @@ __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int group
     const RawGroup rz = pack<T>(z);
     const __amdgpu_buffer_rsrc_t ry = make_image_rsrc(yi, hw);
     for (int gw = blockIdx.x * kThreads + (threadIdx.x & ~63); gw * PPL < hw; gw += stride)
-      store_raw<kStoreCached>(ry, chunk_byte_offset<T>(gw, threadIdx.x & 63), rz);
+      store_raw<IoCached::kStore>(ry, chunk_byte_offset<T>(gw, threadIdx.x & 63), rz);
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) store_slow<T>(yi, g, hw, z);
   }
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
 // rounding of intermediates): ONE read and ONE write of the image instead of one per step.
 // Each wave owns exactly one 3 KiB chunk, so the per-step parameters are fetched once per wave
 // through scalar loads; the step loop is rolled (block-uniform switch per step).
-template <typename T, bool VEC>
+template <typename T, bool VEC, class IO>
 __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t* __restrict__ ids,
                                                                    const float* __restrict__ params, int steps,
                                                                    const T* __restrict__ x, T* __restrict__ y,
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
   const int stride = gridDim.x * kThreads;
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, false, kStoreCached>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, true, false, IO>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                      [&](float (&v)[1][PPL * 3], int) { run(v[0]); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
 // ------------------------------------------------------------- per-image reductions
 // critics.py:48-62.  Raw sums {sum(l-1/2), sum (l-1/2)^2, sum sat} are accumulated
 // (shifted to tame the E[l^2]-E[l]^2 cancellation) and finished by stats_finish_kernel.
-template <typename T, bool VEC>
+template <typename T, bool VEC, class IO>
 __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x, float* __restrict__ sums,
                                                          int hw, int groups) {
   constexpr int PPL = PixTraits<T>::PPL;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, false, true, kStoreCached>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, false, true, IO>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                       [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -555,7 +555,7 @@ __global__ void stats_finish_kernel(float* __restrict__ stats, int n, float inv_
   stats[i * 3 + 2] = stats[i * 3 + 2] * inv_hw;
 }
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, class IO>
 __global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__ y, float* __restrict__ pen,
                                                            int hw, int groups, float inv_count) {
   constexpr int PPL = PixTraits<T>::PPL;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__
   };
   if constexpr (VEC) {
     const T* const ins[1] = {yi};
-    stream_groups<T, 1, false, true, kStoreCached>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, false, true, IO>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                       [&](float (&v)[1][PPL * 3], int) { compute(v[0]); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
@@ -586,11 +586,11 @@ __global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__
 
 #ifdef EXPO_PROBE
 // register-pressure probe builds (tools/probe.sh): instantiate a few kernels, skip the host side
-template __global__ void filter_bwd_kernel<ToneF, half_t, true, true, 0>(const half_t*, const half_t*, half_t*,
+template __global__ void filter_bwd_kernel<ToneF, half_t, true, true, 0, IoStream>(const half_t*, const half_t*, half_t*,
                                                                                 const float*, float*, int, int);
-template __global__ void filter_bwd_kernel<ColorF, half_t, true, true, 0>(const half_t*, const half_t*, half_t*,
+template __global__ void filter_bwd_kernel<ColorF, half_t, true, true, 0, IoStream>(const half_t*, const half_t*, half_t*,
                                                                                  const float*, float*, int, int);
-template __global__ void filter_bwd_kernel<WnbF, half_t, true, true, 0>(const half_t*, const half_t*, half_t*,
+template __global__ void filter_bwd_kernel<WnbF, half_t, true, true, 0, IoStream>(const half_t*, const half_t*, half_t*,
                                                                                const float*, float*, int, int);
 }  // namespace expo
 #else
@@ -616,6 +616,7 @@ static const int kNumParams[EXPO_NUM_FILTERS] = {1, 1, 3, 1, 8, 1, 1, 24, 2};
 struct Geom {
   int hw, groups, blocks_x;
   bool vec;
+  bool stream;  // IoStream policy (pixel_io.h): vector path and the tensor is far beyond L2
 };
 
 static int env_int(const char* name, int dflt) {
@@ -648,6 +649,9 @@ static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
   if (bx > max_bx) bx = max_bx;
   if (bx < 1) bx = 1;
   g.blocks_x = bx;
+  // cache policy: tensors of at least EXPO_STREAM_MIN_BYTES (default 8 MiB; L2 is 8 x 4 MiB) stream
+  static const long stream_min = env_int("EXPO_STREAM_MIN_BYTES", 8 << 20);
+  g.stream = g.vec && long(n) * g.hw * 3L * long(sizeof(T)) >= stream_min;
   return g;
 }
 
@@ -662,18 +666,15 @@ static int check_common(int n, int h, int w, int dtype) {
 }
 
 template <class F, typename T>
-static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s,
-                      bool stream_out = false) {
+static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {x, y}, false);
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  // stream_out: the output is not re-read by the work that follows (the chain's final activation):
-  // store it with the nt policy so it does not evict / dirty the Infinity Cache (pixel_io.h)
-  if (g.vec && stream_out)
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, kStoreStream>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+  if (g.stream)
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, IoStream>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
   else if (g.vec)
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, kStoreCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, IoCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
   else
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, false, kStoreCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, false, IoCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
   HIP_TRY(hipGetLastError(), "filter_fwd launch");
   return EXPO_OK;
 }
@@ -684,9 +685,18 @@ static int launch_bwd(const void* x, const void* dy, void* dx, const float* para
   const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
   const dim3 grid(g.blocks_x, n), block(kThreads);
   if (!zeroed) HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * F::NP, s), "dparams memset");
-#define EXPO_L(VEC, HAS_DX, MODE)                                                                        \
-  hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, HAS_DX, MODE>), grid, block, 0, s, (const T*)x, \
+#define EXPO_LIO(VEC, HAS_DX, MODE, IO)                                                                  \
+  hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, HAS_DX, MODE, IO>), grid, block, 0, s, (const T*)x, \
                      (const T*)dy, (T*)dx, params, dparams, g.hw, g.groups)
+#define EXPO_L(VEC, HAS_DX, MODE)                                  \
+  do {                                                             \
+    if constexpr (VEC) {                                           \
+      if (g.stream) EXPO_LIO(true, HAS_DX, MODE, IoStream);        \
+      else EXPO_LIO(true, HAS_DX, MODE, IoCached);                 \
+    } else {                                                       \
+      EXPO_LIO(false, HAS_DX, MODE, IoCached);                     \
+    }                                                              \
+  } while (0)
   // only SaturationPlus has a mode-dependent backward
   const bool m1 = std::is_same<F, SatPlusF>::value && mode == 1;
   const int key = (g.vec ? 4 : 0) | (dx ? 2 : 0) | (m1 ? 1 : 0);
@@ -701,23 +711,23 @@ static int launch_bwd(const void* x, const void* dy, void* dx, const float* para
     default: EXPO_L(false, false, 0); break;
   }
 #undef EXPO_L
+#undef EXPO_LIO
   HIP_TRY(hipGetLastError(), "filter_bwd launch");
   return EXPO_OK;
 }
 
 template <typename T>
-static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int h, int w, hipStream_t s,
-                     bool stream_out = false) {
+static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int h, int w, hipStream_t s) {
   switch (id) {
-    case 0: return launch_fwd<ExposureF, T>(x, y, p, n, h, w, s, stream_out);
-    case 1: return launch_fwd<GammaF, T>(x, y, p, n, h, w, s, stream_out);
-    case 2: return launch_fwd<WhiteBalanceF, T>(x, y, p, n, h, w, s, stream_out);
-    case 3: return launch_fwd<SatPlusF, T>(x, y, p, n, h, w, s, stream_out);
-    case 4: return launch_fwd<ToneF, T>(x, y, p, n, h, w, s, stream_out);
-    case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s, stream_out);
-    case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s, stream_out);
-    case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s, stream_out);
-    case 8: return launch_fwd<LevelF, T>(x, y, p, n, h, w, s, stream_out);
+    case 0: return launch_fwd<ExposureF, T>(x, y, p, n, h, w, s);
+    case 1: return launch_fwd<GammaF, T>(x, y, p, n, h, w, s);
+    case 2: return launch_fwd<WhiteBalanceF, T>(x, y, p, n, h, w, s);
+    case 3: return launch_fwd<SatPlusF, T>(x, y, p, n, h, w, s);
+    case 4: return launch_fwd<ToneF, T>(x, y, p, n, h, w, s);
+    case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s);
+    case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s);
+    case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s);
+    case 8: return launch_fwd<LevelF, T>(x, y, p, n, h, w, s);
   }
   return fail(EXPO_E_BADARG, "filter_id out of range");
 }
@@ -875,10 +885,12 @@ static int chain_fused_fwd_t(const int32_t* ids, const float* params, int steps,
   Geom g = make_geom<T>(n, h, w, {x, y}, false);
   g.blocks_x = (g.groups + kThreads - 1) / kThreads;  // one chunk per wave: parameters fetched once
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  if (g.vec)
-    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, true>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
+  if (g.stream)
+    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, true, IoStream>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
+  else if (g.vec)
+    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, true, IoCached>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
   else
-    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, false>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
+    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, false, IoCached>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
   HIP_TRY(hipGetLastError(), "chain_fused_fwd launch");
   return EXPO_OK;
 }
@@ -888,8 +900,9 @@ static int stats_t(const void* x, float* stats, int n, int h, int w, hipStream_t
   const Geom g = make_geom<T>(n, h, w, {x});
   const dim3 grid(g.blocks_x, n), block(kThreads);
   HIP_TRY(hipMemsetAsync(stats, 0, sizeof(float) * size_t(n) * 3, s), "stats memset");
-  if (g.vec) hipLaunchKernelGGL((stats_kernel<T, true>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
-  else hipLaunchKernelGGL((stats_kernel<T, false>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
+  if (g.stream) hipLaunchKernelGGL((stats_kernel<T, true, IoStream>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
+  else if (g.vec) hipLaunchKernelGGL((stats_kernel<T, true, IoCached>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
+  else hipLaunchKernelGGL((stats_kernel<T, false, IoCached>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
   HIP_TRY(hipGetLastError(), "stats launch");
   hipLaunchKernelGGL(stats_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, s, stats, n, 1.0f / float(g.hw));
   HIP_TRY(hipGetLastError(), "stats_finish launch");
@@ -902,8 +915,9 @@ static int penalty_t(const void* y, float* pen, int n, int h, int w, hipStream_t
   const dim3 grid(g.blocks_x, n), block(kThreads);
   HIP_TRY(hipMemsetAsync(pen, 0, sizeof(float) * size_t(n), s), "penalty memset");
   const float inv_count = 1.0f / (float(g.hw) * 3.0f);
-  if (g.vec) hipLaunchKernelGGL((penalty_kernel<T, true>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
-  else hipLaunchKernelGGL((penalty_kernel<T, false>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
+  if (g.stream) hipLaunchKernelGGL((penalty_kernel<T, true, IoStream>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
+  else if (g.vec) hipLaunchKernelGGL((penalty_kernel<T, true, IoCached>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
+  else hipLaunchKernelGGL((penalty_kernel<T, false, IoCached>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
   HIP_TRY(hipGetLastError(), "penalty launch");
   return EXPO_OK;
 }
@@ -1022,11 +1036,8 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
   for (int i = 0; i < steps; ++i) {
     if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
     if (!acts[i] || !acts[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
-    // acts[1..steps-1] are re-read at once by the next step (and later by the backward); the final
-    // output is not an input of anything this library launches next -> streaming store
-    const bool last = (i == steps - 1);
-    const int rc = dtype == EXPO_F16 ? fwd_by_id<half_t>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, last)
-                                     : fwd_by_id<float>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, last);
+    const int rc = dtype == EXPO_F16 ? fwd_by_id<half_t>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s)
+                                     : fwd_by_id<float>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s);
     if (rc) return rc;
   }
   return EXPO_OK;

@@ -61,22 +61,28 @@ __device__ __forceinline__ int chunk_byte_offset(int gw, int lane) {
   return (gw * (PPL / PPV) + lane) * 12;
 }
 
+// Cache policy of the image streams (buffer-instruction aux bits on gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
+// IoCached: default policy everywhere -- right while a tensor fits the 32 MiB of L2 (training on
+//   64x64 proxies: the next kernel, ours or a MIOpen conv, finds the lines in L2).
+// IoStream: nt loads (stream through L2, evict first) + sc1 stores (write through, line dropped from
+//   L2) for tensors far beyond L2.  Measured on MI355X (tools/membench.hip, 96 MiB buffers, dwordx3
+//   SRD skeleton, launch i+1 reads what launch i wrote):
+//     copy  plain/plain 6.26 TB/s | nt loads 7.44 | sc1 stores 6.59 | nt loads + sc1 stores 7.73
+//     read-read-write  plain 6.28 TB/s | nt x 7.21 | nt x, nt dy, sc1 store 7.61
+//     (nt STORES lose: 6.13; sc1|nt stores 6.17; sc0|sc1 stores = sc1.)
+//   8-step chain 64x512x512x3 fp16: 0.668-0.690 ms/step cached -> 0.616 ms/step streaming, and the
+//   backward "hangover" of the cached policy (the forward's dirty lines draining from the 256 MiB
+//   Infinity Cache under the first two backward kernels, +10..20 us) disappears.
+struct IoCached { static constexpr int kLoadX = 0, kLoadDy = 0, kStore = 0; };
+struct IoStream { static constexpr int kLoadX = 2, kLoadDy = 2, kStore = 16; };
+
+template <int AUX>
 __device__ __forceinline__ RawGroup load_raw(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
   RawGroup r;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) r.q[j] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, byte_off + j * 768, 0, 0);
+  for (int j = 0; j < 4; ++j) r.q[j] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, byte_off + j * 768, 0, AUX);
   return r;
 }
-// Cache policy of the output stores (buffer instruction aux bits on gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
-// Measured on the 8-step chain (64x512x512x3 fp16, in-chain HIP-event timings):
-//   cached stores everywhere (default): forward pass 296 us; the first two backward kernels carry
-//     +10..15 us each while the forward's dirty lines drain from the 256 MiB Infinity Cache;
-//   nt stores for the forward outputs only: that backward hangover disappears (-22 us) but every
-//     forward step now re-reads its input from HBM instead of the cache (+19 us): net 0.702 vs
-//     0.705 ms per step, i.e. a wash, with 8 x 96 MiB more HBM reads -> not adopted;
-//   nt stores everywhere: backward kernels lose their cached dy (+9 us each): 0.738 ms.
-// What IS adopted: expo_chain_fwd streams out only the chain's FINAL activation (nothing re-reads it).
-constexpr int kStoreCached = 0, kStoreStream = 2;
 
 template <int AUX>
 __device__ __forceinline__ void store_raw(__amdgpu_buffer_rsrc_t rsrc, int byte_off, const RawGroup& r) {
@@ -144,7 +150,8 @@ template <> __device__ __forceinline__ RawGroup pack<float>(const float* in) {
 // stride; NIN input streams (x, or x and dy) are unpacked to fp32, fn(v, g) transforms them in
 // place, and the LAST stream is written back when HAS_OUT.  With PF the next chunk's loads are in
 // flight while the current one computes (software prefetch; costs 12 VGPRs per stream).
-template <typename T, int NIN, bool HAS_OUT, bool PF, int STORE_AUX, class Fn>
+// Stream 0 is the image x (policy IO::kLoadX), stream 1 the upstream gradient dy (IO::kLoadDy).
+template <typename T, int NIN, bool HAS_OUT, bool PF, class IO, class Fn>
 __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out, int hw, int first_gw,
                                               int stride, Fn&& fn) {
   constexpr int PPL = PixTraits<T>::PPL;
@@ -156,28 +163,26 @@ __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out,
   if constexpr (HAS_OUT) rout = make_image_rsrc(out, hw);
   int gw = first_gw;  // wave-uniform
   if (gw * PPL >= hw) return;
+  static_assert(NIN <= 2, "at most two input streams");
+  auto load_all = [&](RawGroup (&dst)[NIN], int g) {
+    dst[0] = load_raw<IO::kLoadX>(rin[0], chunk_byte_offset<T>(g, lane));
+    if constexpr (NIN > 1) dst[1] = load_raw<IO::kLoadDy>(rin[1], chunk_byte_offset<T>(g, lane));
+  };
   RawGroup cur[NIN];
-#pragma unroll
-  for (int s = 0; s < NIN; ++s) cur[s] = load_raw(rin[s], chunk_byte_offset<T>(gw, lane));
+  load_all(cur, gw);
   while (true) {
     const int gn = gw + stride;
     const bool more = gn * PPL < hw;  // wave-uniform
     RawGroup nxt[NIN];
 #pragma unroll
     for (int s = 0; s < NIN; ++s) nxt[s] = cur[s];
-    if (PF && more) {
-#pragma unroll
-      for (int s = 0; s < NIN; ++s) nxt[s] = load_raw(rin[s], chunk_byte_offset<T>(gn, lane));
-    }
+    if (PF && more) load_all(nxt, gn);
     float v[NIN][PPL * 3];
 #pragma unroll
     for (int s = 0; s < NIN; ++s) unpack<T>(cur[s], v[s]);
     fn(v, gw + lane);
-    if constexpr (HAS_OUT) store_raw<STORE_AUX>(rout, chunk_byte_offset<T>(gw, lane), pack<T>(v[NIN - 1]));
-    if (!PF && more) {
-#pragma unroll
-      for (int s = 0; s < NIN; ++s) nxt[s] = load_raw(rin[s], chunk_byte_offset<T>(gn, lane));
-    }
+    if constexpr (HAS_OUT) store_raw<IO::kStore>(rout, chunk_byte_offset<T>(gw, lane), pack<T>(v[NIN - 1]));
+    if (!PF && more) load_all(nxt, gn);
     if (!more) break;
     gw = gn;
 #pragma unroll

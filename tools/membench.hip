@@ -7,6 +7,7 @@
 //   copy48u2    same, two groups in flight per thread
 //   rrw48       read x, read dy, write dx with the pixel-group pattern (backward skeleton)
 //   rrw48nt     same, nontemporal
+//   cpol / rpol cache-policy sweep (L = load aux, S = store aux) on the SRD dwordx3 skeleton
 // Buffers rotate over NBUF distinct allocations so the 256 MiB Infinity Cache cannot serve re-reads.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -187,6 +188,46 @@ __global__ __launch_bounds__(256) void rrw16(const u32x4* __restrict__ a, const 
   }
 }
 
+
+// Cache-policy sweep on the SRD dwordx3 skeleton (aux bits on gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
+// cpol: copy (read a with LA, write b with SA);  rpol: read a (LA), read c (LC), write b (SA).
+// Launch i writes the buffer launch i+1 reads, like consecutive steps of the filter chain.
+template <int LA, int SA>
+__global__ __launch_bounds__(256) void cpol(const uint32_t* __restrict__ a, uint32_t* __restrict__ b, size_t nrows, int nbytes) {
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, nbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, nbytes, 0x00020000);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (size_t r = (size_t(blockIdx.x) * 4 + wave) * 4; r < nrows; r += size_t(gridDim.x) * 16) {
+    u32x3 v[4];
+    const int off = int(r) * 768 + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b96(ra, off + j * 768, 0, LA);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j].x ^= 1u;
+      __builtin_amdgcn_raw_buffer_store_b96(v[j], rb, off + j * 768, 0, SA);
+    }
+  }
+}
+template <int LA, int LC, int SA>
+__global__ __launch_bounds__(256) void rpol(const uint32_t* __restrict__ a, const uint32_t* __restrict__ c,
+                                            uint32_t* __restrict__ b, size_t nrows, int nbytes) {
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, nbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)c, 0, nbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, nbytes, 0x00020000);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (size_t r = (size_t(blockIdx.x) * 4 + wave) * 4; r < nrows; r += size_t(gridDim.x) * 16) {
+    u32x3 v[4], w[4];
+    const int off = int(r) * 768 + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b96(ra, off + j * 768, 0, LA);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_raw_buffer_load_b96(rc, off + j * 768, 0, LC);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b96(v[j] ^ w[j], rb, off + j * 768, 0, SA);
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = (argc > 1 ? atol(argv[1]) : 96) * (1ul << 20);  // per buffer
   const int nbuf = argc > 2 ? atoi(argv[2]) : 9;
@@ -206,7 +247,7 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      printf("grid %5d  %-9s %8.1f GB/s  (%.1f us/launch)\n", grid, name, double(bytes) * streams * reps / (ms * 1e-3) / 1e9,
+      printf("grid %5d  %-18s %8.1f GB/s  (%.1f us/launch)\n", grid, name, double(bytes) * streams * reps / (ms * 1e-3) / 1e9,
              ms / reps * 1e3);
     };
     run("copy16", 2, [&](int i) { copy16<<<grid, 256>>>(buf[i % nbuf], buf[(i + 1) % nbuf], n16); });
@@ -222,6 +263,15 @@ int main(int argc, char** argv) {
     run("c12bufx4", 2, [&](int i) { copy12buf<4, false><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes), 1.0f); });
     run("c12bufwork", 2, [&](int i) { copy12buf<4, true><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes), 1.0f); });
     run("rrw12x4", 3, [&](int i) { rrw12<4><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (const uint32_t*)buf[(i + 4) % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768); });
+
+    if (grid <= 8192) {
+#define CPOL(LA, SA) run("cpol L" #LA " S" #SA, 2, [&](int i) { cpol<LA, SA><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes)); });
+      CPOL(0, 0) CPOL(2, 0) CPOL(0, 16) CPOL(2, 16) CPOL(2, 17) CPOL(2, 18) CPOL(2, 2) CPOL(18, 16) CPOL(16, 16)
+#undef CPOL
+#define RPOL(LA, LC, SA) run("rpol L" #LA " L" #LC " S" #SA, 3, [&](int i) { rpol<LA, LC, SA><<<grid, 256>>>((const uint32_t*)buf[(i + 4) % nbuf], (const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes)); });
+      RPOL(0, 0, 0) RPOL(2, 0, 0) RPOL(2, 0, 16) RPOL(2, 2, 16) RPOL(2, 2, 17) RPOL(0, 0, 16) RPOL(2, 2, 0) RPOL(2, 16, 16)
+#undef RPOL
+    }
     run("rrw48nt", 3, [&](int i) { rrw48<true><<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], ngroups); });
   }
   return 0;
