@@ -24,6 +24,11 @@
 #include "filter_math.h"
 #include "pixel_io.h"
 
+// forward launches give every wave exactly one chunk (EXPO_FWD_GROUPS_PER_THREAD = 1), so a
+// prefetch stage would only cost registers there
+#ifndef EXPO_FWD_PREFETCH
+#define EXPO_FWD_PREFETCH 0
+#endif
 #ifndef EXPO_CURVE_PREFETCH
 #define EXPO_CURVE_PREFETCH 1
 #endif
@@ -119,7 +124,7 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, EXPO_PREFETCH != 0, IO>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+    stream_groups<T, 1, true, EXPO_FWD_PREFETCH != 0, IO>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                   [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {

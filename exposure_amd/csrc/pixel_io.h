@@ -34,6 +34,11 @@ template <> struct PixTraits<float> { static constexpr int PPL = 4; };
 // coalesced pattern -- tools/membench.hip copy48 vs copy12/copy16, profiles/r01_*_membench.txt.)
 // Requirements: fp16: H*W even and a 4-byte aligned base; fp32: always (4-byte aligned).
 // ---------------------------------------------------------------------------------------
+// fp16 stores saturate at +-65504 through MODE.FP16_OVFL (set once per wave by stream_groups)
+// instead of 24 packed min/max per pixel group; 0 = explicit clamps.
+#ifndef EXPO_FP16_OVFL
+#define EXPO_FP16_OVFL 1
+#endif
 #ifndef EXPO_PREFETCH
 #define EXPO_PREFETCH 1
 #endif
@@ -125,12 +130,16 @@ template <> __device__ __forceinline__ RawGroup pack<half_t>(const float* in) {
     for (int e = 0; e < 3; ++e) {
       // round-to-nearest-even, SATURATING at +-65504: five +3.5 EV exposure steps of an untrained
       // policy exceed the fp16 range, and an inf pixel would poison every later loss (the fp32
-      // reference just carries the large value; fp16 storage carries the largest finite one)
+      // reference just carries the large value; fp16 storage carries the largest finite one).
+      // With EXPO_FP16_OVFL the conversion itself saturates (MODE.FP16_OVFL; a true +-inf input
+      // stays inf), otherwise an explicit packed clamp does (+-inf -> +-65504 too).
       half2_t h;
       h[0] = half_t(in[j * 6 + e * 2]);
       h[1] = half_t(in[j * 6 + e * 2 + 1]);
+#if !EXPO_FP16_OVFL
       const half2_t hi = {half_t(65504.0f), half_t(65504.0f)}, lo = {half_t(-65504.0f), half_t(-65504.0f)};
       h = __builtin_elementwise_max(__builtin_elementwise_min(h, hi), lo);  // +-inf -> +-65504 (packed)
+#endif
       r.q[j][e] = __builtin_bit_cast(uint32_t, h);
     }
   }
@@ -156,6 +165,10 @@ __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out,
                                               int stride, Fn&& fn) {
   constexpr int PPL = PixTraits<T>::PPL;
   const int lane = threadIdx.x & 63;
+#if EXPO_FP16_OVFL
+  // MODE.FP16_OVFL (hwreg 1, bit 23): fp16 results that overflow clamp to +-65504 instead of +-inf
+  if constexpr (HAS_OUT && sizeof(T) == 2) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+#endif
   __amdgpu_buffer_rsrc_t rin[NIN];
 #pragma unroll
   for (int s = 0; s < NIN; ++s) rin[s] = make_image_rsrc(in[s], hw);

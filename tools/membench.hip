@@ -228,10 +228,51 @@ __global__ __launch_bounds__(256) void rpol(const uint32_t* __restrict__ a, cons
   }
 }
 
+
+// cpol2: the copy skeleton moved stepwise towards a real forward kernel, all with nt loads + sc1
+// stores: WORK = fp16 -> fp32 -> scale -> fp16 round trip; GRID2D = (blocks per image, images) grid
+// with a per-image SRD; PARAM = per-image scale fetched through a dependent scalar load.
+template <bool WORK, bool GRID2D, bool PARAM>
+__global__ __launch_bounds__(256) void cpol2(const uint32_t* __restrict__ a, uint32_t* __restrict__ b, size_t nrows,
+                                             int nbytes, const float* __restrict__ prm) {
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  const int img = GRID2D ? blockIdx.y : 0;
+  const int nimg = GRID2D ? gridDim.y : 1;
+  const int img_bytes = nbytes / nimg;
+  const size_t rows_img = nrows / nimg;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a + size_t(img) * img_bytes), 0, img_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)b + size_t(img) * img_bytes), 0, img_bytes, 0x00020000);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float scale = PARAM ? __builtin_exp2f(prm[img]) : 1.0f;
+  for (size_t r = (size_t(blockIdx.x) * 4 + wave) * 4; r < rows_img; r += size_t(gridDim.x) * 16) {
+    u32x3 v[4];
+    const int off = int(r) * 768 + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b96(ra, off + j * 768, 0, 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (WORK) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const uint32_t w = v[j][e];
+          half2_t h = __builtin_bit_cast(half2_t, w);
+          h[0] = _Float16(float(h[0]) * scale);
+          h[1] = _Float16(float(h[1]) * scale);
+          v[j][e] = __builtin_bit_cast(uint32_t, h);
+        }
+      } else {
+        v[j].x ^= 1u;
+      }
+      __builtin_amdgcn_raw_buffer_store_b96(v[j], rb, off + j * 768, 0, 16);
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = (argc > 1 ? atol(argv[1]) : 96) * (1ul << 20);  // per buffer
   const int nbuf = argc > 2 ? atoi(argv[2]) : 9;
-  const int reps = 40;
+  const int reps = argc > 3 ? atoi(argv[3]) : 40;
+  const bool pol_only = argc > 4;  // any 4th argument: cache-policy sweep only (PMC calibration runs)
   std::vector<u32x4*> buf(nbuf);
   for (auto& p : buf) { CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 1, bytes)); }
   const size_t n16 = bytes / 16, ngroups = bytes / 48;
@@ -240,6 +281,7 @@ int main(int argc, char** argv) {
   const int grids[] = {2048, 8192, 32768};
   printf("buffer %zu MiB x %d, %d reps\n", bytes >> 20, nbuf, reps);
   for (int grid : grids) {
+    if (pol_only && grid != 8192) continue;
     auto run = [&](const char* name, int streams, auto launch) {
       for (int i = 0; i < 3; ++i) launch(i);
       CK(hipEventRecord(e0));
@@ -250,6 +292,7 @@ int main(int argc, char** argv) {
       printf("grid %5d  %-18s %8.1f GB/s  (%.1f us/launch)\n", grid, name, double(bytes) * streams * reps / (ms * 1e-3) / 1e9,
              ms / reps * 1e3);
     };
+    if (!pol_only) {
     run("copy16", 2, [&](int i) { copy16<<<grid, 256>>>(buf[i % nbuf], buf[(i + 1) % nbuf], n16); });
     run("copy48", 2, [&](int i) { copy48<false, 1><<<grid, 256>>>(buf[i % nbuf], buf[(i + 1) % nbuf], ngroups); });
     run("copy48nt", 2, [&](int i) { copy48<true, 1><<<grid, 256>>>(buf[i % nbuf], buf[(i + 1) % nbuf], ngroups); });
@@ -263,6 +306,7 @@ int main(int argc, char** argv) {
     run("c12bufx4", 2, [&](int i) { copy12buf<4, false><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes), 1.0f); });
     run("c12bufwork", 2, [&](int i) { copy12buf<4, true><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes), 1.0f); });
     run("rrw12x4", 3, [&](int i) { rrw12<4><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (const uint32_t*)buf[(i + 4) % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768); });
+    }
 
     if (grid <= 8192) {
 #define CPOL(LA, SA) run("cpol L" #LA " S" #SA, 2, [&](int i) { cpol<LA, SA><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes)); });
@@ -272,7 +316,15 @@ int main(int argc, char** argv) {
       RPOL(0, 0, 0) RPOL(2, 0, 0) RPOL(2, 0, 16) RPOL(2, 2, 16) RPOL(2, 2, 17) RPOL(0, 0, 16) RPOL(2, 2, 0) RPOL(2, 16, 16)
 #undef RPOL
     }
-    run("rrw48nt", 3, [&](int i) { rrw48<true><<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], ngroups); });
+
+    if (grid <= 8192) {
+      static float* prm = nullptr;
+      if (!prm) { CK(hipMalloc(&prm, 64 * sizeof(float))); CK(hipMemset(prm, 0, 64 * sizeof(float))); }
+#define CPOL2(W, G, P) run("cpol2 w" #W " g" #G " p" #P, 2, [&](int i) { cpol2<W, G, P><<<dim3(G ? grid / 64 : grid, G ? 64 : 1), 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes), prm); });
+      CPOL2(0, 0, 0) CPOL2(1, 0, 0) CPOL2(0, 1, 0) CPOL2(1, 1, 0) CPOL2(1, 1, 1)
+#undef CPOL2
+    }
+    if (!pol_only) run("rrw48nt", 3, [&](int i) { rrw48<true><<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], ngroups); });
   }
   return 0;
 }
