@@ -41,14 +41,14 @@ def parse():
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--shape', default=None, help='A|B|C (synthetic.SHAPES) or N,H,W; default C (chain), B (infer)')
   ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
-  ap.add_argument('--kernel-reps', type=int, default=20, help='launches per kernel for the roofline timing')
+  ap.add_argument('--kernel-reps', type=int, default=50, help='launches per kernel for the roofline timing')
   ap.add_argument('--prewarm-s', type=float, default=0.3, help='untimed clock warm-up before the W warm-up steps')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-per-kernel', action='store_true')
   ap.add_argument('--seed', type=int, default=1234)
   ap.add_argument('--order', default='0,1,2,3,4,5,6,7', help='filter ids of the chain steps (experiments only; the '
                   'metric is defined on the cfg.filters order 0..7)')
-  ap.add_argument('--workload', default='chain', choices=['chain', 'train', 'infer'],
+  ap.add_argument('--workload', default='chain', choices=['chain', 'train', 'infer', 'allreduce'],
                   help="chain: the headline filter-chain metric; train: one reference training iteration "
                   "(1 generator/value step + cfg.citers critic steps, net.py:307-365) on 64 images per GPU")
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
@@ -284,6 +284,72 @@ def run_train(args, world, rank, dev, dist):
     dist.destroy_process_group()
 
 
+def run_allreduce(args, world, rank, dev, dist):
+  """SURVEY.md section 8(e) "all-reduce only": the three flat fp32 gradient buckets of one training
+  iteration (theta_g 24.5 MB + theta_v 4.9 MB once, theta_c 4.9 MB x citers) reduced over RCCL, no
+  compute.  With one rank the collective degenerates to nothing and the line reports 0 bytes."""
+  from exposure_amd.config import make_cfg
+  from exposure_amd.gan import GAN
+  cfg = make_cfg()
+  torch.manual_seed(args.seed)
+  gan = GAN(cfg, device=dev, use_graphs=False)
+  sizes = {name: b.numel for name, b in gan.buckets.items()}
+  bufs = {k: torch.zeros(v, dtype=torch.float32, device=dev) for k, v in sizes.items()}
+
+  def iteration():
+    if dist is None:
+      return
+    dist.all_reduce(bufs['g'])
+    dist.all_reduce(bufs['v'])
+    for _ in range(cfg.citers):
+      dist.all_reduce(bufs['c'])
+
+  for _ in range(args.warmup):
+    iteration()
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    iteration()
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  nbytes = 4 * (sizes['g'] + sizes['v'] + cfg.citers * sizes['c'])
+  if rank == 0:
+    ms = elapsed / args.steps * 1e3
+    print(json.dumps({
+        'metric': 'gradient all-reduce GB/s per training iteration (bucket bytes / time)',
+        'value': (nbytes / 1e9) / (elapsed / args.steps) if world > 1 else 0.0,
+        'unit': 'GB/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': ms,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': 'all-reduce only: theta_g %d + theta_v %d + %d x theta_c %d fp32 elements per iteration'
+                        % (sizes['g'], sizes['v'], cfg.citers, sizes['c']),
+            'bytes_per_iteration': nbytes,
+            'parallelism': 'dp%d, flat buckets over RCCL' % world,
+        },
+    }))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def run_infer(args, world, rank, dev, dist):
   """BASELINE config 5: high-resolution inference, 16x512x512x3 fp16, the 8 filters of cfg.filters
   applied to every image -- (a) one kernel per step (8 reads + 8 writes of the image), (b) the fused
@@ -374,6 +440,8 @@ def main():
     return run_train(args, world, rank, dev, dist)
   if args.workload == 'infer':
     return run_infer(args, world, rank, dev, dist)
+  if args.workload == 'allreduce':
+    return run_allreduce(args, world, rank, dev, dist)
 
   shape = parse_shape(args.shape or 'C')
   dtype = torch.float16 if args.dtype == 'f16' else torch.float32

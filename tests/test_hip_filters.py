@@ -417,3 +417,37 @@ def test_fp16_stores_saturate(gpu_device):
   y5 = torch.empty_like(x5)
   _cabi.filter_fwd(0, x5, y5, torch.full((1, 1), 3.5, device=dev))
   assert float(y5.max()) == 65504.0
+  # negative side, and the backward's dx store (dx = dy * 2^p)
+  _cabi.filter_fwd(0, -x, y, torch.full((1, 1), 3.5, device=dev))
+  assert torch.isfinite(y).all() and float(y.min()) == -65504.0
+  _cabi.filter_fwd(0, -x5, y5, torch.full((1, 1), 3.5, device=dev))
+  assert float(y5.min()) == -65504.0
+  dx, dp = torch.empty_like(x), torch.empty(1, 1, device=dev)
+  _cabi.filter_bwd(0, x * 0 + 1, -x, dx, torch.full((1, 1), 3.5, device=dev), dp)
+  assert torch.isfinite(dx).all() and float(dx.min()) == -65504.0
+
+
+def test_streaming_policy_equals_cached_policy(gpu_device):
+  """Tensors >= 8 MiB take the nt-load / write-through-store kernels (IoStream), smaller ones the
+  default cache policy.  The policy must not change a single bit of y or dx: run one 12.6 MB batch
+  (streaming) and the same images as two 6.3 MB halves (cached)."""
+  dev = gpu_device
+  shape = (8, 512, 512, 3)
+  g = torch.Generator(device=dev).manual_seed(11)
+  x = (torch.rand(shape, device=dev, generator=g)**2.2 * 1.02).half()
+  dy = torch.randn(shape, device=dev, generator=g).half()
+  assert x.numel() * 2 >= (8 << 20) > x[:4].numel() * 2
+  for fid in range(9):
+    p = torch.from_numpy(synthetic.make_params(np.random.default_rng(40 + fid), fid, shape[0])).to(dev)
+    y, dx, dp = torch.empty_like(x), torch.empty_like(x), torch.empty_like(p)
+    _cabi.filter_fwd(fid, x, y, p)
+    _cabi.filter_bwd(fid, x, dy, dx, p, dp)
+    for lo in (0, 4):
+      xs, dys, ps = x[lo:lo + 4].contiguous(), dy[lo:lo + 4].contiguous(), p[lo:lo + 4].contiguous()
+      ys, dxs, dps = torch.empty_like(xs), torch.empty_like(xs), torch.empty_like(ps)
+      _cabi.filter_fwd(fid, xs, ys, ps)
+      _cabi.filter_bwd(fid, xs, dys, dxs, ps, dps)
+      assert torch.equal(ys, y[lo:lo + 4]), fid
+      assert torch.equal(dxs, dx[lo:lo + 4]), fid
+      scale = dps.abs().max().item() + 1.0
+      assert (dps - dp[lo:lo + 4]).abs().max().item() <= 1e-3 * scale, fid  # fp32 sums in another order

@@ -268,6 +268,46 @@ __global__ __launch_bounds__(256) void cpol2(const uint32_t* __restrict__ a, uin
   }
 }
 
+
+// rpol3: read-read-write with nt loads + sc1 stores, moved towards a real backward kernel:
+// LDSKB limits the occupancy (160 KiB LDS per CU / LDSKB blocks), PF prefetches the next chunk pair.
+template <int LDSKB, bool PF>
+__global__ __launch_bounds__(256) void rpol3(const uint32_t* __restrict__ a, const uint32_t* __restrict__ c,
+                                             uint32_t* __restrict__ b, size_t nrows, int nbytes) {
+  __shared__ uint32_t pad[LDSKB * 256];
+  if (nbytes < 0) pad[threadIdx.x] = 1;  // keep the allocation
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, nbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)c, 0, nbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, nbytes, 0x00020000);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t step = size_t(gridDim.x) * 16;
+  size_t r = (size_t(blockIdx.x) * 4 + wave) * 4;
+  if (r >= nrows) return;
+  u32x3 v[4], w[4], nv[4], nw[4];
+  auto load = [&](u32x3* pv, u32x3* pw, size_t row) {
+    const int off = int(row) * 768 + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = __builtin_amdgcn_raw_buffer_load_b96(ra, off + j * 768, 0, 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pw[j] = __builtin_amdgcn_raw_buffer_load_b96(rc, off + j * 768, 0, 2);
+  };
+  load(v, w, r);
+  while (true) {
+    const size_t rn = r + step;
+    const bool more = rn < nrows;
+    if (PF && more) load(nv, nw, rn);
+    const int off = int(r) * 768 + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b96(v[j] ^ w[j], rb, off + j * 768, 0, 16);
+    if (!PF && more) load(nv, nw, rn);
+    if (!more) break;
+    r = rn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = nv[j]; w[j] = nw[j]; }
+  }
+  if (nbytes < 0) b[0] = pad[lane];
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = (argc > 1 ? atol(argv[1]) : 96) * (1ul << 20);  // per buffer
   const int nbuf = argc > 2 ? atoi(argv[2]) : 9;
@@ -281,7 +321,7 @@ int main(int argc, char** argv) {
   const int grids[] = {2048, 8192, 32768};
   printf("buffer %zu MiB x %d, %d reps\n", bytes >> 20, nbuf, reps);
   for (int grid : grids) {
-    if (pol_only && grid != 8192) continue;
+    if (pol_only && grid > 8192) continue;
     auto run = [&](const char* name, int streams, auto launch) {
       for (int i = 0; i < 3; ++i) launch(i);
       CK(hipEventRecord(e0));
@@ -323,6 +363,12 @@ int main(int argc, char** argv) {
 #define CPOL2(W, G, P) run("cpol2 w" #W " g" #G " p" #P, 2, [&](int i) { cpol2<W, G, P><<<dim3(G ? grid / 64 : grid, G ? 64 : 1), 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes), prm); });
       CPOL2(0, 0, 0) CPOL2(1, 0, 0) CPOL2(0, 1, 0) CPOL2(1, 1, 0) CPOL2(1, 1, 1)
 #undef CPOL2
+    }
+
+    if (grid <= 8192) {
+#define RPOL3(K, P) run("rpol3 lds" #K " pf" #P, 3, [&](int i) { rpol3<K, P><<<grid, 256>>>((const uint32_t*)buf[(i + 4) % nbuf], (const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes)); });
+      RPOL3(1, 0) RPOL3(1, 1) RPOL3(26, 0) RPOL3(26, 1) RPOL3(32, 0) RPOL3(32, 1) RPOL3(40, 0) RPOL3(40, 1)
+#undef RPOL3
     }
     if (!pol_only) run("rrw48nt", 3, [&](int i) { rrw48<true><<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], ngroups); });
   }
