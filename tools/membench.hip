@@ -308,6 +308,44 @@ __global__ __launch_bounds__(256) void rpol3(const uint32_t* __restrict__ a, con
   if (nbytes < 0) b[0] = pad[lane];
 }
 
+
+// rpol4: rpol3 (prefetching, nt loads, sc1 stores) with the filter kernels' 2-D mapping: grid =
+// (blocks per image, images), per-image SRDs.  MAP 1: a block's k-th chunk group is blockIdx.x +
+// k * gridDim.x (what the filter kernels do); MAP 2: each wave walks ITER adjacent 3 KiB chunks.
+template <int MAP>
+__global__ __launch_bounds__(256) void rpol4(const uint32_t* __restrict__ a, const uint32_t* __restrict__ c,
+                                             uint32_t* __restrict__ b, int rows_img, int iters) {
+  const int img = blockIdx.y;
+  const int img_bytes = rows_img * 768;
+  const size_t base = size_t(img) * img_bytes;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a + base), 0, img_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)c + base), 0, img_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)b + base), 0, img_bytes, 0x00020000);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int step = MAP == 1 ? gridDim.x * 16 : 4;
+  int r = MAP == 1 ? (blockIdx.x * 4 + wave) * 4 : (blockIdx.x * 4 + wave) * 4 * iters;
+  u32x3 v[4], w[4], nv[4], nw[4];
+  auto load = [&](u32x3* pv, u32x3* pw, int row) {
+    const int off = row * 768 + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = __builtin_amdgcn_raw_buffer_load_b96(ra, off + j * 768, 0, 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pw[j] = __builtin_amdgcn_raw_buffer_load_b96(rc, off + j * 768, 0, 2);
+  };
+  load(v, w, r);
+  for (int k = 0; k < iters; ++k) {
+    const int rn = r + step;
+    const bool more = k + 1 < iters;
+    if (more) load(nv, nw, rn);
+    const int off = r * 768 + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b96(v[j] ^ w[j], rb, off + j * 768, 0, 16);
+    r = rn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = nv[j]; w[j] = nw[j]; }
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = (argc > 1 ? atol(argv[1]) : 96) * (1ul << 20);  // per buffer
   const int nbuf = argc > 2 ? atoi(argv[2]) : 9;
@@ -369,6 +407,13 @@ int main(int argc, char** argv) {
 #define RPOL3(K, P) run("rpol3 lds" #K " pf" #P, 3, [&](int i) { rpol3<K, P><<<grid, 256>>>((const uint32_t*)buf[(i + 4) % nbuf], (const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes)); });
       RPOL3(1, 0) RPOL3(1, 1) RPOL3(26, 0) RPOL3(26, 1) RPOL3(32, 0) RPOL3(32, 1) RPOL3(40, 0) RPOL3(40, 1)
 #undef RPOL3
+    }
+
+    if (grid == 2048) {  // 64 images x 32 blocks x 4 iterations x 4 waves x 4 rows = bytes / 768 rows
+      const int rows_img = int(bytes / 768 / 64);
+#define RPOL4(M) run("rpol4 map" #M, 3, [&](int i) { rpol4<M><<<dim3(32, 64), 256>>>((const uint32_t*)buf[(i + 4) % nbuf], (const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], rows_img, rows_img / (32 * 16)); });
+      RPOL4(1) RPOL4(2)
+#undef RPOL4
     }
     if (!pol_only) run("rrw48nt", 3, [&](int i) { rrw48<true><<<grid, 256>>>(buf[i % nbuf], buf[(i + 4) % nbuf], buf[(i + 1) % nbuf], ngroups); });
   }
