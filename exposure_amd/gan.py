@@ -7,6 +7,8 @@ HIP library.
 ``GAN.critic_step`` == one ``sess.run(opt_c)`` (net.py:358-365).  With a process group the
 gradients are all-reduced in flat buckets (``exposure_amd.dist``) before the optimiser steps.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -32,6 +34,8 @@ class GAN(nn.Module):
     if device is not None:
       self.to(device)
     adam = dict(betas=(cfg.adam_beta1, cfg.adam_beta2), eps=1e-8)  # config_example.py:158
+    if device is not None and torch.device(device).type == 'cuda' and os.environ.get('EXPO_FUSED_ADAM', '1') == '1':
+      adam['fused'] = True  # one multi-tensor kernel per optimiser step instead of ~10 foreach launches
     if self.use_graphs:
       # hipGraph replay of a whole step: learning rates live in device tensors, Adam is capturable
       assert device is not None and torch.device(device).type == 'cuda', 'graphs need a ROCm device'
