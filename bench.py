@@ -52,7 +52,7 @@ def parse():
                   help="chain: the headline filter-chain metric; train: one reference training iteration "
                   "(1 generator/value step + cfg.citers critic steps, net.py:307-365) on 64 images per GPU")
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                  help='replay the 17 launches of a step from one hipGraph (auto: on for launch-bound small shapes)')
+                  help='replay the 17 launches of a step from one hipGraph (auto = on; off: eager C-ABI calls)')
   return ap.parse_args()
 
 
@@ -205,6 +205,22 @@ def load_traffic(kernel):
     return None
 
 
+_BARRIER_FLAG = {}
+
+
+def light_barrier(dist, dev):
+  """Cross-rank barrier for the timed region: a 1-element all-reduce enqueued on the device (every
+  rank must contribute before any rank's copy completes); the torch.cuda.synchronize() that follows
+  it in the timing bracket waits for it.  `dist.barrier()` costs ~0.5 ms of host-side NCCL work per
+  call, which is 5 % of a 20-step chain measurement; this costs one small kernel."""
+  if dist is None:
+    return
+  flag = _BARRIER_FLAG.get(dev)
+  if flag is None:
+    flag = _BARRIER_FLAG[dev] = torch.zeros(1, device=dev)
+  dist.all_reduce(flag)
+
+
 def run_train(args, world, rank, dev, dist):
   """BASELINE configs 3/4: agent rollout step + policy CNN + WGAN-GP critic, batch 64 per GPU,
   random-init weights, synthetic FiveK-shaped inputs, gradients all-reduced over RCCL."""
@@ -236,8 +252,7 @@ def run_train(args, world, rank, dev, dist):
     return out
 
   def barrier():
-    if dist is not None:
-      dist.barrier()
+    light_barrier(dist, dev)
 
   for i in range(args.warmup):
     iteration(i + 1)
@@ -307,15 +322,13 @@ def run_allreduce(args, world, rank, dev, dist):
   for _ in range(args.warmup):
     iteration()
   torch.cuda.synchronize()
-  if dist is not None:
-    dist.barrier()
+  light_barrier(dist, dev)
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     iteration()
   torch.cuda.synchronize()
-  if dist is not None:
-    dist.barrier()
+  light_barrier(dist, dev)
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
   if dist is not None:
@@ -371,15 +384,13 @@ def run_infer(args, world, rank, dev, dist):
     for _ in range(args.warmup):
       fn()
     torch.cuda.synchronize()
-    if dist is not None:
-      dist.barrier()
+    light_barrier(dist, dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
       fn()
     torch.cuda.synchronize()
-    if dist is not None:
-      dist.barrier()
+    light_barrier(dist, dev)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if dist is not None:
@@ -448,13 +459,16 @@ def main():
   esz = 2 if args.dtype == 'f16' else 4
   chain = Chain(shape, dtype, dev, args.seed + rank, [int(v) for v in args.order.split(',')])
   px = shape[0] * shape[1] * shape[2]
-  use_graph = args.graph == 'on' or (args.graph == 'auto' and px * 3 * esz < (32 << 20))
+  # One hipGraph replay per step by default.  Small shapes are launch-bound (17 launches in 87 us
+  # eagerly vs 57 us replayed at 64x64x64); at 64x512x512 eager launches are ~0.5 % faster in a
+  # plain process but 1.5-4 % slower and noisy once a process group exists (torchrun, RCCL's extra
+  # queues), while the replay measures the same +-0.3 % either way -- so every N uses the replay.
+  use_graph = args.graph != 'off'
   if use_graph:
     chain.capture()
 
   def barrier():
-    if dist is not None:
-      dist.barrier()
+    light_barrier(dist, dev)
 
   # untimed: leave the idle power state first (the first ~100 ms after idle run at lower clocks and
   # would make a 20-step measurement read ~3 % slow), then the W warm-up steps of the contract
@@ -502,7 +516,7 @@ def main():
           'height': shape[1],
           'width': shape[2],
           'parallelism': 'image-sharded replicas x%d (no data-path collective)' % world,
-          'launch': 'hipGraph replay' if use_graph else 'eager (one C-ABI call per direction)',
+          'launch': 'one hipGraph replay per step (17 captured launches)' if use_graph else 'eager (one C-ABI call per direction)',
           'chain_algorithmic_GBps': 8 * 5 * 3 * esz * px / (elapsed / args.steps) / 1e9 * 1.0,
       },
   }
