@@ -228,7 +228,7 @@ def run_train(args, world, rank, dev, dist):
   from exposure_amd.gan import GAN
   cfg = make_cfg()
   torch.manual_seed(args.seed)  # identical initial weights on every rank
-  gan = GAN(cfg, device=dev, use_graphs=(world == 1 and args.graph != 'off'))
+  gan = GAN(cfg, device=dev, use_graphs=(args.graph != 'off'))
   n = cfg.batch_size
   from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
   pool_dtype = torch.float16 if args.dtype == 'f16' else torch.float32

@@ -50,8 +50,8 @@ def per_image_generator(seed, global_index, device):
   return g
 
 
-def all_reduce_mean_(t, group=None):
-  if world_size(group) > 1:
+def all_reduce_mean_(t, group=None, force=False):
+  if world_size(group) > 1 or (force and dist.is_available() and dist.is_initialized()):
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     t.div_(world_size(group))
   return t
@@ -103,13 +103,14 @@ class GradBucket:
         p.grad.copy_(g).mul_(scale)
       off += n
 
-  def all_reduce_mean(self, group=None, async_op=False):
+  def all_reduce_mean(self, group=None, async_op=False, force=False):
     """SUM all-reduce of the flat buffer, scaled by 1/p on scatter (each rank's loss is a mean over
-    its local shard of equal size, so the global-batch mean gradient is the rank average)."""
+    its local shard of equal size, so the global-batch mean gradient is the rank average).
+    ``force`` issues the collective even in a one-rank group (exercises the RCCL path on one GPU)."""
     flat = self.gather()
     p = world_size(group)
     work = None
-    if p > 1:
+    if p > 1 or (force and dist.is_initialized()):
       work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
       if not async_op:
         work.wait()

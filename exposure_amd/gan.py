@@ -48,6 +48,9 @@ class GAN(nn.Module):
     self.opt_c = torch.optim.Adam(self.critic.parameters(), lr=lr(cfg.lr_c(0)), **adam)
     self.process_group = process_group
     self.world_size = xdist.world_size(process_group)
+    # EXPO_FORCE_COLLECTIVES=1: issue the gradient all-reduces even in a one-rank group, so the RCCL
+    # path (and its hipGraph capture) can be exercised on a single GPU
+    self.force_collectives = os.environ.get('EXPO_FORCE_COLLECTIVES', '0') == '1'
     self.buckets = {
         'g': xdist.GradBucket(self.generator.parameters()),
         'v': xdist.GradBucket(self.value.parameters()),
@@ -109,10 +112,11 @@ class GAN(nn.Module):
       p.grad = g if g is not None else torch.zeros_like(p)
     for p, g in zip(vp, v_grads):
       p.grad = g if g is not None else torch.zeros_like(p)
-    if self.world_size > 1:
+    if self.world_size > 1 or self.force_collectives:
       # losses are means over the GLOBAL batch: average the per-rank (local-mean) gradients
-      hg = self.buckets['g'].all_reduce_mean(self.process_group, async_op=True)
-      hv = self.buckets['v'].all_reduce_mean(self.process_group, async_op=True)
+      f = self.force_collectives
+      hg = self.buckets['g'].all_reduce_mean(self.process_group, async_op=True, force=f)
+      hv = self.buckets['v'].all_reduce_mean(self.process_group, async_op=True, force=f)
       hg.wait_and_scatter()
       hv.wait_and_scatter()
     self.opt_g.step()
@@ -126,7 +130,7 @@ class GAN(nn.Module):
   def generator_step(self, fake_input, z, states, progress, it=1, dropout_masks=None):
     """opt_g on g_loss w.r.t. theta_g and opt_v on v_loss w.r.t. theta_v (net.py:222-241)."""
     self.set_lrs(it, zero_g=(it == 0))
-    if self.use_graphs and self.world_size == 1:
+    if self.use_graphs:
       masks = dropout_masks or self._draw_masks(fake_input.shape[0], fake_input.device)
       prog = torch.as_tensor(float(progress), device=fake_input.device)
       return self._replay('g', self._generator_body_graph, (fake_input, z, states, prog, masks[0], masks[1]))
@@ -149,11 +153,20 @@ class GAN(nn.Module):
       self._graphs[sig] = 'warm'
       return body(*inputs)
     if entry == 'warm':
+      # (with a process group the gradient all-reduces are captured too: RCCL collectives are
+      # stream-ordered kernels, and the eager first call has already initialised the communicator)
       static_in = [t.clone() for t in inputs]
       torch.cuda.synchronize()
       graph = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(graph):
-        static_out = body(*static_in)
+      try:
+        with torch.cuda.graph(graph):
+          static_out = body(*static_in)
+      except RuntimeError as e:  # e.g. a collective that refuses capture: keep training, eagerly
+        import warnings
+        warnings.warn('hipGraph capture of the %r step failed (%s); continuing with eager launches' % (key, e))
+        torch.cuda.synchronize()
+        self.use_graphs = False
+        return body(*inputs)
       entry = (graph, static_in, static_out)
       self._graphs[sig] = entry
     graph, static_in, static_out = entry
@@ -189,17 +202,18 @@ class GAN(nn.Module):
     out = self.critic_losses(real_data, fake_output, alpha)
     self.opt_c.zero_grad(set_to_none=True)
     out['c_loss'].backward()
-    if self.world_size > 1:
-      self.buckets['c'].all_reduce_mean(self.process_group, async_op=True).wait_and_scatter()
+    if self.world_size > 1 or self.force_collectives:
+      f = self.force_collectives
+      self.buckets['c'].all_reduce_mean(self.process_group, async_op=True, force=f).wait_and_scatter()
       ca = out['c_average'].clone()
-      xdist.all_reduce_mean_(ca, self.process_group)
+      xdist.all_reduce_mean_(ca, self.process_group, force=f)
       out['c_average'] = ca
     self.opt_c.step()
     return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
   def critic_step(self, real_data, fake_output, it=1, alpha=None):
     self.set_lrs(it)
-    if self.use_graphs and self.world_size == 1:
+    if self.use_graphs:
       if alpha is None:
         alpha = torch.rand((real_data.shape[0], 1, 1, 1), device=real_data.device)
       out = dict(self._replay('c', self._critic_body, (real_data, fake_output, alpha)))
