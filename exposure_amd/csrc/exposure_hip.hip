@@ -161,10 +161,14 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   // fp16-exact fast path of the curve filters (bit-pattern LUT + packed accumulators); with the
   // fused penalty dy is no longer an fp16 value, and the masked path scales it -> generic path there
   constexpr bool kF16X = std::is_same<T, half_t>::value && !PEN;
-  if constexpr (F::kLutFloats > 0) {
-    F::template stage_for<kF16X>(prm, lut);
-    __syncthreads();
-  }
+  // staged AFTER the first chunk's loads are in flight on the vector path (stream_groups' prologue)
+  auto stage_lut = [&]() {
+    if constexpr (F::kLutFloats > 0) {
+      F::template stage_for<kF16X>(prm, lut);
+      __syncthreads();
+    }
+  };
+  if constexpr (!VEC) stage_lut();
   float acc[F::NACC];
 #pragma unroll
   for (int j = 0; j < F::NACC; ++j) acc[j] = 0.f;
@@ -197,7 +201,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   if constexpr (VEC) {
     const T* const ins[2] = {xi, dyi};
     stream_groups<T, 2, HAS_DX, (F::kLutFloats > 0 ? EXPO_CURVE_PREFETCH : EXPO_PREFETCH) != 0, IO>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                    [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
+                                    [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); }, stage_lut);
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3], d[PPL * 3];

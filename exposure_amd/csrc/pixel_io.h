@@ -160,9 +160,13 @@ template <> __device__ __forceinline__ RawGroup pack<float>(const float* in) {
 // place, and the LAST stream is written back when HAS_OUT.  With PF the next chunk's loads are in
 // flight while the current one computes (software prefetch; costs 12 VGPRs per stream).
 // Stream 0 is the image x (policy IO::kLoadX), stream 1 the upstream gradient dy (IO::kLoadDy).
-template <typename T, int NIN, bool HAS_OUT, bool PF, class IO, class Fn>
+// `pre` runs once per wave AFTER the first chunk's loads are issued and before anything waits on
+// them: block-wide set-up that must not delay the first loads (the curve backward stages its LDS
+// slope table there, including the __syncthreads -- every wave calls it, also one without work).
+struct NoPrologue { __device__ void operator()() const {} };
+template <typename T, int NIN, bool HAS_OUT, bool PF, class IO, class Fn, class Pre = NoPrologue>
 __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out, int hw, int first_gw,
-                                              int stride, Fn&& fn) {
+                                              int stride, Fn&& fn, Pre&& pre = Pre()) {
   constexpr int PPL = PixTraits<T>::PPL;
   const int lane = threadIdx.x & 63;
 #if EXPO_FP16_OVFL
@@ -175,14 +179,16 @@ __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out,
   __amdgpu_buffer_rsrc_t rout = rin[0];
   if constexpr (HAS_OUT) rout = make_image_rsrc(out, hw);
   int gw = first_gw;  // wave-uniform
-  if (gw * PPL >= hw) return;
+  const bool work = gw * PPL < hw;
   static_assert(NIN <= 2, "at most two input streams");
   auto load_all = [&](RawGroup (&dst)[NIN], int g) {
     dst[0] = load_raw<IO::kLoadX>(rin[0], chunk_byte_offset<T>(g, lane));
     if constexpr (NIN > 1) dst[1] = load_raw<IO::kLoadDy>(rin[1], chunk_byte_offset<T>(g, lane));
   };
   RawGroup cur[NIN];
-  load_all(cur, gw);
+  if (work) load_all(cur, gw);
+  pre();
+  if (!work) return;
   while (true) {
     const int gn = gw + stride;
     const bool more = gn * PPL < hw;  // wave-uniform

@@ -451,3 +451,34 @@ def test_streaming_policy_equals_cached_policy(gpu_device):
       assert torch.equal(dxs, dx[lo:lo + 4]), fid
       scale = dps.abs().max().item() + 1.0
       assert (dps - dp[lo:lo + 4]).abs().max().item() <= 1e-3 * scale, fid  # fp32 sums in another order
+
+
+@pytest.mark.parametrize('fid', [4, 7])
+def test_curve_backward_on_every_fp16_value(fid, gpu_device):
+  """The fp16 curve backward looks the slope up by the HIGH BYTE of x's bit pattern (two entries per
+  byte: low byte zero / non-zero).  Feed every finite fp16 bit pattern (and +-inf) as x: dx must be
+  the oracle's slope -- TF's inclusive knot rule included -- for each of the 63 490 values, and the
+  forward must agree on them as well."""
+  dev = gpu_device
+  bits = np.arange(65536, dtype=np.uint16)
+  xs = bits.view(np.float16)
+  xs = xs[~np.isnan(xs)]
+  rng = np.random.default_rng(7)
+  # three channels = three independent permutations of the value set (Color has a curve per channel)
+  chans = [xs, rng.permutation(xs), rng.permutation(xs)]
+  hw = xs.size
+  pad = (-hw) % 8  # keep H*W a multiple of 8 pixels (vector path); pad with zeros
+  x = np.stack([np.concatenate([c, np.zeros(pad, np.float16)]) for c in chans], axis=-1).reshape(1, 1, hw + pad, 3)
+  p = synthetic.make_params(np.random.default_rng(70 + fid), fid, 1)
+  dy = np.ones_like(x)
+  y, dx, dp = run_fwd_bwd(fid, x, dy, p, torch.float16, dev)
+  finite = np.isfinite(x.astype(np.float64))
+  xo = np.where(finite, x.astype(np.float64), np.sign(x.astype(np.float64)) * 1e30)  # +-inf: far outside [0, 1]
+  ry = fnp.process_packed(fid, xo, p.astype(np.float64))
+  rdx, _ = fnp.backward_packed(fid, xo, p.astype(np.float64), dy.astype(np.float64))
+  assert_image_close(y, ry, np.float16, 'y fid %d' % fid)
+  # the slope itself is exact in fp32; dx is its fp16 rounding
+  err = np.abs(dx.astype(np.float64) - rdx)
+  tol = np.abs(rdx) * 2.0**-11 + 1e-6
+  bad = err > tol
+  assert not bad.any(), 'dx wrong for x = %r (got %r, want %r)' % (x[bad][:8], dx[bad][:8], rdx[bad][:8])
