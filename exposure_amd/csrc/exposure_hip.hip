@@ -356,9 +356,10 @@ __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int group
   }
 }
 
-// SET is a bit mask of the filter ids this launch handles (bit 15 = id -1).  The dispatch is
-// issued as two launches -- light filters and the register-heavy curve filters -- so each gets
+// SET is a bit mask of the filter ids this launch handles (bit 15 = id -1).  The BACKWARD dispatch
+// is issued as two launches -- light filters and the register-heavy curve filters -- so each gets
 // its own VGPR budget / occupancy; blocks whose image selected a filter outside SET exit at once.
+// The forward needs no split (its curve bodies are light): one launch with kSetAll.
 constexpr int kSetLight = 0x8000 | 0x100 | 0x6F;  // -1, E, G, W, S+, Ct, BW, Le
 constexpr int kSetCurves = 0x90;         // T, C
 constexpr int kSetAll = kSetLight | kSetCurves;
