@@ -183,8 +183,11 @@ class GAN(nn.Module):
     cfg = self.cfg
     fake_output = fake_output.detach().float()
     real_data = real_data.float()
-    real_logit = self.critic(real_data)
-    fake_logit = self.critic(fake_output)
+    # one batched pass for the real and the fake half (the critic is per-sample: no normalisation
+    # layers), so their forward and backward are single launches of twice the batch
+    n = real_data.shape[0]
+    logits = self.critic(torch.cat([real_data, fake_output], dim=0))
+    real_logit, fake_logit = logits[:n], logits[n:]
     c_loss = (fake_logit - real_logit).mean()
     if alpha is None:
       alpha = torch.rand((real_data.shape[0], 1, 1, 1), device=real_data.device)
