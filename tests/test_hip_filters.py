@@ -442,6 +442,10 @@ def test_streaming_policy_equals_cached_policy(gpu_device):
     y, dx, dp = torch.empty_like(x), torch.empty_like(x), torch.empty_like(p)
     _cabi.filter_fwd(fid, x, y, p)
     _cabi.filter_bwd(fid, x, dy, dx, p, dp)
+    # dx may alias dy (include/exposure_hip.h) -- also under the streaming policy
+    inplace, dp_in = dy.clone(), torch.empty_like(p)
+    _cabi.filter_bwd(fid, x, inplace, inplace, p, dp_in)
+    assert torch.equal(inplace, dx), fid
     for lo in (0, 4):
       xs, dys, ps = x[lo:lo + 4].contiguous(), dy[lo:lo + 4].contiguous(), p[lo:lo + 4].contiguous()
       ys, dxs, dps = torch.empty_like(xs), torch.empty_like(xs), torch.empty_like(ps)
