@@ -440,6 +440,47 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
 // rounding of intermediates): ONE read and ONE write of the image instead of one per step.
 // Each wave owns exactly one 3 KiB chunk, so the per-step parameters are fetched once per wave
 // through scalar loads; the step loop is rolled (block-uniform switch per step).
+// Curve forward for the fused (VALU-bound) kernel: instead of the telescoped 7 x v_min + 8 x v_fma
+// per element, a per-wave table of the L segments in LDS -- entry (c, j) = {a, b} with
+//   y = a x^ + b on segment j,  a = (L/S) k_j,  b = (L/S) (sum_{i<j} k_i - j k_j) / L
+// -- looked up with j = min(int(L x^), L-1): clamp, mul, cvt, min, address, ds_read_b64, fma.
+// Lane l < NC*L holds parameter k[l] (a per-lane copy fetched by a vector load); the exclusive prefix
+// sums come from three shuffles inside each group of L lanes.  One wave builds and reads its own
+// table region, LDS operations of a wave execute in order, so no block barrier is involved.
+template <int NC, int NPIX>
+__device__ __forceinline__ void curve_fwd_lut(float* v, float klane, float2_lut* tab) {
+  constexpr int L = kCurveSteps;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (L - 1);
+  float incl = klane;  // inclusive scan over the L lanes of a curve
+#pragma unroll
+  for (int d = 1; d < L; d <<= 1) {
+    const float t = __shfl_up(incl, d, L);
+    if (j >= d) incl += t;
+  }
+  const float S = __shfl(incl, L - 1, L) + 1e-30f;
+  const float scale = float(L) / S;
+  if (lane < NC * L) {
+    float2_lut e;
+    e.x = scale * klane;
+    e.y = scale * ((incl - klane) - float(j) * klane) * (1.0f / float(L));
+    tab[lane] = e;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < NPIX; ++k) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xc = clamp01x(v[3 * k + c], 0.0f, 1.0f);
+      int seg = int(xc * float(L));
+      seg = seg < L - 1 ? seg : L - 1;
+      const float2_lut e = tab[(NC == 1 ? 0 : c * L) + seg];
+      v[3 * k + c] = fmaf(xc, e.x, e.y);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // the next curve step of this wave rewrites the table
+}
+
 template <typename T, bool VEC, class IO>
 __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t* __restrict__ ids,
                                                                    const float* __restrict__ params, int steps,
@@ -452,13 +493,19 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
   T* yi = y + off;
   const int32_t* idn = ids + size_t(n) * steps;
   const float* prn = params + size_t(n) * steps * EXPO_MAX_PARAMS;
+  __shared__ float2_lut curve_tab[kWaves][32];
+  float2_lut* const tab = curve_tab[threadIdx.x >> 6];
+  const int plane = (threadIdx.x & 63) % EXPO_MAX_PARAMS;  // which parameter this lane mirrors
   auto run = [&](float* v) {
     // software-pipelined parameter fetch: step st+1's id and 24 parameters (wave-uniform -> scalar
-    // loads into SGPRs) are requested before step st computes, hiding the scalar-load latency
+    // loads into SGPRs) are requested before step st computes, hiding the scalar-load latency;
+    // `klane` is a per-lane copy (lane l <-> parameter l) for the curve table of curve_fwd_lut
     float cur[EXPO_MAX_PARAMS], nxt[EXPO_MAX_PARAMS];
+    float klane = 0.f, klane_next = 0.f;
     int id = -1, id_next = -1;
     if (steps > 0) {
       id = idn[0];
+      klane = prn[plane];
 #pragma unroll
       for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = prn[j];
     }
@@ -466,6 +513,7 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
     for (int st = 0; st < steps; ++st) {
       const int sn = (st + 1 < steps) ? st + 1 : st;
       id_next = idn[sn];
+      klane_next = prn[sn * EXPO_MAX_PARAMS + plane];
 #pragma unroll
       for (int j = 0; j < EXPO_MAX_PARAMS; ++j) nxt[j] = prn[sn * EXPO_MAX_PARAMS + j];
       const float* prm = cur;
@@ -485,10 +533,10 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
         EXPO_CASE(1, GammaF)
         EXPO_CASE(2, WhiteBalanceF)
         EXPO_CASE(3, SatPlusF)
-        EXPO_CASE(4, ToneF)
+        case 4: curve_fwd_lut<1, PPL>(v, klane, tab); break;
         EXPO_CASE(5, ContrastF)
         EXPO_CASE(6, WnbF)
-        EXPO_CASE(7, ColorF)
+        case 7: curve_fwd_lut<3, PPL>(v, klane, tab); break;
         EXPO_CASE(8, LevelF)
         default:  // id -1: the all-zero one-hot selects nothing -> the image becomes 0
 #pragma unroll
@@ -497,6 +545,7 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
       }
 #undef EXPO_CASE
       id = id_next;
+      klane = klane_next;
 #pragma unroll
       for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = nxt[j];
     }
@@ -507,7 +556,10 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
     stream_groups<T, 1, true, false, IO>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
                                      [&](float (&v)[1][PPL * 3], int) { run(v[0]); });
   } else {
-    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+    // wave-uniform trip count: curve_fwd_lut needs lanes 0..23 of every wave alive (groups past the
+    // end load zeros and store nothing)
+    for (int g0 = blockIdx.x * kThreads + (threadIdx.x & ~63); g0 < groups; g0 += stride) {
+      const int g = g0 + (threadIdx.x & 63);
       float v[PPL * 3];
       load_slow<T>(xi, g, hw, v);
       run(v);
