@@ -290,7 +290,7 @@ def run_train(args, world, rank, dev, dist):
                         'WGAN-GP critic; batch %d x 64x64x3 per GPU; random-init weights' % n,
             'global_batch': world * n,
             'parallelism': 'dp%d image-sharded, 3 flat gradient buckets over RCCL' % world,
-            'launch': 'one hipGraph replay per G/V step and per critic step' if gan.use_graphs else 'eager',
+            'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
             'reference_note': 'README.md:43: ~0.30 s/iteration on a GTX 1080 Ti (whole run ~100 min / 20000 it)',
         },
     }))

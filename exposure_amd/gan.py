@@ -51,6 +51,11 @@ class GAN(nn.Module):
     # EXPO_FORCE_COLLECTIVES=1: issue the gradient all-reduces even in a one-rank group, so the RCCL
     # path (and its hipGraph capture) can be exercised on a single GPU
     self.force_collectives = os.environ.get('EXPO_FORCE_COLLECTIVES', '0') == '1'
+    # hipGraph replay of steps that contain RCCL collectives is opt-in (EXPO_GRAPH_COLLECTIVES=1):
+    # it works (24 vs 38 ms per iteration on one forced-collective rank) but one run in ~15 of the
+    # single-GPU soak aborted, so multi-rank training defaults to eager launches
+    collectives = self.world_size > 1 or self.force_collectives
+    self._replay_steps = self.use_graphs and (not collectives or os.environ.get('EXPO_GRAPH_COLLECTIVES', '0') == '1')
     self.buckets = {
         'g': xdist.GradBucket(self.generator.parameters()),
         'v': xdist.GradBucket(self.value.parameters()),
@@ -130,7 +135,7 @@ class GAN(nn.Module):
   def generator_step(self, fake_input, z, states, progress, it=1, dropout_masks=None):
     """opt_g on g_loss w.r.t. theta_g and opt_v on v_loss w.r.t. theta_v (net.py:222-241)."""
     self.set_lrs(it, zero_g=(it == 0))
-    if self.use_graphs:
+    if self._replay_steps:
       masks = dropout_masks or self._draw_masks(fake_input.shape[0], fake_input.device)
       prog = torch.as_tensor(float(progress), device=fake_input.device)
       return self._replay('g', self._generator_body_graph, (fake_input, z, states, prog, masks[0], masks[1]))
@@ -158,14 +163,17 @@ class GAN(nn.Module):
       static_in = [t.clone() for t in inputs]
       torch.cuda.synchronize()
       graph = torch.cuda.CUDAGraph()
+      # thread_local: RCCL's watchdog thread polls events while this thread captures; under the
+      # default "global" mode such a call from another thread aborts the process
+      mode = 'thread_local' if xdist.world_size(self.process_group) > 1 or self.force_collectives else 'global'
       try:
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode=mode):
           static_out = body(*static_in)
       except RuntimeError as e:  # e.g. a collective that refuses capture: keep training, eagerly
         import warnings
         warnings.warn('hipGraph capture of the %r step failed (%s); continuing with eager launches' % (key, e))
         torch.cuda.synchronize()
-        self.use_graphs = False
+        self.use_graphs = self._replay_steps = False
         return body(*inputs)
       entry = (graph, static_in, static_out)
       self._graphs[sig] = entry
@@ -216,7 +224,7 @@ class GAN(nn.Module):
 
   def critic_step(self, real_data, fake_output, it=1, alpha=None):
     self.set_lrs(it)
-    if self.use_graphs:
+    if self._replay_steps:
       if alpha is None:
         alpha = torch.rand((real_data.shape[0], 1, 1, 1), device=real_data.device)
       out = dict(self._replay('c', self._critic_body, (real_data, fake_output, alpha)))
