@@ -107,8 +107,15 @@ class Chain:
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     self.graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(self.graph):
-      self.launch()
+    # thread_local: with a process group alive, RCCL's watchdog thread may poll events while this
+    # thread captures; under the default "global" mode such a call aborts the process
+    try:
+      with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+        self.launch()
+    except RuntimeError as e:  # never lose the run over the launch method
+      print('warning: hipGraph capture failed (%s); eager launches' % e, file=sys.stderr)
+      torch.cuda.synchronize()
+      self.graph = None
 
   def step(self):
     if self.graph is not None:
@@ -516,7 +523,7 @@ def main():
           'height': shape[1],
           'width': shape[2],
           'parallelism': 'image-sharded replicas x%d (no data-path collective)' % world,
-          'launch': 'one hipGraph replay per step (17 captured launches)' if use_graph else 'eager (one C-ABI call per direction)',
+          'launch': 'one hipGraph replay per step (17 captured launches)' if chain.graph is not None else 'eager (one C-ABI call per direction)',
           'chain_algorithmic_GBps': 8 * 5 * 3 * esz * px / (elapsed / args.steps) / 1e9 * 1.0,
       },
   }
