@@ -10,6 +10,10 @@ tensorflow / cv2; ``util.py:658`` is a SyntaxError on Python >= 3.7).  The
 restatement is therefore pinned by (i) closed-form identities of the reference
 code, (ii) hand-computed points, (iii) float64 finite differences, and (iv)
 agreement of two independently written restatements (``filters_np`` with
-hand-derived backward, ``filters_torch`` with autograd) -- see
-``tests/test_oracle_*.py`` and DESIGN.md section 3.
+hand-derived backward, ``filters_torch`` with autograd), and (v) for the two
+TensorFlow image ops the reference calls but does not contain
+(``tf.image.rgb_to_hsv`` / ``hsv_to_rgb``, tensorflow 1.x), the check TensorFlow's
+own unit test applies to them: agreement with Python's ``colorsys`` tuple by
+tuple (plus matplotlib as a second implementation) -- see
+``tests/test_oracle_*.py`` and DESIGN.md section 1(c).
 """

@@ -105,7 +105,25 @@ def test_color_packing_is_channel_major():
   assert y[0, 0, 0, 1] == pytest.approx(0.05 * 1.1 * 8 / 8.1)
 
 
-# ----------------------------------------------------------- HSV vs matplotlib
+# ----------------------------------------------------------- HSV vs colorsys / matplotlib
+def test_hsv_matches_colorsys():
+  """TensorFlow's own unit test of tf.image.rgb_to_hsv / hsv_to_rgb (image_ops_test.py,
+  RGBToHSVTest.testBatch, TF 1.x) checks the ops against Python's ``colorsys`` tuple by tuple; the
+  oracle's restatement of the two ops (which are not in the reference tree) is held to the same
+  check, grey and black pixels (rng = 0, v = 0) included."""
+  import colorsys
+  rng = np.random.default_rng(12)
+  rgb = rng.random((2, 8, 8, 3))
+  rgb[0, 0, :3] = [[0.0, 0.0, 0.0], [0.5, 0.5, 0.5], [1.0, 1.0, 1.0]]  # black / grey / white
+  rgb[0, 1, :3] = [[0.7, 0.7, 0.2], [0.2, 0.7, 0.7], [0.7, 0.2, 0.7]]  # tied maxima
+  hsv = fnp.rgb_to_hsv(rgb)
+  back = fnp.hsv_to_rgb(hsv)
+  for px, got, rt in zip(rgb.reshape(-1, 3), hsv.reshape(-1, 3), back.reshape(-1, 3)):
+    np.testing.assert_allclose(got, colorsys.rgb_to_hsv(*px), atol=1e-12)
+    np.testing.assert_allclose(rt, colorsys.hsv_to_rgb(*got), atol=1e-12)
+
+
+# ----------------------------------------------------------- HSV vs matplotlib (a second independent implementation)
 def test_hsv_matches_matplotlib():
   mc = pytest.importorskip('matplotlib.colors')
   rgb = np.random.default_rng(3).random((4, 16, 16, 3))
