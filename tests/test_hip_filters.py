@@ -212,10 +212,45 @@ def test_chain_matches_stepwise_oracle(gpu_device):
     assert_param_grad_close(dprm[i].cpu().numpy(), rdp, grad_scale(i, xin, gin, params[i]), 'chain dp step %d' % i)
 
 
-def test_full_size_properties(gpu_device):
-  """BASELINE config 5 size (16x512x512x3 fp16): size-independent properties instead of a full
-  oracle run -- identities, linearity of the backward in dy, determinism of y."""
-  shape = synthetic.SHAPES['B']
+def test_full_size_identity_chain(gpu_device):
+  """The headline workload (64x512x512x3 fp16, 8-step chain fwd+bwd through expo_chain_*) with
+  every filter at its identity parameters: E 0 EV, gamma 1, WB (1,1,1), S+ 0, flat tone curve,
+  contrast 0, BW 0, flat colour curves.  For x in (0.001, 1) every activation equals the input and
+  the gradient passes through unchanged -- a size-independent check of the whole chain path."""
+  dev = gpu_device
+  shape = synthetic.SHAPES['C']
+  n = shape[0]
+  g = torch.Generator(device=dev).manual_seed(21)
+  x = (torch.rand(shape, device=dev, generator=g) * 0.98 + 0.01).half()
+  # keep x off the curve knots i/8: exactly on a knot TF's inclusive clip gradient adds both
+  # neighbouring slopes (tested in test_gradient_ties_follow_tf), which is not the identity
+  x = torch.where((x.float() * 8).frac() == 0, x + 0.001, x)
+  dy = torch.randn(shape, device=dev, generator=g).half()
+  ones = lambda k, v=1.0: torch.full((n, k), v, device=dev)
+  prm = [ones(1, 0.0), ones(1), ones(3), ones(1, 0.0), ones(8, 0.7), ones(1, 0.0), ones(1, 0.0), ones(24, 1.3)]
+  acts = [x] + [torch.empty_like(x) for _ in range(8)]
+  grads = [torch.empty_like(x) for _ in range(8)] + [dy]
+  dprm = [torch.empty_like(p) for p in prm]
+  _cabi.chain_fwd(list(range(8)), acts, prm)
+  _cabi.chain_bwd(list(range(8)), acts, grads, prm, dprm)
+  for i in range(1, 9):
+    # E, W, S+, Ct, BW are exact; gamma and the two curves may move a value by one fp16 ulp each
+    assert (acts[i].float() - x.float()).abs().max().item() <= 3 * 2.0**-11, i
+  for i in range(8):
+    assert (grads[i].float() - dy.float()).abs().max().item() <= 3 * 2.0**-8, i  # |dy| < 8: 3 ulps
+  assert all(torch.isfinite(d).all() for d in dprm)
+  # exposure: d/dEV = ln2 * sum(dy * y); against a float64 sum of the same fp16 tensors
+  ref = (grads[1].double() * acts[1].double()).sum(dim=(1, 2, 3)) * np.log(2.0)
+  scale = (grads[1].double().abs() * acts[1].double()).sum(dim=(1, 2, 3)) * np.log(2.0)
+  assert ((dprm[0][:, 0].double() - ref).abs() <= 2e-4 * scale + 1e-6).all()
+
+
+@pytest.mark.parametrize('shape_name', ['B', 'C'])
+def test_full_size_properties(shape_name, gpu_device):
+  """BASELINE config 5 size (16x512x512x3 fp16) and the headline size (64x512x512x3 fp16):
+  size-independent properties instead of a full oracle run -- identities, linearity of the backward
+  in dy, and a sampled oracle check."""
+  shape = synthetic.SHAPES[shape_name]
   dev = gpu_device
   g = torch.Generator(device=dev).manual_seed(5)
   x = (torch.rand(shape, device=dev, generator=g)**2.2 * 1.02).half()
