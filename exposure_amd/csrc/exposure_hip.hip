@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
 }
 
 // --------------------------------------------------- per-image dispatch (one-hot select)
-template <typename T, bool VEC>
+template <typename T, bool VEC, class IO = IoCached>
 __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int groups) {
   constexpr int PPL = PixTraits<T>::PPL;
   float z[PPL * 3];
@@ -350,7 +350,7 @@ __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int group
     const RawGroup rz = pack<T>(z);
     const __amdgpu_buffer_rsrc_t ry = make_image_rsrc(yi, hw);
     for (int gw = blockIdx.x * kThreads + (threadIdx.x & ~63); gw * PPL < hw; gw += stride)
-      store_raw<IoCached::kStore>(ry, chunk_byte_offset<T>(gw, threadIdx.x & 63), rz);
+      store_raw<IO::kStore>(ry, chunk_byte_offset<T>(gw, threadIdx.x & 63), rz);
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) store_slow<T>(yi, g, hw, z);
   }
@@ -364,7 +364,7 @@ constexpr int kSetLight = 0x8000 | 0x100 | 0x6F;  // -1, E, G, W, S+, Ct, BW, Le
 constexpr int kSetCurves = 0x90;         // T, C
 constexpr int kSetAll = kSetLight | kSetCurves;
 
-template <typename T, bool VEC, bool PEN, int SET>
+template <typename T, bool VEC, bool PEN, int SET, class IO>
 __global__ __launch_bounds__(kThreads) void dispatch_fwd_kernel(const int32_t* __restrict__ ids,
                                                                 const T* __restrict__ x, T* __restrict__ y,
                                                                 const float* __restrict__ params,
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void dispatch_fwd_kernel(const int32_t* _
   const int id = ids[n];  // block-uniform
 #define EXPO_CASE(ID, F)                                                                              \
   case ID:                                                                                            \
-    if constexpr ((SET >> ID) & 1) fwd_body<F, T, VEC, PEN>(x + off, y + off, prm, pen, hw, groups, inv_count); \
+    if constexpr ((SET >> ID) & 1) fwd_body<F, T, VEC, PEN, IO>(x + off, y + off, prm, pen, hw, groups, inv_count); \
     break;
   switch (id) {
     EXPO_CASE(0, ExposureF)
@@ -390,13 +390,13 @@ __global__ __launch_bounds__(kThreads) void dispatch_fwd_kernel(const int32_t* _
     EXPO_CASE(7, ColorF)
     EXPO_CASE(8, LevelF)
     default:  // id -1: all-zero one-hot
-      if constexpr ((SET >> 15) & 1) zero_image<T, VEC>(y + off, hw, groups);
+      if constexpr ((SET >> 15) & 1) zero_image<T, VEC, IO>(y + off, hw, groups);
       break;
   }
 #undef EXPO_CASE
 }
 
-template <typename T, bool VEC, bool HAS_DX, bool PEN, int MODE, int SET>
+template <typename T, bool VEC, bool HAS_DX, bool PEN, int MODE, int SET, class IO>
 __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* __restrict__ ids,
                                                                 const T* __restrict__ x, const T* __restrict__ dy,
                                                                 T* __restrict__ dx, const float* __restrict__ params,
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
 #define EXPO_CASE(ID, F)                                                                                  \
   case ID:                                                                                                \
     if constexpr ((SET >> ID) & 1)                                                                        \
-      bwd_body<F, T, VEC, HAS_DX, PEN, MODE>(x + off, dy + off, dxi, prm, dprm, hw, groups, ps);   \
+      bwd_body<F, T, VEC, HAS_DX, PEN, MODE, IO>(x + off, dy + off, dxi, prm, dprm, hw, groups, ps); \
     break;
   switch (id) {
     EXPO_CASE(0, ExposureF)
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
     EXPO_CASE(7, ColorF)
     EXPO_CASE(8, LevelF)
     default:
-      if constexpr (HAS_DX && ((SET >> 15) & 1)) zero_image<T, VEC>(dxi, hw, groups);
+      if constexpr (HAS_DX && ((SET >> 15) & 1)) zero_image<T, VEC, IO>(dxi, hw, groups);
       break;
   }
 #undef EXPO_CASE
@@ -654,6 +654,16 @@ template __global__ void filter_bwd_kernel<ColorF, half_t, true, true, 0, IoStre
                                                                                  const float*, float*, int, int);
 template __global__ void filter_bwd_kernel<WnbF, half_t, true, true, 0, IoStream>(const half_t*, const half_t*, half_t*,
                                                                                const float*, float*, int, int);
+#define EXPO_PROBE_APPLY(F)                                                                                   \
+  template __global__ void apply_bwd_kernel<F, half_t, true, true, 0>(const half_t*, const half_t*, half_t*, \
+                                                                      const float*, float*, const float*,   \
+                                                                      float*, float, float, int, int, int);
+EXPO_PROBE_APPLY(ExposureF)
+EXPO_PROBE_APPLY(ContrastF)
+EXPO_PROBE_APPLY(SatPlusF)
+EXPO_PROBE_APPLY(ToneF)
+EXPO_PROBE_APPLY(ColorF)
+#undef EXPO_PROBE_APPLY
 }  // namespace expo
 #else
 // ==================================================================== host side
@@ -896,13 +906,15 @@ static int dispatch_fwd_t(const int32_t* ids, const void* x, void* y, const floa
   if (penalty) HIP_TRY(hipMemsetAsync(penalty, 0, sizeof(float) * size_t(n), s), "penalty memset");
   // forward: one launch handles every filter (the heaviest forward body needs ~106 VGPRs, fine for a
   // streaming kernel); only the backward is split into light / curve launches (124 vs 190 VGPRs)
-#define EXPO_L(VEC, PEN)                                                                             \
-  hipLaunchKernelGGL((dispatch_fwd_kernel<T, VEC, PEN, kSetAll>), grid, block, 0, s, ids, (const T*)x, \
+#define EXPO_L(VEC, PEN, IO)                                                                              \
+  hipLaunchKernelGGL((dispatch_fwd_kernel<T, VEC, PEN, kSetAll, IO>), grid, block, 0, s, ids, (const T*)x, \
                      (T*)y, params, penalty, g.hw, g.groups, inv_count)
-  if (g.vec) {
-    if (penalty) EXPO_L(true, true); else EXPO_L(true, false);
+  if (g.stream) {
+    if (penalty) EXPO_L(true, true, IoStream); else EXPO_L(true, false, IoStream);
+  } else if (g.vec) {
+    if (penalty) EXPO_L(true, true, IoCached); else EXPO_L(true, false, IoCached);
   } else {
-    if (penalty) EXPO_L(false, true); else EXPO_L(false, false);
+    if (penalty) EXPO_L(false, true, IoCached); else EXPO_L(false, false, IoCached);
   }
 #undef EXPO_L
   HIP_TRY(hipGetLastError(), "dispatch_fwd launch");
@@ -916,24 +928,28 @@ static int dispatch_bwd_t(const int32_t* ids, const void* x, const void* dy, voi
   const dim3 grid(g.blocks_x, n), block(kThreads);
   const float inv_count = 1.0f / (float(g.hw) * 3.0f);
   HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * EXPO_MAX_PARAMS, s), "dparams memset");
-#define EXPO_L2(VEC, HAS_DX, PEN, MODE, SET)                                                              \
-  hipLaunchKernelGGL((dispatch_bwd_kernel<T, VEC, HAS_DX, PEN, MODE, SET>), grid, block, 0, s, ids,       \
+#define EXPO_L2(VEC, HAS_DX, PEN, MODE, SET, IO)                                                          \
+  hipLaunchKernelGGL((dispatch_bwd_kernel<T, VEC, HAS_DX, PEN, MODE, SET, IO>), grid, block, 0, s, ids,   \
                      (const T*)x, (const T*)dy, (T*)dx, params, dparams, dpenalty, g.hw, g.groups, inv_count)
-#define EXPO_L(VEC, HAS_DX, PEN)                                                                          \
+#define EXPO_L(VEC, HAS_DX, PEN, IO)                                                                      \
   do {                                                                                                    \
-    if (mode == 1) EXPO_L2(VEC, HAS_DX, PEN, 1, kSetLight); else EXPO_L2(VEC, HAS_DX, PEN, 0, kSetLight); \
-    EXPO_L2(VEC, HAS_DX, PEN, 0, kSetCurves);                                                             \
+    if (mode == 1) EXPO_L2(VEC, HAS_DX, PEN, 1, kSetLight, IO);                                           \
+    else EXPO_L2(VEC, HAS_DX, PEN, 0, kSetLight, IO);                                                     \
+    EXPO_L2(VEC, HAS_DX, PEN, 0, kSetCurves, IO);                                                         \
   } while (0)
-  const int key = (g.vec ? 4 : 0) | (dx ? 2 : 0) | (dpenalty ? 1 : 0);
+  // the streaming policy is instantiated for the full backward (dx wanted) only
+  const int key = (g.stream && dx ? 8 : 0) | (g.vec ? 4 : 0) | (dx ? 2 : 0) | (dpenalty ? 1 : 0);
   switch (key) {
-    case 7: EXPO_L(true, true, true); break;
-    case 6: EXPO_L(true, true, false); break;
-    case 5: EXPO_L(true, false, true); break;
-    case 4: EXPO_L(true, false, false); break;
-    case 3: EXPO_L(false, true, true); break;
-    case 2: EXPO_L(false, true, false); break;
-    case 1: EXPO_L(false, false, true); break;
-    default: EXPO_L(false, false, false); break;
+    case 15: EXPO_L(true, true, true, IoStream); break;
+    case 14: EXPO_L(true, true, false, IoStream); break;
+    case 7: EXPO_L(true, true, true, IoCached); break;
+    case 6: EXPO_L(true, true, false, IoCached); break;
+    case 5: EXPO_L(true, false, true, IoCached); break;
+    case 4: EXPO_L(true, false, false, IoCached); break;
+    case 3: EXPO_L(false, true, true, IoCached); break;
+    case 2: EXPO_L(false, true, false, IoCached); break;
+    case 1: EXPO_L(false, false, true, IoCached); break;
+    default: EXPO_L(false, false, false, IoCached); break;
   }
 #undef EXPO_L
 #undef EXPO_L2

@@ -521,3 +521,38 @@ def test_curve_backward_on_every_fp16_value(fid, gpu_device):
   tol = np.abs(rdx) * 2.0**-11 + 1e-6
   bad = err > tol
   assert not bad.any(), 'dx wrong for x = %r (got %r, want %r)' % (x[bad][:8], dx[bad][:8], rdx[bad][:8])
+
+
+def test_dispatch_streaming_policy_equals_cached_policy(gpu_device):
+  """Same check for the per-image dispatch (the agent's one-hot select): 10 images x 512x512 (15.7 MB,
+  streaming kernels) against the same images in two 5-image calls (7.9 MB, cached kernels); every
+  filter id incl. the all-zero one-hot (-1), with the fused penalty and its gradient."""
+  dev = gpu_device
+  n, shape = 10, (10, 512, 512, 3)
+  g = torch.Generator(device=dev).manual_seed(12)
+  x = (torch.rand(shape, device=dev, generator=g)**2.2 * 1.3).half()
+  dy = torch.randn(shape, device=dev, generator=g).half()
+  assert x.numel() * 2 >= (8 << 20) > x[:5].numel() * 2
+  ids = torch.tensor([0, 1, 2, 3, 4, 5, 6, 7, 8, -1], dtype=torch.int32, device=dev)
+  rng = np.random.default_rng(13)
+  p24 = torch.zeros((n, 24), device=dev)
+  for i, fid in enumerate(ids.tolist()):
+    if fid >= 0:
+      q = synthetic.make_params(rng, fid, 1)[0]
+      p24[i, :q.size] = torch.from_numpy(q).to(dev)
+  dpen = torch.rand(n, device=dev, generator=g)
+  y, pen = torch.empty_like(x), torch.empty(n, device=dev)
+  dx, dp = torch.empty_like(x), torch.empty_like(p24)
+  _cabi.dispatch_fwd(ids, x, y, p24, pen)
+  _cabi.dispatch_bwd(ids, x, dy, dx, p24, dp, dpen)
+  for lo in (0, 5):
+    sl = slice(lo, lo + 5)
+    xs, dys = x[sl].contiguous(), dy[sl].contiguous()
+    ys, pens = torch.empty_like(xs), torch.empty(5, device=dev)
+    dxs, dps = torch.empty_like(xs), torch.empty((5, 24), device=dev)
+    _cabi.dispatch_fwd(ids[sl].contiguous(), xs, ys, p24[sl].contiguous(), pens)
+    _cabi.dispatch_bwd(ids[sl].contiguous(), xs, dys, dxs, p24[sl].contiguous(), dps, dpen[sl].contiguous())
+    assert torch.equal(ys, y[sl]) and torch.equal(dxs, dx[sl])
+    assert torch.allclose(pens, pen[sl], rtol=1e-4, atol=1e-7)
+    scale = dps.abs().max().item() + 1.0
+    assert (dps - dp[sl]).abs().max().item() <= 1e-3 * scale
