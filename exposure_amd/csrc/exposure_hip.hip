@@ -10,9 +10,13 @@
 //   dispatch_{fwd,bwd}       same bodies behind a block-uniform switch on filter_ids[n]
 //                            (the reference's one-hot select, agent.py:119-125) with the
 //                            over-exposure penalty (agent.py:249-251) fused in
+//   apply_{fwd,bwd}          Filter.apply with the spatial mask (cfg.masking = True) in one pass
+//   chain_fused_fwd          all steps of a per-image filter sequence in registers (inference)
 //   stats / penalty          per-image reductions (critics.py:48-62, agent.py:249-251)
 // Grid: blockIdx.y = image (so parameters are block-uniform -> SGPRs), blockIdx.x =
 // chunk of the image; each thread walks 48-byte pixel groups with a block stride.
+// Cache policy: tensors >= EXPO_STREAM_MIN_BYTES run the IoStream instantiations (nt loads,
+// write-through stores), smaller ones IoCached -- pixel_io.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
