@@ -546,6 +546,9 @@ def main():
                      'MI355X_MICROARCH.md (nt loads + sc1 stores reach 7.0-7.7 TB/s: tools/membench, DESIGN.md 3.1)',
         'frac_of_copy_ceiling': achieved / 6290.0,
         'algorithmic_bytes_per_launch': bpp * px,
+        # the whole timed region (16 kernels + 1 fill per step): 240 B/pixel/step over the step time
+        'chain_achieved': result['config']['chain_algorithmic_GBps'],
+        'chain_frac': result['config']['chain_algorithmic_GBps'] / HBM_PEAK_GBPS,
     }
     result['per_kernel'] = {
         k: {
