@@ -92,14 +92,17 @@ class Chain:
       off += p.numel()
 
     self.graph = None
+    self.unroll = 1
 
   def launch(self):
     _cabi.chain_fwd(self.ids, self.acts, self.params)
     _cabi.chain_bwd(self.ids, self.acts, self.grads, self.params, self.dparams)
 
-  def capture(self):
-    """Capture one step (8 fwd + 1 fill + 8 bwd launches) into a hipGraph: small shapes are bound
-    by the ~5 us host cost per launch, a graph replay pays it once."""
+  def capture(self, unroll=1):
+    """Capture `unroll` steps (each 8 fwd + 1 fill + 8 bwd launches) into one hipGraph: small shapes
+    are bound by the ~5 us host cost per launch, a graph replay pays it once; every replay boundary
+    costs ~3 us on the device, so several steps share a replay when the step count allows."""
+    self.unroll = unroll
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -111,16 +114,22 @@ class Chain:
     # thread captures; under the default "global" mode such a call aborts the process
     try:
       with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-        self.launch()
+        for _ in range(unroll):
+          self.launch()
     except RuntimeError as e:  # never lose the run over the launch method
       print('warning: hipGraph capture failed (%s); eager launches' % e, file=sys.stderr)
       torch.cuda.synchronize()
       self.graph = None
 
-  def step(self):
-    if self.graph is not None:
+  def run(self, steps):
+    """Exactly `steps` chain steps: whole replays of the captured graph, the remainder eagerly."""
+    if self.graph is None:
+      for _ in range(steps):
+        self.launch()
+      return
+    for _ in range(steps // self.unroll):
       self.graph.replay()
-    else:
+    for _ in range(steps % self.unroll):
       self.launch()
 
 
@@ -472,7 +481,8 @@ def main():
   # queues), while the replay measures the same +-0.3 % either way -- so every N uses the replay.
   use_graph = args.graph != 'off'
   if use_graph:
-    chain.capture()
+    # as many steps per replay as divide the timed step count (at most 10): K stays exact
+    chain.capture(max(u for u in range(1, 11) if args.steps % u == 0))
 
   def barrier():
     light_barrier(dist, dev)
@@ -481,17 +491,14 @@ def main():
   # would make a 20-step measurement read ~3 % slow), then the W warm-up steps of the contract
   t_pre = time.perf_counter()
   while time.perf_counter() - t_pre < args.prewarm_s:
-    for _ in range(10):
-      chain.step()
+    chain.run(10)
     torch.cuda.synchronize()
-  for _ in range(args.warmup):
-    chain.step()
+  chain.run(args.warmup)
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
-  for _ in range(args.steps):
-    chain.step()
+  chain.run(args.steps)
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
@@ -523,7 +530,7 @@ def main():
           'height': shape[1],
           'width': shape[2],
           'parallelism': 'image-sharded replicas x%d (no data-path collective)' % world,
-          'launch': 'one hipGraph replay per step (17 captured launches)' if chain.graph is not None else 'eager (one C-ABI call per direction)',
+          'launch': ('hipGraph replay, %d steps (%d captured launches) per replay' % (chain.unroll, 17 * chain.unroll)) if chain.graph is not None else 'eager (one C-ABI call per direction)',
           'chain_algorithmic_GBps': 8 * 5 * 3 * esz * px / (elapsed / args.steps) / 1e9 * 1.0,
       },
   }
