@@ -100,6 +100,58 @@ __device__ __forceinline__ void block_reduce_atomic(float* acc, float* __restric
   if (threadIdx.x < NOUT) atomicAdd(out + threadIdx.x, fin(tot, threadIdx.x));
 }
 
+// Curve forward by table: instead of the telescoped 7 x v_min + 8 x v_fma per element, a per-wave
+// table of the L segments in LDS -- entry (c, j) = {a, b} with
+//   y = a x^ + b on segment j,  a = (L/S) k_j,  b = (L/S) (sum_{i<j} k_i - j k_j) / L
+// -- looked up with j = min(int(L x^), L-1): clamp, mul, cvt, min, address, ds_read_b64, fma.
+// Build: lane l < NC*L holds parameter k[l] (a per-lane copy fetched by a vector load); the exclusive
+// prefix sums come from three shuffles inside each group of L lanes.  One wave builds and reads its
+// own table region and LDS operations of a wave execute in order, so no block barrier is involved;
+// ALL lanes 0..NC*L-1 of the wave must be active.  Used by the fused inference kernel (a new table
+// per step) and by the per-step forward kernels (one table per wave for the whole launch).
+template <int NC>
+__device__ __forceinline__ void curve_lut_build(float klane, float2_lut* tab) {
+  constexpr int L = kCurveSteps;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (L - 1);
+  float incl = klane;  // inclusive scan over the L lanes of a curve
+#pragma unroll
+  for (int d = 1; d < L; d <<= 1) {
+    const float t = __shfl_up(incl, d, L);
+    if (j >= d) incl += t;
+  }
+  const float S = __shfl(incl, L - 1, L) + 1e-30f;
+  const float scale = float(L) / S;
+  if (lane < NC * L) {
+    float2_lut e;
+    e.x = scale * klane;
+    e.y = scale * ((incl - klane) - float(j) * klane) * (1.0f / float(L));
+    tab[lane] = e;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+template <int NC, int NPIX>
+__device__ __forceinline__ void curve_lut_apply(float* v, const float2_lut* tab) {
+  constexpr int L = kCurveSteps;
+#pragma unroll
+  for (int k = 0; k < NPIX; ++k) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xc = clamp01x(v[3 * k + c], 0.0f, 1.0f);
+      int seg = int(xc * float(L));
+      seg = seg < L - 1 ? seg : L - 1;
+      const float2_lut e = tab[(NC == 1 ? 0 : c * L) + seg];
+      v[3 * k + c] = fmaf(xc, e.x, e.y);
+    }
+  }
+}
+template <int NC, int NPIX>
+__device__ __forceinline__ void curve_fwd_lut(float* v, float klane, float2_lut* tab) {
+  curve_lut_build<NC>(klane, tab);
+  curve_lut_apply<NC, NPIX>(v, tab);
+  __builtin_amdgcn_wave_barrier();  // the next curve step of this wave rewrites the table
+}
+
 // --------------------------------------------------------------------------- forward
 template <class F, typename T, bool VEC, bool PEN, class IO = IoCached>
 __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict__ yi,
@@ -109,8 +161,25 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   const typename F::Prm q = F::load(prm);
   float pen = 0.f;
   const int stride = gridDim.x * kThreads;
+  // Tone / Color on the vector path (all lanes of a wave alive): segment table instead of the
+  // telescoped min/fma chain; built once per wave behind the first loads (stream_groups' prologue)
+  constexpr bool kCurveTab = VEC && F::kLutFloats > 0;
+  constexpr int kNC = kCurveTab ? F::NP / kCurveSteps : 1;
+  __shared__ float2_lut ftab[kCurveTab ? kWaves : 1][32];
+  float2_lut* const tab = ftab[kCurveTab ? (threadIdx.x >> 6) : 0];
   // per-group work, shared by the prefetching (VEC) and the element-wise loop
   auto compute = [&](float* v, int g) {
+    if constexpr (kCurveTab) {
+      curve_lut_apply<kNC, PPL>(v, tab);
+      if constexpr (PEN) {
+#pragma unroll
+        for (int j = 0; j < PPL * 3; ++j) {
+          const float o = fmaxf(v[j] - 1.0f, 0.0f);
+          pen = fmaf(o, o, pen);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       float y[3];
@@ -128,8 +197,12 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, EXPO_FWD_PREFETCH != 0, IO>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                  [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
+    stream_groups<T, 1, true, EXPO_FWD_PREFETCH != 0, IO>(
+        ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+        [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); },
+        [&]() {
+          if constexpr (kCurveTab) curve_lut_build<kNC>(prm[(threadIdx.x & 63) % F::NP], tab);
+        });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3];
@@ -444,47 +517,6 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
 // rounding of intermediates): ONE read and ONE write of the image instead of one per step.
 // Each wave owns exactly one 3 KiB chunk, so the per-step parameters are fetched once per wave
 // through scalar loads; the step loop is rolled (block-uniform switch per step).
-// Curve forward for the fused (VALU-bound) kernel: instead of the telescoped 7 x v_min + 8 x v_fma
-// per element, a per-wave table of the L segments in LDS -- entry (c, j) = {a, b} with
-//   y = a x^ + b on segment j,  a = (L/S) k_j,  b = (L/S) (sum_{i<j} k_i - j k_j) / L
-// -- looked up with j = min(int(L x^), L-1): clamp, mul, cvt, min, address, ds_read_b64, fma.
-// Lane l < NC*L holds parameter k[l] (a per-lane copy fetched by a vector load); the exclusive prefix
-// sums come from three shuffles inside each group of L lanes.  One wave builds and reads its own
-// table region, LDS operations of a wave execute in order, so no block barrier is involved.
-template <int NC, int NPIX>
-__device__ __forceinline__ void curve_fwd_lut(float* v, float klane, float2_lut* tab) {
-  constexpr int L = kCurveSteps;
-  const int lane = threadIdx.x & 63;
-  const int j = lane & (L - 1);
-  float incl = klane;  // inclusive scan over the L lanes of a curve
-#pragma unroll
-  for (int d = 1; d < L; d <<= 1) {
-    const float t = __shfl_up(incl, d, L);
-    if (j >= d) incl += t;
-  }
-  const float S = __shfl(incl, L - 1, L) + 1e-30f;
-  const float scale = float(L) / S;
-  if (lane < NC * L) {
-    float2_lut e;
-    e.x = scale * klane;
-    e.y = scale * ((incl - klane) - float(j) * klane) * (1.0f / float(L));
-    tab[lane] = e;
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int k = 0; k < NPIX; ++k) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float xc = clamp01x(v[3 * k + c], 0.0f, 1.0f);
-      int seg = int(xc * float(L));
-      seg = seg < L - 1 ? seg : L - 1;
-      const float2_lut e = tab[(NC == 1 ? 0 : c * L) + seg];
-      v[3 * k + c] = fmaf(xc, e.x, e.y);
-    }
-  }
-  __builtin_amdgcn_wave_barrier();  // the next curve step of this wave rewrites the table
-}
-
 template <typename T, bool VEC, class IO>
 __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t* __restrict__ ids,
                                                                    const float* __restrict__ params, int steps,
