@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerates every measured artefact under profiles/ in ONE gpurun call:
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_all.sh'
-# then, back in the container:  python tools/make_traffic.py gpurun_out/final && cp gpurun_out/final/* profiles/ (renamed r01_final_*)
+# then, back in the container:  tools/collect_profiles.sh  (copies gpurun_out/final/* to profiles/r01_final_* and
+# rebuilds profiles/traffic.json with tools/make_traffic.py)
 # rocprofv3 passes: --kernel-trace alone (durations) and one --pmc counter per pass (never combined
 # with sys/runtime tracing); the rocpd databases stay on the GPU box, only CSV summaries come back.
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -13,6 +14,7 @@ db() { find "$1" -name "*.db" | head -1; }
 python -m pytest $R/tests -x -q -m gpu 2>&1 | tail -2 > $OUT/pytest_gpu.txt
 python $R/bench.py > $OUT/bench_chain.json 2> $OUT/bench_chain.err
 python $R/bench.py --shape A --no-cpu-baseline > $OUT/bench_chain_A.json 2>/dev/null
+python $R/bench.py --dtype f32 --no-cpu-baseline > $OUT/bench_chain_f32.json 2>/dev/null
 python $R/bench.py --shape B --no-cpu-baseline > $OUT/bench_chain_B.json 2>/dev/null
 python $R/bench.py --workload infer --shape B --no-cpu-baseline > $OUT/bench_infer_B.json 2>/dev/null
 python $R/bench.py --workload train --no-cpu-baseline > $OUT/bench_train.json 2>/dev/null
