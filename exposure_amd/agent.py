@@ -80,10 +80,42 @@ def feature_extractor(net, output_dim, cfg, module, dropout_mask=None):
   return module(net, dropout_mask)
 
 
+def exclusive_cumsum(pdf):
+  """``tf.cumsum(pdf, axis=1, exclusive=True)`` (pdf_sample_layer.py:7): a SHIFTED prefix scan --
+  out[:, 0] = 0, out[:, j] = out[:, j-1] + pdf[:, j-1], accumulated left to right in the input dtype
+  exactly like TF's CPU scan functor.  (``cumsum(pdf) - pdf`` is NOT the same in floating point: it
+  differs by one ulp in ~22 % of the entries, enough to flip a sampled id when the noise lands on that
+  ulp.)  K is the number of filters (8): the explicit column loop is K-1 tiny adds, runs identically on
+  any device and does not depend on the association order of a parallel device scan."""
+  k = pdf.shape[1]
+  cols = [torch.zeros_like(pdf[:, 0])]
+  for j in range(1, k):
+    cols.append(cols[-1] + pdf[:, j - 1])
+  return torch.stack(cols, dim=1)
+
+
+def row_sum(pdf):
+  """``tf.reduce_sum(pdf, axis=1, keep_dims=True)`` (pdf_sample_layer.py:6) with an EXPLICIT association
+  order, so the integer ids that follow do not depend on the device's reduction tree: for K == 8 the
+  order of Eigen's packet reducer that TF-1 CPU kernels use (accumulate 4-wide packets, then the
+  horizontal add (x0+x2)+(x1+x3): ((p0+p4)+(p2+p6)) + ((p1+p5)+(p3+p7)), the same for SSE and AVX
+  builds); any other K sums left to right.  TF's own order is an implementation detail of an absent
+  dependency (parity unpinned); what is guaranteed is product == oracle, bit for bit, on any device."""
+  k = pdf.shape[1]
+  c = [pdf[:, j] for j in range(k)]
+  if k == 8:
+    total = ((c[0] + c[4]) + (c[2] + c[6])) + ((c[1] + c[5]) + (c[3] + c[7]))
+  else:
+    total = c[0]
+    for j in range(1, k):
+      total = total + c[j]
+  return total[:, None]
+
+
 def pdf_sample(pdf, uniform_noise):
   """pdf_sample_layer.py:5-10 (bit-identical integer result for identical pdf / noise)."""
-  pdf = pdf / (pdf.sum(dim=1, keepdim=True) + 1e-36)
-  cdf = torch.cumsum(pdf, dim=1) - pdf  # exclusive
+  pdf = pdf / (row_sum(pdf) + 1e-36)
+  cdf = exclusive_cumsum(pdf)
   return ((cdf < uniform_noise).sum(dim=1) - 1).to(torch.int32)
 
 

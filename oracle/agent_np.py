@@ -19,11 +19,37 @@ STATE_STEP_DIM = 2
 STATE_DROPOUT_BEGIN = 3
 
 
+def exclusive_cumsum(pdf):
+  """tf.cumsum(pdf, axis=1, exclusive=True) (pdf_sample_layer.py:7): a shifted prefix scan, out[:, 0] = 0
+  and out[:, j] = out[:, j-1] + pdf[:, j-1], accumulated left to right in the dtype of ``pdf`` (TF's CPU
+  scan functor walks the axis sequentially).  Not ``cumsum(pdf) - pdf``, which differs by an ulp in fp32."""
+  out = np.zeros_like(pdf)
+  for j in range(1, pdf.shape[1]):
+    out[:, j] = out[:, j - 1] + pdf[:, j - 1]
+  return out
+
+
+def row_sum(pdf):
+  """tf.reduce_sum(pdf, axis=1, keep_dims=True) (pdf_sample_layer.py:6) with an explicit association
+  order (the device/library default tree must not decide an integer output): K == 8 follows Eigen's
+  packet reducer as TF-1 CPU kernels run it -- ((p0+p4)+(p2+p6)) + ((p1+p5)+(p3+p7)) -- any other K
+  sums left to right.  TensorFlow is absent from the tree: this order is PARITY UNPINNED."""
+  k = pdf.shape[1]
+  c = [pdf[:, j] for j in range(k)]
+  if k == 8:
+    total = ((c[0] + c[4]) + (c[2] + c[6])) + ((c[1] + c[5]) + (c[3] + c[7]))
+  else:
+    total = c[0]
+    for j in range(1, k):
+      total = total + c[j]
+  return total[:, None]
+
+
 def pdf_sample(pdf, uniform_noise):
   """pdf_sample_layer.py:5-10.  pdf (N,K); uniform_noise (N,1) -> int32 (N,).
   cumsum(exclusive) < u summed, minus one; u == 0 gives -1 (nothing selected)."""
-  pdf = pdf / (np.sum(pdf, axis=1, keepdims=True) + pdf.dtype.type(1e-36))
-  cdf = np.cumsum(pdf, axis=1) - pdf  # exclusive cumsum
+  pdf = pdf / (row_sum(pdf) + pdf.dtype.type(1e-36))
+  cdf = exclusive_cumsum(pdf)
   return (cdf < uniform_noise).astype(np.int32).sum(axis=1) - 1
 
 

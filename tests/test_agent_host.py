@@ -28,6 +28,55 @@ def test_pdf_sample_known_answers():
   assert np.abs(freq - np.array([1, 2, 4]) / 7).max() < 0.01
 
 
+def _scan_reference(pdf_row):
+  """Independent scalar restatement of tf.cumsum(exclusive=True) in fp32: out[j] = out[j-1] + p[j-1]."""
+  out, acc = [], np.float32(0.0)
+  for v in pdf_row:
+    out.append(acc)
+    acc = np.float32(acc + np.float32(v))
+  return np.array(out, dtype=np.float32)
+
+
+def test_exclusive_cumsum_is_a_shifted_scan_not_cumsum_minus_pdf():
+  """pdf_sample_layer.py:7.  The round-1 form ``cumsum(pdf) - pdf`` differs from the true exclusive
+  scan by one ulp in ~22 % of fp32 entries; both the product and the oracle must be the scan."""
+  rng = np.random.default_rng(5)
+  pdf = rng.random((4096, 8), dtype=np.float32) + np.float32(1e-3)
+  pdf = (pdf / pdf.sum(axis=1, keepdims=True)).astype(np.float32)
+  want = np.stack([_scan_reference(r) for r in pdf])
+  assert np.array_equal(agent_np.exclusive_cumsum(pdf), want)
+  assert np.array_equal(xagent.exclusive_cumsum(torch.from_numpy(pdf)).numpy(), want)
+  naive = np.cumsum(pdf, axis=1) - pdf
+  assert (naive != want).mean() > 0.05  # the two forms really differ -> this test can catch a regression
+
+
+def test_pdf_sample_noise_on_every_cdf_knot_plus_minus_one_ulp():
+  """north_star: bit-identical step indices.  Put the selection noise exactly on each cdf knot and one
+  fp32 ulp either side: ``cdf < u`` is a strict comparison, so u == knot_j selects j-1, u just above
+  selects j.  Product (torch) and oracle (numpy) must agree with a scalar restatement on every case."""
+  rng = np.random.default_rng(6)
+  pdf = rng.random((512, 8), dtype=np.float32) + np.float32(1e-3)
+  norm = (pdf / (agent_np.row_sum(pdf) + np.float32(1e-36))).astype(np.float32)
+  knots = np.stack([_scan_reference(r) for r in norm])  # (512, 8)
+  rows, noise, want = [], [], []
+  for i in range(pdf.shape[0]):
+    for j in range(8):
+      for u in (np.nextafter(knots[i, j], np.float32(-1)), knots[i, j], np.nextafter(knots[i, j], np.float32(2))):
+        rows.append(pdf[i])
+        noise.append(u)
+        want.append(int((knots[i] < u).sum()) - 1)
+  rows = np.stack(rows).astype(np.float32)
+  noise = np.array(noise, dtype=np.float32)[:, None]
+  want = np.array(want, dtype=np.int32)
+  got_np = agent_np.pdf_sample(rows, noise)
+  got_t = xagent.pdf_sample(torch.from_numpy(rows), torch.from_numpy(noise)).numpy()
+  assert np.array_equal(got_np, want)
+  assert np.array_equal(got_t, want)
+  # on a knot the strict '<' excludes segment j itself; one ulp above includes it
+  assert (want.reshape(-1, 3)[:, 2] >= want.reshape(-1, 3)[:, 1]).all()
+  assert (want.reshape(-1, 3)[:, 2] > want.reshape(-1, 3)[:, 1]).mean() > 0.9
+
+
 def make_inputs(n=6, seed=0, s=64):
   rng = np.random.default_rng(seed)
   img = (rng.random((n, s, s, 3), dtype=np.float32)**2.2).astype(np.float32)
