@@ -1,0 +1,350 @@
+"""NumPy (float64) restatement of the convnet / loss CALLERS of the filter path:
+
+* ``feature_extractor``                      ``/root/reference/agent.py:11-37``
+* ``enrich_image_input``                     ``util.py:31-36``
+* ``Filter.extract_parameters``              ``filters.py:28-44``
+* ``agent_generator`` (one rollout step)     ``agent.py:41-125, 207-260``
+* ``cnn`` / ``critic`` (+ value network)     ``critics.py:6-98``
+* the loss graph of the trainer              ``net.py:92-194``
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``); PARITY UNPINNED by the reference (no tests, no
+fixtures, TensorFlow absent).  Pinned instead by: float64 finite differences of the hand-written
+backward passes (``tests/test_oracle_nets.py``), TF's documented SAME-padding arithmetic restated
+below, and agreement with the torch modules of ``exposure_amd`` holding the SAME weights.
+
+Weights are passed as ``{tf_variable_name: ndarray}`` in TF-1 layout -- ``ly.conv2d`` kernels HWIO,
+``ly.fully_connected`` weights (in, out) -- with the variable scopes of the reference graph
+(``exposure_amd/checkpoint.py::export_tf_dict`` produces exactly this dict from the torch modules).
+All stochastic inputs are explicit: dropout masks (0/1), the selection noise ``z[:, 0]``, ``alpha``.
+
+TensorFlow semantics encoded here (the ops live in an absent dependency, TF 1.x):
+* ``ly.conv2d(kernel_size=4, stride=2)``: padding 'SAME' -> out = ceil(in / stride),
+  pad_total = max((out - 1) * stride + k - in, 0), pad_before = pad_total // 2 (the extra pixel, if
+  any, goes AFTER); cross-correlation (no kernel flip); bias add; then the activation.
+* ``tf.reshape(net, [-1, output_dim])`` flattens NHWC in (H, W, C) order.
+* ``tf.nn.dropout(x, keep_prob)`` = ``x / keep_prob * mask``, mask in {0, 1}.
+* gradient conventions: ``abs'(0) = 0`` (so lrelu'(0) = f1), ``tf.maximum(x, c)`` passes on ``x >= c``,
+  ``clip_by_value`` passes on ``lo <= x <= hi``, ``tf.minimum(x=a, y=b)`` sends ties to ``a``,
+  ``reduce_max`` / ``reduce_min`` split the gradient evenly between tied extrema.
+"""
+import math
+
+import numpy as np
+
+from . import agent_np
+from . import filters_np as fnp
+
+# util.py:13-16
+STATE_REWARD_DIM = 0
+STATE_STOPPED_DIM = 1
+STATE_STEP_DIM = 2
+STATE_DROPOUT_BEGIN = 3
+
+# config_example.py (the fields the callers read), as plain data
+DEFAULT_CFG = dict(
+    fnp.DEFAULT_CFG,
+    base_channels=32,
+    source_img_size=64,
+    dropout_keep_prob=0.5,
+    feature_extractor_dims=4096,
+    fc1_size=128,
+    img_include_states=True,
+    exploration=0.05,
+    exploration_penalty=0.05,
+    early_stop_penalty=1.0,
+    filter_usage_penalty=1.0,
+    test_steps=5,
+    clamp=False,
+    num_filters=8,
+    # net.py / config_example.py:44-118
+    critic_logit_multiplier=0.05,
+    discount_factor=1.0,
+    maximum_trajectory_length=7,
+    all_reward=1.0,
+    use_penalty=True,
+    parameter_lr_mul=1,
+    gradient_penalty_lambda=10,
+)
+
+
+# ------------------------------------------------------------------------------------- layers
+def lrelu(x, leak=0.2):
+  """util.py:225-229."""
+  f1 = 0.5 * (1 + leak)
+  f2 = 0.5 * (1 - leak)
+  return f1 * x + f2 * np.abs(x)
+
+
+def lrelu_grad(x, leak=0.2):
+  """d lrelu / dx with TF's abs'(0) = 0."""
+  f1 = 0.5 * (1 + leak)
+  f2 = 0.5 * (1 - leak)
+  return f1 + f2 * np.sign(x)
+
+
+def _same_pads(size, k, stride):
+  out = -(-size // stride)
+  total = max((out - 1) * stride + k - size, 0)
+  return out, total // 2, total - total // 2
+
+
+def conv2d_same(x, w, b, stride=2):
+  """ly.conv2d(..., padding='SAME') before the activation.  x NHWC, w HWIO, b (O,)."""
+  n, h, wd, c = x.shape
+  kh, kw, ci, co = w.shape
+  assert ci == c, (x.shape, w.shape)
+  ho, pt, pb = _same_pads(h, kh, stride)
+  wo, pl, pr = _same_pads(wd, kw, stride)
+  xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+  out = np.zeros((n, ho, wo, co), dtype=x.dtype)
+  for i in range(kh):
+    for j in range(kw):
+      patch = xp[:, i:i + stride * ho:stride, j:j + stride * wo:stride, :]  # (n, ho, wo, ci)
+      out += patch @ w[i, j]
+  return out + b
+
+
+def conv2d_same_input_grad(dy, w, in_shape, stride=2):
+  """d/dx of conv2d_same: scatter dy @ w[i,j]^T back onto the padded input."""
+  n, h, wd, c = in_shape
+  kh, kw, ci, co = w.shape
+  ho, pt, pb = _same_pads(h, kh, stride)
+  wo, pl, pr = _same_pads(wd, kw, stride)
+  dxp = np.zeros((n, h + pt + pb, wd + pl + pr, c), dtype=dy.dtype)
+  for i in range(kh):
+    for j in range(kw):
+      dxp[:, i:i + stride * ho:stride, j:j + stride * wo:stride, :] += dy @ w[i, j].T
+  return dxp[:, pt:pt + h, pl:pl + wd, :]
+
+
+def fully_connected(x, w, b):
+  """ly.fully_connected before the activation; w is (in, out)."""
+  return x @ w + b
+
+
+def conv_names(prefix, n):
+  """ly.conv2d default scopes inside one variable scope: Conv, Conv_1, Conv_2, ..."""
+  return [prefix + ('Conv' if i == 0 else 'Conv_%d' % i) for i in range(n)]
+
+
+def enrich_image_input(cfg, net, states):
+  """util.py:31-36."""
+  if cfg['img_include_states']:
+    planes = states[:, None, None, :] + (net[:, :, :, 0:1] * 0)
+    net = np.concatenate([net, planes], axis=3)
+  return net
+
+
+def feature_extractor(net, output_dim, cfg, weights, prefix, dropout_mask):
+  """agent.py:11-37.  ``prefix`` is the variable scope ('generator/' or 'generator/action_selection/')."""
+  net = net - 0.5
+  min_feature_map_size = 4
+  assert output_dim % (min_feature_map_size**2) == 0
+  size = int(net.shape[2])
+  channels = cfg['base_channels']
+  plan = [channels]
+  size //= 2
+  while size > min_feature_map_size:
+    if size == min_feature_map_size * 2:
+      channels = output_dim // (min_feature_map_size**2)
+    else:
+      channels *= 2
+    assert size % 2 == 0
+    size //= 2
+    plan.append(channels)
+  for name, ch in zip(conv_names(prefix, len(plan)), plan):
+    w, b = weights[name + '/weights'], weights[name + '/biases']
+    assert w.shape[3] == ch, (name, w.shape, ch)
+    net = lrelu(conv2d_same(net, w, b, stride=2))
+  net = net.reshape(-1, output_dim)
+  # tf.nn.dropout(net, keep_prob): always on (agent.py:36)
+  return net / cfg['dropout_keep_prob'] * dropout_mask
+
+
+def extract_parameters(features, weights, scope, num_filter_parameters):
+  """filters.py:28-44 -> (filter features (N,P), mask features (N,6))."""
+  h = lrelu(fully_connected(features, weights[scope + 'fc1/weights'], weights[scope + 'fc1/biases']))
+  f = fully_connected(h, weights[scope + 'fc2/weights'], weights[scope + 'fc2/biases'])
+  return f[:, :num_filter_parameters], f[:, num_filter_parameters:]
+
+
+# ------------------------------------------------------------------------------ agent_generator
+def agent_generator(inp, is_train, progress, cfg, weights, dropout_masks, filter_ids=tuple(range(8))):
+  """agent.py:41-260 with ``cfg.shared_feature_extractor`` (the only branch of the reference that runs:
+  agent.py:63-65 calls ``enrich_image_input(cfg, net)`` with a missing argument) and masking off.
+  Returns ((net, new_states, surrogate, penalty), debug)."""
+  net, z, states = inp
+  k = len(filter_ids)
+  selection_noise = z[:, 0:1]
+  filter_features = feature_extractor(enrich_image_input(cfg, net, states), cfg['feature_extractor_dims'], cfg,
+                                      weights, 'generator/', dropout_masks[0])
+  filtered_images, packed_params = [], []
+  for j, fid in enumerate(filter_ids):
+    f, _mask_parameters = extract_parameters(filter_features, weights, 'generator/filter_%d/' % j, fnp.NUM_PARAMS[fid])
+    packed = fnp.regress_packed(fid, f, cfg)
+    packed_params.append(packed)
+    # Filter.apply with masking off: lerp(img, process(img), ones) (filters.py:86-88, 111-113)
+    filtered_images.append(fnp.lerp(net, fnp.process_packed(fid, net, packed), 1.0))
+  selector_features = feature_extractor(enrich_image_input(cfg, net, states), cfg['feature_extractor_dims'], cfg,
+                                        weights, 'generator/action_selection/', dropout_masks[1])
+  h = lrelu(fully_connected(selector_features, weights['generator/action_selection/selector_fc1/weights'],
+                            weights['generator/action_selection/selector_fc1/biases']))
+  logits = fully_connected(h, weights['generator/action_selection/selector_fc2/weights'],
+                           weights['generator/action_selection/selector_fc2/biases'])
+  pdf, entropy, selected, one_hot, surrogate = agent_np.action_selection(logits, selection_noise, is_train,
+                                                                         cfg['exploration'])
+  out = agent_np.select_filtered(filtered_images, one_hot)
+  new_states, usage_penalty, is_last_step, submitted = agent_np.new_states(states, one_hot, cfg['test_steps'])
+  if cfg['clamp']:
+    out = np.clip(out, 0.0, 5.0)
+  penalty = agent_np.penalty(out, entropy, usage_penalty, is_last_step, submitted, progress, k,
+                             cfg['exploration_penalty'], cfg['filter_usage_penalty'], cfg['early_stop_penalty'])
+  debug = dict(pdf=pdf, logits=logits, selected_filter_id=selected, filter_features=filter_features,
+               selector_features=selector_features, packed_params=packed_params, entropy=entropy)
+  return (out, new_states, surrogate, penalty), debug
+
+
+# ------------------------------------------------------------------------------------ critic
+def stat_features(images):
+  """critics.py:48-73 -> (stats (N,3), cache for the backward)."""
+  lum = images[:, :, :, 0] * 0.27 + images[:, :, :, 1] * 0.67 + images[:, :, :, 2] * 0.06 + 1e-5
+  luminance = lum.mean(axis=(1, 2))
+  contrast = ((lum - luminance[:, None, None])**2).mean(axis=(1, 2))  # tf.nn.moments: population variance
+  clipped = np.clip(images, 0.0, 1.0)
+  i_max = clipped.max(axis=3)
+  i_min = clipped.min(axis=3)
+  a = i_max + i_min
+  b = 2.0 - i_max - i_min
+  denom = np.minimum(a, b) + 1e-2
+  sat = (i_max - i_min) / denom
+  saturation = sat.mean(axis=(1, 2))
+  cache = dict(images=images, lum=luminance, lumpix=lum, clipped=clipped, i_max=i_max, i_min=i_min, a=a, b=b,
+               denom=denom, sat=sat)
+  return np.stack([luminance, contrast, saturation], axis=1), cache
+
+
+def stat_features_backward(cache, dstats):
+  """d (sum_n dstats[n] . stats[n]) / d images."""
+  images = cache['images']
+  n, h, w, _ = images.shape
+  hw = float(h * w)
+  g_lum, g_con, g_sat = dstats[:, 0], dstats[:, 1], dstats[:, 2]
+  # luminance mean + variance: d var / d lum_p = 2 (lum_p - mean) / HW  (the mean's own dependence cancels)
+  dlum = g_lum[:, None, None] / hw + g_con[:, None, None] * 2.0 * (cache['lumpix'] - cache['lum'][:, None, None]) / hw
+  dimg = dlum[..., None] * np.array([0.27, 0.67, 0.06])
+  # saturation
+  dsat = np.broadcast_to(g_sat[:, None, None] / hw, cache['sat'].shape)
+  i_max, i_min, denom = cache['i_max'], cache['i_min'], cache['denom']
+  num = i_max - i_min
+  d_num = dsat / denom
+  d_den = -dsat * num / denom**2
+  use_a = cache['a'] <= cache['b']  # tf.minimum(x=a, y=b): ties -> a
+  d_a = np.where(use_a, d_den, 0.0)
+  d_b = np.where(use_a, 0.0, d_den)
+  d_max = d_num + d_a - d_b
+  d_min = -d_num + d_a - d_b
+  clipped = cache['clipped']
+  is_max = clipped == i_max[..., None]
+  is_min = clipped == i_min[..., None]
+  d_clip = d_max[..., None] * is_max / is_max.sum(axis=3, keepdims=True) + \
+      d_min[..., None] * is_min / is_min.sum(axis=3, keepdims=True)
+  inside = (images >= 0.0) & (images <= 1.0)  # clip_by_value: inclusive both sides
+  return dimg + np.where(inside, d_clip, 0.0)
+
+
+def critic_forward(images, cfg, weights, prefix, states=None):
+  """critics.py:42-98.  ``prefix``: 'critic/' or 'rl_value/critic/'.  Returns (outputs (N,1), cache)."""
+  stats, scache = stat_features(images)
+  st = stats if states is None else np.concatenate([states, stats], axis=1)
+  planes = st[:, None, None, :] + (images[:, :, :, 0:1] * 0)
+  net = np.concatenate([images, planes], axis=3)
+  # cnn (critics.py:6-38)
+  net = net - 0.5
+  channels = cfg['base_channels']
+  size = int(net.shape[2]) // 2
+  plan = [channels]
+  while size > 4:
+    channels *= 2
+    size //= 2
+    plan.append(channels)
+  pre, inputs = [], []
+  for name in conv_names(prefix, len(plan)):
+    inputs.append(net)
+    p = conv2d_same(net, weights[name + '/weights'], weights[name + '/biases'], stride=2)
+    pre.append(p)
+    net = lrelu(p)
+  flat = net.reshape(-1, 4 * 4 * channels)
+  p1 = fully_connected(flat, weights[prefix + 'fully_connected/weights'], weights[prefix + 'fully_connected/biases'])
+  h1 = lrelu(p1)
+  out = fully_connected(h1, weights[prefix + 'fully_connected_1/weights'],
+                        weights[prefix + 'fully_connected_1/biases'])
+  cache = dict(scache=scache, pre=pre, inputs=inputs, p1=p1, conv_out_shape=net.shape, prefix=prefix,
+               n_extra=st.shape[1], n_given=0 if states is None else states.shape[1], plan=plan)
+  return out, cache
+
+
+def critic(images, cfg, weights, prefix='critic/', states=None):
+  return critic_forward(images, cfg, weights, prefix, states)[0]
+
+
+def critic_input_grad(cache, weights, dout=None):
+  """d (sum outputs . dout) / d images, through the conv stack AND the statistics planes
+  (what ``tf.gradients(inte_logit, [interpolated])`` returns, net.py:174-183)."""
+  prefix = cache['prefix']
+  n = cache['p1'].shape[0]
+  dout = np.ones((n, 1)) if dout is None else dout
+  g = dout @ weights[prefix + 'fully_connected_1/weights'].T
+  g = g * lrelu_grad(cache['p1'])
+  g = g @ weights[prefix + 'fully_connected/weights'].T
+  g = g.reshape(cache['conv_out_shape'])
+  names = conv_names(prefix, len(cache['plan']))
+  for name, p, x in zip(reversed(names), reversed(cache['pre']), reversed(cache['inputs'])):
+    g = g * lrelu_grad(p)
+    g = conv2d_same_input_grad(g, weights[name + '/weights'], x.shape, stride=2)
+  # g: gradient w.r.t. concat([images, planes]) - 0.5
+  dimg = g[..., :3].copy()
+  dplanes = g[..., 3:].sum(axis=(1, 2))  # planes are broadcasts of per-image scalars
+  dstats = dplanes[:, cache['n_given']:]  # the last 3 extra channels are the statistics
+  return dimg + stat_features_backward(cache['scache'], dstats)
+
+
+# --------------------------------------------------------------------------------- loss graph
+def generator_losses(fake_input, z, states, progress, cfg, weights, dropout_masks, is_train=1):
+  """net.py:56-165, WGAN branch with use_TD and use_penalty (the shipped configuration)."""
+  (fake_output, new_states, surrogate, penalty), debug = agent_generator((fake_input, z, states), is_train, progress,
+                                                                         cfg, weights, dropout_masks)
+  fake_logit = critic(fake_output, cfg, weights, 'critic/')
+  fake_input_logit = critic(fake_input, cfg, weights, 'critic/')
+  old_value = critic(fake_input, cfg, weights, 'rl_value/critic/', states=states)
+  new_value = critic(fake_output, cfg, weights, 'rl_value/critic/', states=new_states)
+  stopped = new_states[:, STATE_STOPPED_DIM:STATE_STOPPED_DIM + 1]
+  clear_final = (new_states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1] > cfg['maximum_trajectory_length']).astype(
+      fake_input.dtype)
+  new_value = new_value * (1.0 - clear_final)
+  raw_reward = (cfg['all_reward'] + (1 - cfg['all_reward']) * stopped) * (fake_logit - fake_input_logit) * \
+      cfg['critic_logit_multiplier']
+  reward = raw_reward - penalty if cfg['use_penalty'] else raw_reward
+  q_value = reward + (1.0 - stopped) * cfg['discount_factor'] * new_value
+  advantage = q_value - old_value  # tf.stop_gradient(q_value) - old_value: same VALUE
+  v_loss = np.mean(advantage**2)
+  routine_loss = -q_value * cfg['parameter_lr_mul']
+  g_loss = np.mean(routine_loss + surrogate * (-advantage))
+  return dict(g_loss=g_loss, v_loss=v_loss, fake_output=fake_output, new_states=new_states, reward=reward,
+              q_value=q_value, advantage=advantage, fake_logit=fake_logit, penalty=penalty, surrogate=surrogate,
+              old_value=old_value, new_value=new_value, debug=debug)
+
+
+def critic_losses(real_data, fake_output, alpha, cfg, weights):
+  """net.py:126-194: c_loss = mean(fake - real) + lambda mean(max(||grad|| - 1, 0)^2),
+  ||grad|| = sqrt(1e-6 + sum grad^2) at interpolated = real + alpha (fake - real)."""
+  real_logit = critic(real_data, cfg, weights, 'critic/')
+  fake_logit = critic(fake_output, cfg, weights, 'critic/')
+  c_loss = np.mean(fake_logit - real_logit)
+  interpolated = real_data + alpha * (fake_output - real_data)
+  inte_logit, cache = critic_forward(interpolated, cfg, weights, 'critic/')
+  gradients = critic_input_grad(cache, weights)
+  gradient_norm = np.sqrt(1e-6 + np.sum(gradients**2, axis=(1, 2, 3)))
+  gradient_penalty = cfg['gradient_penalty_lambda'] * np.mean(np.maximum(gradient_norm - 1.0, 0.0)**2)
+  total = c_loss + gradient_penalty if cfg['gradient_penalty_lambda'] > 0 else c_loss
+  return dict(c_loss=total, emd=-c_loss, gradient_norm=np.mean(gradient_norm), gradient_penalty=gradient_penalty,
+              c_average=np.mean(fake_logit + real_logit) * 0.5, gradients=gradients, inte_logit=inte_logit)

@@ -1,0 +1,214 @@
+"""Pins oracle/nets_np.py (the float64 restatement of feature_extractor / critic / loss graph,
+agent.py:11-37, critics.py:6-98, net.py:92-194): hand-written backward passes against float64 central
+finite differences, TF SAME-padding arithmetic against an independent implementation (torch's
+cross-correlation with explicit padding), and then the torch modules of exposure_amd -- holding the
+SAME weights -- against the oracle (CPU: the C-ABI binding is mocked by the oracle's filter maths;
+the -m gpu twin of the last part is tests/test_hip_nets.py)."""
+import numpy as np
+import pytest
+import torch
+
+from exposure_amd import checkpoint
+from exposure_amd.config import make_cfg
+from exposure_amd.gan import GAN
+from oracle import nets_np as nn_np
+from tests._fake_hip import fake_hip
+
+
+def small_cfg():
+  return dict(nn_np.DEFAULT_CFG, base_channels=4, source_img_size=16)
+
+
+def random_critic_weights(rng, cfg, prefix, in_ch):
+  w = {}
+  ch, size, cin, i = cfg['base_channels'], cfg['source_img_size'] // 2, in_ch, 0
+  while True:
+    name = nn_np.conv_names(prefix, i + 1)[i]
+    w[name + '/weights'] = rng.normal(size=(4, 4, cin, ch)) * 0.3
+    w[name + '/biases'] = rng.normal(size=(ch,)) * 0.1
+    cin, i = ch, i + 1
+    if size <= 4:
+      break
+    ch, size = ch * 2, size // 2
+  flat = 4 * 4 * cin
+  w[prefix + 'fully_connected/weights'] = rng.normal(size=(flat, cfg['fc1_size'])) * 0.1
+  w[prefix + 'fully_connected/biases'] = rng.normal(size=(cfg['fc1_size'],)) * 0.1
+  w[prefix + 'fully_connected_1/weights'] = rng.normal(size=(cfg['fc1_size'], 1)) * 0.3
+  w[prefix + 'fully_connected_1/biases'] = rng.normal(size=(1,)) * 0.1
+  return w
+
+
+@pytest.mark.parametrize('size,stride', [(8, 2), (7, 2), (5, 1), (64, 2)])
+def test_conv2d_same_matches_independent_cross_correlation(size, stride):
+  rng = np.random.default_rng(size)
+  n = 1 if size == 64 else 2
+  x = rng.normal(size=(n, size, size + (0 if size == 64 else 1), 3))
+  w = rng.normal(size=(4, 4, 3, 5))
+  b = rng.normal(size=(5,))
+  got = nn_np.conv2d_same(x, w, b, stride)
+  # TF SAME: out = ceil(in/stride); pad_total = max((out-1)*stride + k - in, 0); extra pixel AFTER
+  def pads(s):
+    out = -(-s // stride)
+    tot = max((out - 1) * stride + 4 - s, 0)
+    return tot // 2, tot - tot // 2
+  (pt, pb), (pl, pr) = pads(x.shape[1]), pads(x.shape[2])
+  xt = torch.nn.functional.pad(torch.from_numpy(x).permute(0, 3, 1, 2), (pl, pr, pt, pb))
+  ref = torch.nn.functional.conv2d(xt, torch.from_numpy(w).permute(3, 2, 0, 1), torch.from_numpy(b), stride=stride)
+  ref = ref.permute(0, 2, 3, 1).numpy()
+  assert got.shape == ref.shape == (n, -(-x.shape[1] // stride), -(-x.shape[2] // stride), 5)
+  assert np.abs(got - ref).max() < 1e-12
+  if size == 64:  # the networks' case: SAME for k=4, s=2 on even sizes is symmetric padding 1
+    assert (pt, pb, pl, pr) == (1, 1, 1, 1)
+
+
+def test_conv2d_input_grad_matches_finite_differences():
+  rng = np.random.default_rng(1)
+  x = rng.normal(size=(2, 7, 8, 3))
+  w = rng.normal(size=(4, 4, 3, 4))
+  b = rng.normal(size=(4,))
+  dy = rng.normal(size=nn_np.conv2d_same(x, w, b).shape)
+  got = nn_np.conv2d_same_input_grad(dy, w, x.shape)
+  f = lambda xx: float((nn_np.conv2d_same(xx, w, b) * dy).sum())
+  for idx in [(0, 0, 0, 0), (1, 6, 7, 2), (0, 3, 4, 1), (1, 0, 7, 0)]:
+    e = np.zeros_like(x)
+    e[idx] = 1e-5
+    fd = (f(x + e) - f(x - e)) / 2e-5
+    assert abs(fd - got[idx]) < 1e-7 * max(1.0, abs(fd))
+
+
+def test_lrelu_is_the_reference_formula_and_gradient():
+  x = np.array([-2.0, -0.0, 0.0, 3.0])
+  assert np.allclose(nn_np.lrelu(x), [-0.4, 0.0, 0.0, 3.0])
+  assert np.allclose(nn_np.lrelu_grad(x), [0.2, 0.6, 0.6, 1.0])  # abs'(0) = 0 -> f1 at 0
+
+
+def test_stat_features_backward_matches_finite_differences():
+  rng = np.random.default_rng(2)
+  img = rng.random((2, 6, 5, 3)) * 1.3 - 0.1  # some values outside [0,1]
+  dstats = rng.normal(size=(2, 3))
+  _, cache = nn_np.stat_features(img)
+  got = nn_np.stat_features_backward(cache, dstats)
+  f = lambda a: float((nn_np.stat_features(a)[0] * dstats).sum())
+  for idx in [(0, 0, 0, 0), (1, 5, 4, 2), (0, 2, 3, 1), (1, 1, 1, 0), (0, 4, 0, 2)]:
+    e = np.zeros_like(img)
+    e[idx] = 1e-6
+    fd = (f(img + e) - f(img - e)) / 2e-6
+    assert abs(fd - got[idx]) < 1e-6 * max(1.0, abs(fd)), idx
+
+
+@pytest.mark.parametrize('with_states', [False, True])
+def test_critic_input_grad_matches_finite_differences(with_states):
+  cfg = small_cfg()
+  rng = np.random.default_rng(3)
+  nstate = 11 if with_states else 0
+  prefix = 'rl_value/critic/' if with_states else 'critic/'
+  w = random_critic_weights(rng, cfg, prefix, 3 + nstate + 3)
+  img = rng.random((2, 16, 16, 3))
+  states = rng.random((2, nstate)) if with_states else None
+  out, cache = nn_np.critic_forward(img, cfg, w, prefix, states)
+  assert out.shape == (2, 1)
+  got = nn_np.critic_input_grad(cache, w)
+  f = lambda a: float(nn_np.critic(a, cfg, w, prefix, states).sum())
+  worst = 0.0
+  for idx in [(0, 0, 0, 0), (1, 15, 15, 2), (0, 7, 8, 1), (1, 3, 12, 0), (0, 15, 0, 2), (1, 8, 8, 1)]:
+    e = np.zeros_like(img)
+    e[idx] = 1e-6
+    fd = (f(img + e) - f(img - e)) / 2e-6
+    worst = max(worst, abs(fd - got[idx]) / max(1e-3, abs(fd)))
+  assert worst < 1e-5, worst
+
+
+def test_gradient_penalty_is_one_sided_with_the_reference_epsilon():
+  """net.py:186-189: sqrt(1e-6 + sum g^2), max(norm - 1, 0)^2, lambda = 10."""
+  cfg = small_cfg()
+  rng = np.random.default_rng(4)
+  w = random_critic_weights(rng, cfg, 'critic/', 6)
+  real, fake = rng.random((3, 16, 16, 3)), rng.random((3, 16, 16, 3))
+  alpha = rng.random((3, 1, 1, 1))
+  out = nn_np.critic_losses(real, fake, alpha, cfg, w)
+  norm = np.sqrt(1e-6 + (out['gradients']**2).sum(axis=(1, 2, 3)))
+  gp = 10 * np.mean(np.maximum(norm - 1, 0)**2)
+  assert np.isclose(out['gradient_penalty'], gp) and np.isclose(out['gradient_norm'], norm.mean())
+  assert np.isclose(out['c_loss'], -out['emd'] + gp)
+  # zero weights in the last layer -> zero gradient -> norm = 1e-3 exactly, no penalty (one-sided)
+  w0 = dict(w)
+  w0['critic/fully_connected_1/weights'] = np.zeros_like(w['critic/fully_connected_1/weights'])
+  out0 = nn_np.critic_losses(real, fake, alpha, cfg, w0)
+  assert np.isclose(out0['gradient_norm'], 1e-3) and out0['gradient_penalty'] == 0.0
+
+
+# ------------------------------------------------------------------ torch modules vs the oracle
+def make_batch(n, seed, dtype=np.float32):
+  rng = np.random.default_rng(seed)
+  fake_input = (rng.random((n, 64, 64, 3))**2.2).astype(dtype)
+  real = (rng.random((n, 64, 64, 3))).astype(dtype)
+  states = np.zeros((n, 11), dtype=np.float32)
+  states[:, 2] = rng.integers(0, 7, n)  # step (some == 4 -> last step; some > trajectory length after +1)
+  states[-1, 2] = 7
+  states[:, 3:] = (rng.random((n, 8)) < 0.3)
+  z = rng.random((n, 131)).astype(np.float32)
+  masks = [(rng.random((n, 4096)) < 0.5).astype(np.float32) for _ in range(2)]
+  alpha = rng.random((n, 1, 1, 1)).astype(np.float32)
+  return fake_input, real, states, z, masks, alpha
+
+
+def compare_gan_with_oracle(gan, dev, n=4, seed=11, rel=1e-4):
+  """Shared by the CPU (mocked C-ABI) and GPU (HIP library) tests."""
+  cfg = nn_np.DEFAULT_CFG
+  weights = {k: v.astype(np.float64) for k, v in checkpoint.export_tf_dict(gan).items()}
+  fake_input, real, states, z, masks, alpha = make_batch(n, seed)
+  t = lambda a: torch.from_numpy(a).to(dev)
+  d = lambda a: a.astype(np.float64)
+  progress = 0.3
+  # --- features / logits (rows a-12, a-13)
+  ag = gan.generator
+  from exposure_amd.util import enrich_image_input
+  enriched = enrich_image_input(gan.cfg, t(fake_input), t(states))
+  feats = ag.filter_features(enriched, t(masks[0])).detach().cpu().numpy()
+  o_feats = nn_np.feature_extractor(nn_np.enrich_image_input(cfg, d(fake_input), d(states)), 4096, cfg, weights,
+                                    'generator/', d(masks[0]))
+  scale = np.abs(o_feats).max()
+  assert np.abs(feats - o_feats).max() <= rel * scale, ('feature_extractor', np.abs(feats - o_feats).max(), scale)
+  # --- critic / value logits (row a-14)
+  logit = gan.critic(t(fake_input)).detach().cpu().numpy()
+  o_logit = nn_np.critic(d(fake_input), cfg, weights, 'critic/')
+  assert np.abs(logit - o_logit).max() <= rel * max(1.0, np.abs(o_logit).max())
+  value = gan.value(t(fake_input), t(states)).detach().cpu().numpy()
+  o_value = nn_np.critic(d(fake_input), cfg, weights, 'rl_value/critic/', states=d(states))
+  assert np.abs(value - o_value).max() <= rel * max(1.0, np.abs(o_value).max())
+  # --- generator / value losses (row a-15)
+  out = gan.generator_losses(t(fake_input), t(z), t(states), progress, 1, [t(m) for m in masks])
+  ref = nn_np.generator_losses(d(fake_input), d(z), d(states), progress, cfg, weights, [d(m) for m in masks], 1)
+  ids = out['debug']['selected_filter_ids'].cpu().numpy()
+  assert ids.dtype == np.int32 and np.array_equal(ids, ref['debug']['selected_filter_id'])
+  assert np.array_equal(out['new_states'].detach().cpu().numpy(), ref['new_states'])
+  img_tol = 1e-3 + 1e-3 * np.abs(ref['fake_output'])
+  assert (np.abs(out['fake_output'].detach().float().cpu().numpy() - ref['fake_output']) <= img_tol).all()
+  for key in ('reward', 'q_value', 'fake_logit'):
+    got = out[key].detach().cpu().numpy()
+    assert np.abs(got - ref[key]).max() <= rel * max(1.0, np.abs(ref[key]).max()), key
+  for key in ('g_loss', 'v_loss'):
+    got = float(out[key].detach())
+    assert abs(got - ref[key]) <= rel * max(1.0, abs(ref[key])), (key, got, ref[key])
+  # --- critic loss with the gradient penalty (double backward in torch, hand backward in the oracle)
+  c = gan.critic_losses(t(real), t(fake_input), t(alpha))
+  rc = nn_np.critic_losses(d(real), d(fake_input), d(alpha), cfg, weights)
+  for key in ('c_loss', 'emd', 'gradient_norm', 'gradient_penalty', 'c_average'):
+    got = float(c[key].detach())
+    assert abs(got - rc[key]) <= rel * max(1.0, abs(rc[key])), (key, got, rc[key])
+  return dict(g_loss=float(out['g_loss'].detach()), c_loss=float(c['c_loss'].detach()),
+              gradient_norm=float(c['gradient_norm'].detach()))
+
+
+def test_torch_nets_and_losses_match_oracle_cpu():
+  torch.manual_seed(0)
+  cfg = make_cfg()
+  gan = GAN(cfg)
+  with torch.no_grad():  # non-trivial biases and a gradient norm above 1 somewhere (exercise the penalty)
+    for p in gan.parameters():
+      if p.dim() == 1:
+        p.normal_(0.0, 0.05)
+    gan.critic.fc2.weight.mul_(40.0)
+  with fake_hip():
+    res = compare_gan_with_oracle(gan, torch.device('cpu'))
+  assert res['gradient_norm'] > 1e-3
