@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """Headline benchmark: Mpixels/s through the 8-step filter chain, forward + backward.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N --steps K --warmup W          (N > 1: re-launches itself as N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W                  (same thing, external launcher)
+  --workload chain|train|infer|allreduce   --scaling weak|strong        (SURVEY.md 8(e) scaling report rows)
 
 One "step" = one pass of the hot path over one synthetic batch: the 8 filters of cfg.filters
 (E,G,W,S+,T,Ct,BW,C; /root/reference/config_example.py:22-25) applied sequentially, one HIP
@@ -51,6 +52,15 @@ def parse():
   ap.add_argument('--workload', default='chain', choices=['chain', 'train', 'infer', 'allreduce'],
                   help="chain: the headline filter-chain metric; train: one reference training iteration "
                   "(1 generator/value step + cfg.citers critic steps, net.py:307-365) on 64 images per GPU")
+  ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                  help='weak: every rank runs the full batch shape (per-GPU work fixed); strong: the global batch '
+                  '(--shape N / cfg.batch_size) is split image-wise over the ranks (total work fixed)')
+  ap.add_argument('--dry-run', action='store_true',
+                  help='launcher / rendezvous check without a GPU: ranks meet over gloo and rank 0 prints the line '
+                  'with value 0 (CPU test of the self-launch path)')
+  ap.add_argument('--cold-shape', default='256,512,512',
+                  help="chain workload: also time the dominant kernel on tensors of this shape (384 MiB each, beyond "
+                  "the 256 MiB Infinity Cache) for roofline.hbm_cold; 'none' disables")
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                   help='replay the 17 launches of a step from one hipGraph (auto = on; off: eager C-ABI calls)')
   return ap.parse_args()
@@ -93,6 +103,7 @@ class Chain:
 
     self.graph = None
     self.unroll = 1
+    self.launches_per_step = 2 * len(self.ids) + 1  # 8 fwd + 1 dparams fill + 8 bwd
 
   def launch(self):
     _cabi.chain_fwd(self.ids, self.acts, self.params)
@@ -169,30 +180,14 @@ def time_kernels(chain, reps):
 
 
 def cpu_baseline():
-  """torch-CPU fp32 op-by-op restatement (oracle/filters_torch.py) timed on the host cores on a
-  bounded sample (4x512x512x3 = 1 Mpixel per pass).  torch's intra-op pool does not scale to every
-  core of a big host for this op mix, so a few thread counts are tried (1 warm-up + best of 2 each)
-  and the best is reported together with the thread count that produced it."""
+  """the torch-CPU fp32 op-by-op restatement (oracle/filters_torch.py, autograd
+  backward -- the granularity at which TF-1 executes the reference graph) timed on the host cores on the
+  same synthetic workload: shapes A (64x64x64x3) and B (16x512x512x3), chain fwd-only and fwd+bwd, best of
+  5 after 2 warm-ups, once with every logical CPU (torch.set_num_threads(os.cpu_count())) and once per
+  thread count of a small sweep (torch's intra-op pool does not scale to every core of a big host for this
+  op mix).  `value` = the best fwd+bwd rate on shape B; ~10-20 s of CPU work in total."""
   from oracle import filters_torch as ft
   ncpu = os.cpu_count() or 1
-  shape = (4, 512, 512, 3)
-  x, dy, params = synthetic.make_case(1234, shape, np.float16)
-  tx = torch.from_numpy(x.astype(np.float32))
-  tdy = torch.from_numpy(dy.astype(np.float32))
-  tp = [torch.from_numpy(p) for p in params]
-  px = shape[0] * shape[1] * shape[2]
-  best, best_threads = float('inf'), 1
-  t_start = time.perf_counter()
-  for threads in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)}):
-    torch.set_num_threads(threads)
-    for it in range(3):
-      t0 = time.perf_counter()
-      ft.chain_fwd_bwd(tx, tp, tdy)
-      dt = time.perf_counter() - t0
-      if it > 0 and dt < best:
-        best, best_threads = dt, threads
-    if time.perf_counter() - t_start > 25.0:
-      break
   model = ''
   try:
     for line in open('/proc/cpuinfo'):
@@ -201,23 +196,72 @@ def cpu_baseline():
         break
   except OSError:
     pass
+  sweep = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8), ncpu})
+  t_start = time.perf_counter()
+  by_shape = {}
+  for name in ('A', 'B'):
+    shape = synthetic.SHAPES[name]
+    x, dy, params = synthetic.make_case(1234, shape, np.float16)
+    tx = torch.from_numpy(x.astype(np.float32))
+    tdy = torch.from_numpy(dy.astype(np.float32))
+    tp = [torch.from_numpy(p) for p in params]
+    px = shape[0] * shape[1] * shape[2]
+
+    def fwd_only():
+      with torch.no_grad():
+        cur = tx
+        for fid, p in enumerate(tp):
+          cur = ft.process_packed(fid, cur, p)
+      return cur
+
+    rows = {}
+    for threads in sweep:
+      if time.perf_counter() - t_start > 40.0 and rows:  # bound the whole leg on slow hosts
+        break
+      torch.set_num_threads(threads)
+      best = {}
+      for kind, fn in (('fwd_bwd', lambda: ft.chain_fwd_bwd(tx, tp, tdy)), ('fwd', fwd_only)):
+        times = []
+        for it in range(7):
+          t0 = time.perf_counter()
+          fn()
+          times.append(time.perf_counter() - t0)
+        best[kind] = px / min(times[2:]) / 1e6  # best of 5 after 2 warm-ups
+      rows[threads] = best
+    bt = max(rows, key=lambda t: rows[t]['fwd_bwd'])
+    by_shape[name] = {
+        'shape': 'x'.join(str(v) for v in shape),
+        'best_threads': bt,
+        'fwd_bwd_Mpixels_per_s': rows[bt]['fwd_bwd'],
+        'fwd_Mpixels_per_s': rows[bt]['fwd'],
+        'all_cores_threads': ncpu if ncpu in rows else None,
+        'all_cores_fwd_bwd_Mpixels_per_s': rows[ncpu]['fwd_bwd'] if ncpu in rows else None,
+        'sweep_fwd_bwd': {str(t): r['fwd_bwd'] for t, r in rows.items()},
+    }
+  b = by_shape['B']
   return {
-      'value': px / best / 1e6,
+      'value': b['fwd_bwd_Mpixels_per_s'],
       'unit': 'Mpixels/s',
-      'cores': best_threads,
+      'cores': b['best_threads'],
       'kind': 'port',
-      'sample': 'CPU restatement (torch fp32 op-by-op, best of {8,16,32,64} threads = %d, host %s with %d '
-                'logical CPUs): 8-step chain fwd+bwd on 4x512x512x3, best of 2 after 1 warm-up' %
-                (best_threads, model or 'unknown CPU', ncpu),
+      'sample': 'CPU restatement (torch fp32 op-by-op, autograd backward; never TF1) on host %s with %d logical CPUs: '
+                '8-step chain fwd+bwd on 16x512x512x3 (4.19 Mpixel per pass), best of 5 after 2 warm-ups, best '
+                'thread count of %s = %d; by_shape also holds 64x64x64x3, fwd-only and the all-core run' %
+                (model or 'unknown CPU', ncpu, sweep, b['best_threads']),
+      'by_shape': by_shape,
+      'seconds': time.perf_counter() - t_start,
   }
 
 
-def load_traffic(kernel):
-  """Per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+def load_traffic(kernel, shape, dtype):
+  """Per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/traffic.json), keyed by
+  the workload they were collected on ("64x512x512x3:f16"); None when no PMC pass exists for THIS
+  shape / dtype (a number measured on another shape would be wrong, not approximate)."""
   path = os.path.join(ROOT, 'profiles', 'traffic.json')
+  key = '%s:%s' % ('x'.join(str(v) for v in shape), dtype)
   try:
-    return json.load(open(path)).get(kernel)
-  except (OSError, ValueError):
+    return json.load(open(path)).get(key, {}).get(kernel)
+  except (OSError, ValueError, AttributeError):
     return None
 
 
@@ -245,7 +289,8 @@ def run_train(args, world, rank, dev, dist):
   cfg = make_cfg()
   torch.manual_seed(args.seed)  # identical initial weights on every rank
   gan = GAN(cfg, device=dev, use_graphs=(args.graph != 'off'))
-  n = cfg.batch_size
+  # weak: cfg.batch_size (64) images per GPU; strong: the reference's global batch of 64 split image-wise
+  n = local_shape((cfg.batch_size,), world, args.scaling)[0]
   from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
   pool_dtype = torch.float16 if args.dtype == 'f16' else torch.float32
   memory = ReplayMemory(cfg, SyntheticProvider(dev, dtype=pool_dtype, seed=args.seed + 10 * rank + 1),
@@ -297,7 +342,7 @@ def run_train(args, world, rank, dev, dist):
         'warmup': args.warmup,
         'ms_per_step': ms,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': args.scaling,
         'vs_baseline': None,
         'dtype': '%s images / f32 nets' % args.dtype,
         'data': 'synthetic',
@@ -363,7 +408,7 @@ def run_allreduce(args, world, rank, dev, dist):
         'warmup': args.warmup,
         'ms_per_step': ms,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': args.scaling,
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
@@ -383,7 +428,7 @@ def run_infer(args, world, rank, dev, dist):
   """BASELINE config 5: high-resolution inference, 16x512x512x3 fp16, the 8 filters of cfg.filters
   applied to every image -- (a) one kernel per step (8 reads + 8 writes of the image), (b) the fused
   multi-step forward (1 read + 1 write).  Forward only."""
-  shape = parse_shape(args.shape or 'B')
+  shape = local_shape(parse_shape(args.shape or 'B'), world, args.scaling)
   dtype = torch.float16 if args.dtype == 'f16' else torch.float32
   esz = 2 if args.dtype == 'f16' else 4
   x, _dy, params = make_device_case(shape, dtype, dev, args.seed + rank)
@@ -428,7 +473,7 @@ def run_infer(args, world, rank, dev, dist):
         'warmup': args.warmup,
         'ms_per_step': t_fused * 1e3,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': args.scaling,
         'vs_baseline': None,
         'dtype': args.dtype,
         'data': 'synthetic',
@@ -448,13 +493,101 @@ def run_infer(args, world, rank, dev, dist):
     dist.destroy_process_group()
 
 
+def self_launch(args):
+  """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this same command
+  (one process per GPU, `torch.distributed.run`, rendezvous on 127.0.0.1) and return their exit code.  Rank 0
+  of the children prints the ONE JSON line; it passes straight through to our stdout."""
+  import socket
+  import subprocess
+  with socket.socket() as sock:
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC (RCCL across processes on this driver)
+  env.setdefault('OMP_NUM_THREADS', '8')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
+def run_dry(args, world, rank):
+  """--dry-run: no GPU is touched.  The ranks meet over gloo, agree on the slowest rank's (empty) timed
+  region exactly like the real path does, and rank 0 prints the line -- the CPU test of the launcher."""
+  import torch.distributed as dist
+  if world > 1 or 'LOCAL_RANK' in os.environ:
+    dist.init_process_group('gloo')
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert int(t.item()) == world - 1
+    dist.barrier()
+  if rank == 0:
+    print(json.dumps({
+        'metric': 'Mpixels/s through 8-step filter chain fwd+bwd', 'value': 0.0, 'unit': 'Mpixels/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 0.0, 'higher_is_better': True,
+        'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'dry_run': True,
+        'config': {'workload': 'dry run of the %s workload launcher (no GPU work)' % args.workload},
+    }))
+  if dist.is_initialized():
+    dist.destroy_process_group()
+
+
+def local_shape(shape, world, scaling):
+  """weak: the full batch shape on every rank; strong: the global batch split image-wise."""
+  if scaling == 'weak' or world == 1:
+    return tuple(shape)
+  if shape[0] % world:
+    raise SystemExit('--scaling strong: global batch %d is not divisible by %d ranks' % (shape[0], world))
+  return (shape[0] // world,) + tuple(shape[1:])
+
+
+def time_cold(args, dev, dom, ids):
+  """roofline.hbm_cold: the dominant kernel's launch time on tensors far beyond the 256 MiB Infinity Cache
+  (default 256x512x512x3: 384 MiB per tensor, 4.6 GB for the chain), measured exactly like `per_kernel`."""
+  if args.cold_shape in ('none', '', None):
+    return None
+  shape = parse_shape(args.cold_shape)
+  dtype = torch.float16 if args.dtype == 'f16' else torch.float32
+  esz = 2 if args.dtype == 'f16' else 4
+  try:
+    chain = Chain(shape, dtype, dev, args.seed + 77, ids)
+    chain.launch()
+    per = time_kernels(chain, max(5, args.kernel_reps // 5))
+  except RuntimeError as e:  # e.g. out of memory on a shared device: report nothing rather than die
+    print('warning: cold-shape measurement skipped (%s)' % e, file=sys.stderr)
+    return None
+  finally:
+    torch.cuda.empty_cache()
+  px = shape[0] * shape[1] * shape[2]
+  gbps = lambda k: (2 if k.startswith('fwd') else 3) * 3 * esz * px / (per[k] * 1e-3) / 1e9
+  chain_ms = sum(per.values())
+  return {
+      'shape': 'x'.join(str(v) for v in shape),
+      'tensor_MiB': px * 3 * esz / 2**20,
+      'kernel': dom,
+      'achieved': gbps(dom),
+      'frac': gbps(dom) / HBM_PEAK_GBPS,
+      'avg_launch_ms': per[dom],
+      'slowest_kernel': min(per, key=gbps),
+      'slowest_achieved': min(gbps(k) for k in per),
+      'chain_achieved': 8 * 5 * 3 * esz * px / (chain_ms * 1e-3) / 1e9,
+      'note': 'HIP-event pairs around every launch (~2.3 us each included); chain_achieved = 240 B/px over the sum '
+              'of the 16 launch times',
+  }
+
+
 def main():
   args = parse()
+  if args.gpus > 1 and 'LOCAL_RANK' not in os.environ and 'RANK' not in os.environ:
+    raise SystemExit(self_launch(args))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if args.dry_run:
+    return run_dry(args, world, rank)
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
+  if local_rank >= torch.cuda.device_count():
+    raise SystemExit('rank %d: only %d GPU(s) visible' % (local_rank, torch.cuda.device_count()))
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
   dist = None
@@ -470,10 +603,12 @@ def main():
   if args.workload == 'allreduce':
     return run_allreduce(args, world, rank, dev, dist)
 
-  shape = parse_shape(args.shape or 'C')
+  gshape = parse_shape(args.shape or 'C')
+  shape = local_shape(gshape, world, args.scaling)
   dtype = torch.float16 if args.dtype == 'f16' else torch.float32
   esz = 2 if args.dtype == 'f16' else 4
-  chain = Chain(shape, dtype, dev, args.seed + rank, [int(v) for v in args.order.split(',')])
+  ids = [int(v) for v in args.order.split(',')]
+  chain = Chain(shape, dtype, dev, args.seed + rank, ids)
   px = shape[0] * shape[1] * shape[2]
   # One hipGraph replay per step by default.  Small shapes are launch-bound (17 launches in 87 us
   # eagerly vs 57 us replayed at 64x64x64); at 64x512x512 eager launches are ~0.5 % faster in a
@@ -509,6 +644,7 @@ def main():
     elapsed = float(t.item())
   ms_per_step = elapsed / args.steps * 1e3
   value = world * px / (elapsed / args.steps) / 1e6
+  launches = chain.launches_per_step
 
   result = {
       'metric': 'Mpixels/s through 8-step filter chain fwd+bwd',
@@ -519,7 +655,7 @@ def main():
       'warmup': args.warmup,
       'ms_per_step': ms_per_step,
       'higher_is_better': True,
-      'scaling': 'weak',
+      'scaling': args.scaling,
       'vs_baseline': None,
       'dtype': args.dtype,
       'data': 'synthetic',
@@ -527,10 +663,11 @@ def main():
           'workload': '8-step filter chain (E,G,W,S+,T,Ct,BW,C) fwd+bwd, %dx%dx%dx3 %s NHWC per GPU, one HIP '
                       'kernel per filter step and direction' % (shape[0], shape[1], shape[2], args.dtype),
           'batch_per_gpu': shape[0],
+          'global_batch': shape[0] * world,
           'height': shape[1],
           'width': shape[2],
-          'parallelism': 'image-sharded replicas x%d (no data-path collective)' % world,
-          'launch': ('hipGraph replay, %d steps (%d captured launches) per replay' % (chain.unroll, 17 * chain.unroll)) if chain.graph is not None else 'eager (one C-ABI call per direction)',
+          'parallelism': 'image-sharded replicas x%d (no data-path collective), %s scaling' % (world, args.scaling),
+          'launch': ('hipGraph replay, %d steps (%d captured launches) per replay' % (chain.unroll, launches * chain.unroll)) if chain.graph is not None else 'eager (one C-ABI call per direction)',
           'chain_algorithmic_GBps': 8 * 5 * 3 * esz * px / (elapsed / args.steps) / 1e9 * 1.0,
       },
   }
@@ -540,6 +677,7 @@ def main():
     dom = max(per, key=per.get)
     bpp = (2 if dom.startswith('fwd') else 3) * 3 * esz  # algorithmic bytes per pixel per launch
     achieved = bpp * px / (per[dom] * 1e-3) / 1e9
+    tensor_mib = px * 3 * esz / 2**20
     result['roofline'] = {
         'bound': 'hbm',
         'kernel': dom,
@@ -547,13 +685,18 @@ def main():
         'peak': HBM_PEAK_GBPS,
         'unit': 'GB/s',
         'frac': achieved / HBM_PEAK_GBPS,
-        'traffic': load_traffic(dom),
+        'traffic': load_traffic(dom, shape, args.dtype),
         'avg_launch_ms': per[dom],
-        'peak_note': 'spec 8.0 TB/s; frac_of_copy_ceiling is against the 6.29 TB/s default-policy float4 copy of '
-                     'MI355X_MICROARCH.md (nt loads + sc1 stores reach 7.0-7.7 TB/s: tools/membench, DESIGN.md 3.1)',
+        # 12 tensors of this size cycle through a 256 MiB Infinity Cache (MALL): below ~256 MiB per tensor the
+        # consumer of a just-written tensor is partly served from it, so `achieved` is an EFFECTIVE bandwidth
+        # (FETCH_SIZE/WRITE_SIZE count MALL hits too); `hbm_cold` is the same kernel on 384 MiB tensors
+        'regime': 'mall_assisted' if tensor_mib < 256 else 'hbm_cold',
+        'peak_note': 'spec 8.0 TB/s HBM3E. Measured copy ceilings of this access pattern (tools/membench, '
+                     'profiles/r02_membench_*.txt): 7.0-7.7 TB/s on 96 MiB buffers (Infinity-Cache assisted), '
+                     '5.4-5.9 TB/s on 512-1024 MiB buffers (HBM-cold); guide float4 copy 6.29 TB/s',
         'frac_of_copy_ceiling': achieved / 6290.0,
         'algorithmic_bytes_per_launch': bpp * px,
-        # the whole timed region (16 kernels + 1 fill per step): 240 B/pixel/step over the step time
+        # the whole timed region (16 kernels per step): 240 B/pixel/step over the step time
         'chain_achieved': result['config']['chain_algorithmic_GBps'],
         'chain_frac': result['config']['chain_algorithmic_GBps'] / HBM_PEAK_GBPS,
     }
@@ -563,6 +706,11 @@ def main():
             'GBps': (2 if k.startswith('fwd') else 3) * 3 * esz * px / (v * 1e-3) / 1e9
         } for k, v in per.items()
     }
+    if world == 1 and tensor_mib < 256:
+      del chain  # free the 1.2 GB of the timed chain before the 4.6 GB cold one
+      cold = time_cold(args, dev, dom, ids)
+      if cold is not None:
+        result['roofline']['hbm_cold'] = cold
   barrier()
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     result['cpu_baseline'] = cpu_baseline()

@@ -21,8 +21,8 @@ def test_traffic_json_matches_the_committed_counters(tmp_path):
   out = tmp_path / 'traffic.json'
   subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'make_traffic.py'), str(d), str(out)], check=True,
                  capture_output=True)
-  derived = json.load(open(out))
-  committed = json.load(open(os.path.join(PROF, 'traffic.json')))
+  derived = json.load(open(out))['64x512x512x3:f16']
+  committed = json.load(open(os.path.join(PROF, 'traffic.json')))['64x512x512x3:f16']
   keys = sorted(k for k in committed if not k.startswith('_'))
   assert len(keys) == 16 and keys == sorted(k for k in derived if not k.startswith('_'))
   for k in keys:

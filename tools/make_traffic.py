@@ -1,6 +1,10 @@
 """profiles/traffic.json (HBM bytes per launch, read by bench.py for roofline.traffic) from the
 FETCH_SIZE / WRITE_SIZE CSVs that tools/profile_all.sh produced.
-usage: python tools/make_traffic.py gpurun_out/final [out.json]
+usage: python tools/make_traffic.py gpurun_out/final [out.json [workload-key [px]]]
+
+The file is keyed by the workload the counters were collected on ("64x512x512x3:f16", the default);
+an existing file's other keys are kept, so passes on several shapes accumulate.  bench.py reports
+roofline.traffic = null for a shape / dtype without an entry.
 
 traffic = kf * FETCH_SIZE * 1024 + kw * WRITE_SIZE * 1024.  The factors are calibrated in the same
 run on tools/membench kernels that move a known byte count with the same dwordx3 access pattern and
@@ -28,7 +32,7 @@ def calib(rows, counter, kernel, known_bytes):
   raise SystemExit('calibration kernel %s not found' % kernel)
 
 
-def main(d, out):
+def main(d, out, wkey='64x512x512x3:f16'):
   kf_c = calib(read(d + '/pmc_fetch_size_calibration.csv'), 'FETCH_SIZE', 'void cpol<2, 16>', MIB96)
   kf_r = calib(read(d + '/pmc_fetch_size_calibration.csv'), 'FETCH_SIZE', 'void rpol<2, 2, 16>', 2 * MIB96)
   kw_c = calib(read(d + '/pmc_write_size_calibration.csv'), 'WRITE_SIZE', 'void cpol<2, 16>', MIB96)
@@ -53,10 +57,20 @@ def main(d, out):
                      'dwordx3 access pattern and cache policy (measured factors: cpol<2,16> fetch %.4f write %.4f; '
                      'rpol<2,2,16> fetch %.4f write %.4f). Algorithmic bytes: fwd 201 326 592, bwd 301 989 888.'
                      % (kf, kw, kf_c, kw_c, kf_r, kw_r)}
-  doc.update(traffic)
+  try:
+    old = json.load(open(out))
+  except (OSError, ValueError):
+    old = {}
+  merged = {k: v for k, v in old.items() if isinstance(v, dict)}
+  merged[wkey] = dict(traffic, _calibration=doc['_comment'])
+  doc = {'_comment': 'HBM bytes per launch by workload key "NxHxWx3:dtype" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in '
+                     'separate passes; traffic = kf*FETCH_SIZE*1024 + kw*WRITE_SIZE*1024, factors calibrated in-run: '
+                     'see _calibration of each entry)'}
+  doc.update(merged)
   json.dump(doc, open(out, 'w'), indent=1)
   print(json.dumps(doc, indent=1))
 
 
 if __name__ == '__main__':
-  main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'profiles/traffic.json')
+  main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'profiles/traffic.json',
+       sys.argv[3] if len(sys.argv) > 3 else '64x512x512x3:f16')
