@@ -130,6 +130,10 @@ class Agent(nn.Module):
     img_shape = img_shape or (1, s, s, cfg.real_img_channels)
     self.filters = nn.ModuleList([x(img_shape, cfg) for x in cfg.filters])  # agent.py:45
     in_ch = cfg.real_img_channels + (cfg.num_state_dim if cfg.img_include_states else 0)
+    # agent.py:62-65: the non-shared branch calls enrich_image_input(cfg, net) with a missing argument,
+    # i.e. it raises a TypeError in the reference itself -- there is nothing to mirror
+    # agent.py:62-65: the non-shared branch calls enrich_image_input(cfg, net) with a missing argument, i.e.
+    # it raises a TypeError in the reference itself -- there is nothing to mirror
     assert cfg.shared_feature_extractor, 'only the shared feature extractor of the shipped configs is built'
     self.filter_features = FeatureExtractor(in_ch, cfg.feature_extractor_dims, cfg)
     self.selector_features = FeatureExtractor(in_ch, cfg.feature_extractor_dims, cfg)
@@ -143,12 +147,30 @@ class Agent(nn.Module):
                          persistent=False)
 
   def regress_all(self, filter_features):
-    """Per-filter FC heads + range squashing -> list of reference-shaped parameter tensors."""
-    out = []
+    """Per-filter FC heads + range squashing -> (reference-shaped parameter tensors, raw mask parameters)."""
+    out, mask_params = [], []
     for filt in self.filters:
-      f, _mask_params = filt.extract_parameters(filter_features)
+      f, mp = filt.extract_parameters(filter_features)
       out.append(filt.filter_param_regressor(f))
-    return out
+      mask_params.append(mp)
+    return out, mask_params
+
+  def _apply_masked(self, net, params, mask_params, filter_one_hot):
+    """cfg.masking = True (off in both shipped configs): the reference's own schedule -- every filter's
+    masked ``apply`` on the whole batch (one fused HIP kernel each: mask + process + lerp,
+    ``expo_filter_apply_fwd``), stacked and reduced with the one-hot (agent.py:58-77, 119-125).  The
+    dispatch-by-id kernels carry no mask parameters, so this path trades the 8x image work back for
+    correct mask gradients; the proxies are 64x64."""
+    from .util import tanh_range
+    cfg = self.cfg
+    out = None
+    for j, (filt, p, mp) in enumerate(zip(self.filters, params, mask_params)):
+      yj = F._MaskedApplyFunction.apply(net, filt.pack(p), tanh_range(-5, 5, initial=0)(mp), filt.filter_id,
+                                        float(cfg.maximum_sharpness), float(cfg.minimum_strength),
+                                        int(cfg.get('hsv_grad_mode', 0)))
+      term = yj.float() * filter_one_hot[:, j, None, None, None]
+      out = term if out is None else out + term
+    return out.to(net.dtype)
 
   def action_pdf(self, selector_features):
     """agent.py:87-107 -> (pdf, entropy)."""
@@ -170,7 +192,7 @@ class Agent(nn.Module):
 
     enriched = enrich_image_input(cfg, net.float(), states)
     filter_features = self.filter_features(enriched, masks[0])
-    params = self.regress_all(filter_features)  # 8 x reference-shaped
+    params, mask_params = self.regress_all(filter_features)  # 8 x reference-shaped, 8 x (N, 6)
 
     selector_features = self.selector_features(enriched, masks[1])
     pdf, entropy = self.action_pdf(selector_features)
@@ -191,10 +213,16 @@ class Agent(nn.Module):
     hsv_mode = int(cfg.get('hsv_grad_mode', 0))
     abi_ids = torch.where(selected_filter_id >= 0, self.abi_filter_ids[selected_filter_id.clamp_min(0).long()],
                           torch.full_like(selected_filter_id, -1))
-    out, overexposure = F.dispatch_filters(net, params24, abi_ids, hsv_mode)
     high_res_output = None
-    if high_res is not None:
-      high_res_output, _ = F.dispatch_filters(high_res, params24, abi_ids, hsv_mode)
+    if cfg.masking:
+      out = self._apply_masked(net, params, mask_params, filter_one_hot)
+      overexposure = (torch.clamp_min(out.float() - 1.0, 0.0)**2).mean(dim=(1, 2, 3))
+      if high_res is not None:
+        high_res_output = self._apply_masked(high_res, params, mask_params, filter_one_hot)
+    else:
+      out, overexposure = F.dispatch_filters(net, params24, abi_ids, hsv_mode)
+      if high_res is not None:
+        high_res_output, _ = F.dispatch_filters(high_res, params24, abi_ids, hsv_mode)
 
     debug_info = {
         'state': states,

@@ -7,7 +7,8 @@ four conv4x4/s2 + lrelu, no norm) -> FC128 lrelu -> FC1.
 The statistics are computed with differentiable torch ops inside the training graph (the
 gradient-penalty term needs a double backward through everything the critic does to its input,
 net.py:174-194); :func:`critic_stats` is the fused HIP reduction (``expo_critic_stats``) for
-inference-side callers.  ``lrelu`` is written ``0.6 x + 0.4 |x|`` so the double backward exists.
+inference-side callers.  ``lrelu`` (``util.py:225-229``: ``0.6 x + 0.4 |x|``) is one fused forward kernel with a
+differentiable backward (``exposure_amd.util._Lrelu``), so the double backward exists.
 """
 import torch
 from torch import nn

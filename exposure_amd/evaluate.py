@@ -59,6 +59,8 @@ def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trac
   every step also filters the full-resolution tensor and feeds it back -- identical maths, one
   fp16 rounding per step, ``steps`` times the HBM traffic."""
   cfg = agent.cfg
+  if cfg.masking:
+    fused = False  # the spatial mask depends on the running image: no parameters-only replay
   steps = steps or cfg.test_steps
   n = high_res.shape[0]
   dev = high_res.device
@@ -72,16 +74,19 @@ def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trac
     masks = dropout_masks[i] if dropout_masks is not None else None
     if fused:
       (low, states, _s, _p), dbg, _ = agent((low, z, states), is_train=0, progress=0.0, dropout_masks=masks)
-      abi_ids.append(dbg['abi_filter_ids'])
-      params.append(dbg['params24'])
     else:
       (low, states, hi), dbg, _ = agent((low, z, states), is_train=0, progress=0.0, high_res=hi,
                                         dropout_masks=masks)
+    abi_ids.append(dbg['abi_filter_ids'])
+    params.append(dbg['params24'])
     trace.append(dbg['selected_filter_ids'].clone())
     if bool((states[:, STATE_STOPPED_DIM] > 0).all()):
       break
   if fused:
     hi = fused_chain(hi, torch.stack(abi_ids, dim=1), torch.stack(params, dim=1))
+  if return_trace == 'full':  # the per-step operations (what net.py:825-877 pickles as decisions / operations)
+    return hi, low, states, dict(selected=torch.stack(trace, dim=1), abi_filter_ids=torch.stack(abi_ids, dim=1),
+                                 params24=torch.stack(params, dim=1))
   if return_trace:
     return hi, low, states, torch.stack(trace, dim=1)
   return hi, low, states
@@ -89,41 +94,103 @@ def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trac
 
 def load_image(path):
   """net.py:726-747: ``.tif`` -> 16-bit ProPhoto, linearised (x**1.8); anything else readable by
-  PIL -> 8-bit sRGB-ish, ``/255``, ``**2.2``, scaled by ``1 / (2 max)``."""
+  PIL -> sRGB-ish: ``/255`` (uint8) or ``/65535`` (uint16), ``**2.2``, scaled by ``1 / (2 max)``."""
   import numpy as np
   if path.lower().endswith(('.tif', '.tiff')):
     from .tiff16 import read_tiff16
     return linearize_ProPhotoRGB(read_tiff16(path))
   from PIL import Image
-  img = (np.asarray(Image.open(path).convert('RGB'), dtype=np.float32) / 255.0)**2.2
-  return img / (2 * img.max())
+  pil = Image.open(path)
+  raw = np.asarray(pil)
+  if raw.dtype == np.uint16:  # net.py:738-739 (16-bit grey / multi-channel arrays PIL can deliver)
+    img = raw.astype(np.float32) / 65535.0
+    if img.ndim == 2:
+      img = np.repeat(img[:, :, None], 3, axis=2)
+    img = img[:, :, :3]
+  else:
+    img = np.asarray(pil.convert('RGB'), dtype=np.float32) / 255.0
+  img = img**2.2  # linearise sRGB
+  return img / (2 * img.max())  # mimic RAW exposure
+
+
+def load_agent_weights(agent, state):
+  """Accepts an ``Agent`` state dict or the ``GAN.state_dict()`` that ``python -m exposure_amd.train
+  --save`` writes (keys prefixed 'generator.' / 'critic.' / 'value.'): the generator's entries are
+  picked out and the prefix stripped."""
+  if any(k.startswith('generator.') for k in state):
+    state = {k[len('generator.'):]: v for k, v in state.items() if k.startswith('generator.')}
+  agent.load_state_dict(state)
+  return agent
+
+
+def output_path(out, image_path, many):
+  """--out: a directory (existing, or ending in a path separator) receives <name>.retouched.npy per
+  image; with one image it may also be the file itself; with several images and a plain name the
+  image's stem is inserted so results do not overwrite each other."""
+  import os
+  base = os.path.basename(image_path)
+  if out is None:
+    return image_path + '.retouched.npy'
+  if os.path.isdir(out) or out.endswith(os.sep):
+    os.makedirs(out, exist_ok=True)
+    return os.path.join(out, base + '.retouched.npy')
+  if not many:
+    return out
+  root, ext = os.path.splitext(out)
+  return '%s.%s%s' % (root, os.path.splitext(base)[0], ext or '.npy')
+
+
+FILTER_BY_SHORT_NAME = {'E': 'ExposureFilter', 'G': 'GammaFilter', 'W': 'ImprovedWhiteBalanceFilter',
+                        'S+': 'SaturationPlusFilter', 'T': 'ToneFilter', 'Ct': 'ContrastFilter', 'BW': 'WNBFilter',
+                        'C': 'ColorFilter'}
 
 
 def main(argv=None):
-  """``python -m exposure_amd.evaluate [--weights w.pt] [--out out.npy] img ...`` -- the tensor part
-  of ``evaluate.py:8-31``: 5 retouching steps per image on the GPU; writes the linear result."""
+  """``python -m exposure_amd.evaluate [--filters E,G] [--weights w.pt] [--out dir|file] img ...`` -- the
+  tensor part of ``evaluate.py:8-31`` / ``GAN.eval`` (``net.py:711-821``): per image, load (16-bit TIFF or
+  8-bit sRGB), 5 retouching steps on the GPU, write the linear result.  Returns one record per image."""
   import argparse
   import numpy as np
+  from . import filters as F
   from .agent import Agent
   from .config import make_cfg
   ap = argparse.ArgumentParser()
   ap.add_argument('images', nargs='+')
-  ap.add_argument('--weights', default=None, help='torch state_dict of exposure_amd.agent.Agent (random init if absent)')
-  ap.add_argument('--out', default=None)
+  ap.add_argument('--weights', default=None,
+                  help='torch state_dict of exposure_amd.agent.Agent, or the GAN state dict train.py --save writes '
+                  '(random init if absent)')
+  ap.add_argument('--out', default=None, help='output file (one image) or directory; default <image>.retouched.npy')
   ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
+  ap.add_argument('--filters', default=None,
+                  help="cfg.filters as comma-separated short names, e.g. 'E,G' (BASELINE config 1); default: all 8")
+  ap.add_argument('--seed', type=int, default=None, help='seeds the random-init weights / dropout / noise')
+  ap.add_argument('--stepwise', action='store_true', help="the reference's schedule: filter the full-resolution "
+                  'tensor at every step instead of one fused pass at the end')
   args = ap.parse_args(argv)
   dev = torch.device('cuda:0')
-  cfg = make_cfg()
+  if args.seed is not None:
+    torch.manual_seed(args.seed)
+  flt = None
+  if args.filters:
+    flt = [getattr(F, FILTER_BY_SHORT_NAME[name.strip()]) for name in args.filters.split(',')]
+  cfg = make_cfg(filters=flt)
   agent = Agent(cfg).to(dev)
   if args.weights:
-    agent.load_state_dict(torch.load(args.weights, map_location=dev))
+    load_agent_weights(agent, torch.load(args.weights, map_location=dev))
   dt = torch.float16 if args.dtype == 'f16' else torch.float32
+  records = []
   for path in args.images:
     hi = torch.from_numpy(np.ascontiguousarray(load_image(path))).to(dev).to(dt)[None]
-    out, _low, states, trace = retouch(agent, hi, return_trace=True)
+    out, _low, states, ops = retouch(agent, hi, return_trace='full', fused=not args.stepwise)
+    trace = ops['selected']
     names = [agent.filters[int(j)].get_short_name() for j in trace[0]]
     print('%s: %dx%d  filters: %s' % (path, hi.shape[2], hi.shape[1], ' '.join(names)))
-    np.save(args.out or (path + '.retouched.npy'), out[0].float().cpu().numpy())
+    dst = output_path(args.out, path, len(args.images) > 1)
+    np.save(dst, out[0].float().cpu().numpy())
+    records.append(dict(image=path, output=dst, filters=names, states=states[0].cpu().tolist(),
+                        abi_filter_ids=ops['abi_filter_ids'][0].cpu().tolist(),
+                        params24=ops['params24'][0].cpu().numpy()))
+  return records
 
 
 if __name__ == '__main__':

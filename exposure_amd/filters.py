@@ -148,7 +148,14 @@ class Filter(nn.Module):
 
   # Apply the whole filter with masking
   def apply(self, img, img_features=None, specified_parameter=None, high_res=None):
-    """filters.py:62-99 -> (low_res_output, high_res_output or None, debug_info)."""
+    """filters.py:62-99 -> (low_res_output, high_res_output or None, debug_info).
+
+    The reference's method name shadows ``nn.Module.apply(fn)``; a callable first argument (what
+    ``module.apply(init_fn)`` passes when it recurses into the children of an Agent / GAN) is routed
+    to the module protocol instead of tripping the assertion below."""
+    if callable(img) and not isinstance(img, torch.Tensor) and img_features is None and \
+        specified_parameter is None and high_res is None:
+      return nn.Module.apply(self, img)
     assert (img_features is None) ^ (specified_parameter is None)
     if img_features is not None:
       filter_features, mask_parameters = self.extract_parameters(img_features)
@@ -156,6 +163,9 @@ class Filter(nn.Module):
     else:
       assert not self.use_masking()
       filter_parameters = specified_parameter
+      # the reference broadcasts a (1, P...) parameter over the batch (``param[:, None, None, :]``)
+      if filter_parameters.shape[0] == 1 and img.shape[0] > 1:
+        filter_parameters = filter_parameters.expand(img.shape[0], *filter_parameters.shape[1:])
       mask_parameters = torch.zeros((1, self.get_num_mask_parameters()), dtype=torch.float32,
                                     device=img.device)
     debug_info = {}
@@ -359,20 +369,69 @@ class LevelFilter(Filter):
 
 
 class VignetFilter(Filter):
-  """filters.py:341-401.  In the reference ``process`` is a stub that returns ``img * 0`` and the
-  class is in no config; it is kept here only so the name resolves."""
+  """filters.py:341-401.  In the reference ``process`` is ``img * 0`` (the additive term is commented
+  out, filters.py:351-352) and the class is in no config, so ``apply`` = ``lerp(img, 0, mask)`` =
+  ``img * (1 - mask)`` with the elliptical mask of filters.py:360-396 (5 mask parameters; with masking
+  off the mask is forced to 1 and the output is 0).  No HIP kernel backs it: it is a two-op tensor
+  expression on whatever device ``img`` lives on, kept so the ``Filter`` surface is complete."""
   filter_id = None
 
   def __init__(self, net, cfg):
     Filter.__init__(self, net, cfg)
     self.short_name = 'V'
     self.num_filter_parameters = 1
+    self._build_regressor()
+
+  def filter_param_regressor(self, features):
+    return torch.sigmoid(features)
+
+  def process(self, img, param):
+    return img * 0  # + param[:, None, None, :]
 
   def get_num_mask_parameters(self):
     return 5
 
-  def apply(self, *args, **kwargs):
-    raise NotImplementedError('VignetFilter is a stub in the reference (process returns img * 0) and is unused')
+  def get_mask(self, img, mask_parameters):
+    """filters.py:360-396: sigmoid(((gx A)^2 + (gy B)^2 + C - 5) * sharp * D / 5) * (E / 5 * .5 + .5)."""
+    filter_input_range = 5
+    assert mask_parameters.shape[1] == self.get_num_mask_parameters()
+    mp = tanh_range(-filter_input_range, filter_input_range, initial=0)(mask_parameters)
+    h, w = int(img.shape[1]), int(img.shape[2])
+    se = min(h, w)
+    gi = ((torch.arange(h, dtype=torch.float64) + (se - h) / 2.0) / se - 0.5).float().to(img.device)
+    gj = ((torch.arange(w, dtype=torch.float64) + (se - w) / 2.0) / se - 0.5).float().to(img.device)
+    inp = (gi[None, :, None, None] * mp[:, None, None, 0, None])**2 + \
+        (gj[None, None, :, None] * mp[:, None, None, 1, None])**2 + \
+        mp[:, None, None, 2, None] - filter_input_range
+    inp = inp * (self.cfg.maximum_sharpness * mp[:, None, None, 3, None] / filter_input_range)
+    mask = torch.sigmoid(inp)
+    mask = mask * (mp[:, None, None, 4, None] / filter_input_range * 0.5 + 0.5)
+    if not self.use_masking():
+      mask = mask * 0 + 1
+    return mask
+
+  def apply(self, img, img_features=None, specified_parameter=None, high_res=None):
+    if callable(img) and not isinstance(img, torch.Tensor):
+      return nn.Module.apply(self, img)
+    assert (img_features is None) ^ (specified_parameter is None)
+    if img_features is not None:
+      filter_features, mask_parameters = self.extract_parameters(img_features)
+      filter_parameters = self.filter_param_regressor(filter_features)
+    else:
+      assert not self.use_masking()
+      filter_parameters = specified_parameter
+      mask_parameters = torch.zeros((1, self.get_num_mask_parameters()), dtype=torch.float32, device=img.device)
+    from .util import lerp
+    debug_info = {'filter_parameters': filter_parameters[0]}
+    self.mask_parameters = mask_parameters
+    self.mask = self.get_mask(img, mask_parameters)
+    debug_info['mask'] = self.mask[0]
+    low = lerp(img.float(), self.process(img.float(), filter_parameters), self.mask).to(img.dtype)
+    high = None
+    if high_res is not None:
+      hmask = self.get_mask(high_res, mask_parameters)
+      high = lerp(high_res.float(), self.process(high_res.float(), filter_parameters), hmask).to(high_res.dtype)
+    return low, high, debug_info
 
 
 class SaturationPlusFilter(Filter):

@@ -314,6 +314,29 @@ def apply_masked(fid, img, packed, mask_parameters, maximum_sharpness=1, minimum
   return lerp(img, process_packed(fid, img, packed), mask)
 
 
+def vignet_mask(img, mask_parameters, maximum_sharpness=1, masking=True):
+  """VignetFilter.get_mask, filters.py:360-396; mask_parameters (N,5) RAW:
+  sigmoid(((gx A)^2 + (gy B)^2 + C - 5) * sharp * D / 5) * (E / 5 * .5 + .5); forced to 1 with masking off."""
+  dt = _ft(img)
+  filter_input_range = 5
+  mp = tanh_range(-filter_input_range, filter_input_range, initial=0)(mask_parameters)
+  grid = mask_grid(img.shape[1], img.shape[2], dt)
+  inp = (grid[:, :, :, 0, None] * mp[:, None, None, 0, None])**2 + \
+      (grid[:, :, :, 1, None] * mp[:, None, None, 1, None])**2 + \
+      mp[:, None, None, 2, None] - filter_input_range
+  inp = inp * (maximum_sharpness * mp[:, None, None, 3, None] / filter_input_range)
+  mask = sigmoid(inp)
+  mask = mask * (mp[:, None, None, 4, None] / filter_input_range * dt.type(0.5) + dt.type(0.5))
+  if not masking:
+    mask = mask * 0 + 1
+  return mask
+
+
+def vignet_apply(img, mask_parameters, maximum_sharpness=1, masking=True):
+  """VignetFilter: process = img * 0 (filters.py:351-352), out = lerp(img, 0, mask) (filters.py:86-88)."""
+  return lerp(img, img * 0, vignet_mask(img, mask_parameters, maximum_sharpness, masking))
+
+
 # ---------------------------------------------------------------------------
 # packed <-> reference-shaped parameters
 # ---------------------------------------------------------------------------

@@ -76,6 +76,31 @@ def _chain_fused_fwd(ids, params, x, y):
   y.copy_(cur.to(y.dtype))
 
 
+def _raw_mask(mp):
+  """the C-ABI takes tanh_range(-5, 5)(raw) = 5 tanh(raw); the oracle takes raw"""
+  return torch.atanh((mp.double() / 5.0).clamp(-1 + 1e-15, 1 - 1e-15))
+
+
+def _apply_fwd(fid, x, y, params, mask_params, maximum_sharpness, minimum_strength):
+  y.copy_(ft.apply_masked(fid, x.double(), params.double(), _raw_mask(mask_params), maximum_sharpness,
+                          minimum_strength).to(y.dtype))
+
+
+def _apply_bwd(fid, x, dy, dx, params, dparams, mask_params, dmask_params, maximum_sharpness, minimum_strength,
+               hsv_grad_mode=0):
+  with torch.enable_grad():
+    mp = mask_params.double().detach().clone().requires_grad_(True)
+    xi = x.double().detach().clone().requires_grad_(True)
+    pi = params.double().detach().clone().requires_grad_(True)
+    out = ft.apply_masked(fid, xi, pi, torch.atanh((mp / 5.0).clamp(-1 + 1e-15, 1 - 1e-15)), maximum_sharpness,
+                          minimum_strength, hsv_grad_mode)
+    gx, gp, gm = torch.autograd.grad(out, [xi, pi, mp], dy.double())
+  if dx is not None:
+    dx.copy_(gx.to(dx.dtype))
+  dparams.copy_(gp.float())
+  dmask_params.copy_(gm.float())
+
+
 def _stats(x, stats):
   stats.copy_(torch.from_numpy(agent_np.critic_stats(x.double().numpy())).float())
 
@@ -88,5 +113,5 @@ def _penalty(y, pen):
 def fake_hip():
   with mock.patch.multiple('exposure_amd._cabi', filter_fwd=_fwd, filter_bwd=_bwd, dispatch_fwd=_dispatch_fwd,
                            dispatch_bwd=_dispatch_bwd, critic_stats=_stats, overexposure_penalty=_penalty,
-                           chain_fused_fwd=_chain_fused_fwd):
+                           chain_fused_fwd=_chain_fused_fwd, apply_fwd=_apply_fwd, apply_bwd=_apply_bwd):
     yield

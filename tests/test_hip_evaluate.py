@@ -1,0 +1,97 @@
+"""BASELINE config 1 on the HIP path: `evaluate.py` on ONE 64x64 16-bit TIFF with
+cfg.filters = [ExposureFilter, GammaFilter] (evaluate.py:8-31; net.py:726-747, 779, 796-821), through
+the real CLI entry (`exposure_amd.evaluate.main`): load_image -> retouch (5 steps on the proxy, the
+recorded operations applied to the full-resolution tensor by libexposure_hip.so) -> .npy.  The written
+result is compared with an oracle replay of the recorded operations on the same loaded image."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from exposure_amd import evaluate
+from exposure_amd.tiff16 import write_tiff
+from oracle import filters_np as fnp
+from tests._tol import assert_image_close
+
+pytestmark = pytest.mark.gpu
+
+
+def replay(image, rec, dtype):
+  """Oracle replay of the recorded (filter id, parameters) sequence on the loaded image.  fused: fp32 between
+  the steps, ONE rounding to the storage dtype at the end; stepwise: one rounding per step."""
+  x = image.astype(dtype).astype(np.float64)[None]
+  outs = []
+  for fid, p24 in zip(rec['abi_filter_ids'], rec['params24']):
+    p = p24[None, :fnp.NUM_PARAMS[fid]].astype(np.float64)
+    x = fnp.process_packed(fid, x, p)
+    outs.append(x)
+  return x[0], outs
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f16'])
+def test_evaluate_cli_on_a_64x64_tiff_with_exposure_and_gamma(gpu_device, tmp_path, dtype):
+  rng = np.random.default_rng(5)
+  raw = (rng.random((64, 64, 3))**1.5 * 40000).astype(np.uint16)  # a dark 16-bit ProPhoto "RAW export"
+  tif = str(tmp_path / 'a0001.tif')
+  write_tiff(tif, raw)
+  out_dir = str(tmp_path / 'outputs') + os.sep
+  recs = evaluate.main(['--filters', 'E,G', '--seed', '7', '--dtype', dtype, '--out', out_dir, tif])
+  assert len(recs) == 1
+  rec = recs[0]
+  assert rec['filters'] == [{0: 'E', 1: 'G'}[i] for i in rec['abi_filter_ids']] and len(rec['filters']) == 5
+  assert rec['states'][:3] == [1.0, 1.0, 5.0]  # submitted after test_steps = 5 (agent.py:210-217)
+  got = np.load(rec['output'])
+  assert got.shape == (64, 64, 3) and got.dtype == np.float32
+  np_dtype = np.float16 if dtype == 'f16' else np.float32
+  image = evaluate.load_image(tif)
+  assert np.abs(image - (raw / 65535.0)**1.8).max() < 1e-6
+  ref, _ = replay(image, rec, np_dtype)
+  assert_image_close(got, ref, np_dtype, 'evaluate.main (%s)' % dtype)
+  assert np.isfinite(got).all() and float(np.abs(got - image).max()) > 1e-3  # it did retouch something
+
+
+def test_evaluate_cli_non_tif_branch_and_two_images(gpu_device, tmp_path):
+  """net.py:735-747 (8-bit sRGB-ish input) + several inputs with distinct outputs; full 8-filter cfg,
+  non-square high-resolution image (the proxy is the centre crop, net.py:779)."""
+  from PIL import Image
+  rng = np.random.default_rng(6)
+  paths = []
+  for k, (h, w) in enumerate([(96, 160), (128, 80)]):
+    p = str(tmp_path / ('img%d.png' % k))
+    Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(p)
+    paths.append(p)
+  recs = evaluate.main(['--seed', '8', '--dtype', 'f16', '--out', str(tmp_path / 'res.npy'), *paths])
+  assert len({r['output'] for r in recs}) == 2
+  for p, rec in zip(paths, recs):
+    image = evaluate.load_image(p)
+    got = np.load(rec['output'])
+    assert got.shape == image.shape
+    ref, _ = replay(image, rec, np.float16)
+    assert_image_close(got, ref, np.float16, 'evaluate.main non-tif')
+
+
+def test_stepwise_schedule_matches_fused(gpu_device, tmp_path):
+  """--stepwise = the reference's schedule (the high-res tensor filtered at every step, net.py:796-821):
+  same operations, one fp16 rounding per step instead of one at the end."""
+  rng = np.random.default_rng(9)
+  raw = (rng.random((48, 72, 3))**1.5 * 30000).astype(np.uint16)
+  tif = str(tmp_path / 'b.tif')
+  write_tiff(tif, raw)
+  a = evaluate.main(['--filters', 'E,G', '--seed', '3', '--dtype', 'f32', '--out', str(tmp_path / 'f.npy'), tif])[0]
+  b = evaluate.main(['--filters', 'E,G', '--seed', '3', '--dtype', 'f32', '--stepwise', '--out',
+                     str(tmp_path / 's.npy'), tif])[0]
+  assert a['abi_filter_ids'] == b['abi_filter_ids']
+  fa, fb = np.load(a['output']), np.load(b['output'])
+  assert np.abs(fa - fb).max() <= 2e-5 * max(1.0, np.abs(fa).max())
+
+
+def test_train_save_then_evaluate_round_trip(gpu_device, tmp_path):
+  from exposure_amd import train
+  w = str(tmp_path / 'gan.pt')
+  train.main(['--iters', '1', '--no-graphs', '--clamp', '--save', w, '--log-every', '0'])
+  raw = (np.random.default_rng(2).random((64, 64, 3)) * 30000).astype(np.uint16)
+  tif = str(tmp_path / 'c.tif')
+  write_tiff(tif, raw)
+  rec = evaluate.main(['--weights', w, '--seed', '1', '--out', str(tmp_path / 'o.npy'), tif])[0]
+  assert np.isfinite(np.load(rec['output'])).all()

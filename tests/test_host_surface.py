@@ -1,0 +1,139 @@
+"""Host-side surface around the hot path (CPU; the C-ABI binding mocked by the oracle where a filter
+runs): the train -> evaluate weight round trip, evaluate's I/O helpers (net.py:726-747), the Filter
+protocol corners the advisor flagged, VignetFilter (filters.py:341-401) and the masking=True agent path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from exposure_amd import agent as xagent
+from exposure_amd import evaluate, filters
+from exposure_amd.config import make_cfg
+from exposure_amd.gan import GAN
+from oracle import filters_np as fnp
+from tests._fake_hip import fake_hip
+
+
+def test_train_save_loads_into_evaluate_agent(tmp_path):
+  torch.manual_seed(0)
+  cfg = make_cfg()
+  gan = GAN(cfg)
+  path = tmp_path / 'w.pt'
+  torch.save(gan.state_dict(), path)  # what `python -m exposure_amd.train --save` writes
+  fresh = xagent.Agent(make_cfg())
+  evaluate.load_agent_weights(fresh, torch.load(path))
+  for (k, a), (_, b) in zip(gan.generator.state_dict().items(), fresh.state_dict().items()):
+    assert torch.equal(a, b), k
+  # a plain Agent state dict still loads
+  evaluate.load_agent_weights(xagent.Agent(make_cfg()), gan.generator.state_dict())
+
+
+def test_output_paths_do_not_collide(tmp_path):
+  d = str(tmp_path / 'out') + os.sep
+  a = evaluate.output_path(d, '/x/a.tif', True)
+  b = evaluate.output_path(d, '/x/b.tif', True)
+  assert a != b and os.path.dirname(a) == str(tmp_path / 'out')
+  f = str(tmp_path / 'res.npy')
+  assert evaluate.output_path(f, '/x/a.tif', False) == f
+  assert evaluate.output_path(f, '/x/a.tif', True) != evaluate.output_path(f, '/x/b.tif', True)
+  assert evaluate.output_path(None, '/x/a.tif', True) == '/x/a.tif.retouched.npy'
+
+
+def test_load_image_non_tif_branch(tmp_path):
+  """net.py:739-747: /255, **2.2, / (2 max)."""
+  from PIL import Image
+  rng = np.random.default_rng(0)
+  raw = rng.integers(0, 256, (9, 7, 3), dtype=np.uint8)
+  p = str(tmp_path / 'a.png')
+  Image.fromarray(raw).save(p)
+  got = evaluate.load_image(p)
+  lin = (raw.astype(np.float64) / 255.0)**2.2
+  want = lin / (2 * lin.max())
+  assert got.shape == (9, 7, 3) and np.abs(got - want).max() < 1e-6 and abs(got.max() - 0.5) < 1e-6
+
+
+def test_load_image_tif_branch(tmp_path):
+  """net.py:729-733: 16-bit TIFF / 65535, ProPhoto linearisation x**1.8 (util.py:495-501)."""
+  from exposure_amd.tiff16 import write_tiff
+  raw = np.random.default_rng(1).integers(0, 65536, (64, 64, 3), dtype=np.uint16)
+  p = str(tmp_path / 'a.tif')
+  write_tiff(p, raw)
+  got = evaluate.load_image(p)
+  assert np.abs(got - (raw.astype(np.float64) / 65535.0)**1.8).max() < 1e-6
+
+
+def test_module_apply_recurses_through_filters():
+  """nn.Module.apply(fn) reaches every Filter although the reference's `apply` shadows it."""
+  ag = xagent.Agent(make_cfg())
+  seen = []
+  ag.apply(lambda m: seen.append(type(m).__name__))
+  assert 'ExposureFilter' in seen and 'Agent' in seen and seen.count('Linear') >= 18
+
+
+def test_specified_parameter_broadcasts_over_the_batch():
+  cfg = make_cfg()
+  f = filters.ExposureFilter((1, 8, 8, 3), cfg)
+  img = torch.rand(3, 8, 8, 3)
+  with fake_hip():
+    low, high, dbg = f.apply(img, specified_parameter=torch.tensor([[1.0]]))
+  assert high is None and torch.allclose(low, img * 2.0, atol=1e-6)
+  t = filters.ToneFilter((1, 8, 8, 3), cfg)
+  with fake_hip():
+    low, _, _ = t.apply(img, specified_parameter=torch.ones(1, 1, 1, 1, 8))
+  assert torch.allclose(low, img.clamp(0, 1), atol=1e-6)
+
+
+@pytest.mark.parametrize('masking', [False, True])
+def test_vignet_filter_matches_oracle(masking):
+  cfg = make_cfg()
+  cfg.masking = masking
+  torch.manual_seed(1)
+  v = filters.VignetFilter((1, 10, 14, 3), cfg)
+  img = torch.rand(2, 10, 14, 3)
+  feats = torch.randn(2, cfg.feature_extractor_dims)
+  low, high, dbg = v.apply(img, img_features=feats, high_res=torch.rand(2, 20, 12, 3))
+  with torch.no_grad():
+    _, mraw = v.extract_parameters(feats)
+  assert mraw.shape == (2, 5)
+  ref = fnp.vignet_apply(img.numpy().astype(np.float64), mraw.numpy().astype(np.float64), cfg.maximum_sharpness,
+                         masking)
+  assert np.abs(low.detach().numpy() - ref).max() < 1e-6
+  assert high.shape == (2, 20, 12, 3)
+  if not masking:
+    assert float(low.detach().abs().max()) == 0.0  # mask forced to 1, process = img * 0
+
+
+def test_agent_masking_path_matches_oracle_and_gives_mask_gradients():
+  """cfg.masking = True: out = sum_j onehot_j lerp(img, process_j(img), mask_j(img)) (agent.py:58-77,
+  119-125; filters.py:86-88, 110-148) and the mask half of every selected head's fc2 gets a gradient."""
+  cfg = make_cfg()
+  cfg.masking = True
+  torch.manual_seed(2)
+  ag = xagent.Agent(cfg)
+  n = 4
+  rng = np.random.default_rng(3)
+  img = torch.from_numpy((rng.random((n, 64, 64, 3))**2.2).astype(np.float32))
+  states = torch.zeros(n, 11)
+  z = torch.from_numpy(rng.random((n, 131)).astype(np.float32))
+  masks = [torch.from_numpy((rng.random((n, 4096)) < 0.5).astype(np.float32)) for _ in range(2)]
+  with fake_hip():
+    (out, new_states, surrogate, penalty), dbg, _ = ag((img, z, states), is_train=1, progress=0.5,
+                                                      dropout_masks=masks)
+    out.sum().backward()
+  ids = dbg['selected_filter_ids'].numpy()
+  with torch.no_grad():
+    feats = ag.filter_features(xagent.enrich_image_input(cfg, img, states), masks[0])
+  for i in range(n):
+    j = int(ids[i])
+    filt = ag.filters[j]
+    with torch.no_grad():
+      f, mraw = filt.extract_parameters(feats[i:i + 1])
+      packed = filt.pack(filt.filter_param_regressor(f)).numpy().astype(np.float64)
+    ref = fnp.apply_masked(filt.filter_id, img[i:i + 1].numpy().astype(np.float64), packed,
+                           mraw.numpy().astype(np.float64), cfg.maximum_sharpness, cfg.minimum_strength)
+    assert np.abs(out[i:i + 1].detach().numpy() - ref).max() < 2e-5
+  for j in set(int(v) for v in ids):
+    filt = ag.filters[j]
+    p = filt.get_num_filter_parameters()
+    assert float(filt.fc2.weight.grad[p:].abs().max()) > 0.0  # the 6 mask rows
