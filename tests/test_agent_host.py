@@ -109,7 +109,7 @@ def test_agent_step_matches_oracle(is_train):
     sel = ag.selector_features(enriched, t(masks[1]))
     logits = ag.selector_fc2(xagent.lrelu(ag.selector_fc1(sel))).numpy()
     feats = ag.filter_features(enriched, t(masks[0]))
-    params = [f.pack(p).numpy() for f, p in zip(ag.filters, ag.regress_all(feats))]
+    params = [f.pack(p).numpy() for f, p in zip(ag.filters, ag.regress_all(feats)[0])]
   o_pdf, o_ent, o_ids, o_onehot, o_sur = agent_np.action_selection(logits.astype(np.float64), z[:, 0:1].astype(np.float64),
                                                                     is_train)
   assert np.array_equal(ids, o_ids), (ids, o_ids)
