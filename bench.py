@@ -61,8 +61,9 @@ def parse():
   ap.add_argument('--cold-shape', default='256,512,512',
                   help="chain workload: also time the dominant kernel on tensors of this shape (384 MiB each, beyond "
                   "the 256 MiB Infinity Cache) for roofline.hbm_cold; 'none' disables")
+  ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                  help='replay the 17 launches of a step from one hipGraph (auto = on; off: eager C-ABI calls)')
+                  help='replay the 16 launches of a step from one hipGraph (auto = on; off: eager C-ABI calls)')
   return ap.parse_args()
 
 
@@ -94,7 +95,7 @@ class Chain:
     # gradients ping-pong between two buffers; grads[8] = upstream dy
     ga, gb = torch.empty_like(x), torch.empty_like(x)
     self.grads = [ga if (i % 2 == 0) else gb for i in range(8)] + [dy]
-    # per-step parameter gradients carved from one flat buffer -> a single zero-fill per backward
+    # per-step parameter gradients carved from one flat buffer
     flat = torch.empty(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
     self.dparams, off = [], 0
     for p in self.params:
@@ -103,14 +104,14 @@ class Chain:
 
     self.graph = None
     self.unroll = 1
-    self.launches_per_step = 2 * len(self.ids) + 1  # 8 fwd + 1 dparams fill + 8 bwd
+    self.launches_per_step = 2 * len(self.ids)  # 8 fwd + 8 bwd (no fill: the reductions need none)
 
   def launch(self):
     _cabi.chain_fwd(self.ids, self.acts, self.params)
     _cabi.chain_bwd(self.ids, self.acts, self.grads, self.params, self.dparams)
 
   def capture(self, unroll=1):
-    """Capture `unroll` steps (each 8 fwd + 1 fill + 8 bwd launches) into one hipGraph: small shapes
+    """Capture `unroll` steps (each 8 fwd + 8 bwd launches) into one hipGraph: small shapes
     are bound by the ~5 us host cost per launch, a graph replay pays it once; every replay boundary
     costs ~3 us on the device, so several steps share a replay when the step count allows."""
     self.unroll = unroll
@@ -167,8 +168,7 @@ def time_kernels(chain, reps):
     for i in reversed(range(nsteps)):
       if r >= 0:
         ev[r][k][0].record()
-      _cabi.filter_bwd(ids[i], chain.acts[i], chain.grads[i + 1], chain.grads[i], chain.params[i], chain.dparams[i],
-                       accumulate=True)  # kernel only: the chain zero-fills all dparams once per step
+      _cabi.filter_bwd(ids[i], chain.acts[i], chain.grads[i + 1], chain.grads[i], chain.params[i], chain.dparams[i])
       if r >= 0:
         ev[r][k][1].record()
       k += 1
@@ -179,14 +179,55 @@ def time_kernels(chain, reps):
   return out
 
 
+def _cpu_chain_rates(name, threads, budget_s=4.0):
+  """Best-of-5-after-2-warm-ups rates (Mpixels/s) of the torch-CPU restatement on SHAPES[name] with
+  `threads` intra-op threads; a configuration that needs more than `budget_s` per kind is cut short."""
+  from oracle import filters_torch as ft
+  shape = synthetic.SHAPES[name]
+  x, dy, params = synthetic.make_case(1234, shape, np.float16)
+  tx = torch.from_numpy(x.astype(np.float32))
+  tdy = torch.from_numpy(dy.astype(np.float32))
+  tp = [torch.from_numpy(p) for p in params]
+  px = shape[0] * shape[1] * shape[2]
+
+  def fwd_only():
+    with torch.no_grad():
+      cur = tx
+      for fid, p in enumerate(tp):
+        cur = ft.process_packed(fid, cur, p)
+    return cur
+
+  torch.set_num_threads(threads)
+  best = {}
+  for kind, fn in (('fwd_bwd', lambda: ft.chain_fwd_bwd(tx, tp, tdy)), ('fwd', fwd_only)):
+    times, t_cfg = [], time.perf_counter()
+    for it in range(7):
+      t0 = time.perf_counter()
+      fn()
+      times.append(time.perf_counter() - t0)
+      if time.perf_counter() - t_cfg > budget_s and len(times) >= 2:
+        break
+    best[kind] = px / min(times[min(2, len(times) - 1):]) / 1e6
+  return best
+
+
+def cpu_worker(spec):
+  """`bench.py --cpu-worker NAME:THREADS`: one configuration in its own process (so that a pathological
+  one -- every logical CPU of a 256-thread host oversubscribing torch's intra-op pool -- can be timed
+  out and killed by the parent instead of stalling the whole benchmark)."""
+  name, threads = spec.split(':')
+  print(json.dumps(_cpu_chain_rates(name, int(threads), budget_s=3.0)))
+
+
 def cpu_baseline():
   """the torch-CPU fp32 op-by-op restatement (oracle/filters_torch.py, autograd
   backward -- the granularity at which TF-1 executes the reference graph) timed on the host cores on the
   same synthetic workload: shapes A (64x64x64x3) and B (16x512x512x3), chain fwd-only and fwd+bwd, best of
-  5 after 2 warm-ups, once with every logical CPU (torch.set_num_threads(os.cpu_count())) and once per
-  thread count of a small sweep (torch's intra-op pool does not scale to every core of a big host for this
-  op mix).  `value` = the best fwd+bwd rate on shape B; ~10-20 s of CPU work in total."""
-  from oracle import filters_torch as ft
+  5 after 2 warm-ups, for a small sweep of thread counts, plus the all-logical-CPUs run of the plan
+  (torch.set_num_threads(os.cpu_count())) in a child process with a 25 s limit -- on a 256-thread host
+  torch's intra-op pool oversubscribes badly for this op mix (one pass took > 70 s).  `value` = the best
+  fwd+bwd rate on shape B; ~15-30 s of CPU work in total."""
+  import subprocess
   ncpu = os.cpu_count() or 1
   model = ''
   try:
@@ -196,48 +237,38 @@ def cpu_baseline():
         break
   except OSError:
     pass
-  sweep = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8), ncpu})
+  sweep = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)})
   t_start = time.perf_counter()
   by_shape = {}
   for name in ('A', 'B'):
-    shape = synthetic.SHAPES[name]
-    x, dy, params = synthetic.make_case(1234, shape, np.float16)
-    tx = torch.from_numpy(x.astype(np.float32))
-    tdy = torch.from_numpy(dy.astype(np.float32))
-    tp = [torch.from_numpy(p) for p in params]
-    px = shape[0] * shape[1] * shape[2]
-
-    def fwd_only():
-      with torch.no_grad():
-        cur = tx
-        for fid, p in enumerate(tp):
-          cur = ft.process_packed(fid, cur, p)
-      return cur
-
     rows = {}
     for threads in sweep:
-      if time.perf_counter() - t_start > 40.0 and rows:  # bound the whole leg on slow hosts
+      if time.perf_counter() - t_start > 30.0 and rows:  # bound the whole leg on slow hosts
         break
-      torch.set_num_threads(threads)
-      best = {}
-      for kind, fn in (('fwd_bwd', lambda: ft.chain_fwd_bwd(tx, tp, tdy)), ('fwd', fwd_only)):
-        times = []
-        for it in range(7):
-          t0 = time.perf_counter()
-          fn()
-          times.append(time.perf_counter() - t0)
-        best[kind] = px / min(times[2:]) / 1e6  # best of 5 after 2 warm-ups
-      rows[threads] = best
+      rows[threads] = _cpu_chain_rates(name, threads)
+      print('cpu_baseline: shape %s, %d threads: %.1f Mpixels/s fwd+bwd (%.1f s so far)' %
+            (name, threads, rows[threads]['fwd_bwd'], time.perf_counter() - t_start), file=sys.stderr)
     bt = max(rows, key=lambda t: rows[t]['fwd_bwd'])
     by_shape[name] = {
-        'shape': 'x'.join(str(v) for v in shape),
+        'shape': 'x'.join(str(v) for v in synthetic.SHAPES[name]),
         'best_threads': bt,
         'fwd_bwd_Mpixels_per_s': rows[bt]['fwd_bwd'],
         'fwd_Mpixels_per_s': rows[bt]['fwd'],
-        'all_cores_threads': ncpu if ncpu in rows else None,
-        'all_cores_fwd_bwd_Mpixels_per_s': rows[ncpu]['fwd_bwd'] if ncpu in rows else None,
         'sweep_fwd_bwd': {str(t): r['fwd_bwd'] for t, r in rows.items()},
     }
+  # the plan's all-core run (shape B), in a child that can be killed
+  all_cores = {'threads': ncpu, 'fwd_bwd_Mpixels_per_s': None, 'note': ''}
+  if ncpu in sweep:
+    all_cores['fwd_bwd_Mpixels_per_s'] = by_shape['B']['sweep_fwd_bwd'][str(ncpu)]
+  else:
+    try:
+      out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', 'B:%d' % ncpu],
+                           capture_output=True, text=True, timeout=25)
+      all_cores['fwd_bwd_Mpixels_per_s'] = json.loads(out.stdout.strip().splitlines()[-1])['fwd_bwd']
+    except subprocess.TimeoutExpired:
+      all_cores['note'] = 'killed after 25 s: torch intra-op pool oversubscribed at %d threads' % ncpu
+    except (ValueError, IndexError, KeyError):
+      all_cores['note'] = 'worker failed'
   b = by_shape['B']
   return {
       'value': b['fwd_bwd_Mpixels_per_s'],
@@ -246,9 +277,10 @@ def cpu_baseline():
       'kind': 'port',
       'sample': 'CPU restatement (torch fp32 op-by-op, autograd backward; never TF1) on host %s with %d logical CPUs: '
                 '8-step chain fwd+bwd on 16x512x512x3 (4.19 Mpixel per pass), best of 5 after 2 warm-ups, best '
-                'thread count of %s = %d; by_shape also holds 64x64x64x3, fwd-only and the all-core run' %
-                (model or 'unknown CPU', ncpu, sweep, b['best_threads']),
+                'thread count of %s = %d; by_shape also holds 64x64x64x3 and fwd-only; all_cores = the %d-thread run' %
+                (model or 'unknown CPU', ncpu, sweep, b['best_threads'], ncpu),
       'by_shape': by_shape,
+      'all_cores': all_cores,
       'seconds': time.perf_counter() - t_start,
   }
 
@@ -279,6 +311,12 @@ def light_barrier(dist, dev):
   if flag is None:
     flag = _BARRIER_FLAG[dev] = torch.zeros(1, device=dev)
   dist.all_reduce(flag)
+
+
+def trace(msg):
+  """EXPO_TRACE=1: phase markers on stderr (soak runs: where does a rank die?)."""
+  if os.environ.get('EXPO_TRACE') == '1':
+    print('[trace rank %s] %s' % (os.environ.get('RANK', '0'), msg), file=sys.stderr, flush=True)
 
 
 def run_train(args, world, rank, dev, dist):
@@ -315,11 +353,14 @@ def run_train(args, world, rank, dev, dist):
   def barrier():
     light_barrier(dist, dev)
 
+  trace('pool primed')
   for i in range(args.warmup):
     iteration(i + 1)
+    trace('warm-up iteration %d done' % i)
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
+  trace('timed region starts')
   t0 = time.perf_counter()
   for i in range(args.steps):
     iteration(i + 1)
@@ -327,6 +368,7 @@ def run_train(args, world, rank, dev, dist):
   barrier()
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
+  trace('timed region done')
   if dist is not None:
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -350,19 +392,23 @@ def run_train(args, world, rank, dev, dist):
             'workload': 'reference training iteration (net.py:307-365): agent rollout step, policy CNN, value net, '
                         'WGAN-GP critic; batch %d x 64x64x3 per GPU; random-init weights' % n,
             'global_batch': world * n,
-            'parallelism': 'dp%d image-sharded, 3 flat gradient buckets over RCCL' % world,
+            'parallelism': 'dp%d image-sharded; flat gradient buckets (theta_g heads / trunks, theta_v, theta_c) '
+                           'all-reduced over RCCL from backward hooks' % world,
             'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
             'reference_note': 'README.md:43: ~0.30 s/iteration on a GTX 1080 Ti (whole run ~100 min / 20000 it)',
         },
-    }))
+    }), flush=True)
+  trace('line printed')
   if dist is not None:
     dist.barrier()
+    trace('final barrier done')
     dist.destroy_process_group()
+    trace('process group destroyed')
 
 
 def run_allreduce(args, world, rank, dev, dist):
-  """SURVEY.md section 8(e) "all-reduce only": the three flat fp32 gradient buckets of one training
-  iteration (theta_g 24.5 MB + theta_v 4.9 MB once, theta_c 4.9 MB x citers) reduced over RCCL, no
+  """SURVEY.md section 8(e) "all-reduce only": the flat fp32 gradient buckets of one training iteration
+  (theta_v 4.9 MB, theta_g heads 18.9 MB + trunks 5.6 MB once, theta_c 4.9 MB x citers) reduced over RCCL, no
   compute.  With one rank the collective degenerates to nothing and the line reports 0 bytes."""
   from exposure_amd.config import make_cfg
   from exposure_amd.gan import GAN
@@ -375,8 +421,9 @@ def run_allreduce(args, world, rank, dev, dist):
   def iteration():
     if dist is None:
       return
-    dist.all_reduce(bufs['g'])
     dist.all_reduce(bufs['v'])
+    dist.all_reduce(bufs['g_head'])
+    dist.all_reduce(bufs['g_trunk'])
     for _ in range(cfg.citers):
       dist.all_reduce(bufs['c'])
 
@@ -396,6 +443,7 @@ def run_allreduce(args, world, rank, dev, dist):
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+  sizes['g'] = sizes['g_head'] + sizes['g_trunk']
   nbytes = 4 * (sizes['g'] + sizes['v'] + cfg.citers * sizes['c'])
   if rank == 0:
     ms = elapsed / args.steps * 1e3
@@ -413,7 +461,7 @@ def run_allreduce(args, world, rank, dev, dist):
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {
-            'workload': 'all-reduce only: theta_g %d + theta_v %d + %d x theta_c %d fp32 elements per iteration'
+            'workload': 'all-reduce only: theta_g %d (2 buckets) + theta_v %d + %d x theta_c %d fp32 elements per iteration'
                         % (sizes['g'], sizes['v'], cfg.citers, sizes['c']),
             'bytes_per_iteration': nbytes,
             'parallelism': 'dp%d, flat buckets over RCCL' % world,
@@ -577,6 +625,8 @@ def time_cold(args, dev, dom, ids):
 
 def main():
   args = parse()
+  if args.cpu_worker:
+    return cpu_worker(args.cpu_worker)
   if args.gpus > 1 and 'LOCAL_RANK' not in os.environ and 'RANK' not in os.environ:
     raise SystemExit(self_launch(args))
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -610,7 +660,7 @@ def main():
   ids = [int(v) for v in args.order.split(',')]
   chain = Chain(shape, dtype, dev, args.seed + rank, ids)
   px = shape[0] * shape[1] * shape[2]
-  # One hipGraph replay per step by default.  Small shapes are launch-bound (17 launches in 87 us
+  # One hipGraph replay per step by default.  Small shapes are launch-bound (16 launches in ~85 us
   # eagerly vs 57 us replayed at 64x64x64); at 64x512x512 eager launches are ~0.5 % faster in a
   # plain process but 1.5-4 % slower and noisy once a process group exists (torchrun, RCCL's extra
   # queues), while the replay measures the same +-0.3 % either way -- so every N uses the replay.
@@ -708,7 +758,9 @@ def main():
     }
     if world == 1 and tensor_mib < 256:
       del chain  # free the 1.2 GB of the timed chain before the 4.6 GB cold one
+      t_cold = time.perf_counter()
       cold = time_cold(args, dev, dom, ids)
+      print('hbm_cold leg: %.1f s' % (time.perf_counter() - t_cold), file=sys.stderr)
       if cold is not None:
         result['roofline']['hbm_cold'] = cold
   barrier()

@@ -17,31 +17,33 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # never a non-HIP implementation.
 LIB_PATH = os.environ.get('EXPO_HIP_LIB') or os.path.join(_HERE, 'libexposure_hip.so')
 
-EXPO_ABI_VERSION = 1
+EXPO_ABI_VERSION = 2
 EXPO_F16, EXPO_F32 = 0, 1
 EXPO_MAX_PARAMS = 24
 NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24, 2)  # ids 0..7 = cfg.filters order, 8 = LevelFilter
 
 # every symbol include/exposure_hip.h declares: name -> (restype, argtypes)
-_vp, _i, _fp, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_float
+_vp, _i, _fp, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
 SIGNATURES = {
     'expo_version': (_i, []),
     'expo_last_error': (ctypes.c_char_p, []),
     'expo_num_filter_params': (_i, [_i]),
+    'expo_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'expo_filter_fwd': (_i, [_i, _vp, _vp, _fp, _i, _i, _i, _i, _vp]),
-    'expo_filter_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
-    'expo_filter_bwd_accumulate': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    'expo_filter_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_filter_bwd_accumulate': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_filter_apply_fwd': (_i, [_i, _vp, _vp, _fp, _fp, _f, _f, _i, _i, _i, _i, _vp]),
-    'expo_filter_apply_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _i, _i, _vp]),
-    'expo_filter_dispatch_fwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
-    'expo_filter_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    'expo_filter_apply_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _i, _i, _vp, _sz,
+                                   _vp]),
+    'expo_filter_dispatch_fwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_filter_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
                             _vp]),
     'expo_chain_bwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
-                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp]),
+                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_chain_fused_fwd': (_i, [_vp, _fp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'expo_critic_stats': (_i, [_vp, _fp, _i, _i, _i, _i, _vp]),
-    'expo_overexposure_penalty': (_i, [_vp, _fp, _i, _i, _i, _i, _vp]),
+    'expo_critic_stats': (_i, [_vp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_overexposure_penalty': (_i, [_vp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 _lib = None
@@ -116,6 +118,53 @@ def num_filter_params(fid):
   return load().expo_num_filter_params(fid)
 
 
+# ---- reduction workspace (include/exposure_hip.h "Reduction workspace") -------------------------
+# One scratch buffer per device, grown on demand and never freed or moved while the process lives (a
+# captured hipGraph keeps the raw pointer).  It needs no initialisation and carries no state between
+# calls.  It serves ONE stream at a time: callers that run filter kernels concurrently on several
+# streams of a device pass their own ``workspace=`` tensors (``new_workspace``).  It must exist before
+# a hipGraph capture starts: run the step once eagerly first (bench.py and GAN._replay do), or call
+# ``reserve_workspace``.
+_WORKSPACES = {}
+_RETIRED = []
+_MIN_WORKSPACE = 4 << 20
+
+
+def workspace_bytes(n, h, w, dtype_code, steps=1):
+  return int(load().expo_workspace_bytes(int(n), int(h), int(w), int(dtype_code))) * int(steps)
+
+
+def new_workspace(device, nbytes):
+  """A private workspace tensor (uint8) for callers that manage their own."""
+  return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def reserve_workspace(device, nbytes):
+  """Make the device's shared workspace at least ``nbytes`` large and return it."""
+  key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+  ws = _WORKSPACES.get(key)
+  if ws is None or ws.numel() < nbytes:
+    if torch.cuda.is_current_stream_capturing():
+      raise ExposureHipError('exposure_amd: the reduction workspace must exist before a hipGraph capture starts '
+                             '(run the step once eagerly, or call _cabi.reserve_workspace)')
+    if ws is not None:
+      _RETIRED.append(ws)  # earlier captures may still point into it
+    ws = new_workspace(torch.device('cuda', key), max(int(nbytes), _MIN_WORKSPACE))
+    _WORKSPACES[key] = ws
+  return ws
+
+
+def _ws(x, workspace, steps=1):
+  """(pointer, size) of the workspace for an image tensor ``x``."""
+  n, h, w, _ = x.shape
+  need = workspace_bytes(n, h, w, _dtype_code(x), steps)
+  ws = workspace if workspace is not None else reserve_workspace(x.device, need)
+  if not ws.is_cuda or ws.device != x.device or ws.numel() * ws.element_size() < need:
+    raise ExposureHipError('exposure_amd: workspace must be a device tensor of at least %d bytes on %s' %
+                           (need, x.device))
+  return ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel() * ws.element_size())
+
+
 def filter_fwd(fid, x, y, params):
   lib = load()
   _img(x, 'x'), _img(y, 'y')
@@ -127,7 +176,7 @@ def filter_fwd(fid, x, y, params):
            'expo_filter_fwd')
 
 
-def filter_bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0, accumulate=False):
+def filter_bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0, accumulate=False, workspace=None):
   lib = load()
   _img(x, 'x'), _img(dy, 'dy')
   n, h, w, _ = x.shape
@@ -139,8 +188,9 @@ def filter_bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0, accumulate=Fals
   _f32(dparams, 'dparams', (n, NUM_PARAMS[fid]))
   fn = lib.expo_filter_bwd_accumulate if accumulate else lib.expo_filter_bwd
   with torch.cuda.device(x.device):
+    wsp, wsb = _ws(x, workspace)
     _check(fn(fid, _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams), n, h, w, _dtype_code(x),
-              hsv_grad_mode, _stream()), 'expo_filter_bwd')
+              hsv_grad_mode, wsp, wsb, _stream()), 'expo_filter_bwd')
 
 
 def apply_fwd(fid, x, y, params, mask_params, maximum_sharpness, minimum_strength):
@@ -157,7 +207,7 @@ def apply_fwd(fid, x, y, params, mask_params, maximum_sharpness, minimum_strengt
 
 
 def apply_bwd(fid, x, dy, dx, params, dparams, mask_params, dmask_params, maximum_sharpness, minimum_strength,
-              hsv_grad_mode=0):
+              hsv_grad_mode=0, workspace=None):
   lib = load()
   _img(x, 'x'), _img(dy, 'dy')
   n, h, w, _ = x.shape
@@ -168,10 +218,11 @@ def apply_bwd(fid, x, dy, dx, params, dparams, mask_params, dmask_params, maximu
   _f32(mask_params, 'mask_params', (n, 6))
   _f32(dmask_params, 'dmask_params', (n, 6))
   with torch.cuda.device(x.device):
+    wsp, wsb = _ws(x, workspace)
     _check(
         lib.expo_filter_apply_bwd(fid, _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams), _ptr(mask_params),
                                   _ptr(dmask_params), float(maximum_sharpness), float(minimum_strength), n, h, w,
-                                  _dtype_code(x), hsv_grad_mode, _stream()), 'expo_filter_apply_bwd')
+                                  _dtype_code(x), hsv_grad_mode, wsp, wsb, _stream()), 'expo_filter_apply_bwd')
 
 
 def _ids(ids, n):
@@ -180,7 +231,7 @@ def _ids(ids, n):
   return ids
 
 
-def dispatch_fwd(ids, x, y, params, penalty=None):
+def dispatch_fwd(ids, x, y, params, penalty=None, workspace=None):
   lib = load()
   _img(x, 'x'), _img(y, 'y')
   n, h, w, _ = x.shape
@@ -189,12 +240,13 @@ def dispatch_fwd(ids, x, y, params, penalty=None):
   if penalty is not None:
     _f32(penalty, 'penalty', (n,))
   with torch.cuda.device(x.device):
+    wsp, wsb = _ws(x, workspace)
     _check(
         lib.expo_filter_dispatch_fwd(_ptr(ids), _ptr(x), _ptr(y), _ptr(params), _ptr(penalty), n, h, w,
-                                     _dtype_code(x), _stream()), 'expo_filter_dispatch_fwd')
+                                     _dtype_code(x), wsp, wsb, _stream()), 'expo_filter_dispatch_fwd')
 
 
-def dispatch_bwd(ids, x, dy, dx, params, dparams, dpenalty=None, hsv_grad_mode=0):
+def dispatch_bwd(ids, x, dy, dx, params, dparams, dpenalty=None, hsv_grad_mode=0, workspace=None):
   lib = load()
   _img(x, 'x'), _img(dy, 'dy')
   n, h, w, _ = x.shape
@@ -206,9 +258,10 @@ def dispatch_bwd(ids, x, dy, dx, params, dparams, dpenalty=None, hsv_grad_mode=0
   if dpenalty is not None:
     _f32(dpenalty, 'dpenalty', (n,))
   with torch.cuda.device(x.device):
+    wsp, wsb = _ws(x, workspace)
     _check(
         lib.expo_filter_dispatch_bwd(_ptr(ids), _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams),
-                                     _ptr(dpenalty), n, h, w, _dtype_code(x), hsv_grad_mode, _stream()),
+                                     _ptr(dpenalty), n, h, w, _dtype_code(x), hsv_grad_mode, wsp, wsb, _stream()),
         'expo_filter_dispatch_bwd')
 
 
@@ -236,7 +289,7 @@ def chain_fwd(filter_ids, acts, params):
                               _stream()), 'expo_chain_fwd')
 
 
-def chain_bwd(filter_ids, acts, grads, params, dparams, hsv_grad_mode=0):
+def chain_bwd(filter_ids, acts, grads, params, dparams, hsv_grad_mode=0, workspace=None):
   lib = load()
   steps = len(filter_ids)
   assert len(acts) == steps + 1 and len(grads) == steps + 1 and len(params) == steps and len(dparams) == steps
@@ -249,9 +302,10 @@ def chain_bwd(filter_ids, acts, grads, params, dparams, hsv_grad_mode=0):
     _f32(dp, 'dparams', (n, NUM_PARAMS[fid]))
   ids = (ctypes.c_int * steps)(*filter_ids)
   with torch.cuda.device(acts[0].device):
+    wsp, wsb = _ws(acts[0], workspace, steps)
     _check(
         lib.expo_chain_bwd(ids, steps, _ptr_array(acts), _ptr_array(grads), _ptr_array(params),
-                           _ptr_array(dparams), n, h, w, _dtype_code(acts[0]), hsv_grad_mode, _stream()),
+                           _ptr_array(dparams), n, h, w, _dtype_code(acts[0]), hsv_grad_mode, wsp, wsb, _stream()),
         'expo_chain_bwd')
 
 
@@ -270,20 +324,23 @@ def chain_fused_fwd(filter_ids, params, x, y):
                                     _dtype_code(x), _stream()), 'expo_chain_fused_fwd')
 
 
-def critic_stats(x, stats):
+def critic_stats(x, stats, workspace=None):
   lib = load()
   _img(x, 'x')
   n, h, w, _ = x.shape
   _f32(stats, 'stats', (n, 3))
   with torch.cuda.device(x.device):
-    _check(lib.expo_critic_stats(_ptr(x), _ptr(stats), n, h, w, _dtype_code(x), _stream()), 'expo_critic_stats')
+    wsp, wsb = _ws(x, workspace)
+    _check(lib.expo_critic_stats(_ptr(x), _ptr(stats), n, h, w, _dtype_code(x), wsp, wsb, _stream()),
+           'expo_critic_stats')
 
 
-def overexposure_penalty(y, penalty):
+def overexposure_penalty(y, penalty, workspace=None):
   lib = load()
   _img(y, 'y')
   n, h, w, _ = y.shape
   _f32(penalty, 'penalty', (n,))
   with torch.cuda.device(y.device):
-    _check(lib.expo_overexposure_penalty(_ptr(y), _ptr(penalty), n, h, w, _dtype_code(y), _stream()),
+    wsp, wsb = _ws(y, workspace)
+    _check(lib.expo_overexposure_penalty(_ptr(y), _ptr(penalty), n, h, w, _dtype_code(y), wsp, wsb, _stream()),
            'expo_overexposure_penalty')

@@ -5,8 +5,11 @@
 //   filter_fwd_kernel<F,T>   one pass:  read x (6 B/px fp16), write y (6 B/px)
 //   filter_bwd_kernel<F,T>   one pass:  read x, dy, write dx (18 B/px); y is recomputed;
 //                            per-image parameter gradients: per-thread fp32 partials ->
-//                            wave shuffle reduce -> LDS across the 4 waves -> one atomic
-//                            per (block, parameter)
+//                            wave shuffle reduce -> LDS across the 4 waves -> one record per
+//                            block in the caller's workspace -> finish_kernel (one tiny launch
+//                            per call / per chain) sums an image's records in a fixed order and
+//                            writes dparams: no float atomics, no zero-fill launch, and the
+//                            result is bit-reproducible (block_reduce_record / finish_kernel)
 //   dispatch_{fwd,bwd}       same bodies behind a block-uniform switch on filter_ids[n]
 //                            (the reference's one-hot select, agent.py:119-125) with the
 //                            over-exposure penalty (agent.py:249-251) fused in
@@ -35,6 +38,11 @@
 #endif
 #ifndef EXPO_CURVE_PREFETCH
 #define EXPO_CURVE_PREFETCH 1
+#endif
+// chunk -> wave mapping of the backward kernels: 1 = a block's k-th chunk group is blockIdx.x + k * gridDim.x
+// (block-strided), 2 = every wave walks adjacent 3 KiB chunks (block-contiguous; tools/membench rpol4 map2)
+#ifndef EXPO_BWD_MAP
+#define EXPO_BWD_MAP 1
 #endif
 
 namespace expo {
@@ -81,23 +89,38 @@ __device__ __forceinline__ int wave_reduce_scatter(float* acc, int lane) {
   return ok ? l : -1;
 }
 
-// Block-reduce NACC accumulators, finish them to NOUT outputs, add atomically to out[].
-template <int NACC, int NOUT, class Finish>
-__device__ __forceinline__ void block_reduce_atomic(float* acc, float* __restrict__ out, Finish fin) {
+// ---------------------------------------------------------------------------------------------
+// Per-image reductions without float atomics: block -> workspace record -> finish kernel.
+//
+// A reducing kernel leaves ONE record of <= 32 partial sums per block in the caller's workspace
+// (records[n][bx][kWsSlots], plain fire-and-forget stores: a block exits as soon as it has streamed
+// its pixels -- no returning atomic, no drain of its write-through image stores, nothing that keeps
+// an occupancy slot busy).  finish_kernel, launched behind it on the same stream, adds the bx records
+// of an image in a FIXED order and writes the final values (parameter gradients, penalty, statistics).
+// One finish launch serves all steps of a chain.  No zero-fill, no float atomics, results are
+// bit-reproducible run to run, and the workspace needs no initialisation (records are fully
+// overwritten before they are read).
+// Measured on MI355X, 64x512x512x3 fp16 (gpurun r02p3): a last-block-finishes variant (ticket +
+// agent-scope hand-off inside the kernel) cost 6.6 ns per block of tail latency -- 51.9 us per light
+// backward kernel vs 47.9 us with round 1's float atomics -- which is why the finish is a launch.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWsSlots = 32;
+
+// Block-reduce NACC accumulators into this block's record.  Must be the last block-wide action.
+template <int NACC>
+__device__ __forceinline__ void block_reduce_record(float* acc, float* __restrict__ records_img) {
+  static_assert(NACC <= kWsSlots, "one record per block");
   __shared__ float red[kWaves][NACC];
-  __shared__ float tot[NACC];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int idx = wave_reduce_scatter<NACC>(acc, lane);
   if ((lane & 1) == 0 && idx >= 0) red[wv][idx] = acc[0];
   __syncthreads();
   if (threadIdx.x < NACC) {
-    float s = 0.f;
+    float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < kWaves; ++k) s += red[k][threadIdx.x];
-    tot[threadIdx.x] = s;
+    for (int k = 0; k < kWaves; ++k) v += red[k][threadIdx.x];
+    records_img[size_t(blockIdx.x) * kWsSlots + threadIdx.x] = v;
   }
-  __syncthreads();
-  if (threadIdx.x < NOUT) atomicAdd(out + threadIdx.x, fin(tot, threadIdx.x));
 }
 
 // Curve forward by table: instead of the telescoped 7 x v_min + 8 x v_fma per element, a per-wave
@@ -155,8 +178,8 @@ __device__ __forceinline__ void curve_fwd_lut(float* v, float klane, float2_lut*
 // --------------------------------------------------------------------------- forward
 template <class F, typename T, bool VEC, bool PEN, class IO = IoCached>
 __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict__ yi,
-                                         const float* __restrict__ prm, float* pen_out,
-                                         int hw, int groups, float inv_count) {
+                                         const float* __restrict__ prm, float* __restrict__ rec,
+                                         int hw, int groups) {
   constexpr int PPL = PixTraits<T>::PPL;
   const typename F::Prm q = F::load(prm);
   float pen = 0.f;
@@ -213,7 +236,7 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   }
   if constexpr (PEN) {
     float a[1] = {pen};
-    block_reduce_atomic<1, 1>(a, pen_out, [=](const float* t, int) { return t[0] * inv_count; });
+    block_reduce_record<1>(a, rec);  // finish_kernel: penalty[n] = sum * inv_count
   }
 }
 
@@ -223,14 +246,14 @@ __global__ __launch_bounds__(kThreads) void filter_fwd_kernel(const T* __restric
                                                               int hw, int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
-  fwd_body<F, T, VEC, false, IO>(x + off, y + off, params + n * F::NP, nullptr, hw, groups, 0.f);
+  fwd_body<F, T, VEC, false, IO>(x + off, y + off, params + n * F::NP, nullptr, hw, groups);
 }
 
 // -------------------------------------------------------------------------- backward
 template <class F, typename T, bool VEC, bool HAS_DX, bool PEN, int MODE, class IO = IoCached>
 __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __restrict__ dyi,
                                          T* __restrict__ dxi, const float* __restrict__ prm,
-                                         float* __restrict__ dprm, int hw, int groups, float pen_scale) {
+                                         float* __restrict__ rec, int hw, int groups, float pen_scale) {
   constexpr int PPL = PixTraits<T>::PPL;
   const typename F::Prm q = F::load(prm);
   // per-image curve LUT (Tone / Color backward) staged in LDS once per block
@@ -277,8 +300,16 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   };
   if constexpr (VEC) {
     const T* const ins[2] = {xi, dyi};
-    stream_groups<T, 2, HAS_DX, (F::kLutFloats > 0 ? EXPO_CURVE_PREFETCH : EXPO_PREFETCH) != 0, IO>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                    [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); }, stage_lut);
+    constexpr bool kPF = (F::kLutFloats > 0 ? EXPO_CURVE_PREFETCH : EXPO_PREFETCH) != 0;
+#if EXPO_BWD_MAP == 2
+    const int iters = (groups + stride - 1) / stride;  // chunks per wave
+    stream_groups<T, 2, HAS_DX, kPF, IO>(ins, dxi, hw, (blockIdx.x * kWaves + (threadIdx.x >> 6)) * 64 * iters, 64,
+                                         [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); }, stage_lut,
+                                         iters);
+#else
+    stream_groups<T, 2, HAS_DX, kPF, IO>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                         [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); }, stage_lut);
+#endif
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3], d[PPL * 3];
@@ -288,19 +319,18 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
       if constexpr (HAS_DX) store_slow<T>(dxi, g, hw, d);
     }
   }
-  block_reduce_atomic<F::NACC, F::NP>(acc, dprm, [=](const float* t, int j) { return F::finish_one(prm, t, j); });
+  block_reduce_record<F::NACC>(acc, rec);  // finish_kernel applies F::finish_one to the image totals
 }
 
 template <class F, typename T, bool VEC, bool HAS_DX, int MODE, class IO>
 __global__ __launch_bounds__(kThreads) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                               T* __restrict__ dx,
                                                               const float* __restrict__ params,
-                                                              float* __restrict__ dparams, int hw,
-                                                              int groups) {
+                                                              float* __restrict__ records, int hw, int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
-  bwd_body<F, T, VEC, HAS_DX, false, MODE, IO>(x + off, dy + off, HAS_DX ? dx + off : nullptr,
-                                               params + n * F::NP, dparams + n * F::NP, hw, groups, 0.f);
+  bwd_body<F, T, VEC, HAS_DX, false, MODE, IO>(x + off, dy + off, HAS_DX ? dx + off : nullptr, params + n * F::NP,
+                                               records + size_t(n) * gridDim.x * kWsSlots, hw, groups, 0.f);
 }
 
 // ------------------------------------------------ Filter.apply with a spatial mask (masking on)
@@ -346,9 +376,8 @@ __global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict
 template <class F, typename T, bool VEC, bool HAS_DX, int MODE>
 __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                              T* __restrict__ dx, const float* __restrict__ params,
-                                                             float* __restrict__ dparams,
                                                              const float* __restrict__ mask_params,
-                                                             float* __restrict__ dmask, float sharp,
+                                                             float* __restrict__ records, float sharp,
                                                              float min_strength, int h, int w, int groups) {
   constexpr int PPL = PixTraits<T>::PPL;
   const int n = blockIdx.y, hw = h * w;
@@ -364,11 +393,11 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
     F::stage(prm, lut);
     __syncthreads();
   }
-  float acc[F::NACC], macc[6];
+  // filter accumulators and the 6 mask-parameter accumulators share ONE per-block record
+  float acc[F::NACC + 6];
+  float* const macc = acc + F::NACC;
 #pragma unroll
-  for (int j = 0; j < F::NACC; ++j) acc[j] = 0.f;
-#pragma unroll
-  for (int j = 0; j < 6; ++j) macc[j] = 0.f;
+  for (int j = 0; j < F::NACC + 6; ++j) acc[j] = 0.f;
   const int stride = gridDim.x * kThreads;
   auto compute = [&](float* v, float* d, int g) {
     const int lane = threadIdx.x & 63;
@@ -410,9 +439,8 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
       if constexpr (HAS_DX) store_slow<T>(dxi, g, hw, d);
     }
   }
-  block_reduce_atomic<F::NACC, F::NP>(acc, dparams + n * F::NP, [=](const float* t, int j) { return F::finish_one(prm, t, j); });
-  __syncthreads();
-  block_reduce_atomic<6, 6>(macc, dmask + n * 6, [](const float* t, int j) { return t[j]; });
+  // record = [filter accumulators | 6 mask accumulators]; finish_kernel splits them
+  block_reduce_record<F::NACC + 6>(acc, records + size_t(n) * gridDim.x * kWsSlots);
 }
 
 // --------------------------------------------------- per-image dispatch (one-hot select)
@@ -445,16 +473,16 @@ template <typename T, bool VEC, bool PEN, int SET, class IO>
 __global__ __launch_bounds__(kThreads) void dispatch_fwd_kernel(const int32_t* __restrict__ ids,
                                                                 const T* __restrict__ x, T* __restrict__ y,
                                                                 const float* __restrict__ params,
-                                                                float* __restrict__ penalty, int hw, int groups,
-                                                                float inv_count) {
+                                                                float* __restrict__ records, int hw,
+                                                                int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
   const float* prm = params + n * EXPO_MAX_PARAMS;
-  float* pen = PEN ? penalty + n : nullptr;
+  float* rec = PEN ? records + size_t(n) * gridDim.x * kWsSlots : nullptr;
   const int id = ids[n];  // block-uniform
-#define EXPO_CASE(ID, F)                                                                              \
-  case ID:                                                                                            \
-    if constexpr ((SET >> ID) & 1) fwd_body<F, T, VEC, PEN, IO>(x + off, y + off, prm, pen, hw, groups, inv_count); \
+#define EXPO_CASE(ID, F)                                                                                   \
+  case ID:                                                                                                 \
+    if constexpr ((SET >> ID) & 1) fwd_body<F, T, VEC, PEN, IO>(x + off, y + off, prm, rec, hw, groups);   \
     break;
   switch (id) {
     EXPO_CASE(0, ExposureF)
@@ -466,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void dispatch_fwd_kernel(const int32_t* _
     EXPO_CASE(6, WnbF)
     EXPO_CASE(7, ColorF)
     EXPO_CASE(8, LevelF)
-    default:  // id -1: all-zero one-hot
+    default:  // id -1: all-zero one-hot -> y = 0 (finish_kernel writes penalty = 0 without reading records)
       if constexpr ((SET >> 15) & 1) zero_image<T, VEC, IO>(y + off, hw, groups);
       break;
   }
@@ -477,20 +505,20 @@ template <typename T, bool VEC, bool HAS_DX, bool PEN, int MODE, int SET, class 
 __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* __restrict__ ids,
                                                                 const T* __restrict__ x, const T* __restrict__ dy,
                                                                 T* __restrict__ dx, const float* __restrict__ params,
-                                                                float* __restrict__ dparams,
+                                                                float* __restrict__ records,
                                                                 const float* __restrict__ dpenalty, int hw,
                                                                 int groups, float inv_count) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
   const float* prm = params + n * EXPO_MAX_PARAMS;
-  float* dprm = dparams + n * EXPO_MAX_PARAMS;
+  float* rec = records + size_t(n) * gridDim.x * kWsSlots;
   const float ps = PEN ? 2.0f * inv_count * dpenalty[n] : 0.f;
   T* dxi = HAS_DX ? dx + off : nullptr;
   const int id = ids[n];
 #define EXPO_CASE(ID, F)                                                                                  \
   case ID:                                                                                                \
     if constexpr ((SET >> ID) & 1)                                                                        \
-      bwd_body<F, T, VEC, HAS_DX, PEN, MODE, IO>(x + off, dy + off, dxi, prm, dprm, hw, groups, ps); \
+      bwd_body<F, T, VEC, HAS_DX, PEN, MODE, IO>(x + off, dy + off, dxi, prm, rec, hw, groups, ps);       \
     break;
   switch (id) {
     EXPO_CASE(0, ExposureF)
@@ -502,7 +530,7 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
     EXPO_CASE(6, WnbF)
     EXPO_CASE(7, ColorF)
     EXPO_CASE(8, LevelF)
-    default:
+    default:  // id -1 selects nothing: dx = 0 (finish_kernel writes the all-zero dparams row)
       if constexpr (HAS_DX && ((SET >> 15) & 1)) zero_image<T, VEC, IO>(dxi, hw, groups);
       break;
   }
@@ -605,10 +633,10 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
 }
 
 // ------------------------------------------------------------- per-image reductions
-// critics.py:48-62.  Raw sums {sum(l-1/2), sum (l-1/2)^2, sum sat} are accumulated
-// (shifted to tame the E[l^2]-E[l]^2 cancellation) and finished by stats_finish_kernel.
+// critics.py:48-62.  Raw sums {sum(l-1/2), sum (l-1/2)^2, sum sat} are accumulated (shifted to tame
+// the E[l^2]-E[l]^2 cancellation); finish_kernel turns them into {mean, variance, mean sat}.
 template <typename T, bool VEC, class IO>
-__global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x, float* __restrict__ sums,
+__global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x, float* __restrict__ records,
                                                          int hw, int groups) {
   constexpr int PPL = PixTraits<T>::PPL;
   const int n = blockIdx.y;
@@ -641,21 +669,12 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const T* __restrict__ x
       compute(v, g);
     }
   }
-  block_reduce_atomic<3, 3>(acc, sums + n * 3, [](const float* t, int j) { return t[j]; });
-}
-
-__global__ void stats_finish_kernel(float* __restrict__ stats, int n, float inv_hw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float m = stats[i * 3 + 0] * inv_hw, m2 = stats[i * 3 + 1] * inv_hw;
-  stats[i * 3 + 0] = m + 0.5f;
-  stats[i * 3 + 1] = m2 - m * m;  // tf.nn.moments: population variance
-  stats[i * 3 + 2] = stats[i * 3 + 2] * inv_hw;
+  block_reduce_record<3>(acc, records + size_t(n) * gridDim.x * kWsSlots);
 }
 
 template <typename T, bool VEC, class IO>
-__global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__ y, float* __restrict__ pen,
-                                                           int hw, int groups, float inv_count) {
+__global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__ y, float* __restrict__ records,
+                                                           int hw, int groups) {
   constexpr int PPL = PixTraits<T>::PPL;
   const int n = blockIdx.y;
   const T* yi = y + size_t(n) * hw * 3;
@@ -679,21 +698,112 @@ __global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__
       compute(v);
     }
   }
-  block_reduce_atomic<1, 1>(acc, pen + n, [=](const float* t, int) { return t[0] * inv_count; });
+  block_reduce_record<1>(acc, records + size_t(n) * gridDim.x * kWsSlots);
+}
+
+// ------------------------------------------------------------------------------- finish
+// One wave per (image, step): adds the image's bx block records in a fixed order and writes the final
+// per-image values.  Steps of a chain (or the single step of any other entry point) are described by
+// value in the kernel arguments.
+enum FinishKind : int { kFinFilter = 0, kFinDispatch = 1, kFinApply = 2, kFinStats = 3, kFinPenalty = 4 };
+struct FinishStep {
+  const float* params;    // [n][P] (filter / apply), [n][EXPO_MAX_PARAMS] (dispatch)
+  float* out;             // dparams [n][P] | [n][24]; stats [n][3]; penalty [n]
+  float* out2;            // apply: dmask_params [n][6]
+  const float* records;   // [n][bx][kWsSlots]
+  const int32_t* ids;     // dispatch: per-image filter ids
+  int kind, filter_id, accumulate;
+  float scale;            // stats: 1 / (H W); penalty: 1 / (H W 3)
+};
+constexpr int kMaxFinishSteps = 12;
+struct FinishArgs { FinishStep s[kMaxFinishSteps]; };
+
+template <class F>
+__device__ __forceinline__ void finish_filter(const FinishStep& st, const float* prm, const float* tot, float* dprm,
+                                              int nout, int lane) {
+  if (lane < nout) {
+    const float g = lane < F::NP ? F::finish_one(prm, tot, lane) : 0.0f;
+    dprm[lane] = st.accumulate ? dprm[lane] + g : g;
+  }
+}
+
+__global__ __launch_bounds__(64) void finish_kernel(const FinishArgs args, int bx) {
+  const FinishStep st = args.s[blockIdx.y];
+  const int n = blockIdx.x, lane = threadIdx.x;
+  __shared__ float tot[kWsSlots];
+  int fid = st.filter_id;
+  if (st.ids) fid = st.ids[n];  // per-image choice (dispatch entry points)
+  const bool nothing = st.ids && (fid < 0 || fid >= EXPO_NUM_FILTERS);  // id -1: the image wrote no records
+  // fixed summation order: two interleaved chains over the blocks, combined at the end
+  const int j = lane & 31, half = lane >> 5;
+  float s0 = 0.f, s1 = 0.f;
+  if (!nothing) {
+    const float* r = st.records + (size_t(n) * bx) * kWsSlots + j;
+    int b = half;
+    for (; b + 2 < bx; b += 4) {
+      const float a0 = r[size_t(b) * kWsSlots], a1 = r[size_t(b + 2) * kWsSlots];
+      s0 += a0;
+      s1 += a1;
+    }
+    if (b < bx) s0 += r[size_t(b) * kWsSlots];
+  }
+  float v = s0 + s1;
+  v += __shfl_xor(v, 32, 64);
+  if (lane < kWsSlots) tot[lane] = v;
+  __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in order
+  switch (st.kind) {
+    case kFinStats: {  // critics.py:51-62: mean, population variance (tf.nn.moments), mean saturation
+      if (lane < 3) {
+        const float m = tot[0] * st.scale, m2 = tot[1] * st.scale;
+        st.out[n * 3 + lane] = lane == 0 ? m + 0.5f : (lane == 1 ? m2 - m * m : tot[2] * st.scale);
+      }
+    } break;
+    case kFinPenalty:  // agent.py:249-251 (also the fused penalty of the dispatch forward; id -1 -> 0)
+      if (lane == 0) st.out[n] = nothing ? 0.0f : tot[0] * st.scale;
+      break;
+    default: {
+      const bool disp = st.kind == kFinDispatch;
+      const int stride = disp ? EXPO_MAX_PARAMS : 0;
+      if (nothing) {
+        if (lane < EXPO_MAX_PARAMS) st.out[n * EXPO_MAX_PARAMS + lane] = 0.0f;
+        break;
+      }
+#define EXPO_FIN(ID, F)                                                                                        \
+  case ID: {                                                                                                   \
+    const int row = disp ? stride : F::NP;                                                                     \
+    finish_filter<F>(st, st.params + size_t(n) * row, tot, st.out + size_t(n) * row, row, lane);               \
+    if (st.kind == kFinApply && lane < 6) st.out2[n * 6 + lane] = tot[F::NACC + lane];                        \
+  } break;
+      switch (fid) {
+        EXPO_FIN(0, ExposureF)
+        EXPO_FIN(1, GammaF)
+        EXPO_FIN(2, WhiteBalanceF)
+        EXPO_FIN(3, SatPlusF)
+        EXPO_FIN(4, ToneF)
+        EXPO_FIN(5, ContrastF)
+        EXPO_FIN(6, WnbF)
+        EXPO_FIN(7, ColorF)
+        EXPO_FIN(8, LevelF)
+      }
+#undef EXPO_FIN
+    } break;
+  }
 }
 
 #ifdef EXPO_PROBE
 // register-pressure probe builds (tools/probe.sh): instantiate a few kernels, skip the host side
-template __global__ void filter_bwd_kernel<ToneF, half_t, true, true, 0, IoStream>(const half_t*, const half_t*, half_t*,
-                                                                                const float*, float*, int, int);
-template __global__ void filter_bwd_kernel<ColorF, half_t, true, true, 0, IoStream>(const half_t*, const half_t*, half_t*,
+#define EXPO_PROBE_BWD(F)                                                                                         \
+  template __global__ void filter_bwd_kernel<F, half_t, true, true, 0, IoStream>(const half_t*, const half_t*, half_t*, \
                                                                                  const float*, float*, int, int);
-template __global__ void filter_bwd_kernel<WnbF, half_t, true, true, 0, IoStream>(const half_t*, const half_t*, half_t*,
-                                                                               const float*, float*, int, int);
+EXPO_PROBE_BWD(ToneF)
+EXPO_PROBE_BWD(ColorF)
+EXPO_PROBE_BWD(WnbF)
+EXPO_PROBE_BWD(ExposureF)
+#undef EXPO_PROBE_BWD
 #define EXPO_PROBE_APPLY(F)                                                                                   \
   template __global__ void apply_bwd_kernel<F, half_t, true, true, 0>(const half_t*, const half_t*, half_t*, \
-                                                                      const float*, float*, const float*,   \
-                                                                      float*, float, float, int, int, int);
+                                                                      const float*, const float*, float*,   \
+                                                                      float, float, int, int, int);
 EXPO_PROBE_APPLY(ExposureF)
 EXPO_PROBE_APPLY(ContrastF)
 EXPO_PROBE_APPLY(SatPlusF)
@@ -734,11 +844,16 @@ static int env_int(const char* name, int dflt) {
   return x > 0 ? x : dflt;
 }
 
+// a reducing kernel writes one workspace record per block: bound the records of one image
+constexpr int kMaxReduceBlocksX = 1024;
+enum GeomKind { kGeomMap = 0, kGeomReduce = 1, kGeomReadReduce = 2 };
+
 // groups of 48 bytes per image; blocks per image chosen so the whole grid is >= ~1024
 // blocks when the problem allows and each thread walks a few groups (amortises the
 // reduction epilogue); capped at 2048-ish total blocks (grid-stride the rest).
 template <typename T>
-static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> ptrs, bool reduces = true) {
+static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> ptrs, int kind = kGeomReduce) {
+  const bool reduces = kind != kGeomMap;
   constexpr int PPL = PixTraits<T>::PPL;
   Geom g;
   g.hw = h * w;
@@ -746,21 +861,41 @@ static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
   g.vec = (g.hw % VecTraits<T>::PPV) == 0;  // dwordx3 path: whole 12-byte vectors, 4-byte aligned
   for (const void* p : ptrs) g.vec = g.vec && (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 3) == 0);
   const int max_bx = (g.groups + kThreads - 1) / kThreads;
-  // groups each thread walks: kernels with a reduction epilogue (atomics per block) want fewer,
-  // fatter blocks; pure maps (forward) stream best with many blocks (tools/membench.hip)
+  // groups each thread walks: kernels with a reduction epilogue (one workspace record per block) want
+  // fewer, fatter blocks; pure maps (forward) stream best with many blocks (tools/membench.hip)
   static const int gpt_red = env_int("EXPO_BWD_GROUPS_PER_THREAD", 4);
   static const int gpt_map = env_int("EXPO_FWD_GROUPS_PER_THREAD", 1);
-  const int gpt = reduces ? gpt_red : gpt_map;
+  static const int gpt_read = env_int("EXPO_RED_GROUPS_PER_THREAD", 1);  // read-only reductions (stats, penalty)
+  const int gpt = kind == kGeomReduce ? gpt_red : (kind == kGeomReadReduce ? gpt_read : gpt_map);
   int bx = (g.groups + kThreads * gpt - 1) / (kThreads * gpt);
   const long want = 1024;
   if (long(bx) * n < want) bx = int((want + n - 1) / n);
   if (bx > max_bx) bx = max_bx;
+  if (reduces && bx > kMaxReduceBlocksX) bx = kMaxReduceBlocksX;
   if (bx < 1) bx = 1;
   g.blocks_x = bx;
   // cache policy: tensors of at least EXPO_STREAM_MIN_BYTES (default 8 MiB; L2 is 8 x 4 MiB) stream
   static const long stream_min = env_int("EXPO_STREAM_MIN_BYTES", 8 << 20);
   g.stream = g.vec && long(n) * g.hw * 3L * long(sizeof(T)) >= stream_min;
   return g;
+}
+
+// ---- workspace of the reducing kernels: float records[steps][n][bx][kWsSlots]; no initialisation needed
+static size_t ws_step_bytes(int n, int blocks_x) { return size_t(n) * size_t(blocks_x) * kWsSlots * sizeof(float); }
+static int ws_check(void* workspace, size_t workspace_bytes, int n, int blocks_x, int steps, float** records) {
+  *records = nullptr;
+  if (!workspace) return fail(EXPO_E_BADARG, "workspace is NULL (size it with expo_workspace_bytes)");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 3) != 0) return fail(EXPO_E_BADARG, "workspace must be 4-byte aligned");
+  if (workspace_bytes < ws_step_bytes(n, blocks_x) * size_t(steps))
+    return fail(EXPO_E_BADARG, "workspace too small (expo_workspace_bytes, times the steps of a chain)");
+  *records = static_cast<float*>(workspace);
+  return EXPO_OK;
+}
+
+static int launch_finish(const FinishArgs& args, int steps, int n, int bx, hipStream_t s) {
+  hipLaunchKernelGGL(finish_kernel, dim3(n, steps), dim3(64), 0, s, args, bx);
+  HIP_TRY(hipGetLastError(), "finish launch");
+  return EXPO_OK;
 }
 
 static int check_common(int n, int h, int w, int dtype) {
@@ -775,7 +910,7 @@ static int check_common(int n, int h, int w, int dtype) {
 
 template <class F, typename T>
 static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s) {
-  const Geom g = make_geom<T>(n, h, w, {x, y}, false);
+  const Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
   const dim3 grid(g.blocks_x, n), block(kThreads);
   if (g.stream)
     hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, IoStream>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
@@ -788,14 +923,13 @@ static int launch_fwd(const void* x, void* y, const float* params, int n, int h,
 }
 
 template <class F, typename T>
-static int launch_bwd(const void* x, const void* dy, void* dx, const float* params, float* dparams, int n,
-                      int h, int w, int mode, hipStream_t s, bool zeroed) {
+static int launch_bwd(const void* x, const void* dy, void* dx, const float* params, float* records, int n,
+                      int h, int w, int mode, hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  if (!zeroed) HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * F::NP, s), "dparams memset");
 #define EXPO_LIO(VEC, HAS_DX, MODE, IO)                                                                  \
   hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, HAS_DX, MODE, IO>), grid, block, 0, s, (const T*)x, \
-                     (const T*)dy, (T*)dx, params, dparams, g.hw, g.groups)
+                     (const T*)dy, (T*)dx, params, records, g.hw, g.groups)
 #define EXPO_L(VEC, HAS_DX, MODE)                                  \
   do {                                                             \
     if constexpr (VEC) {                                           \
@@ -841,18 +975,18 @@ static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int 
 }
 
 template <typename T>
-static int bwd_by_id(int id, const void* x, const void* dy, void* dx, const float* p, float* dp, int n, int h,
-                     int w, int mode, hipStream_t s, bool zeroed = false) {
+static int bwd_by_id(int id, const void* x, const void* dy, void* dx, const float* p, float* records, int n, int h,
+                     int w, int mode, hipStream_t s) {
   switch (id) {
-    case 0: return launch_bwd<ExposureF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
-    case 1: return launch_bwd<GammaF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
-    case 2: return launch_bwd<WhiteBalanceF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
-    case 3: return launch_bwd<SatPlusF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
-    case 4: return launch_bwd<ToneF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
-    case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
-    case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
-    case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
-    case 8: return launch_bwd<LevelF, T>(x, dy, dx, p, dp, n, h, w, mode, s, zeroed);
+    case 0: return launch_bwd<ExposureF, T>(x, dy, dx, p, records, n, h, w, mode, s);
+    case 1: return launch_bwd<GammaF, T>(x, dy, dx, p, records, n, h, w, mode, s);
+    case 2: return launch_bwd<WhiteBalanceF, T>(x, dy, dx, p, records, n, h, w, mode, s);
+    case 3: return launch_bwd<SatPlusF, T>(x, dy, dx, p, records, n, h, w, mode, s);
+    case 4: return launch_bwd<ToneF, T>(x, dy, dx, p, records, n, h, w, mode, s);
+    case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, records, n, h, w, mode, s);
+    case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, records, n, h, w, mode, s);
+    case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, records, n, h, w, mode, s);
+    case 8: return launch_bwd<LevelF, T>(x, dy, dx, p, records, n, h, w, mode, s);
   }
   return fail(EXPO_E_BADARG, "filter_id out of range");
 }
@@ -860,7 +994,7 @@ static int bwd_by_id(int id, const void* x, const void* dy, void* dx, const floa
 template <class F, typename T>
 static int launch_apply_fwd(const void* x, void* y, const float* params, const float* mp, float sharp, float ms,
                             int n, int h, int w, hipStream_t s) {
-  const Geom g = make_geom<T>(n, h, w, {x, y}, false);
+  const Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
   const dim3 grid(g.blocks_x, n), block(kThreads);
   if (g.vec)
     hipLaunchKernelGGL((apply_fwd_kernel<F, T, true>), grid, block, 0, s, (const T*)x, (T*)y, params, mp, sharp, ms, h, w, g.groups);
@@ -871,16 +1005,13 @@ static int launch_apply_fwd(const void* x, void* y, const float* params, const f
 }
 
 template <class F, typename T>
-static int launch_apply_bwd(const void* x, const void* dy, void* dx, const float* params, float* dparams,
-                            const float* mp, float* dmp, float sharp, float ms, int n, int h, int w, int mode,
-                            hipStream_t s) {
+static int launch_apply_bwd(const void* x, const void* dy, void* dx, const float* params, const float* mp,
+                            float* records, float sharp, float ms, int n, int h, int w, int mode, hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * F::NP, s), "dparams memset");
-  HIP_TRY(hipMemsetAsync(dmp, 0, sizeof(float) * size_t(n) * 6, s), "dmask memset");
 #define EXPO_L(VEC, HAS_DX, MODE)                                                                          \
   hipLaunchKernelGGL((apply_bwd_kernel<F, T, VEC, HAS_DX, MODE>), grid, block, 0, s, (const T*)x,          \
-                     (const T*)dy, (T*)dx, params, dparams, mp, dmp, sharp, ms, h, w, g.groups)
+                     (const T*)dy, (T*)dx, params, mp, records, sharp, ms, h, w, g.groups)
   const bool m1 = std::is_same<F, SatPlusF>::value && mode == 1;
   const int key = (g.vec ? 4 : 0) | (dx ? 2 : 0) | (m1 ? 1 : 0);
   switch (key) {
@@ -916,35 +1047,36 @@ static int apply_fwd_by_id(int id, const void* x, void* y, const float* p, const
 }
 
 template <typename T>
-static int apply_bwd_by_id(int id, const void* x, const void* dy, void* dx, const float* p, float* dp,
-                           const float* mp, float* dmp, float sharp, float ms, int n, int h, int w, int mode,
-                           hipStream_t s) {
+static int apply_bwd_by_id(int id, const void* x, const void* dy, void* dx, const float* p, const float* mp,
+                           float* records, float sharp, float ms, int n, int h, int w, int mode, hipStream_t s) {
   switch (id) {
-    case 0: return launch_apply_bwd<ExposureF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
-    case 1: return launch_apply_bwd<GammaF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
-    case 2: return launch_apply_bwd<WhiteBalanceF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
-    case 3: return launch_apply_bwd<SatPlusF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
-    case 4: return launch_apply_bwd<ToneF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
-    case 5: return launch_apply_bwd<ContrastF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
-    case 6: return launch_apply_bwd<WnbF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
-    case 7: return launch_apply_bwd<ColorF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
-    case 8: return launch_apply_bwd<LevelF, T>(x, dy, dx, p, dp, mp, dmp, sharp, ms, n, h, w, mode, s);
+    case 0: return launch_apply_bwd<ExposureF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
+    case 1: return launch_apply_bwd<GammaF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
+    case 2: return launch_apply_bwd<WhiteBalanceF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
+    case 3: return launch_apply_bwd<SatPlusF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
+    case 4: return launch_apply_bwd<ToneF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
+    case 5: return launch_apply_bwd<ContrastF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
+    case 6: return launch_apply_bwd<WnbF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
+    case 7: return launch_apply_bwd<ColorF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
+    case 8: return launch_apply_bwd<LevelF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
   }
   return fail(EXPO_E_BADARG, "filter_id out of range");
 }
 
 template <typename T>
 static int dispatch_fwd_t(const int32_t* ids, const void* x, void* y, const float* params, float* penalty, int n,
-                          int h, int w, hipStream_t s) {
+                          int h, int w, void* workspace, size_t workspace_bytes, hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {x, y});
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  const float inv_count = 1.0f / (float(g.hw) * 3.0f);
-  if (penalty) HIP_TRY(hipMemsetAsync(penalty, 0, sizeof(float) * size_t(n), s), "penalty memset");
+  float* records = nullptr;
+  if (penalty) {
+    if (int rc = ws_check(workspace, workspace_bytes, n, g.blocks_x, 1, &records)) return rc;
+  }
   // forward: one launch handles every filter (the heaviest forward body needs ~106 VGPRs, fine for a
   // streaming kernel); only the backward is split into light / curve launches (124 vs 190 VGPRs)
 #define EXPO_L(VEC, PEN, IO)                                                                              \
   hipLaunchKernelGGL((dispatch_fwd_kernel<T, VEC, PEN, kSetAll, IO>), grid, block, 0, s, ids, (const T*)x, \
-                     (T*)y, params, penalty, g.hw, g.groups, inv_count)
+                     (T*)y, params, records, g.hw, g.groups)
   if (g.stream) {
     if (penalty) EXPO_L(true, true, IoStream); else EXPO_L(true, false, IoStream);
   } else if (g.vec) {
@@ -954,19 +1086,28 @@ static int dispatch_fwd_t(const int32_t* ids, const void* x, void* y, const floa
   }
 #undef EXPO_L
   HIP_TRY(hipGetLastError(), "dispatch_fwd launch");
+  if (penalty) {
+    FinishArgs fa{};
+    fa.s[0] = FinishStep{nullptr, penalty, nullptr, records, ids, kFinPenalty, 0, 0, 1.0f / (float(g.hw) * 3.0f)};
+    return launch_finish(fa, 1, n, g.blocks_x, s);
+  }
   return EXPO_OK;
 }
 
 template <typename T>
 static int dispatch_bwd_t(const int32_t* ids, const void* x, const void* dy, void* dx, const float* params,
-                          float* dparams, const float* dpenalty, int n, int h, int w, int mode, hipStream_t s) {
+                          float* dparams, const float* dpenalty, int n, int h, int w, int mode, void* workspace,
+                          size_t workspace_bytes, hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
   const dim3 grid(g.blocks_x, n), block(kThreads);
   const float inv_count = 1.0f / (float(g.hw) * 3.0f);
-  HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * size_t(n) * EXPO_MAX_PARAMS, s), "dparams memset");
+  float* records;
+  if (int rc = ws_check(workspace, workspace_bytes, n, g.blocks_x, 1, &records)) return rc;
+  // two launches (light filters / curve filters): an image's records are written by exactly one of them
+  // (none for id -1); ONE finish launch then writes every dparams row -- no zero-fill
 #define EXPO_L2(VEC, HAS_DX, PEN, MODE, SET, IO)                                                          \
   hipLaunchKernelGGL((dispatch_bwd_kernel<T, VEC, HAS_DX, PEN, MODE, SET, IO>), grid, block, 0, s, ids,   \
-                     (const T*)x, (const T*)dy, (T*)dx, params, dparams, dpenalty, g.hw, g.groups, inv_count)
+                     (const T*)x, (const T*)dy, (T*)dx, params, records, dpenalty, g.hw, g.groups, inv_count)
 #define EXPO_L(VEC, HAS_DX, PEN, IO)                                                                      \
   do {                                                                                                    \
     if (mode == 1) EXPO_L2(VEC, HAS_DX, PEN, 1, kSetLight, IO);                                           \
@@ -990,13 +1131,15 @@ static int dispatch_bwd_t(const int32_t* ids, const void* x, const void* dy, voi
 #undef EXPO_L
 #undef EXPO_L2
   HIP_TRY(hipGetLastError(), "dispatch_bwd launch");
-  return EXPO_OK;
+  FinishArgs fa{};
+  fa.s[0] = FinishStep{params, dparams, nullptr, records, ids, kFinDispatch, 0, 0, 0.f};
+  return launch_finish(fa, 1, n, g.blocks_x, s);
 }
 
 template <typename T>
 static int chain_fused_fwd_t(const int32_t* ids, const float* params, int steps, const void* x, void* y, int n,
                              int h, int w, hipStream_t s) {
-  Geom g = make_geom<T>(n, h, w, {x, y}, false);
+  Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
   g.blocks_x = (g.groups + kThreads - 1) / kThreads;  // one chunk per wave: parameters fetched once
   const dim3 grid(g.blocks_x, n), block(kThreads);
   if (g.stream)
@@ -1010,30 +1153,35 @@ static int chain_fused_fwd_t(const int32_t* ids, const float* params, int steps,
 }
 
 template <typename T>
-static int stats_t(const void* x, float* stats, int n, int h, int w, hipStream_t s) {
-  const Geom g = make_geom<T>(n, h, w, {x});
+static int stats_t(const void* x, float* stats, int n, int h, int w, void* workspace, size_t workspace_bytes,
+                   hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x}, kGeomReadReduce);  // read-only: the forward geometry streams best
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  HIP_TRY(hipMemsetAsync(stats, 0, sizeof(float) * size_t(n) * 3, s), "stats memset");
-  if (g.stream) hipLaunchKernelGGL((stats_kernel<T, true, IoStream>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
-  else if (g.vec) hipLaunchKernelGGL((stats_kernel<T, true, IoCached>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
-  else hipLaunchKernelGGL((stats_kernel<T, false, IoCached>), grid, block, 0, s, (const T*)x, stats, g.hw, g.groups);
+  float* records;
+  if (int rc = ws_check(workspace, workspace_bytes, n, g.blocks_x, 1, &records)) return rc;
+  if (g.stream) hipLaunchKernelGGL((stats_kernel<T, true, IoStream>), grid, block, 0, s, (const T*)x, records, g.hw, g.groups);
+  else if (g.vec) hipLaunchKernelGGL((stats_kernel<T, true, IoCached>), grid, block, 0, s, (const T*)x, records, g.hw, g.groups);
+  else hipLaunchKernelGGL((stats_kernel<T, false, IoCached>), grid, block, 0, s, (const T*)x, records, g.hw, g.groups);
   HIP_TRY(hipGetLastError(), "stats launch");
-  hipLaunchKernelGGL(stats_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, s, stats, n, 1.0f / float(g.hw));
-  HIP_TRY(hipGetLastError(), "stats_finish launch");
-  return EXPO_OK;
+  FinishArgs fa{};
+  fa.s[0] = FinishStep{nullptr, stats, nullptr, records, nullptr, kFinStats, 0, 0, 1.0f / float(g.hw)};
+  return launch_finish(fa, 1, n, g.blocks_x, s);
 }
 
 template <typename T>
-static int penalty_t(const void* y, float* pen, int n, int h, int w, hipStream_t s) {
-  const Geom g = make_geom<T>(n, h, w, {y});
+static int penalty_t(const void* y, float* pen, int n, int h, int w, void* workspace, size_t workspace_bytes,
+                     hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {y}, kGeomReadReduce);
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  HIP_TRY(hipMemsetAsync(pen, 0, sizeof(float) * size_t(n), s), "penalty memset");
-  const float inv_count = 1.0f / (float(g.hw) * 3.0f);
-  if (g.stream) hipLaunchKernelGGL((penalty_kernel<T, true, IoStream>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
-  else if (g.vec) hipLaunchKernelGGL((penalty_kernel<T, true, IoCached>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
-  else hipLaunchKernelGGL((penalty_kernel<T, false, IoCached>), grid, block, 0, s, (const T*)y, pen, g.hw, g.groups, inv_count);
+  float* records;
+  if (int rc = ws_check(workspace, workspace_bytes, n, g.blocks_x, 1, &records)) return rc;
+  if (g.stream) hipLaunchKernelGGL((penalty_kernel<T, true, IoStream>), grid, block, 0, s, (const T*)y, records, g.hw, g.groups);
+  else if (g.vec) hipLaunchKernelGGL((penalty_kernel<T, true, IoCached>), grid, block, 0, s, (const T*)y, records, g.hw, g.groups);
+  else hipLaunchKernelGGL((penalty_kernel<T, false, IoCached>), grid, block, 0, s, (const T*)y, records, g.hw, g.groups);
   HIP_TRY(hipGetLastError(), "penalty launch");
-  return EXPO_OK;
+  FinishArgs fa{};
+  fa.s[0] = FinishStep{nullptr, pen, nullptr, records, nullptr, kFinPenalty, 0, 0, 1.0f / (float(g.hw) * 3.0f)};
+  return launch_finish(fa, 1, n, g.blocks_x, s);
 }
 
 }  // namespace expo
@@ -1052,6 +1200,16 @@ int expo_num_filter_params(int filter_id) {
   return kNumParams[filter_id];
 }
 
+size_t expo_workspace_bytes(int n, int h, int w, int dtype) {
+  if (check_common(n, h, w, dtype) != EXPO_OK || n == 0) return 0;
+  int bx = 1;
+  for (int kind : {int(kGeomReduce), int(kGeomReadReduce)}) {
+    const Geom g = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}, kind) : make_geom<float>(n, h, w, {}, kind);
+    if (g.blocks_x > bx) bx = g.blocks_x;
+  }
+  return ws_step_bytes(n, bx);
+}
+
 int expo_filter_fwd(int filter_id, const void* x, void* y, const float* params, int n, int h, int w, int dtype,
                     void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
@@ -1063,29 +1221,39 @@ int expo_filter_fwd(int filter_id, const void* x, void* y, const float* params, 
                            : fwd_by_id<float>(filter_id, x, y, params, n, h, w, s);
 }
 
-int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx, const float* params, float* dparams,
-                    int n, int h, int w, int dtype, int hsv_grad_mode, void* stream) {
+static int filter_bwd_common(int filter_id, const void* x, const void* dy, void* dx, const float* params,
+                             float* dparams, int n, int h, int w, int dtype, int hsv_grad_mode, void* workspace,
+                             size_t workspace_bytes, void* stream, bool accum) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
   if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
   if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
   if (n == 0) return EXPO_OK;
   if (!x || !dy || !params || !dparams) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == EXPO_F16 ? bwd_by_id<half_t>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s)
-                           : bwd_by_id<float>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s);
+  const int bx = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}).blocks_x : make_geom<float>(n, h, w, {}).blocks_x;
+  float* records;
+  if (int rc = ws_check(workspace, workspace_bytes, n, bx, 1, &records)) return rc;
+  const int rc = dtype == EXPO_F16
+                     ? bwd_by_id<half_t>(filter_id, x, dy, dx, params, records, n, h, w, hsv_grad_mode, s)
+                     : bwd_by_id<float>(filter_id, x, dy, dx, params, records, n, h, w, hsv_grad_mode, s);
+  if (rc) return rc;
+  FinishArgs fa{};
+  fa.s[0] = FinishStep{params, dparams, nullptr, records, nullptr, kFinFilter, filter_id, accum ? 1 : 0, 0.f};
+  return launch_finish(fa, 1, n, bx, s);
+}
+
+int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx, const float* params, float* dparams,
+                    int n, int h, int w, int dtype, int hsv_grad_mode, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  return filter_bwd_common(filter_id, x, dy, dx, params, dparams, n, h, w, dtype, hsv_grad_mode, workspace,
+                           workspace_bytes, stream, false);
 }
 
 int expo_filter_bwd_accumulate(int filter_id, const void* x, const void* dy, void* dx, const float* params,
-                               float* dparams, int n, int h, int w, int dtype, int hsv_grad_mode, void* stream) {
-  if (int rc = check_common(n, h, w, dtype)) return rc;
-  if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
-  if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
-  if (n == 0) return EXPO_OK;
-  if (!x || !dy || !params || !dparams) return fail(EXPO_E_BADARG, "null pointer");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == EXPO_F16
-             ? bwd_by_id<half_t>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s, true)
-             : bwd_by_id<float>(filter_id, x, dy, dx, params, dparams, n, h, w, hsv_grad_mode, s, true);
+                               float* dparams, int n, int h, int w, int dtype, int hsv_grad_mode, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  return filter_bwd_common(filter_id, x, dy, dx, params, dparams, n, h, w, dtype, hsv_grad_mode, workspace,
+                           workspace_bytes, stream, true);
 }
 
 int expo_filter_apply_fwd(int filter_id, const void* x, void* y, const float* params, const float* mask_params,
@@ -1104,41 +1272,52 @@ int expo_filter_apply_fwd(int filter_id, const void* x, void* y, const float* pa
 
 int expo_filter_apply_bwd(int filter_id, const void* x, const void* dy, void* dx, const float* params,
                           float* dparams, const float* mask_params, float* dmask_params, float maximum_sharpness,
-                          float minimum_strength, int n, int h, int w, int dtype, int hsv_grad_mode, void* stream) {
+                          float minimum_strength, int n, int h, int w, int dtype, int hsv_grad_mode, void* workspace,
+                          size_t workspace_bytes, void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
   if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
   if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
   if (n == 0) return EXPO_OK;
   if (!x || !dy || !params || !dparams || !mask_params || !dmask_params) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == EXPO_F16
-             ? apply_bwd_by_id<half_t>(filter_id, x, dy, dx, params, dparams, mask_params, dmask_params,
-                                       maximum_sharpness, minimum_strength, n, h, w, hsv_grad_mode, s)
-             : apply_bwd_by_id<float>(filter_id, x, dy, dx, params, dparams, mask_params, dmask_params,
-                                      maximum_sharpness, minimum_strength, n, h, w, hsv_grad_mode, s);
+  const int bx = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}).blocks_x : make_geom<float>(n, h, w, {}).blocks_x;
+  float* records;
+  if (int rc = ws_check(workspace, workspace_bytes, n, bx, 1, &records)) return rc;
+  const int rc = dtype == EXPO_F16
+                     ? apply_bwd_by_id<half_t>(filter_id, x, dy, dx, params, mask_params, records, maximum_sharpness,
+                                               minimum_strength, n, h, w, hsv_grad_mode, s)
+                     : apply_bwd_by_id<float>(filter_id, x, dy, dx, params, mask_params, records, maximum_sharpness,
+                                              minimum_strength, n, h, w, hsv_grad_mode, s);
+  if (rc) return rc;
+  FinishArgs fa{};
+  fa.s[0] = FinishStep{params, dparams, dmask_params, records, nullptr, kFinApply, filter_id, 0, 0.f};
+  return launch_finish(fa, 1, n, bx, s);
 }
 
 int expo_filter_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y, const float* params,
-                             float* penalty, int n, int h, int w, int dtype, void* stream) {
+                             float* penalty, int n, int h, int w, int dtype, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
   if (n == 0) return EXPO_OK;
   if (!filter_ids || !x || !y || !params) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == EXPO_F16 ? dispatch_fwd_t<half_t>(filter_ids, x, y, params, penalty, n, h, w, s)
-                           : dispatch_fwd_t<float>(filter_ids, x, y, params, penalty, n, h, w, s);
+  return dtype == EXPO_F16
+             ? dispatch_fwd_t<half_t>(filter_ids, x, y, params, penalty, n, h, w, workspace, workspace_bytes, s)
+             : dispatch_fwd_t<float>(filter_ids, x, y, params, penalty, n, h, w, workspace, workspace_bytes, s);
 }
 
 int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const void* dy, void* dx,
                              const float* params, float* dparams, const float* dpenalty, int n, int h, int w,
-                             int dtype, int hsv_grad_mode, void* stream) {
+                             int dtype, int hsv_grad_mode, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
   if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
   if (n == 0) return EXPO_OK;
   if (!filter_ids || !x || !dy || !params || !dparams) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == EXPO_F16
-             ? dispatch_bwd_t<half_t>(filter_ids, x, dy, dx, params, dparams, dpenalty, n, h, w, hsv_grad_mode, s)
-             : dispatch_bwd_t<float>(filter_ids, x, dy, dx, params, dparams, dpenalty, n, h, w, hsv_grad_mode, s);
+  return dtype == EXPO_F16 ? dispatch_bwd_t<half_t>(filter_ids, x, dy, dx, params, dparams, dpenalty, n, h, w,
+                                                    hsv_grad_mode, workspace, workspace_bytes, s)
+                           : dispatch_bwd_t<float>(filter_ids, x, dy, dx, params, dparams, dpenalty, n, h, w,
+                                                   hsv_grad_mode, workspace, workspace_bytes, s);
 }
 
 int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const float* const* params, int n, int h,
@@ -1159,32 +1338,40 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
 
 int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* const* grads,
                    const float* const* params, float* const* dparams, int n, int h, int w, int dtype,
-                   int hsv_grad_mode, void* stream) {
+                   int hsv_grad_mode, void* workspace, size_t workspace_bytes, void* stream) {
   if (steps < 0 || !filter_ids || !acts || !grads || !params || !dparams)
     return fail(EXPO_E_BADARG, "bad chain arguments");
   if (int rc = check_common(n, h, w, dtype)) return rc;
   if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
   if (n == 0 || steps == 0) return EXPO_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // If the caller laid the per-step dparams blocks out back to back (in either order), zero them
-  // with ONE fill instead of one per step (each fill is a ~3-5 us launch on the critical path).
-  bool contiguous = true;
-  size_t total = 0;
   for (int i = 0; i < steps; ++i) {
     if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
     if (!dparams[i]) return fail(EXPO_E_BADARG, "null pointer");
-    if (i > 0 && dparams[i] != dparams[i - 1] + size_t(n) * kNumParams[filter_ids[i - 1]]) contiguous = false;
-    total += size_t(n) * kNumParams[filter_ids[i]];
   }
-  if (contiguous) HIP_TRY(hipMemsetAsync(dparams[0], 0, sizeof(float) * total, s), "dparams memset");
+  // every step's kernel writes its block records into its own slice of the workspace; ONE finish launch
+  // (per kMaxFinishSteps steps) then produces all the dparams
+  const int bx = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}).blocks_x : make_geom<float>(n, h, w, {}).blocks_x;
+  float* records;
+  if (int rc = ws_check(workspace, workspace_bytes, n, bx, steps, &records)) return rc;
+  const size_t step_floats = ws_step_bytes(n, bx) / sizeof(float);
   for (int i = steps - 1; i >= 0; --i) {
     if (!acts[i] || !grads[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
+    float* rec = records + size_t(i) * step_floats;
     const int rc = dtype == EXPO_F16
-                       ? bwd_by_id<half_t>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], dparams[i], n,
-                                           h, w, hsv_grad_mode, s, contiguous)
-                       : bwd_by_id<float>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], dparams[i], n,
-                                          h, w, hsv_grad_mode, s, contiguous);
+                       ? bwd_by_id<half_t>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], rec, n, h, w,
+                                           hsv_grad_mode, s)
+                       : bwd_by_id<float>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], rec, n, h, w,
+                                          hsv_grad_mode, s);
     if (rc) return rc;
+  }
+  for (int i0 = 0; i0 < steps; i0 += kMaxFinishSteps) {
+    const int cnt = steps - i0 < kMaxFinishSteps ? steps - i0 : kMaxFinishSteps;
+    FinishArgs fa{};
+    for (int k = 0; k < cnt; ++k)
+      fa.s[k] = FinishStep{params[i0 + k], dparams[i0 + k], nullptr, records + size_t(i0 + k) * step_floats, nullptr,
+                           kFinFilter, filter_ids[i0 + k], 0, 0.f};
+    if (int rc = launch_finish(fa, cnt, n, bx, s)) return rc;
   }
   return EXPO_OK;
 }
@@ -1200,20 +1387,24 @@ int expo_chain_fused_fwd(const int32_t* filter_ids, const float* params, int ste
                            : chain_fused_fwd_t<float>(filter_ids, params, steps, x, y, n, h, w, s);
 }
 
-int expo_critic_stats(const void* x, float* stats, int n, int h, int w, int dtype, void* stream) {
+int expo_critic_stats(const void* x, float* stats, int n, int h, int w, int dtype, void* workspace,
+                      size_t workspace_bytes, void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
   if (n == 0) return EXPO_OK;
   if (!x || !stats) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == EXPO_F16 ? stats_t<half_t>(x, stats, n, h, w, s) : stats_t<float>(x, stats, n, h, w, s);
+  return dtype == EXPO_F16 ? stats_t<half_t>(x, stats, n, h, w, workspace, workspace_bytes, s)
+                           : stats_t<float>(x, stats, n, h, w, workspace, workspace_bytes, s);
 }
 
-int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w, int dtype, void* stream) {
+int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w, int dtype, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   if (int rc = check_common(n, h, w, dtype)) return rc;
   if (n == 0) return EXPO_OK;
   if (!y || !penalty) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == EXPO_F16 ? penalty_t<half_t>(y, penalty, n, h, w, s) : penalty_t<float>(y, penalty, n, h, w, s);
+  return dtype == EXPO_F16 ? penalty_t<half_t>(y, penalty, n, h, w, workspace, workspace_bytes, s)
+                           : penalty_t<float>(y, penalty, n, h, w, workspace, workspace_bytes, s);
 }
 
 }  // extern "C"

@@ -164,9 +164,11 @@ template <> __device__ __forceinline__ RawGroup pack<float>(const float* in) {
 // them: block-wide set-up that must not delay the first loads (the curve backward stages its LDS
 // slope table there, including the __syncthreads -- every wave calls it, also one without work).
 struct NoPrologue { __device__ void operator()() const {} };
+// `count` bounds the number of chunks a wave walks (block-contiguous mapping); the default walks to
+// the end of the image with the given stride.
 template <typename T, int NIN, bool HAS_OUT, bool PF, class IO, class Fn, class Pre = NoPrologue>
 __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out, int hw, int first_gw,
-                                              int stride, Fn&& fn, Pre&& pre = Pre()) {
+                                              int stride, Fn&& fn, Pre&& pre = Pre(), int count = 0x7fffffff) {
   constexpr int PPL = PixTraits<T>::PPL;
   const int lane = threadIdx.x & 63;
 #if EXPO_FP16_OVFL
@@ -191,7 +193,7 @@ __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out,
   if (!work) return;
   while (true) {
     const int gn = gw + stride;
-    const bool more = gn * PPL < hw;  // wave-uniform
+    const bool more = (--count > 0) && gn * PPL < hw;  // wave-uniform
     RawGroup nxt[NIN];
 #pragma unroll
     for (int s = 0; s < NIN; ++s) nxt[s] = cur[s];

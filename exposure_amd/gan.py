@@ -56,11 +56,21 @@ class GAN(nn.Module):
     # single-GPU soak aborted, so multi-rank training defaults to eager launches
     collectives = self.world_size > 1 or self.force_collectives
     self._replay_steps = self.use_graphs and (not collectives or os.environ.get('EXPO_GRAPH_COLLECTIVES', '0') == '1')
+    # Flat gradient buckets (p.grad are views into them).  theta_g is split where the backward pass splits
+    # in time: the FC heads (8 x fc1/fc2 + the selector FCs, 19 MB) receive their gradients first, the two
+    # conv trunks (5.6 MB) last -- so the heads' all-reduce runs under the trunks' backward, and theta_v's
+    # (whose small backward runs first) under the whole generator backward.
+    gen = self.generator
+    trunk = list(gen.filter_features.parameters()) + list(gen.selector_features.parameters())
+    trunk_ids = {id(p) for p in trunk}
+    heads = [p for p in gen.parameters() if id(p) not in trunk_ids]
     self.buckets = {
-        'g': xdist.GradBucket(self.generator.parameters()),
-        'v': xdist.GradBucket(self.value.parameters()),
-        'c': xdist.GradBucket(self.critic.parameters()),
+        'g_head': xdist.GradBucket(heads, on_ready=self._bucket_ready),
+        'g_trunk': xdist.GradBucket(trunk, on_ready=self._bucket_ready),
+        'v': xdist.GradBucket(self.value.parameters(), on_ready=self._bucket_ready),
+        'c': xdist.GradBucket(self.critic.parameters(), on_ready=self._bucket_ready),
     }
+    self._pending = []
     # ExponentialMovingAverage(decay=0.99, zero_debias=True) of c_average (net.py:107-108, 165-168)
     self.c_average_biased = 0.0
     self.c_average_steps = 0
@@ -104,26 +114,41 @@ class GAN(nn.Module):
     return dict(g_loss=g_loss, v_loss=v_loss, fake_output=fake_output, new_states=new_states, reward=reward,
                 q_value=q_value, fake_logit=fake_logit, debug=debug)
 
+  # -- gradient exchange: losses are means over the GLOBAL batch -> average the per-rank gradients
+  def _collectives(self):
+    return self.world_size > 1 or self.force_collectives
+
+  def _bucket_ready(self, bucket):
+    """Backward hook (exposure_amd.dist.GradBucket): the bucket's last gradient has just been accumulated
+    -- start its all-reduce now, on RCCL's stream, while autograd keeps running the rest of the backward."""
+    if self._collectives() and not getattr(bucket, 'launched', False):
+      bucket.launched = True
+      self._pending.append(bucket.all_reduce_mean(self.process_group, async_op=True, force=self.force_collectives))
+
+  def _backward_into(self, loss, names, retain_graph=False):
+    """loss.backward restricted to the named buckets' parameters (the reference's optimize_loss
+    ``variables=`` lists: theta_g sees only g_loss, theta_v only v_loss, theta_c only c_loss)."""
+    params = []
+    for name in names:
+      b = self.buckets[name]
+      b.zero()
+      b.launched = False
+      params += b.params
+    loss.backward(inputs=params, retain_graph=retain_graph)
+    for name in names:  # a bucket whose hook could not fire (a parameter outside the graph): reduce it now
+      self._bucket_ready(self.buckets[name])
+
+  def _finish_collectives(self):
+    for pend in self._pending:
+      pend.wait()
+    self._pending = []
+
   def _generator_body(self, fake_input, z, states, progress, dropout_masks):
     out = self.generator_losses(fake_input, z, states, progress, 1, dropout_masks)
-    self.opt_g.zero_grad(set_to_none=True)
-    self.opt_v.zero_grad(set_to_none=True)
-    gp = list(self.generator.parameters())
-    vp = list(self.value.parameters())
-    # theta_g sees only g_loss; theta_v sees only v_loss (optimize_loss variables= lists)
-    g_grads = torch.autograd.grad(out['g_loss'], gp, retain_graph=True, allow_unused=True)
-    v_grads = torch.autograd.grad(out['v_loss'], vp, allow_unused=True)
-    for p, g in zip(gp, g_grads):
-      p.grad = g if g is not None else torch.zeros_like(p)
-    for p, g in zip(vp, v_grads):
-      p.grad = g if g is not None else torch.zeros_like(p)
-    if self.world_size > 1 or self.force_collectives:
-      # losses are means over the GLOBAL batch: average the per-rank (local-mean) gradients
-      f = self.force_collectives
-      hg = self.buckets['g'].all_reduce_mean(self.process_group, async_op=True, force=f)
-      hv = self.buckets['v'].all_reduce_mean(self.process_group, async_op=True, force=f)
-      hg.wait_and_scatter()
-      hv.wait_and_scatter()
+    # the value net's short backward first: its all-reduce then runs under the whole generator backward
+    self._backward_into(out['v_loss'], ['v'], retain_graph=True)
+    self._backward_into(out['g_loss'], ['g_head', 'g_trunk'])
+    self._finish_collectives()
     self.opt_g.step()
     self.opt_v.step()
     return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
@@ -211,14 +236,12 @@ class GAN(nn.Module):
 
   def _critic_body(self, real_data, fake_output, alpha):
     out = self.critic_losses(real_data, fake_output, alpha)
-    self.opt_c.zero_grad(set_to_none=True)
-    out['c_loss'].backward()
-    if self.world_size > 1 or self.force_collectives:
-      f = self.force_collectives
-      self.buckets['c'].all_reduce_mean(self.process_group, async_op=True, force=f).wait_and_scatter()
+    self._backward_into(out['c_loss'], ['c'])
+    if self._collectives():
       ca = out['c_average'].clone()
-      xdist.all_reduce_mean_(ca, self.process_group, force=f)
+      xdist.all_reduce_mean_(ca, self.process_group, force=self.force_collectives)
       out['c_average'] = ca
+    self._finish_collectives()
     self.opt_c.step()
     return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 

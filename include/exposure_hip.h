@@ -13,6 +13,15 @@
  *     work enqueued on `stream` (a hipStream_t passed as void*, NULL = default
  *     stream) has completed.  No allocation, no ownership transfer, no host sync.
  *   - Stateless and re-entrant; ordering only through `stream`.
+ *   - Reduction workspace.  Every entry point that produces per-image sums (parameter
+ *     gradients, penalty, statistics) takes `workspace` / `workspace_bytes`: a caller-owned,
+ *     4-byte aligned device scratch buffer of at least expo_workspace_bytes(n, h, w, dtype)
+ *     bytes (expo_chain_bwd: that many bytes PER STEP).  It needs no initialisation and
+ *     carries nothing from call to call: the streaming kernel leaves one record of partial
+ *     sums per block in it and a small finish launch enqueued behind it adds an image's
+ *     records in a fixed order -- no float atomics, no zero-fill launch, bit-reproducible
+ *     results.  One workspace serves one stream at a time (calls that may run concurrently on
+ *     different streams need their own).
  *   - Filter ids follow cfg.filters (config_example.py:22-25):
  *       0 E  ExposureFilter              P = 1   params[n][0] = EV stops
  *       1 G  GammaFilter                 P = 1   gamma
@@ -39,7 +48,7 @@
 extern "C" {
 #endif
 
-#define EXPO_ABI_VERSION 1
+#define EXPO_ABI_VERSION 2 /* 2: caller-owned reduction workspace (no float atomics, no fills) */
 
 #define EXPO_OK 0
 #define EXPO_E_BADARG (-1)
@@ -78,6 +87,13 @@ const char* expo_last_error(void);
 int expo_num_filter_params(int filter_id);
 
 /*
+ * Bytes of reduction workspace ONE reducing call needs for images of this shape (the maximum
+ * over the entry points; expo_chain_bwd needs `steps` times as much).  0 on invalid arguments.
+ * New with ABI 2; the reference has no counterpart (TF allocates its reduction scratch itself).
+ */
+size_t expo_workspace_bytes(int n, int h, int w, int dtype);
+
+/*
  * y = <Filter>.process(x, params)      replaces filters.py:181-182 (E), 205-206 (G),
  * 237-238 (W), 484-498 (S+), 312-322 (T), 415-419 (Ct), 438-440 (BW), 264-273 (C).
  * With cfg.masking = False (config_example.py:36) this is also Filter.apply's
@@ -98,17 +114,19 @@ int expo_filter_fwd(int filter_id, const void* x, void* y, const float* params,
  */
 int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx,
                     const float* params, float* dparams, int n, int h, int w,
-                    int dtype, int hsv_grad_mode, void* stream);
+                    int dtype, int hsv_grad_mode, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 /*
- * Same as expo_filter_bwd but dparams is ACCUMULATED into (dparams += ...): no zero-fill is
- * enqueued, the caller owns the initial value.  This is gradient accumulation over several
+ * Same as expo_filter_bwd but dparams is ACCUMULATED into (dparams += ...): the caller owns
+ * the initial value.  This is gradient accumulation over several
  * backward calls that share a parameter tensor (e.g. the low-resolution and the high-resolution
  * application of one filter, filters.py:88-96, or micro-batches).
  */
 int expo_filter_bwd_accumulate(int filter_id, const void* x, const void* dy, void* dx,
                                const float* params, float* dparams, int n, int h, int w,
-                               int dtype, int hsv_grad_mode, void* stream);
+                               int dtype, int hsv_grad_mode, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /*
  * Filter.apply with the spatial mask enabled (cfg.masking = True; filters.py:62-99, 110-148):
@@ -128,7 +146,8 @@ int expo_filter_apply_fwd(int filter_id, const void* x, void* y, const float* pa
 int expo_filter_apply_bwd(int filter_id, const void* x, const void* dy, void* dx,
                           const float* params, float* dparams, const float* mask_params,
                           float* dmask_params, float maximum_sharpness, float minimum_strength,
-                          int n, int h, int w, int dtype, int hsv_grad_mode, void* stream);
+                          int n, int h, int w, int dtype, int hsv_grad_mode, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /*
  * Per-image filter choice == the reference's "compute all 8 filters, stack, multiply
@@ -138,11 +157,12 @@ int expo_filter_apply_bwd(int filter_id, const void* x, const void* dy, void* dx
  * params / dparams: float32 [N][EXPO_MAX_PARAMS]; row n holds the P values of filter
  * filter_ids[n] in its first P slots (remaining slots ignored / written as 0).
  * penalty (nullable): float32 [N], overwritten with mean_{h,w,c} max(y - 1, 0)^2,
- * the over-exposure term of agent.py:249-251, fused into the same pass.
+ * the over-exposure term of agent.py:249-251, fused into the same pass (workspace needed
+ * only when penalty != NULL).
  */
 int expo_filter_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y,
                              const float* params, float* penalty, int n, int h, int w,
-                             int dtype, void* stream);
+                             int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Backward of expo_filter_dispatch_fwd.  dpenalty (nullable): float32 [N], upstream
@@ -152,7 +172,8 @@ int expo_filter_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y,
 int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const void* dy,
                              void* dx, const float* params, float* dparams,
                              const float* dpenalty, int n, int h, int w, int dtype,
-                             int hsv_grad_mode, void* stream);
+                             int hsv_grad_mode, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /*
  * The benchmark construct of SURVEY.md section 8(d): `steps` filters applied
@@ -173,11 +194,13 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts,
  *            ping-pong between two buffers as long as grads[i] != grads[i+1] is not
  *            required (dx may alias dy).
  *   dparams  host array of `steps` device pointers, float32 [N][P_i], overwritten.
+ *   workspace_bytes >= steps * expo_workspace_bytes(n, h, w, dtype): every step keeps its block
+ *   records until the ONE finish launch at the end of the chain has produced all dparams.
  */
 int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts,
                    void* const* grads, const float* const* params,
                    float* const* dparams, int n, int h, int w, int dtype,
-                   int hsv_grad_mode, void* stream);
+                   int hsv_grad_mode, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Fused multi-step forward for the high-resolution inference path (net.py:796-821, evaluate.py:8-31):
@@ -199,13 +222,13 @@ int expo_chain_fused_fwd(const int32_t* filter_ids, const float* params, int ste
  * stats: float32 [N][3], overwritten.
  */
 int expo_critic_stats(const void* x, float* stats, int n, int h, int w, int dtype,
-                      void* stream);
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * mean_{h,w,c} max(y - 1, 0)^2 per image (agent.py:249-251). penalty: float32 [N].
  */
 int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w,
-                              int dtype, void* stream);
+                              int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,8 +43,13 @@ def test_argument_validation_without_gpu():
   assert lib.expo_filter_fwd(0, None, None, None, 1, 0, 1, 0, None) == -1
   assert lib.expo_filter_fwd(0, None, None, None, 1, 1, 1, 0, None) == -1  # null pointers
   assert lib.expo_filter_fwd(0, None, None, None, 0, 1, 1, 0, None) == 0  # empty batch is a no-op
-  assert lib.expo_filter_bwd(0, None, None, None, None, None, 1, 1, 1, 0, 5, None) == -1  # bad hsv mode
-  assert lib.expo_critic_stats(None, None, 0, 4, 4, 0, None) == 0
+  assert lib.expo_filter_bwd(0, None, None, None, None, None, 1, 1, 1, 0, 5, None, 0, None) == -1  # bad hsv mode
+  assert lib.expo_critic_stats(None, None, 0, 4, 4, 0, None, 0, None) == 0
+  # reduction workspace: sized by the library, monotone, 0 for invalid shapes
+  assert lib.expo_workspace_bytes(0, 4, 4, 0) == 0 and lib.expo_workspace_bytes(1, 0, 4, 0) == 0
+  small, big = lib.expo_workspace_bytes(64, 64, 64, 0), lib.expo_workspace_bytes(64, 512, 512, 0)
+  assert 0 < small <= big and big >= 64 * 32 * 32 * 4  # >= one 32-float record per block, 32 blocks per image
+  assert lib.expo_workspace_bytes(64, 512, 512, 1) >= big  # fp32 has more 48-byte groups per image
   assert lib.expo_filter_fwd(0, None, None, None, 1, 40000, 40000, 0, None) == -1  # image >= 2 GiB
   assert b'2 GiB' in lib.expo_last_error()
   assert lib.expo_chain_fwd(None, 1, None, None, 1, 1, 1, 0, None) == -1

@@ -94,11 +94,28 @@ def test_shard_helpers_single_process():
   t = torch.arange(8)
   assert xdist.world_size() == 1 and xdist.rank() == 0
   assert torch.equal(xdist.shard(t), t)
-  b = xdist.GradBucket([torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2, 2))])
+  # gradients live IN the flat bucket: p.grad are views with the parameter's own strides
+  conv = torch.nn.Conv2d(3, 4, 2).to(memory_format=torch.channels_last)
+  lin = torch.nn.Linear(5, 2)
+  ready = []
+  b = xdist.GradBucket(list(conv.parameters()) + list(lin.parameters()), on_ready=ready.append)
+  b.zero()
+  assert b.attached() and b.flat.numel() == sum(p.numel() for p in b.params)
   for p in b.params:
-    p.grad = torch.full_like(p, 2.0)
-  b.all_reduce_mean(None)
-  assert all(torch.equal(p.grad, torch.full_like(p, 2.0)) for p in b.params)
+    assert p.grad.stride() == p.stride() and p.grad.untyped_storage().data_ptr() == b.flat.untyped_storage().data_ptr()
+  x = torch.randn(2, 3, 4, 4)
+  loss = conv(x).sum() + lin(torch.randn(3, 5)).sum()
+  want = torch.autograd.grad(loss, b.params, retain_graph=True)
+  loss.backward(inputs=b.params)
+  assert ready == [b]  # fired once, when the bucket's last gradient had been accumulated
+  assert b.attached()  # autograd accumulated in place: the views are still the gradients
+  for p, g in zip(b.params, want):
+    assert torch.allclose(p.grad, g)
+  before = b.flat.clone()
+  b.all_reduce_mean(None)  # one rank: no collective, scale 1
+  assert torch.equal(b.flat, before)
+  b.zero()
+  assert float(b.flat.abs().max()) == 0.0 and all(float(p.grad.abs().max()) == 0.0 for p in b.params)
   g1 = xdist.per_image_generator(1, 5, 'cpu')
   g2 = xdist.per_image_generator(1, 5, 'cpu')
   assert torch.equal(torch.rand(4, generator=g1), torch.rand(4, generator=g2))

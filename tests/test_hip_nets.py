@@ -44,7 +44,7 @@ def test_losses_match_oracle_with_f16_image_pool(gpu_device):
   assert np.array_equal(out['debug']['selected_filter_ids'].cpu().numpy(), ref['debug']['selected_filter_id'])
   assert out['fake_output'].dtype == torch.float16
   # the fp16-stored step output feeds the critic / value nets: loss tolerance follows the 1e-3 pixel bound
-  got = out['fake_output'].float().cpu().numpy()
+  got = out['fake_output'].detach().float().cpu().numpy()
   assert (np.abs(got - ref['fake_output']) <= 1e-3 + np.abs(ref['fake_output']) * 2.0**-11).all()
   assert abs(float(out['g_loss'].detach()) - ref['g_loss']) <= 2e-3 * max(1.0, abs(ref['g_loss']))
   assert abs(float(out['v_loss'].detach()) - ref['v_loss']) <= 2e-3 * max(1.0, abs(ref['v_loss']))
