@@ -45,6 +45,7 @@
 #define EXPO_BWD_MAP 1
 #endif
 
+
 namespace expo {
 
 constexpr int kThreads = 256;
@@ -181,7 +182,11 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
                                          const float* __restrict__ prm, float* __restrict__ rec,
                                          int hw, int groups) {
   constexpr int PPL = PixTraits<T>::PPL;
-  const typename F::Prm q = F::load(prm);
+  // On the vector path the per-image constants are fetched AFTER the first chunk's loads have been issued
+  // (stream_groups' prologue): the dependent scalar loads (kernel argument -> parameter -> exp2) otherwise sit
+  // in front of the image loads of every wave, and a forward wave lives for exactly one chunk.
+  typename F::Prm q;
+  if constexpr (!VEC) q = F::load(prm);
   float pen = 0.f;
   const int stride = gridDim.x * kThreads;
   // Tone / Color on the vector path (all lanes of a wave alive): segment table instead of the
@@ -224,6 +229,7 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
         ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
         [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); },
         [&]() {
+          q = F::load(prm);
           if constexpr (kCurveTab) curve_lut_build<kNC>(prm[(threadIdx.x & 63) % F::NP], tab);
         });
   } else {
@@ -800,6 +806,13 @@ EXPO_PROBE_BWD(ColorF)
 EXPO_PROBE_BWD(WnbF)
 EXPO_PROBE_BWD(ExposureF)
 #undef EXPO_PROBE_BWD
+#define EXPO_PROBE_FWD(F)                                                                                     \
+  template __global__ void filter_fwd_kernel<F, half_t, true, IoStream>(const half_t*, half_t*, const float*, int, int);
+EXPO_PROBE_FWD(ExposureF)
+EXPO_PROBE_FWD(GammaF)
+EXPO_PROBE_FWD(SatPlusF)
+EXPO_PROBE_FWD(ColorF)
+#undef EXPO_PROBE_FWD
 #define EXPO_PROBE_APPLY(F)                                                                                   \
   template __global__ void apply_bwd_kernel<F, half_t, true, true, 0>(const half_t*, const half_t*, half_t*, \
                                                                       const float*, const float*, float*,   \

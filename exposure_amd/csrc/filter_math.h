@@ -511,8 +511,9 @@ struct LevelF {
 // ---------------------------------------------------------------------------------
 struct MaskPrm {
   float a, b, c, d2, k, S, ms, k_over_mp4, dS;  // k = sharp mp4/5; S = strength factor; dS = dS/dmp5
-  float inv_se, oi, oj;
+  float inv_se, oi, oj, inv_w;
   int w;
+  bool small;
   __device__ static MaskPrm load(const float* __restrict__ mp, float sharp, float min_strength, int h, int w) {
     MaskPrm m;
     m.a = mp[0]; m.b = mp[1]; m.c = mp[2]; m.d2 = 2.0f * mp[3];
@@ -526,12 +527,25 @@ struct MaskPrm {
     m.oi = float(se - h) * 0.5f;
     m.oj = float(se - w) * 0.5f;
     m.w = w;
+    m.inv_w = 1.0f / float(w);
+    m.small = long(h) * long(w) < (1L << 22);
     return m;
   }
   struct Eval { float m, sg, inp_raw, gx, gy, lumc; };
   __device__ Eval eval(int px, const float x[3]) const {
     Eval e;
-    const int row = px / w, col = px - row * w;
+    // row / column of a linear pixel index.  Images below 2^22 pixels (every shape the agent uses) take
+    // one multiply by 1/w and a +-1 correction instead of a ~25-instruction integer division per pixel
+    int row;
+    if (small) {
+      row = int(float(px) * inv_w);
+      const int r = px - row * w;
+      row += (r >= w) ? 1 : 0;
+      row -= (r < 0) ? 1 : 0;
+    } else {
+      row = px / w;
+    }
+    const int col = px - row * w;
     e.gx = (float(row) + oi) * inv_se - 0.5f;
     e.gy = (float(col) + oj) * inv_se - 0.5f;
     e.lumc = lum3(x) - 0.5f;

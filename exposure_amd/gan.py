@@ -8,6 +8,7 @@ HIP library.
 gradients are all-reduced in flat buckets (``exposure_amd.dist``) before the optimiser steps.
 """
 import os
+import time
 
 import torch
 from torch import nn
@@ -51,11 +52,12 @@ class GAN(nn.Module):
     # EXPO_FORCE_COLLECTIVES=1: issue the gradient all-reduces even in a one-rank group, so the RCCL
     # path (and its hipGraph capture) can be exercised on a single GPU
     self.force_collectives = os.environ.get('EXPO_FORCE_COLLECTIVES', '0') == '1'
-    # hipGraph replay of steps that contain RCCL collectives is opt-in (EXPO_GRAPH_COLLECTIVES=1):
-    # it works (24 vs 38 ms per iteration on one forced-collective rank) but one run in ~15 of the
-    # single-GPU soak aborted, so multi-rank training defaults to eager launches
+    # Steps that contain RCCL collectives are captured and replayed like any other (the collectives are
+    # stream-ordered kernels); EXPO_GRAPH_COLLECTIVES=0 falls back to eager launches for multi-rank runs.
+    # (Round 1 kept this opt-in because ~1 run in 15 aborted; the cause -- the NCCL watchdog polling an
+    # eager work's event while RCCL's stream was being captured -- is handled in _replay.)
     collectives = self.world_size > 1 or self.force_collectives
-    self._replay_steps = self.use_graphs and (not collectives or os.environ.get('EXPO_GRAPH_COLLECTIVES', '0') == '1')
+    self._replay_steps = self.use_graphs and (not collectives or os.environ.get('EXPO_GRAPH_COLLECTIVES', '1') == '1')
     # Flat gradient buckets (p.grad are views into them).  theta_g is split where the backward pass splits
     # in time: the FC heads (8 x fc1/fc2 + the selector FCs, 19 MB) receive their gradients first, the two
     # conv trunks (5.6 MB) last -- so the heads' all-reduce runs under the trunks' backward, and theta_v's
@@ -187,6 +189,15 @@ class GAN(nn.Module):
       # stream-ordered kernels, and the eager first call has already initialised the communicator)
       static_in = [t.clone() for t in inputs]
       torch.cuda.synchronize()
+      if self._collectives():
+        # ROOT CAUSE of round 1's "one run in ~15 aborts" (gpurun r02soak, 3 of 28 runs): the eager first call
+        # left WorkNCCL entries in ProcessGroupNCCL's watchdog list; they are complete, but the watchdog only
+        # reaps its list every ~100 ms.  If it polls (hipEventQuery on the work's end event) AFTER this thread
+        # has pulled RCCL's stream into the capture, HIP answers hipErrorCapturedEvent ("operation not permitted
+        # on an event last recorded in a capturing stream") for an event that belongs to a now-capturing stream,
+        # the watchdog thread throws, and the process aborts.  Works issued DURING capture are never enqueued
+        # (ProcessGroupNCCL checks the capture status), so it is enough to let the watchdog drain first.
+        time.sleep(float(os.environ.get('EXPO_CAPTURE_GRACE_S', '0.35')))
       graph = torch.cuda.CUDAGraph()
       # thread_local: RCCL's watchdog thread polls events while this thread captures; under the
       # default "global" mode such a call from another thread aborts the process

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r02soak
 mkdir -p $OUT
 cd $R
-export EXPO_FORCE_COLLECTIVES=1 EXPO_GRAPH_COLLECTIVES=1 HSA_ENABLE_IPC_MODE_LEGACY=0 EXPO_TRACE=1
+export EXPO_FORCE_COLLECTIVES=1 HSA_ENABLE_IPC_MODE_LEGACY=0 EXPO_TRACE=1
 N=${1:-16}
 run_variant() {  # name, extra env...
   name=$1; shift
@@ -21,5 +21,4 @@ run_variant() {  # name, extra env...
   done
   echo "$name: $fails / $N failed" | tee -a $OUT/summary.txt
 }
-run_variant base
-run_variant nomon TORCH_NCCL_ENABLE_MONITORING=0 TORCH_NCCL_ASYNC_ERROR_HANDLING=0
+run_variant ${2:-fixed}
