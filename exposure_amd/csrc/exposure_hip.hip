@@ -150,7 +150,10 @@ __device__ __forceinline__ void curve_lut_build(float klane, float2_lut* tab) {
     float2_lut e;
     e.x = scale * klane;
     e.y = scale * ((incl - klane) - float(j) * klane) * (1.0f / float(L));
-    tab[lane] = e;
+    // L + 1 entries per curve: entry L repeats segment L-1, so x^ == 1 (int(L x^) == L) needs no index clamp
+    const int slot = (lane / L) * (L + 1) + j;
+    tab[slot] = e;
+    if (j == L - 1) tab[slot + 1] = e;
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -162,9 +165,8 @@ __device__ __forceinline__ void curve_lut_apply(float* v, const float2_lut* tab)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float xc = clamp01x(v[3 * k + c], 0.0f, 1.0f);
-      int seg = int(xc * float(L));
-      seg = seg < L - 1 ? seg : L - 1;
-      const float2_lut e = tab[(NC == 1 ? 0 : c * L) + seg];
+      const int seg = int(xc * float(L));  // 0..L; entry L == entry L-1
+      const float2_lut e = tab[(NC == 1 ? 0 : c * (L + 1)) + seg];
       v[3 * k + c] = fmaf(xc, e.x, e.y);
     }
   }
@@ -249,8 +251,10 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
 template <class F, typename T, bool VEC, class IO>
 __global__ __launch_bounds__(kThreads) void filter_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                               const float* __restrict__ params,
-                                                              int hw, int groups) {
-  const int n = blockIdx.y;
+                                                              int hw, int groups, int reverse) {
+  // reverse: walk the images from the last to the first (expo_chain_*: consecutive launches alternate
+  // direction so each starts on the images the previous one touched last -- Infinity-Cache reuse)
+  const int n = reverse ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
   fwd_body<F, T, VEC, false, IO>(x + off, y + off, params + n * F::NP, nullptr, hw, groups);
 }
@@ -332,8 +336,9 @@ template <class F, typename T, bool VEC, bool HAS_DX, int MODE, class IO>
 __global__ __launch_bounds__(kThreads) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                               T* __restrict__ dx,
                                                               const float* __restrict__ params,
-                                                              float* __restrict__ records, int hw, int groups) {
-  const int n = blockIdx.y;
+                                                              float* __restrict__ records, int hw, int groups,
+                                                              int reverse) {
+  const int n = reverse ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
   const size_t off = size_t(n) * hw * 3;
   bwd_body<F, T, VEC, HAS_DX, false, MODE, IO>(x + off, dy + off, HAS_DX ? dx + off : nullptr, params + n * F::NP,
                                                records + size_t(n) * gridDim.x * kWsSlots, hw, groups, 0.f);
@@ -800,14 +805,14 @@ __global__ __launch_bounds__(64) void finish_kernel(const FinishArgs args, int b
 // register-pressure probe builds (tools/probe.sh): instantiate a few kernels, skip the host side
 #define EXPO_PROBE_BWD(F)                                                                                         \
   template __global__ void filter_bwd_kernel<F, half_t, true, true, 0, IoStream>(const half_t*, const half_t*, half_t*, \
-                                                                                 const float*, float*, int, int);
+                                                                                 const float*, float*, int, int, int);
 EXPO_PROBE_BWD(ToneF)
 EXPO_PROBE_BWD(ColorF)
 EXPO_PROBE_BWD(WnbF)
 EXPO_PROBE_BWD(ExposureF)
 #undef EXPO_PROBE_BWD
 #define EXPO_PROBE_FWD(F)                                                                                     \
-  template __global__ void filter_fwd_kernel<F, half_t, true, IoStream>(const half_t*, half_t*, const float*, int, int);
+  template __global__ void filter_fwd_kernel<F, half_t, true, IoStream>(const half_t*, half_t*, const float*, int, int, int);
 EXPO_PROBE_FWD(ExposureF)
 EXPO_PROBE_FWD(GammaF)
 EXPO_PROBE_FWD(SatPlusF)
@@ -922,27 +927,27 @@ static int check_common(int n, int h, int w, int dtype) {
 }
 
 template <class F, typename T>
-static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s) {
+static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s, int rev) {
   const Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
   const dim3 grid(g.blocks_x, n), block(kThreads);
   if (g.stream)
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, IoStream>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, IoStream>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups, rev);
   else if (g.vec)
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, IoCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, IoCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups, rev);
   else
-    hipLaunchKernelGGL((filter_fwd_kernel<F, T, false, IoCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups);
+    hipLaunchKernelGGL((filter_fwd_kernel<F, T, false, IoCached>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups, rev);
   HIP_TRY(hipGetLastError(), "filter_fwd launch");
   return EXPO_OK;
 }
 
 template <class F, typename T>
 static int launch_bwd(const void* x, const void* dy, void* dx, const float* params, float* records, int n,
-                      int h, int w, int mode, hipStream_t s) {
+                      int h, int w, int mode, hipStream_t s, int rev) {
   const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
   const dim3 grid(g.blocks_x, n), block(kThreads);
 #define EXPO_LIO(VEC, HAS_DX, MODE, IO)                                                                  \
   hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, HAS_DX, MODE, IO>), grid, block, 0, s, (const T*)x, \
-                     (const T*)dy, (T*)dx, params, records, g.hw, g.groups)
+                     (const T*)dy, (T*)dx, params, records, g.hw, g.groups, rev)
 #define EXPO_L(VEC, HAS_DX, MODE)                                  \
   do {                                                             \
     if constexpr (VEC) {                                           \
@@ -972,34 +977,35 @@ static int launch_bwd(const void* x, const void* dy, void* dx, const float* para
 }
 
 template <typename T>
-static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int h, int w, hipStream_t s) {
+static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int h, int w, hipStream_t s,
+                     int rev = 0) {
   switch (id) {
-    case 0: return launch_fwd<ExposureF, T>(x, y, p, n, h, w, s);
-    case 1: return launch_fwd<GammaF, T>(x, y, p, n, h, w, s);
-    case 2: return launch_fwd<WhiteBalanceF, T>(x, y, p, n, h, w, s);
-    case 3: return launch_fwd<SatPlusF, T>(x, y, p, n, h, w, s);
-    case 4: return launch_fwd<ToneF, T>(x, y, p, n, h, w, s);
-    case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s);
-    case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s);
-    case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s);
-    case 8: return launch_fwd<LevelF, T>(x, y, p, n, h, w, s);
+    case 0: return launch_fwd<ExposureF, T>(x, y, p, n, h, w, s, rev);
+    case 1: return launch_fwd<GammaF, T>(x, y, p, n, h, w, s, rev);
+    case 2: return launch_fwd<WhiteBalanceF, T>(x, y, p, n, h, w, s, rev);
+    case 3: return launch_fwd<SatPlusF, T>(x, y, p, n, h, w, s, rev);
+    case 4: return launch_fwd<ToneF, T>(x, y, p, n, h, w, s, rev);
+    case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s, rev);
+    case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s, rev);
+    case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s, rev);
+    case 8: return launch_fwd<LevelF, T>(x, y, p, n, h, w, s, rev);
   }
   return fail(EXPO_E_BADARG, "filter_id out of range");
 }
 
 template <typename T>
 static int bwd_by_id(int id, const void* x, const void* dy, void* dx, const float* p, float* records, int n, int h,
-                     int w, int mode, hipStream_t s) {
+                     int w, int mode, hipStream_t s, int rev = 0) {
   switch (id) {
-    case 0: return launch_bwd<ExposureF, T>(x, dy, dx, p, records, n, h, w, mode, s);
-    case 1: return launch_bwd<GammaF, T>(x, dy, dx, p, records, n, h, w, mode, s);
-    case 2: return launch_bwd<WhiteBalanceF, T>(x, dy, dx, p, records, n, h, w, mode, s);
-    case 3: return launch_bwd<SatPlusF, T>(x, dy, dx, p, records, n, h, w, mode, s);
-    case 4: return launch_bwd<ToneF, T>(x, dy, dx, p, records, n, h, w, mode, s);
-    case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, records, n, h, w, mode, s);
-    case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, records, n, h, w, mode, s);
-    case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, records, n, h, w, mode, s);
-    case 8: return launch_bwd<LevelF, T>(x, dy, dx, p, records, n, h, w, mode, s);
+    case 0: return launch_bwd<ExposureF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
+    case 1: return launch_bwd<GammaF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
+    case 2: return launch_bwd<WhiteBalanceF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
+    case 3: return launch_bwd<SatPlusF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
+    case 4: return launch_bwd<ToneF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
+    case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
+    case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
+    case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
+    case 8: return launch_bwd<LevelF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
   }
   return fail(EXPO_E_BADARG, "filter_id out of range");
 }
@@ -1202,6 +1208,12 @@ static int penalty_t(const void* y, float* pen, int n, int h, int w, void* works
 // ======================================================================== C-ABI
 using namespace expo;
 
+// EXPO_CHAIN_SNAKE=1: consecutive launches of a chain walk the images in alternating directions
+static bool chain_snake() {
+  static const bool on = env_int("EXPO_CHAIN_SNAKE", 0) != 0;
+  return on;
+}
+
 extern "C" {
 
 int expo_version(void) { return EXPO_ABI_VERSION; }
@@ -1342,8 +1354,10 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
   for (int i = 0; i < steps; ++i) {
     if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
     if (!acts[i] || !acts[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
-    const int rc = dtype == EXPO_F16 ? fwd_by_id<half_t>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s)
-                                     : fwd_by_id<float>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s);
+    const int rev = chain_snake() ? (i & 1) : 0;
+    const int rc = dtype == EXPO_F16
+                       ? fwd_by_id<half_t>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, rev)
+                       : fwd_by_id<float>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, rev);
     if (rc) return rc;
   }
   return EXPO_OK;
@@ -1371,11 +1385,13 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
   for (int i = steps - 1; i >= 0; --i) {
     if (!acts[i] || !grads[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
     float* rec = records + size_t(i) * step_floats;
+    // the forward chain ended descending (or ascending) on step steps-1; the backward starts where it ended
+    const int rev = chain_snake() ? ((steps - i) & 1) : 0;
     const int rc = dtype == EXPO_F16
                        ? bwd_by_id<half_t>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], rec, n, h, w,
-                                           hsv_grad_mode, s)
+                                           hsv_grad_mode, s, rev)
                        : bwd_by_id<float>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], rec, n, h, w,
-                                          hsv_grad_mode, s);
+                                          hsv_grad_mode, s, rev);
     if (rc) return rc;
   }
   for (int i0 = 0; i0 < steps; i0 += kMaxFinishSteps) {

@@ -4,15 +4,13 @@
 set -euo pipefail
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/final
-TAG=${1:-r01_final}
-for f in bench_chain bench_chain_A bench_chain_B bench_chain_f32 bench_infer_B bench_train bench_extra; do
+TAG=${1:-r02_final}
+for f in bench_chain bench_chain_A bench_chain_B bench_chain_f32 bench_chain_cold bench_infer_B bench_infer_C bench_train bench_extra; do
   [ -s $SRC/$f.json ] && cp $SRC/$f.json profiles/${TAG}_$f.json
 done
-cp $SRC/kernel_stats.csv profiles/${TAG}_kernel_stats.csv
-for c in fetch_size write_size; do
-  cp $SRC/pmc_$c.csv profiles/${TAG}_pmc_$c.csv
-  cp $SRC/pmc_${c}_calibration.csv profiles/${TAG}_pmc_${c}_calibration.csv
+for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt; do
+  cp $f profiles/${TAG}_$(basename $f)
 done
-cp $SRC/membench.txt profiles/${TAG}_membench.txt
-python tools/make_traffic.py $SRC profiles/traffic.json > /dev/null
+python tools/make_traffic.py $SRC profiles/traffic.json 64x512x512x3:f16 > /dev/null
+python tools/make_traffic.py $SRC profiles/traffic.json 256x512x512x3:f16 cold > /dev/null
 python -m pytest tests/test_profiles_consistency.py -q

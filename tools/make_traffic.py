@@ -32,14 +32,17 @@ def calib(rows, counter, kernel, known_bytes):
   raise SystemExit('calibration kernel %s not found' % kernel)
 
 
-def main(d, out, wkey='64x512x512x3:f16'):
-  kf_c = calib(read(d + '/pmc_fetch_size_calibration.csv'), 'FETCH_SIZE', 'void cpol<2, 16>', MIB96)
-  kf_r = calib(read(d + '/pmc_fetch_size_calibration.csv'), 'FETCH_SIZE', 'void rpol<2, 2, 16>', 2 * MIB96)
-  kw_c = calib(read(d + '/pmc_write_size_calibration.csv'), 'WRITE_SIZE', 'void cpol<2, 16>', MIB96)
-  kw_r = calib(read(d + '/pmc_write_size_calibration.csv'), 'WRITE_SIZE', 'void rpol<2, 2, 16>', MIB96)
+def main(d, out, wkey='64x512x512x3:f16', suffix=''):
+  sfx = ('_' + suffix) if suffix else ''
+  cal = '_calibration_512' if suffix == 'cold' else '_calibration'
+  buf = (512 if suffix == 'cold' else 96) * 1024 * 1024  # bytes per stream of the calibration kernels
+  kf_c = calib(read(d + '/pmc_fetch_size%s.csv' % cal), 'FETCH_SIZE', 'void cpol<2, 16>', buf)
+  kf_r = calib(read(d + '/pmc_fetch_size%s.csv' % cal), 'FETCH_SIZE', 'void rpol<2, 2, 16>', 2 * buf)
+  kw_c = calib(read(d + '/pmc_write_size%s.csv' % cal), 'WRITE_SIZE', 'void cpol<2, 16>', buf)
+  kw_r = calib(read(d + '/pmc_write_size%s.csv' % cal), 'WRITE_SIZE', 'void rpol<2, 2, 16>', buf)
   kf, kw = round(0.5 * (kf_c + kf_r)), round(0.5 * (kw_c + kw_r))
   res = {}
-  for kind, rows in (('f', read(d + '/pmc_fetch_size.csv')), ('w', read(d + '/pmc_write_size.csv'))):
+  for kind, rows in (('f', read(d + '/pmc_fetch_size%s.csv' % sfx)), ('w', read(d + '/pmc_write_size%s.csv' % sfx))):
     for r in rows:
       m = re.search(r'filter_(fwd|bwd)_kernelINS_', r['Kernel'])
       if not m or 'DF16_' not in r['Kernel']:
@@ -51,11 +54,11 @@ def main(d, out, wkey='64x512x512x3:f16'):
       key = '%s_%s' % (m.group(1), name)
       res.setdefault(key, {})[kind] = float(r['Mean']) * 1024.0
   traffic = {k: int(round(kf * v['f'] + kw * v['w'])) for k, v in sorted(res.items()) if 'f' in v and 'w' in v}
-  doc = {'_comment': 'HBM bytes per launch at 64x512x512x3 fp16 from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE '
+  doc = {'_comment': 'HBM bytes per launch at ' + wkey + ' from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE '
                      '(separate passes, tools/profile_all.sh). traffic = kf*FETCH_SIZE*1024 + kw*WRITE_SIZE*1024 with '
                      'kf = %d, kw = %d calibrated in the same run on tools/membench kernels of known byte count, same '
                      'dwordx3 access pattern and cache policy (measured factors: cpol<2,16> fetch %.4f write %.4f; '
-                     'rpol<2,2,16> fetch %.4f write %.4f). Algorithmic bytes: fwd 201 326 592, bwd 301 989 888.'
+                     'rpol<2,2,16> fetch %.4f write %.4f).'
                      % (kf, kw, kf_c, kw_c, kf_r, kw_r)}
   try:
     old = json.load(open(out))
@@ -73,4 +76,4 @@ def main(d, out, wkey='64x512x512x3:f16'):
 
 if __name__ == '__main__':
   main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'profiles/traffic.json',
-       sys.argv[3] if len(sys.argv) > 3 else '64x512x512x3:f16')
+       sys.argv[3] if len(sys.argv) > 3 else '64x512x512x3:f16', sys.argv[4] if len(sys.argv) > 4 else '')
