@@ -1,0 +1,149 @@
+// chain_fused.hip -- the fused multi-step forward of the high-resolution inference path
+// (expo_chain_fused_fwd; /root/reference/net.py:796-821, BASELINE config 5), in its own translation unit
+// because it is compiled with -fno-slp-vectorize: this kernel is VALU-bound (8 filter bodies back to
+// back on values that stay in registers), and clang's SLP vectoriser turns pairs of independent fp32
+// operations into v_pk_mul_f32 / v_pk_fma_f32 plus the v_mov's that assemble their operand pairs.  On
+// gfx950 a packed fp32 instruction issues at HALF the rate of a scalar one (same flops per cycle), so
+// the packing buys nothing and the moves cost: 1 203 VALU with 216 v_mov -> 24.6 us, against 1 262
+// scalar VALU with 102 v_mov -> 22.7 us at 16x512x512x3 fp16 (gpurun r02p5).  The streaming kernels of
+// exposure_hip.hip are not VALU-bound and keep the default (-0.8 % for the chain with the flag).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/exposure_hip.h"
+#include "filter_math.h"
+#include "pixel_io.h"
+#include "kernel_common.h"
+#include "host_common.h"
+
+namespace expo {
+
+// ------------------------------------------------------- fused multi-step forward (inference)
+// The high-resolution inference path (net.py:796-821; BASELINE config 5): the per-step parameters
+// are regressed on the 64x64 proxy only, so by the time the full-resolution image is touched the
+// whole per-image sequence (filter id, parameters) x steps is known.  This kernel applies all
+// `steps` filters to a pixel group while it sits in registers (fp32 between steps -- no fp16
+// rounding of intermediates): ONE read and ONE write of the image instead of one per step.
+// Each wave owns exactly one 3 KiB chunk, so the per-step parameters are fetched once per wave
+// through scalar loads; the step loop is rolled (block-uniform switch per step).
+template <typename T, bool VEC, class IO>
+__global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t* __restrict__ ids,
+                                                                   const float* __restrict__ params, int steps,
+                                                                   const T* __restrict__ x, T* __restrict__ y,
+                                                                   int hw, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  const T* xi = x + off;
+  T* yi = y + off;
+  const int32_t* idn = ids + size_t(n) * steps;
+  const float* prn = params + size_t(n) * steps * EXPO_MAX_PARAMS;
+  __shared__ float2_lut curve_tab[kWaves][32];
+  float2_lut* const tab = curve_tab[threadIdx.x >> 6];
+  const int plane = (threadIdx.x & 63) % EXPO_MAX_PARAMS;  // which parameter this lane mirrors
+  auto run = [&](float* v) {
+    // software-pipelined parameter fetch: step st+1's id and 24 parameters (wave-uniform -> scalar
+    // loads into SGPRs) are requested before step st computes, hiding the scalar-load latency;
+    // `klane` is a per-lane copy (lane l <-> parameter l) for the curve table of curve_fwd_lut
+    float cur[EXPO_MAX_PARAMS], nxt[EXPO_MAX_PARAMS];
+    float klane = 0.f, klane_next = 0.f;
+    int id = -1, id_next = -1;
+    if (steps > 0) {
+      id = idn[0];
+      klane = prn[plane];
+#pragma unroll
+      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = prn[j];
+    }
+#pragma unroll 1
+    for (int st = 0; st < steps; ++st) {
+      const int sn = (st + 1 < steps) ? st + 1 : st;
+      id_next = idn[sn];
+      klane_next = prn[sn * EXPO_MAX_PARAMS + plane];
+#pragma unroll
+      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) nxt[j] = prn[sn * EXPO_MAX_PARAMS + j];
+      const float* prm = cur;
+#define EXPO_CASE(ID, F)                              \
+  case ID: {                                          \
+    const typename F::Prm q = F::load(prm);           \
+    _Pragma("unroll") for (int k = 0; k < PPL; ++k) { \
+      float o[3];                                     \
+      F::fwd(q, v + 3 * k, o);                        \
+      v[3 * k] = o[0];                                \
+      v[3 * k + 1] = o[1];                            \
+      v[3 * k + 2] = o[2];                            \
+    }                                                 \
+  } break;
+      switch (id) {
+        EXPO_CASE(0, ExposureF)
+        EXPO_CASE(1, GammaF)
+        EXPO_CASE(2, WhiteBalanceF)
+        EXPO_CASE(3, SatPlusF)
+        case 4: curve_fwd_lut<1, PPL>(v, klane, tab); break;
+        EXPO_CASE(5, ContrastF)
+        EXPO_CASE(6, WnbF)
+        case 7: curve_fwd_lut<3, PPL>(v, klane, tab); break;
+        EXPO_CASE(8, LevelF)
+        default:  // id -1: the all-zero one-hot selects nothing -> the image becomes 0
+#pragma unroll
+          for (int j = 0; j < PPL * 3; ++j) v[j] = 0.f;
+          break;
+      }
+#undef EXPO_CASE
+      id = id_next;
+      klane = klane_next;
+#pragma unroll
+      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = nxt[j];
+    }
+  };
+  const int stride = gridDim.x * kThreads;
+  if constexpr (VEC) {
+    const T* const ins[1] = {xi};
+    stream_groups<T, 1, true, false, IO>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                     [&](float (&v)[1][PPL * 3], int) { run(v[0]); });
+  } else {
+    // wave-uniform trip count: curve_fwd_lut needs lanes 0..23 of every wave alive (groups past the
+    // end load zeros and store nothing)
+    for (int g0 = blockIdx.x * kThreads + (threadIdx.x & ~63); g0 < groups; g0 += stride) {
+      const int g = g0 + (threadIdx.x & 63);
+      float v[PPL * 3];
+      load_slow<T>(xi, g, hw, v);
+      run(v);
+      store_slow<T>(yi, g, hw, v);
+    }
+  }
+}
+
+template <typename T>
+static int chain_fused_fwd_t(const int32_t* ids, const float* params, int steps, const void* x, void* y, int n,
+                             int h, int w, hipStream_t s) {
+  Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
+  g.blocks_x = (g.groups + kThreads - 1) / kThreads;  // one chunk per wave: parameters fetched once
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  if (g.stream)
+    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, true, IoStream>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
+  else if (g.vec)
+    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, true, IoCached>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
+  else
+    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, false, IoCached>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
+  HIP_TRY(hipGetLastError(), "chain_fused_fwd launch");
+  return EXPO_OK;
+}
+
+}  // namespace expo
+
+using namespace expo;
+
+extern "C" {
+
+int expo_chain_fused_fwd(const int32_t* filter_ids, const float* params, int steps, const void* x, void* y, int n,
+                         int h, int w, int dtype, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (steps < 0 || steps > 64) return fail(EXPO_E_BADARG, "steps must be in [0, 64]");
+  if (n == 0) return EXPO_OK;
+  if (!x || !y || (steps > 0 && (!filter_ids || !params))) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? chain_fused_fwd_t<half_t>(filter_ids, params, steps, x, y, n, h, w, s)
+                           : chain_fused_fwd_t<float>(filter_ids, params, steps, x, y, n, h, w, s);
+}
+
+}  // extern "C"

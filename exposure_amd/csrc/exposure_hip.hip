@@ -30,6 +30,8 @@
 #include "../../include/exposure_hip.h"
 #include "filter_math.h"
 #include "pixel_io.h"
+#include "kernel_common.h"
+#include "host_common.h"
 
 // forward launches give every wave exactly one chunk (EXPO_FWD_GROUPS_PER_THREAD = 1), so a
 // prefetch stage would only cost registers there
@@ -47,136 +49,6 @@
 
 
 namespace expo {
-
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
-
-// Wave-level "reduce-scatter" butterfly for N accumulators: at each xor step a lane keeps half of
-// its values and adds the partner's copy of that half, so the 6 steps cost ~N shuffles in total
-// (27 -> 14+7+4+2+1+1 = 29) instead of 6 N.  On return lane l holds, in acc[0], the wave total of
-// accumulator index reduce_index<N>(l) (valid if < N); lanes l and l^1 hold the same value.
-template <int N, int M>
-__device__ __forceinline__ void reduce_scatter_step(float* acc, int lane) {
-  constexpr int H = (N + 1) / 2;
-  const bool upper = (lane & M) != 0;
-#pragma unroll
-  for (int j = 0; j < H; ++j) {
-    const float lo = acc[j];
-    const float hi = (j + H < N) ? acc[j + H] : 0.0f;
-    const float keep = upper ? hi : lo;
-    const float send = upper ? lo : hi;
-    acc[j] = keep + __shfl_xor(send, M, 64);
-  }
-}
-template <int N>
-__device__ __forceinline__ int wave_reduce_scatter(float* acc, int lane) {
-  constexpr int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
-  static_assert(n5 == 1, "at most 32 accumulators");
-  if constexpr (N > 1) reduce_scatter_step<N, 32>(acc, lane); else acc[0] += __shfl_xor(acc[0], 32, 64);
-  if constexpr (n1 > 1) reduce_scatter_step<n1, 16>(acc, lane); else acc[0] += __shfl_xor(acc[0], 16, 64);
-  if constexpr (n2 > 1) reduce_scatter_step<n2, 8>(acc, lane); else acc[0] += __shfl_xor(acc[0], 8, 64);
-  if constexpr (n3 > 1) reduce_scatter_step<n3, 4>(acc, lane); else acc[0] += __shfl_xor(acc[0], 4, 64);
-  if constexpr (n4 > 1) reduce_scatter_step<n4, 2>(acc, lane); else acc[0] += __shfl_xor(acc[0], 2, 64);
-  acc[0] += __shfl_xor(acc[0], 1, 64);
-  // Which accumulator does this lane's surviving slot 0 hold?  Walk the halvings backwards; a slot
-  // that was padding at any level (odd split) is invalid (-1).
-  int l = 0;
-  bool ok = true;
-  if constexpr (n4 > 1) { l += (lane & 2) ? n5 : 0; ok = ok && l < n4; }
-  if constexpr (n3 > 1) { l += (lane & 4) ? n4 : 0; ok = ok && l < n3; }
-  if constexpr (n2 > 1) { l += (lane & 8) ? n3 : 0; ok = ok && l < n2; }
-  if constexpr (n1 > 1) { l += (lane & 16) ? n2 : 0; ok = ok && l < n1; }
-  if constexpr (N > 1) { l += (lane & 32) ? n1 : 0; ok = ok && l < N; }
-  return ok ? l : -1;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Per-image reductions without float atomics: block -> workspace record -> finish kernel.
-//
-// A reducing kernel leaves ONE record of <= 32 partial sums per block in the caller's workspace
-// (records[n][bx][kWsSlots], plain fire-and-forget stores: a block exits as soon as it has streamed
-// its pixels -- no returning atomic, no drain of its write-through image stores, nothing that keeps
-// an occupancy slot busy).  finish_kernel, launched behind it on the same stream, adds the bx records
-// of an image in a FIXED order and writes the final values (parameter gradients, penalty, statistics).
-// One finish launch serves all steps of a chain.  No zero-fill, no float atomics, results are
-// bit-reproducible run to run, and the workspace needs no initialisation (records are fully
-// overwritten before they are read).
-// Measured on MI355X, 64x512x512x3 fp16 (gpurun r02p3): a last-block-finishes variant (ticket +
-// agent-scope hand-off inside the kernel) cost 6.6 ns per block of tail latency -- 51.9 us per light
-// backward kernel vs 47.9 us with round 1's float atomics -- which is why the finish is a launch.
-// ---------------------------------------------------------------------------------------------
-constexpr int kWsSlots = 32;
-
-// Block-reduce NACC accumulators into this block's record.  Must be the last block-wide action.
-template <int NACC>
-__device__ __forceinline__ void block_reduce_record(float* acc, float* __restrict__ records_img) {
-  static_assert(NACC <= kWsSlots, "one record per block");
-  __shared__ float red[kWaves][NACC];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int idx = wave_reduce_scatter<NACC>(acc, lane);
-  if ((lane & 1) == 0 && idx >= 0) red[wv][idx] = acc[0];
-  __syncthreads();
-  if (threadIdx.x < NACC) {
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < kWaves; ++k) v += red[k][threadIdx.x];
-    records_img[size_t(blockIdx.x) * kWsSlots + threadIdx.x] = v;
-  }
-}
-
-// Curve forward by table: instead of the telescoped 7 x v_min + 8 x v_fma per element, a per-wave
-// table of the L segments in LDS -- entry (c, j) = {a, b} with
-//   y = a x^ + b on segment j,  a = (L/S) k_j,  b = (L/S) (sum_{i<j} k_i - j k_j) / L
-// -- looked up with j = min(int(L x^), L-1): clamp, mul, cvt, min, address, ds_read_b64, fma.
-// Build: lane l < NC*L holds parameter k[l] (a per-lane copy fetched by a vector load); the exclusive
-// prefix sums come from three shuffles inside each group of L lanes.  One wave builds and reads its
-// own table region and LDS operations of a wave execute in order, so no block barrier is involved;
-// ALL lanes 0..NC*L-1 of the wave must be active.  Used by the fused inference kernel (a new table
-// per step) and by the per-step forward kernels (one table per wave for the whole launch).
-template <int NC>
-__device__ __forceinline__ void curve_lut_build(float klane, float2_lut* tab) {
-  constexpr int L = kCurveSteps;
-  const int lane = threadIdx.x & 63;
-  const int j = lane & (L - 1);
-  float incl = klane;  // inclusive scan over the L lanes of a curve
-#pragma unroll
-  for (int d = 1; d < L; d <<= 1) {
-    const float t = __shfl_up(incl, d, L);
-    if (j >= d) incl += t;
-  }
-  const float S = __shfl(incl, L - 1, L) + 1e-30f;
-  const float scale = float(L) / S;
-  if (lane < NC * L) {
-    float2_lut e;
-    e.x = scale * klane;
-    e.y = scale * ((incl - klane) - float(j) * klane) * (1.0f / float(L));
-    // L + 1 entries per curve: entry L repeats segment L-1, so x^ == 1 (int(L x^) == L) needs no index clamp
-    const int slot = (lane / L) * (L + 1) + j;
-    tab[slot] = e;
-    if (j == L - 1) tab[slot + 1] = e;
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-template <int NC, int NPIX>
-__device__ __forceinline__ void curve_lut_apply(float* v, const float2_lut* tab) {
-  constexpr int L = kCurveSteps;
-#pragma unroll
-  for (int k = 0; k < NPIX; ++k) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float xc = clamp01x(v[3 * k + c], 0.0f, 1.0f);
-      const int seg = int(xc * float(L));  // 0..L; entry L == entry L-1
-      const float2_lut e = tab[(NC == 1 ? 0 : c * (L + 1)) + seg];
-      v[3 * k + c] = fmaf(xc, e.x, e.y);
-    }
-  }
-}
-template <int NC, int NPIX>
-__device__ __forceinline__ void curve_fwd_lut(float* v, float klane, float2_lut* tab) {
-  curve_lut_build<NC>(klane, tab);
-  curve_lut_apply<NC, NPIX>(v, tab);
-  __builtin_amdgcn_wave_barrier();  // the next curve step of this wave rewrites the table
-}
 
 // --------------------------------------------------------------------------- forward
 template <class F, typename T, bool VEC, bool PEN, class IO = IoCached>
@@ -548,101 +420,6 @@ __global__ __launch_bounds__(kThreads) void dispatch_bwd_kernel(const int32_t* _
 #undef EXPO_CASE
 }
 
-// ------------------------------------------------------- fused multi-step forward (inference)
-// The high-resolution inference path (net.py:796-821; BASELINE config 5): the per-step parameters
-// are regressed on the 64x64 proxy only, so by the time the full-resolution image is touched the
-// whole per-image sequence (filter id, parameters) x steps is known.  This kernel applies all
-// `steps` filters to a pixel group while it sits in registers (fp32 between steps -- no fp16
-// rounding of intermediates): ONE read and ONE write of the image instead of one per step.
-// Each wave owns exactly one 3 KiB chunk, so the per-step parameters are fetched once per wave
-// through scalar loads; the step loop is rolled (block-uniform switch per step).
-template <typename T, bool VEC, class IO>
-__global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t* __restrict__ ids,
-                                                                   const float* __restrict__ params, int steps,
-                                                                   const T* __restrict__ x, T* __restrict__ y,
-                                                                   int hw, int groups) {
-  constexpr int PPL = PixTraits<T>::PPL;
-  const int n = blockIdx.y;
-  const size_t off = size_t(n) * hw * 3;
-  const T* xi = x + off;
-  T* yi = y + off;
-  const int32_t* idn = ids + size_t(n) * steps;
-  const float* prn = params + size_t(n) * steps * EXPO_MAX_PARAMS;
-  __shared__ float2_lut curve_tab[kWaves][32];
-  float2_lut* const tab = curve_tab[threadIdx.x >> 6];
-  const int plane = (threadIdx.x & 63) % EXPO_MAX_PARAMS;  // which parameter this lane mirrors
-  auto run = [&](float* v) {
-    // software-pipelined parameter fetch: step st+1's id and 24 parameters (wave-uniform -> scalar
-    // loads into SGPRs) are requested before step st computes, hiding the scalar-load latency;
-    // `klane` is a per-lane copy (lane l <-> parameter l) for the curve table of curve_fwd_lut
-    float cur[EXPO_MAX_PARAMS], nxt[EXPO_MAX_PARAMS];
-    float klane = 0.f, klane_next = 0.f;
-    int id = -1, id_next = -1;
-    if (steps > 0) {
-      id = idn[0];
-      klane = prn[plane];
-#pragma unroll
-      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = prn[j];
-    }
-#pragma unroll 1
-    for (int st = 0; st < steps; ++st) {
-      const int sn = (st + 1 < steps) ? st + 1 : st;
-      id_next = idn[sn];
-      klane_next = prn[sn * EXPO_MAX_PARAMS + plane];
-#pragma unroll
-      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) nxt[j] = prn[sn * EXPO_MAX_PARAMS + j];
-      const float* prm = cur;
-#define EXPO_CASE(ID, F)                              \
-  case ID: {                                          \
-    const typename F::Prm q = F::load(prm);           \
-    _Pragma("unroll") for (int k = 0; k < PPL; ++k) { \
-      float o[3];                                     \
-      F::fwd(q, v + 3 * k, o);                        \
-      v[3 * k] = o[0];                                \
-      v[3 * k + 1] = o[1];                            \
-      v[3 * k + 2] = o[2];                            \
-    }                                                 \
-  } break;
-      switch (id) {
-        EXPO_CASE(0, ExposureF)
-        EXPO_CASE(1, GammaF)
-        EXPO_CASE(2, WhiteBalanceF)
-        EXPO_CASE(3, SatPlusF)
-        case 4: curve_fwd_lut<1, PPL>(v, klane, tab); break;
-        EXPO_CASE(5, ContrastF)
-        EXPO_CASE(6, WnbF)
-        case 7: curve_fwd_lut<3, PPL>(v, klane, tab); break;
-        EXPO_CASE(8, LevelF)
-        default:  // id -1: the all-zero one-hot selects nothing -> the image becomes 0
-#pragma unroll
-          for (int j = 0; j < PPL * 3; ++j) v[j] = 0.f;
-          break;
-      }
-#undef EXPO_CASE
-      id = id_next;
-      klane = klane_next;
-#pragma unroll
-      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = nxt[j];
-    }
-  };
-  const int stride = gridDim.x * kThreads;
-  if constexpr (VEC) {
-    const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, false, IO>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                     [&](float (&v)[1][PPL * 3], int) { run(v[0]); });
-  } else {
-    // wave-uniform trip count: curve_fwd_lut needs lanes 0..23 of every wave alive (groups past the
-    // end load zeros and store nothing)
-    for (int g0 = blockIdx.x * kThreads + (threadIdx.x & ~63); g0 < groups; g0 += stride) {
-      const int g = g0 + (threadIdx.x & 63);
-      float v[PPL * 3];
-      load_slow<T>(xi, g, hw, v);
-      run(v);
-      store_slow<T>(yi, g, hw, v);
-    }
-  }
-}
-
 // ------------------------------------------------------------- per-image reductions
 // critics.py:48-62.  Raw sums {sum(l-1/2), sum (l-1/2)^2, sum sat} are accumulated (shifted to tame
 // the E[l^2]-E[l]^2 cancellation); finish_kernel turns them into {mean, variance, mean sat}.
@@ -832,72 +609,6 @@ EXPO_PROBE_APPLY(ColorF)
 #else
 // ==================================================================== host side
 thread_local std::string g_err;
-
-static int fail(int code, const char* what) {
-  g_err = what;
-  return code;
-}
-static int fail_hip(hipError_t e, const char* where) {
-  g_err = std::string(where) + ": " + hipGetErrorString(e);
-  return EXPO_E_HIP;
-}
-#define HIP_TRY(expr, where)                         \
-  do {                                               \
-    hipError_t e_ = (expr);                          \
-    if (e_ != hipSuccess) return fail_hip(e_, where); \
-  } while (0)
-
-static const int kNumParams[EXPO_NUM_FILTERS] = {1, 1, 3, 1, 8, 1, 1, 24, 2};
-
-struct Geom {
-  int hw, groups, blocks_x;
-  bool vec;
-  bool stream;  // IoStream policy (pixel_io.h): vector path and the tensor is far beyond L2
-};
-
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  if (!v || !*v) return dflt;
-  const int x = atoi(v);
-  return x > 0 ? x : dflt;
-}
-
-// a reducing kernel writes one workspace record per block: bound the records of one image
-constexpr int kMaxReduceBlocksX = 1024;
-enum GeomKind { kGeomMap = 0, kGeomReduce = 1, kGeomReadReduce = 2 };
-
-// groups of 48 bytes per image; blocks per image chosen so the whole grid is >= ~1024
-// blocks when the problem allows and each thread walks a few groups (amortises the
-// reduction epilogue); capped at 2048-ish total blocks (grid-stride the rest).
-template <typename T>
-static Geom make_geom(int n, int h, int w, std::initializer_list<const void*> ptrs, int kind = kGeomReduce) {
-  const bool reduces = kind != kGeomMap;
-  constexpr int PPL = PixTraits<T>::PPL;
-  Geom g;
-  g.hw = h * w;
-  g.groups = (g.hw + PPL - 1) / PPL;
-  g.vec = (g.hw % VecTraits<T>::PPV) == 0;  // dwordx3 path: whole 12-byte vectors, 4-byte aligned
-  for (const void* p : ptrs) g.vec = g.vec && (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 3) == 0);
-  const int max_bx = (g.groups + kThreads - 1) / kThreads;
-  // groups each thread walks: kernels with a reduction epilogue (one workspace record per block) want
-  // fewer, fatter blocks; pure maps (forward) stream best with many blocks (tools/membench.hip)
-  static const int gpt_red = env_int("EXPO_BWD_GROUPS_PER_THREAD", 4);
-  static const int gpt_map = env_int("EXPO_FWD_GROUPS_PER_THREAD", 1);
-  static const int gpt_read = env_int("EXPO_RED_GROUPS_PER_THREAD", 1);  // read-only reductions (stats, penalty)
-  const int gpt = kind == kGeomReduce ? gpt_red : (kind == kGeomReadReduce ? gpt_read : gpt_map);
-  int bx = (g.groups + kThreads * gpt - 1) / (kThreads * gpt);
-  const long want = 1024;
-  if (long(bx) * n < want) bx = int((want + n - 1) / n);
-  if (bx > max_bx) bx = max_bx;
-  if (reduces && bx > kMaxReduceBlocksX) bx = kMaxReduceBlocksX;
-  if (bx < 1) bx = 1;
-  g.blocks_x = bx;
-  // cache policy: tensors of at least EXPO_STREAM_MIN_BYTES (default 8 MiB; L2 is 8 x 4 MiB) stream
-  static const long stream_min = env_int("EXPO_STREAM_MIN_BYTES", 8 << 20);
-  g.stream = g.vec && long(n) * g.hw * 3L * long(sizeof(T)) >= stream_min;
-  return g;
-}
-
 // ---- workspace of the reducing kernels: float records[steps][n][bx][kWsSlots]; no initialisation needed
 static size_t ws_step_bytes(int n, int blocks_x) { return size_t(n) * size_t(blocks_x) * kWsSlots * sizeof(float); }
 static int ws_check(void* workspace, size_t workspace_bytes, int n, int blocks_x, int steps, float** records) {
@@ -913,16 +624,6 @@ static int ws_check(void* workspace, size_t workspace_bytes, int n, int blocks_x
 static int launch_finish(const FinishArgs& args, int steps, int n, int bx, hipStream_t s) {
   hipLaunchKernelGGL(finish_kernel, dim3(n, steps), dim3(64), 0, s, args, bx);
   HIP_TRY(hipGetLastError(), "finish launch");
-  return EXPO_OK;
-}
-
-static int check_common(int n, int h, int w, int dtype) {
-  if (n < 0 || h < 1 || w < 1) return fail(EXPO_E_BADARG, "n >= 0, h >= 1, w >= 1 required");
-  if (n > 65535) return fail(EXPO_E_BADARG, "n > 65535 not supported (grid.y)");
-  if (dtype != EXPO_F16 && dtype != EXPO_F32) return fail(EXPO_E_BADDTYPE, "dtype must be EXPO_F16 or EXPO_F32");
-  // one image is addressed through a raw buffer resource with 32-bit byte offsets
-  const long image_bytes = long(h) * long(w) * 3L * (dtype == EXPO_F16 ? 2L : 4L);
-  if (image_bytes > (1L << 31) - 8192) return fail(EXPO_E_BADARG, "one image must be smaller than 2 GiB");
   return EXPO_OK;
 }
 
@@ -1153,22 +854,6 @@ static int dispatch_bwd_t(const int32_t* ids, const void* x, const void* dy, voi
   FinishArgs fa{};
   fa.s[0] = FinishStep{params, dparams, nullptr, records, ids, kFinDispatch, 0, 0, 0.f};
   return launch_finish(fa, 1, n, g.blocks_x, s);
-}
-
-template <typename T>
-static int chain_fused_fwd_t(const int32_t* ids, const float* params, int steps, const void* x, void* y, int n,
-                             int h, int w, hipStream_t s) {
-  Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
-  g.blocks_x = (g.groups + kThreads - 1) / kThreads;  // one chunk per wave: parameters fetched once
-  const dim3 grid(g.blocks_x, n), block(kThreads);
-  if (g.stream)
-    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, true, IoStream>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
-  else if (g.vec)
-    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, true, IoCached>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
-  else
-    hipLaunchKernelGGL((chain_fused_fwd_kernel<T, false, IoCached>), grid, block, 0, s, ids, params, steps, (const T*)x, (T*)y, g.hw, g.groups);
-  HIP_TRY(hipGetLastError(), "chain_fused_fwd launch");
-  return EXPO_OK;
 }
 
 template <typename T>
@@ -1407,17 +1092,6 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
     if (int rc = launch_finish(fa, cnt, n, bx, s)) return rc;
   }
   return EXPO_OK;
-}
-
-int expo_chain_fused_fwd(const int32_t* filter_ids, const float* params, int steps, const void* x, void* y, int n,
-                         int h, int w, int dtype, void* stream) {
-  if (int rc = check_common(n, h, w, dtype)) return rc;
-  if (steps < 0 || steps > 64) return fail(EXPO_E_BADARG, "steps must be in [0, 64]");
-  if (n == 0) return EXPO_OK;
-  if (!x || !y || (steps > 0 && (!filter_ids || !params))) return fail(EXPO_E_BADARG, "null pointer");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == EXPO_F16 ? chain_fused_fwd_t<half_t>(filter_ids, params, steps, x, y, n, h, w, s)
-                           : chain_fused_fwd_t<float>(filter_ids, params, steps, x, y, n, h, w, s);
 }
 
 int expo_critic_stats(const void* x, float* stats, int n, int h, int w, int dtype, void* workspace,

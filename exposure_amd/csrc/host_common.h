@@ -1,0 +1,93 @@
+// host_common.h -- host-side helpers shared by the translation units of libexposure_hip.so:
+// error reporting, launch geometry, argument checks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <initializer_list>
+#include <string>
+
+#include "../../include/exposure_hip.h"
+#include "kernel_common.h"
+
+namespace expo {
+
+extern thread_local std::string g_err;  // defined in exposure_hip.hip
+
+inline int fail(int code, const char* what) {
+  g_err = what;
+  return code;
+}
+inline int fail_hip(hipError_t e, const char* where) {
+  g_err = std::string(where) + ": " + hipGetErrorString(e);
+  return EXPO_E_HIP;
+}
+#define HIP_TRY(expr, where)                         \
+  do {                                               \
+    hipError_t e_ = (expr);                          \
+    if (e_ != hipSuccess) return fail_hip(e_, where); \
+  } while (0)
+
+constexpr int kNumParams[EXPO_NUM_FILTERS] = {1, 1, 3, 1, 8, 1, 1, 24, 2};
+
+struct Geom {
+  int hw, groups, blocks_x;
+  bool vec;
+  bool stream;  // IoStream policy (pixel_io.h): vector path and the tensor is far beyond L2
+};
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  const int x = atoi(v);
+  return x > 0 ? x : dflt;
+}
+
+// a reducing kernel writes one workspace record per block: bound the records of one image
+constexpr int kMaxReduceBlocksX = 1024;
+enum GeomKind { kGeomMap = 0, kGeomReduce = 1, kGeomReadReduce = 2 };
+
+// groups of 48 bytes per image; blocks per image chosen so the whole grid is >= ~1024
+// blocks when the problem allows and each thread walks a few groups (amortises the
+// reduction epilogue); capped at 2048-ish total blocks (grid-stride the rest).
+template <typename T>
+inline Geom make_geom(int n, int h, int w, std::initializer_list<const void*> ptrs, int kind = kGeomReduce) {
+  const bool reduces = kind != kGeomMap;
+  constexpr int PPL = PixTraits<T>::PPL;
+  Geom g;
+  g.hw = h * w;
+  g.groups = (g.hw + PPL - 1) / PPL;
+  g.vec = (g.hw % VecTraits<T>::PPV) == 0;  // dwordx3 path: whole 12-byte vectors, 4-byte aligned
+  for (const void* p : ptrs) g.vec = g.vec && (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 3) == 0);
+  const int max_bx = (g.groups + kThreads - 1) / kThreads;
+  // groups each thread walks: kernels with a reduction epilogue (one workspace record per block) want
+  // fewer, fatter blocks; pure maps (forward) stream best with many blocks (tools/membench.hip)
+  static const int gpt_red = env_int("EXPO_BWD_GROUPS_PER_THREAD", 4);
+  static const int gpt_map = env_int("EXPO_FWD_GROUPS_PER_THREAD", 1);
+  static const int gpt_read = env_int("EXPO_RED_GROUPS_PER_THREAD", 1);  // read-only reductions (stats, penalty)
+  const int gpt = kind == kGeomReduce ? gpt_red : (kind == kGeomReadReduce ? gpt_read : gpt_map);
+  int bx = (g.groups + kThreads * gpt - 1) / (kThreads * gpt);
+  const long want = 1024;
+  if (long(bx) * n < want) bx = int((want + n - 1) / n);
+  if (bx > max_bx) bx = max_bx;
+  if (reduces && bx > kMaxReduceBlocksX) bx = kMaxReduceBlocksX;
+  if (bx < 1) bx = 1;
+  g.blocks_x = bx;
+  // cache policy: tensors of at least EXPO_STREAM_MIN_BYTES (default 8 MiB; L2 is 8 x 4 MiB) stream
+  static const long stream_min = env_int("EXPO_STREAM_MIN_BYTES", 8 << 20);
+  g.stream = g.vec && long(n) * g.hw * 3L * long(sizeof(T)) >= stream_min;
+  return g;
+}
+
+inline int check_common(int n, int h, int w, int dtype) {
+  if (n < 0 || h < 1 || w < 1) return fail(EXPO_E_BADARG, "n >= 0, h >= 1, w >= 1 required");
+  if (n > 65535) return fail(EXPO_E_BADARG, "n > 65535 not supported (grid.y)");
+  if (dtype != EXPO_F16 && dtype != EXPO_F32) return fail(EXPO_E_BADDTYPE, "dtype must be EXPO_F16 or EXPO_F32");
+  // one image is addressed through a raw buffer resource with 32-bit byte offsets
+  const long image_bytes = long(h) * long(w) * 3L * (dtype == EXPO_F16 ? 2L : 4L);
+  if (image_bytes > (1L << 31) - 8192) return fail(EXPO_E_BADARG, "one image must be smaller than 2 GiB");
+  return EXPO_OK;
+}
+
+}  // namespace expo

@@ -1,0 +1,142 @@
+// kernel_common.h -- device helpers shared by the translation units of libexposure_hip.so:
+// block geometry, the wave-level reduce-scatter, the per-block reduction records, the curve segment table.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "filter_math.h"
+#include "pixel_io.h"
+
+namespace expo {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+// Wave-level "reduce-scatter" butterfly for N accumulators: at each xor step a lane keeps half of
+// its values and adds the partner's copy of that half, so the 6 steps cost ~N shuffles in total
+// (27 -> 14+7+4+2+1+1 = 29) instead of 6 N.  On return lane l holds, in acc[0], the wave total of
+// accumulator index reduce_index<N>(l) (valid if < N); lanes l and l^1 hold the same value.
+template <int N, int M>
+__device__ __forceinline__ void reduce_scatter_step(float* acc, int lane) {
+  constexpr int H = (N + 1) / 2;
+  const bool upper = (lane & M) != 0;
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const float lo = acc[j];
+    const float hi = (j + H < N) ? acc[j + H] : 0.0f;
+    const float keep = upper ? hi : lo;
+    const float send = upper ? lo : hi;
+    acc[j] = keep + __shfl_xor(send, M, 64);
+  }
+}
+template <int N>
+__device__ __forceinline__ int wave_reduce_scatter(float* acc, int lane) {
+  constexpr int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
+  static_assert(n5 == 1, "at most 32 accumulators");
+  if constexpr (N > 1) reduce_scatter_step<N, 32>(acc, lane); else acc[0] += __shfl_xor(acc[0], 32, 64);
+  if constexpr (n1 > 1) reduce_scatter_step<n1, 16>(acc, lane); else acc[0] += __shfl_xor(acc[0], 16, 64);
+  if constexpr (n2 > 1) reduce_scatter_step<n2, 8>(acc, lane); else acc[0] += __shfl_xor(acc[0], 8, 64);
+  if constexpr (n3 > 1) reduce_scatter_step<n3, 4>(acc, lane); else acc[0] += __shfl_xor(acc[0], 4, 64);
+  if constexpr (n4 > 1) reduce_scatter_step<n4, 2>(acc, lane); else acc[0] += __shfl_xor(acc[0], 2, 64);
+  acc[0] += __shfl_xor(acc[0], 1, 64);
+  // Which accumulator does this lane's surviving slot 0 hold?  Walk the halvings backwards; a slot
+  // that was padding at any level (odd split) is invalid (-1).
+  int l = 0;
+  bool ok = true;
+  if constexpr (n4 > 1) { l += (lane & 2) ? n5 : 0; ok = ok && l < n4; }
+  if constexpr (n3 > 1) { l += (lane & 4) ? n4 : 0; ok = ok && l < n3; }
+  if constexpr (n2 > 1) { l += (lane & 8) ? n3 : 0; ok = ok && l < n2; }
+  if constexpr (n1 > 1) { l += (lane & 16) ? n2 : 0; ok = ok && l < n1; }
+  if constexpr (N > 1) { l += (lane & 32) ? n1 : 0; ok = ok && l < N; }
+  return ok ? l : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-image reductions without float atomics: block -> workspace record -> finish kernel.
+//
+// A reducing kernel leaves ONE record of <= 32 partial sums per block in the caller's workspace
+// (records[n][bx][kWsSlots], plain fire-and-forget stores: a block exits as soon as it has streamed
+// its pixels -- no returning atomic, no drain of its write-through image stores, nothing that keeps
+// an occupancy slot busy).  finish_kernel, launched behind it on the same stream, adds the bx records
+// of an image in a FIXED order and writes the final values (parameter gradients, penalty, statistics).
+// One finish launch serves all steps of a chain.  No zero-fill, no float atomics, results are
+// bit-reproducible run to run, and the workspace needs no initialisation (records are fully
+// overwritten before they are read).
+// Measured on MI355X, 64x512x512x3 fp16 (gpurun r02p3): a last-block-finishes variant (ticket +
+// agent-scope hand-off inside the kernel) cost 6.6 ns per block of tail latency -- 51.9 us per light
+// backward kernel vs 47.9 us with round 1's float atomics -- which is why the finish is a launch.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWsSlots = 32;
+
+// Block-reduce NACC accumulators into this block's record.  Must be the last block-wide action.
+template <int NACC>
+__device__ __forceinline__ void block_reduce_record(float* acc, float* __restrict__ records_img) {
+  static_assert(NACC <= kWsSlots, "one record per block");
+  __shared__ float red[kWaves][NACC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int idx = wave_reduce_scatter<NACC>(acc, lane);
+  if ((lane & 1) == 0 && idx >= 0) red[wv][idx] = acc[0];
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < kWaves; ++k) v += red[k][threadIdx.x];
+    records_img[size_t(blockIdx.x) * kWsSlots + threadIdx.x] = v;
+  }
+}
+
+// Curve forward by table: instead of the telescoped 7 x v_min + 8 x v_fma per element, a per-wave
+// table of the L segments in LDS -- entry (c, j) = {a, b} with
+//   y = a x^ + b on segment j,  a = (L/S) k_j,  b = (L/S) (sum_{i<j} k_i - j k_j) / L
+// -- looked up with j = min(int(L x^), L-1): clamp, mul, cvt, min, address, ds_read_b64, fma.
+// Build: lane l < NC*L holds parameter k[l] (a per-lane copy fetched by a vector load); the exclusive
+// prefix sums come from three shuffles inside each group of L lanes.  One wave builds and reads its
+// own table region and LDS operations of a wave execute in order, so no block barrier is involved;
+// ALL lanes 0..NC*L-1 of the wave must be active.  Used by the fused inference kernel (a new table
+// per step) and by the per-step forward kernels (one table per wave for the whole launch).
+template <int NC>
+__device__ __forceinline__ void curve_lut_build(float klane, float2_lut* tab) {
+  constexpr int L = kCurveSteps;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (L - 1);
+  float incl = klane;  // inclusive scan over the L lanes of a curve
+#pragma unroll
+  for (int d = 1; d < L; d <<= 1) {
+    const float t = __shfl_up(incl, d, L);
+    if (j >= d) incl += t;
+  }
+  const float S = __shfl(incl, L - 1, L) + 1e-30f;
+  const float scale = float(L) / S;
+  if (lane < NC * L) {
+    float2_lut e;
+    e.x = scale * klane;
+    e.y = scale * ((incl - klane) - float(j) * klane) * (1.0f / float(L));
+    // L + 1 entries per curve: entry L repeats segment L-1, so x^ == 1 (int(L x^) == L) needs no index clamp
+    const int slot = (lane / L) * (L + 1) + j;
+    tab[slot] = e;
+    if (j == L - 1) tab[slot + 1] = e;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+template <int NC, int NPIX>
+__device__ __forceinline__ void curve_lut_apply(float* v, const float2_lut* tab) {
+  constexpr int L = kCurveSteps;
+#pragma unroll
+  for (int k = 0; k < NPIX; ++k) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xc = clamp01x(v[3 * k + c], 0.0f, 1.0f);
+      const int seg = int(xc * float(L));  // 0..L; entry L == entry L-1
+      const float2_lut e = tab[(NC == 1 ? 0 : c * (L + 1)) + seg];
+      v[3 * k + c] = fmaf(xc, e.x, e.y);
+    }
+  }
+}
+template <int NC, int NPIX>
+__device__ __forceinline__ void curve_fwd_lut(float* v, float klane, float2_lut* tab) {
+  curve_lut_build<NC>(klane, tab);
+  curve_lut_apply<NC, NPIX>(v, tab);
+  __builtin_amdgcn_wave_barrier();  // the next curve step of this wave rewrites the table
+}
+
+}  // namespace expo

@@ -10,7 +10,7 @@ def short(name):
   if m:
     return 'filter_%s_kernel<%s%s>' % (m.group(1), m.group(2), m.group(4) or '')
   name = re.sub(r'\(.*', '', name)
-  return name[:80]
+  return name[:160]
 
 
 def table(path):
