@@ -32,6 +32,9 @@ SIGNATURES = {
     'expo_filter_fwd': (_i, [_i, _vp, _vp, _fp, _i, _i, _i, _i, _vp]),
     'expo_filter_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_filter_bwd_accumulate': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_filter_bwd_records': (_i, [_i, _vp, _vp, _vp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_finish_bwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _vp, _sz,
+                            _vp]),
     'expo_filter_apply_fwd': (_i, [_i, _vp, _vp, _fp, _fp, _f, _f, _i, _i, _i, _i, _vp]),
     'expo_filter_apply_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _i, _i, _vp, _sz,
                                    _vp]),
@@ -191,6 +194,37 @@ def filter_bwd(fid, x, dy, dx, params, dparams, hsv_grad_mode=0, accumulate=Fals
     wsp, wsb = _ws(x, workspace)
     _check(fn(fid, _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams), n, h, w, _dtype_code(x),
               hsv_grad_mode, wsp, wsb, _stream()), 'expo_filter_bwd')
+
+
+def filter_bwd_records(fid, x, dy, dx, params, hsv_grad_mode=0, workspace=None):
+  """The streaming pass of filter_bwd alone (dx written, block records left in the workspace, no
+  parameter gradients yet); finish with :func:`finish_bwd`.  Per-kernel timing and batched finishes."""
+  lib = load()
+  _img(x, 'x'), _img(dy, 'dy')
+  n, h, w, _ = x.shape
+  if dx is not None:
+    _img(dx, 'dx')
+  _f32(params, 'params', (n, NUM_PARAMS[fid]))
+  with torch.cuda.device(x.device):
+    wsp, wsb = _ws(x, workspace)
+    _check(lib.expo_filter_bwd_records(fid, _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), n, h, w, _dtype_code(x),
+                                       hsv_grad_mode, wsp, wsb, _stream()), 'expo_filter_bwd_records')
+
+
+def finish_bwd(filter_ids, like, params, dparams, workspace=None):
+  """One finish launch for len(filter_ids) record slices of the workspace (``like``: an image tensor of
+  the shape / dtype the records were produced for)."""
+  lib = load()
+  steps = len(filter_ids)
+  n, h, w, _ = like.shape
+  for fid, p, dp in zip(filter_ids, params, dparams):
+    _f32(p, 'params', (n, NUM_PARAMS[fid]))
+    _f32(dp, 'dparams', (n, NUM_PARAMS[fid]))
+  ids = (ctypes.c_int * steps)(*filter_ids)
+  with torch.cuda.device(like.device):
+    wsp, wsb = _ws(like, workspace, steps)
+    _check(lib.expo_finish_bwd(ids, steps, _ptr_array(params), _ptr_array(dparams), n, h, w, _dtype_code(like), wsp,
+                               wsb, _stream()), 'expo_finish_bwd')
 
 
 def apply_fwd(fid, x, y, params, mask_params, maximum_sharpness, minimum_strength):

@@ -148,7 +148,9 @@ class GAN(nn.Module):
   def _generator_body(self, fake_input, z, states, progress, dropout_masks):
     out = self.generator_losses(fake_input, z, states, progress, 1, dropout_masks)
     # the value net's short backward first: its all-reduce then runs under the whole generator backward
-    self._backward_into(out['v_loss'], ['v'], retain_graph=True)
+    # (v_loss reaches theta_v through old_value only, g_loss through new_value / the critic / the agent: the two
+    # backward passes share no graph nodes, so nothing needs to be retained)
+    self._backward_into(out['v_loss'], ['v'])
     self._backward_into(out['g_loss'], ['g_head', 'g_trunk'])
     self._finish_collectives()
     self.opt_g.step()

@@ -176,6 +176,23 @@ int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const voi
                              void* stream);
 
 /*
+ * The two halves of expo_filter_bwd, for callers that finish several passes with one launch
+ * (expo_chain_bwd is exactly: the records pass of every step, then one expo_finish_bwd) and for
+ * per-kernel timing.  expo_filter_bwd_records runs the streaming pass alone: dx is written, the
+ * per-block partial sums stay in `records` (>= expo_workspace_bytes(n, h, w, dtype) bytes), dparams
+ * is not touched.  expo_finish_bwd turns `steps` record slices -- slice k at byte offset
+ * k * expo_workspace_bytes(...) of `workspace` -- into the parameter gradients dparams[k] of the
+ * filters filter_ids[k] (host arrays, as in expo_chain_bwd).  No reference counterpart: TF fuses
+ * nothing here (net.py:222-251 builds one reduction per parameter tensor).
+ */
+int expo_filter_bwd_records(int filter_id, const void* x, const void* dy, void* dx,
+                            const float* params, int n, int h, int w, int dtype,
+                            int hsv_grad_mode, void* records, size_t records_bytes, void* stream);
+int expo_finish_bwd(const int* filter_ids, int steps, const float* const* params,
+                    float* const* dparams, int n, int h, int w, int dtype, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/*
  * The benchmark construct of SURVEY.md section 8(d): `steps` filters applied
  * sequentially, one kernel per step, enqueued by a single call.
  *   filter_ids  host int [steps]

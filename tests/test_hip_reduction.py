@@ -120,6 +120,24 @@ def test_chain_backward_one_finish_for_all_steps(gpu_device):
     _cabi.chain_bwd(ids, acts, grads, tp, dps, workspace=one)
 
 
+def test_records_pass_plus_finish_equals_filter_bwd(gpu_device):
+  """expo_filter_bwd_records + expo_finish_bwd (the two halves a caller may batch) == expo_filter_bwd."""
+  shape = (4, 80, 112, 3)
+  x, dy, params, tx, tdy, tp = device_case(shape, 12, gpu_device)
+  nb = _cabi.workspace_bytes(4, 80, 112, _cabi.EXPO_F16)
+  ws = _cabi.new_workspace(gpu_device, 3 * nb)
+  fids = [7, 2, 5]
+  dxs = [torch.empty_like(tx) for _ in fids]
+  for k, fid in enumerate(fids):
+    _cabi.filter_bwd_records(fid, tx, tdy, dxs[k], tp[fid], workspace=ws[k * nb:])
+  dps = [torch.full_like(tp[fid], float('nan')) for fid in fids]
+  _cabi.finish_bwd(fids, tx, [tp[f] for f in fids], dps, workspace=ws)
+  for k, fid in enumerate(fids):
+    dp, dx = torch.empty_like(tp[fid]), torch.empty_like(tx)
+    _cabi.filter_bwd(fid, tx, tdy, dx, tp[fid], dp)
+    assert torch.equal(dp, dps[k]) and torch.equal(dx, dxs[k]), fid
+
+
 def test_accumulate_adds_to_the_existing_value(gpu_device):
   shape = (3, 64, 64, 3)
   x, dy, params, tx, tdy, tp = device_case(shape, 6, gpu_device)
