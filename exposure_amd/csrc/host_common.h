@@ -46,7 +46,7 @@ inline int env_int(const char* name, int dflt) {
 
 // a reducing kernel writes one workspace record per block: bound the records of one image
 constexpr int kMaxReduceBlocksX = 1024;
-enum GeomKind { kGeomMap = 0, kGeomReduce = 1, kGeomReadReduce = 2 };
+enum GeomKind { kGeomMap = 0, kGeomReduce = 1, kGeomReadReduce = 2, kGeomDispatch = 3 };
 
 // groups of 48 bytes per image; blocks per image chosen so the whole grid is >= ~1024
 // blocks when the problem allows and each thread walks a few groups (amortises the
@@ -65,8 +65,10 @@ inline Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
   // fewer, fatter blocks; pure maps (forward) stream best with many blocks (tools/membench.hip)
   static const int gpt_red = env_int("EXPO_BWD_GROUPS_PER_THREAD", 4);
   static const int gpt_map = env_int("EXPO_FWD_GROUPS_PER_THREAD", 1);
-  static const int gpt_read = env_int("EXPO_RED_GROUPS_PER_THREAD", 1);  // read-only reductions (stats, penalty)
-  const int gpt = kind == kGeomReduce ? gpt_red : (kind == kGeomReadReduce ? gpt_read : gpt_map);
+  static const int gpt_read = env_int("EXPO_RED_GROUPS_PER_THREAD", 4);  // read-only reductions (stats, penalty)
+  static const int gpt_disp = env_int("EXPO_DISPATCH_GROUPS_PER_THREAD", 4);  // per-image dispatch backward
+  const int gpt = kind == kGeomReduce ? gpt_red : kind == kGeomReadReduce ? gpt_read : kind == kGeomDispatch ? gpt_disp
+                                                                                                           : gpt_map;
   int bx = (g.groups + kThreads * gpt - 1) / (kThreads * gpt);
   const long want = 1024;
   if (long(bx) * n < want) bx = int((want + n - 1) / n);
