@@ -46,6 +46,9 @@
 #ifndef EXPO_BWD_MAP
 #define EXPO_BWD_MAP 1
 #endif
+#ifndef EXPO_FWD_LATE_PARAMS
+#define EXPO_FWD_LATE_PARAMS 1
+#endif
 
 
 namespace expo {
@@ -60,7 +63,7 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   // (stream_groups' prologue): the dependent scalar loads (kernel argument -> parameter -> exp2) otherwise sit
   // in front of the image loads of every wave, and a forward wave lives for exactly one chunk.
   typename F::Prm q;
-  if constexpr (!VEC) q = F::load(prm);
+  if constexpr (!VEC || !EXPO_FWD_LATE_PARAMS) q = F::load(prm);
   float pen = 0.f;
   const int stride = gridDim.x * kThreads;
   // Tone / Color on the vector path (all lanes of a wave alive): segment table instead of the
@@ -103,7 +106,7 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
         ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
         [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); },
         [&]() {
-          q = F::load(prm);
+          if constexpr (EXPO_FWD_LATE_PARAMS) q = F::load(prm);
           if constexpr (kCurveTab) curve_lut_build<kNC>(prm[(threadIdx.x & 63) % F::NP], tab);
         });
   } else {
@@ -910,14 +913,20 @@ static int penalty_t(const void* y, float* pen, int n, int h, int w, void* works
 // ======================================================================== C-ABI
 using namespace expo;
 
-// Consecutive launches of a chain walk the images in alternating directions (EXPO_CHAIN_SNAKE=0: always
-// ascending): each launch starts on the images its predecessor touched last, which are the ones still in
-// the 256 MiB Infinity Cache.  Measured on MI355X (gpurun r02p8, 8-step chain fwd+bwd fp16): no effect while
-// a launch's tensors fit the cache anyway (64 and 128 images: 0.615 / 1.206 ms either way), 2.748 -> 2.534 ms
-// (5.86 -> 6.36 TB/s of algorithmic traffic) at 256x512x512 (384 MiB per tensor).
-static bool chain_snake() {
-  static const bool on = getenv("EXPO_CHAIN_SNAKE") ? atoi(getenv("EXPO_CHAIN_SNAKE")) != 0 : true;
-  return on;
+// Consecutive launches of a chain walk the images in alternating directions when ONE tensor is larger than
+// the 256 MiB Infinity Cache: each launch then starts on the images its predecessor touched last, which are
+// the ones still cached.  Measured on MI355X, 8-step chain fwd+bwd fp16 (gpurun r02p8, r02p11):
+//   256x512x512 (384 MiB per tensor)  2.748 -> 2.534 ms  (5.86 -> 6.36 TB/s of algorithmic traffic)
+//   64 / 128 x512x512 (96 / 192 MiB)  0.615 / 1.206 ms either way
+//   64x64x64 (1.5 MiB, L2-resident)   0.0470 -> 0.0578 ms: block b runs on XCD b % 8, so with the SAME order
+//                                     a consumer block finds its producer's lines in its own XCD's L2 --
+//                                     reversing the order sends it to another XCD.  Hence the size gate.
+// EXPO_CHAIN_SNAKE=0 / 1 forces it off / on.
+static bool chain_snake(int n, int h, int w, int dtype) {
+  static const int forced = getenv("EXPO_CHAIN_SNAKE") ? atoi(getenv("EXPO_CHAIN_SNAKE")) : -1;
+  if (forced >= 0) return forced != 0;
+  const long bytes = long(n) * h * w * 3L * (dtype == EXPO_F16 ? 2L : 4L);
+  return bytes >= (256L << 20);
 }
 
 extern "C" {
@@ -1060,7 +1069,7 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
   for (int i = 0; i < steps; ++i) {
     if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
     if (!acts[i] || !acts[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
-    const int rev = chain_snake() ? (i & 1) : 0;
+    const int rev = chain_snake(n, h, w, dtype) ? (i & 1) : 0;
     const int rc = dtype == EXPO_F16
                        ? fwd_by_id<half_t>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, rev)
                        : fwd_by_id<float>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, rev);
@@ -1133,7 +1142,7 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
     if (!acts[i] || !grads[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
     float* rec = records + size_t(i) * step_floats;
     // the forward chain ended descending (or ascending) on step steps-1; the backward starts where it ended
-    const int rev = chain_snake() ? ((steps - i) & 1) : 0;
+    const int rev = chain_snake(n, h, w, dtype) ? ((steps - i) & 1) : 0;
     const int rc = dtype == EXPO_F16
                        ? bwd_by_id<half_t>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], rec, n, h, w,
                                            hsv_grad_mode, s, rev)

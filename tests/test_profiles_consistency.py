@@ -1,6 +1,7 @@
 """The committed measurement artefacts under profiles/ must be mutually consistent: traffic.json is
-what tools/make_traffic.py derives from the committed PMC CSVs, every chain kernel appears in the
-rocprofv3 kernel table, and the measured HBM traffic equals the algorithmic bytes bench.py uses."""
+what tools/make_traffic.py derives from the committed PMC CSVs (both workload keys), every chain kernel
+appears in the rocprofv3 kernel tables, the measured traffic equals the algorithmic bytes bench.py uses,
+and the bench line's dominant-kernel time agrees with rocprofv3's."""
 import csv
 import json
 import os
@@ -10,38 +11,68 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, 'profiles')
-ALGO = {'fwd': 2 * 3 * 2 * 64 * 512 * 512, 'bwd': 3 * 3 * 2 * 64 * 512 * 512}  # bytes per launch, fp16, shape C
+TAG = 'r02_final'
+PX = {'64x512x512x3:f16': 64 * 512 * 512, '256x512x512x3:f16': 256 * 512 * 512}
+FILES = ['pmc_fetch_size', 'pmc_write_size', 'pmc_fetch_size_calibration', 'pmc_write_size_calibration',
+         'pmc_fetch_size_cold', 'pmc_write_size_cold', 'pmc_fetch_size_calibration_512', 'pmc_write_size_calibration_512']
 
 
 def test_traffic_json_matches_the_committed_counters(tmp_path):
   d = tmp_path / 'final'
   d.mkdir()
-  for name in ('pmc_fetch_size', 'pmc_write_size', 'pmc_fetch_size_calibration', 'pmc_write_size_calibration'):
-    shutil.copy(os.path.join(PROF, 'r01_final_%s.csv' % name), d / (name + '.csv'))
+  for name in FILES:
+    shutil.copy(os.path.join(PROF, '%s_%s.csv' % (TAG, name)), d / (name + '.csv'))
   out = tmp_path / 'traffic.json'
-  subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'make_traffic.py'), str(d), str(out)], check=True,
-                 capture_output=True)
-  derived = json.load(open(out))['64x512x512x3:f16']
-  committed = json.load(open(os.path.join(PROF, 'traffic.json')))['64x512x512x3:f16']
-  keys = sorted(k for k in committed if not k.startswith('_'))
-  assert len(keys) == 16 and keys == sorted(k for k in derived if not k.startswith('_'))
-  for k in keys:
-    assert derived[k] == committed[k], k
-    algo = ALGO[k[:3]]
-    assert abs(committed[k] - algo) <= 0.005 * algo, (k, committed[k], algo)  # no wasted re-reads
+  tool = os.path.join(ROOT, 'tools', 'make_traffic.py')
+  subprocess.run([sys.executable, tool, str(d), str(out), '64x512x512x3:f16'], check=True, capture_output=True)
+  subprocess.run([sys.executable, tool, str(d), str(out), '256x512x512x3:f16', 'cold'], check=True, capture_output=True)
+  derived_all = json.load(open(out))
+  committed_all = json.load(open(os.path.join(PROF, 'traffic.json')))
+  for key, px in PX.items():
+    derived, committed = derived_all[key], committed_all[key]
+    keys = sorted(k for k in committed if not k.startswith('_'))
+    assert len(keys) == 16 and keys == sorted(k for k in derived if not k.startswith('_'))
+    for k in keys:
+      assert derived[k] == committed[k], (key, k)
+      algo = (12 if k.startswith('fwd') else 18) * px
+      assert abs(committed[k] - algo) <= 0.005 * algo, (key, k, committed[k], algo)  # no wasted re-reads
 
 
-def test_kernel_table_lists_every_chain_kernel():
-  rows = list(csv.DictReader(open(os.path.join(PROF, 'r01_final_kernel_stats.csv'))))
-  names = [r['Name'] for r in rows]
-  for direction in ('fwd', 'bwd'):
-    mine = [n for n in names if 'filter_%s_kernel' % direction in n]
-    assert len(mine) == 8, (direction, mine)
-  # the bench line's dominant kernel must be one of them and its HIP-event time within 10 % of rocprof's
-  bench = json.load(open(os.path.join(PROF, 'r01_final_bench_chain.json')))
-  dom = bench['roofline']['kernel']
+def test_kernel_tables_list_every_kernel():
+  for wl in ('chain', 'cold'):
+    rows = list(csv.DictReader(open(os.path.join(PROF, '%s_kernel_stats_%s.csv' % (TAG, wl)))))
+    names = [r['Name'] for r in rows]
+    for direction in ('fwd', 'bwd'):
+      mine = [n for n in names if 'filter_%s_kernel' % direction in n]
+      assert len(mine) == 8, (wl, direction, mine)
+    assert any('finish_kernel' in n for n in names), wl
+  extra = [r['Name'] for r in csv.DictReader(open(os.path.join(PROF, '%s_kernel_stats_extra.csv' % TAG)))]
+  for frag in ('dispatch_fwd_kernel', 'dispatch_bwd_kernel', 'apply_fwd_kernel', 'apply_bwd_kernel', 'stats_kernel',
+               'penalty_kernel'):
+    assert any(frag in n for n in extra), frag
+  infer = [r['Name'] for r in csv.DictReader(open(os.path.join(PROF, '%s_kernel_stats_infer_B.csv' % TAG)))]
+  assert any('chain_fused_fwd_kernel' in n for n in infer)
+  table = open(os.path.join(PROF, '%s_kernel_table.md' % TAG)).read()
+  for frag in ('filter_bwd<C>', 'chain_fused_fwd', 'dispatch_bwd (curve launch', 'stats (critic statistics)'):
+    assert frag in table, frag
+
+
+def test_bench_line_agrees_with_rocprof():
+  rows = list(csv.DictReader(open(os.path.join(PROF, '%s_kernel_stats_chain.csv' % TAG))))
+  bench = json.load(open(os.path.join(PROF, '%s_bench_chain.json' % TAG)))
+  roof = bench['roofline']
+  dom = roof['kernel']
   tag = {'E': '9ExposureF', 'G': '6GammaF', 'W': '13WhiteBalanceF', 'S+': '8SatPlusF', 'T': '6CurveFILi1',
          'Ct': '9ContrastF', 'BW': '4WnbF', 'C': '6CurveFILi3'}[dom[4:]]
   row = next(r for r in rows if 'filter_%s_kernelINS_%sE' % (dom[:3], tag) in r['Name'])
   rocprof_ms = float(row['AverageNs']) * 1e-6
-  assert abs(bench['roofline']['avg_launch_ms'] - rocprof_ms) <= 0.10 * rocprof_ms
+  assert abs(roof['avg_launch_ms'] - rocprof_ms) <= 0.10 * rocprof_ms
+  # sum of rocprofv3 averages (16 kernels + the finish launch) == ms_per_step
+  total = sum(float(r['AverageNs']) for r in rows if 'filter_fwd_kernel' in r['Name'] or 'filter_bwd_kernel' in r['Name'])
+  total += next(float(r['AverageNs']) for r in rows if 'finish_kernel' in r['Name'])
+  assert abs(total * 1e-6 - bench['ms_per_step']) <= 0.03 * bench['ms_per_step']
+  assert roof['regime'] == 'mall_assisted' and roof['hbm_cold']['tensor_MiB'] == 384.0
+  # (the bench line is produced BEFORE the PMC passes of the same run: it carries the previous run's figure)
+  tj = json.load(open(os.path.join(PROF, 'traffic.json')))['64x512x512x3:f16'][dom]
+  assert abs(roof['traffic'] - tj) <= 1e-3 * tj
+  assert bench['cpu_baseline']['kind'] == 'port' and bench['cpu_baseline']['seconds'] < 60

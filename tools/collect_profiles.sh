@@ -13,4 +13,5 @@ for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt; do
 done
 python tools/make_traffic.py $SRC profiles/traffic.json 64x512x512x3:f16 > /dev/null
 python tools/make_traffic.py $SRC profiles/traffic.json 256x512x512x3:f16 cold > /dev/null
+python tools/kernel_table.py $SRC > profiles/${TAG}_kernel_table.md
 python -m pytest tests/test_profiles_consistency.py -q
