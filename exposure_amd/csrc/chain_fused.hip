@@ -7,6 +7,9 @@
 // the packing buys nothing and the moves cost: 1 203 VALU with 216 v_mov -> 24.6 us, against 1 262
 // scalar VALU with 102 v_mov -> 22.7 us at 16x512x512x3 fp16 (gpurun r02p5).  The streaming kernels of
 // exposure_hip.hip are not VALU-bound and keep the default (-0.8 % for the chain with the flag).
+// -fno-honor-nans drops the canonicalising v_max_f32 x, x, x in front of every min / max / med3 whose
+// operand comes from memory or LDS (1 218 -> 1 171 VALU): a NaN pixel is not a defined input of the
+// inference path (the result for such a pixel is unspecified; every other pixel is unaffected).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
