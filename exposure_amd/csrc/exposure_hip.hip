@@ -143,9 +143,10 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   const typename F::Prm q = F::load(prm);
   // per-image curve LUT (Tone / Color backward) staged in LDS once per block
   __shared__ __attribute__((aligned(16))) float lut[F::kLutFloats > 0 ? F::kLutFloats : 4];
-  // fp16-exact fast path of the curve filters (bit-pattern LUT + packed accumulators); with the
-  // fused penalty dy is no longer an fp16 value, and the masked path scales it -> generic path there
-  constexpr bool kF16X = std::is_same<T, half_t>::value && !PEN;
+  // fp16-exact fast path of the curve filters (bit-pattern LUT + packed accumulators).  With the fused penalty
+  // dy stays an fp16 value and the penalty's addend travels beside it (CurveF::bwd_group<.., HAS_PEN>); the
+  // masked path scales dy -> generic path there.
+  constexpr bool kF16X = std::is_same<T, half_t>::value;
   // staged AFTER the first chunk's loads are in flight on the vector path (stream_groups' prologue)
   auto stage_lut = [&]() {
     if constexpr (F::kLutFloats > 0) {
@@ -159,6 +160,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   for (int j = 0; j < F::NACC; ++j) acc[j] = 0.f;
   const int stride = gridDim.x * kThreads;
   auto compute = [&](float* v, float* d, int g) {
+    float pen[PEN ? PPL * 3 : 1];
     if constexpr (PEN) {
       // fused over-exposure penalty: dy += 2 max(y-1,0) * dpen / (H W 3)
 #pragma unroll
@@ -166,13 +168,14 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
         float y[3];
         F::fwd(q, v + 3 * k, y);
 #pragma unroll
-        for (int c = 0; c < 3; ++c)  // padding pixels: y = f(0) <= 1 -> no contribution
-          d[3 * k + c] = fmaf(fmaxf(y[c] - 1.0f, 0.0f), pen_scale, d[3 * k + c]);
+        for (int c = 0; c < 3; ++c) {  // padding pixels: y = f(0) <= 1 -> no contribution
+          pen[3 * k + c] = fmaxf(y[c] - 1.0f, 0.0f) * pen_scale;
+          if constexpr (!F::kHasGroupBwd) d[3 * k + c] += pen[3 * k + c];
+        }
       }
     }
     if constexpr (F::kHasGroupBwd) {
-      // with the fused penalty dy is no longer an fp16 value -> use the generic fp32 accumulation
-      F::template bwd_group<PPL, kF16X>(q, lut, v, d, acc);
+      F::template bwd_group<PPL, kF16X, PEN>(q, lut, v, d, acc, pen);
     } else {
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
@@ -854,6 +857,8 @@ static int dispatch_bwd_t(const int32_t* ids, const void* x, const void* dy, voi
     else EXPO_L2(VEC, HAS_DX, PEN, 0, kSetLight, IO);                                                     \
     EXPO_L2(VEC, HAS_DX, PEN, 0, kSetCurves, IO);                                                         \
   } while (0)
+  // (ONE launch for every filter measured the same as this pair -- 66.5-68.5 vs 68.7-68.9 us incl. the finish,
+  // gpurun r02p16 -- and would double the instantiations.)
   // the streaming policy is instantiated for the full backward (dx wanted) only
   const int key = (g.stream && dx ? 8 : 0) | (g.vec ? 4 : 0) | (dx ? 2 : 0) | (dpenalty ? 1 : 0);
   switch (key) {

@@ -336,8 +336,13 @@ struct CurveF {
   // as one v_pk_min_f16 + one v_dot2c_f32_f16 (fp16 x fp16 products are exact in fp32): 17 VALU
   // per element pair instead of 32.  Everything else (LUT, dx, B) stays fp32 per element.
   static constexpr bool kHasGroupBwd = true;
-  template <int PPL, bool F16X>
-  __device__ static void bwd_group(const Prm& q, const float* lut, const float* x, float* d, float acc[NACC]) {
+  // HAS_PEN: `pen` holds a per-element fp32 addend to the upstream gradient (the fused over-exposure penalty of
+  // the dispatch backward, 2 max(y-1,0) dpen / (H W 3)).  dy itself stays an exact fp16 value, so the packed
+  // accumulation keeps running on it; the addend is zero except on over-exposed pixels, where its share of the
+  // eight Q_i is added in fp32 under a (rarely taken) per-lane branch.
+  template <int PPL, bool F16X, bool HAS_PEN = false>
+  __device__ static void bwd_group(const Prm& q, const float* lut, const float* x, float* d, float acc[NACC],
+                                   const float* pen = nullptr) {
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     static_assert(PPL % 2 == 0, "pixels are processed in pairs");
     // Element pairs that share a curve: Tone (one curve for all channels) pairs the two halves of
@@ -351,7 +356,16 @@ struct CurveF {
       const int cc = (NC == 1) ? 0 : (m % 3);
       float* a = acc + cc * L;
       const float xA = x[iA], xB = x[iB];
-      const float gA = d[iA], gB = d[iB];
+      float gA = d[iA], gB = d[iB];
+      float pA = 0.f, pB = 0.f;
+      if constexpr (HAS_PEN) {
+        pA = pen[iA];
+        pB = pen[iB];
+        if constexpr (!F16X) {  // fp32 storage: one fp32 gradient, generic path below
+          gA += pA;
+          gB += pB;
+        }
+      }
       if constexpr (F16X) {
         const half2_t x2 = {_Float16(xA), _Float16(xB)};  // exact: values came from fp16 storage
         const half2_t g2 = {_Float16(gA), _Float16(gB)};
@@ -373,8 +387,20 @@ struct CurveF {
         a[L - 1] = fmaf(gB, xcB, a[L - 1]);
       }
       if constexpr (F16X) {
-        d[iA] = gA * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xA)));
-        d[iB] = gB * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xB)));
+        if constexpr (HAS_PEN) {
+          if (pA != 0.f) {
+            const float xc = clamp01x(xA, 0.0f, 1.0f);
+#pragma unroll
+            for (int i = 1; i <= L; ++i) a[i - 1] = fmaf(pA, fminf(xc, float(i) / L), a[i - 1]);
+          }
+          if (pB != 0.f) {
+            const float xc = clamp01x(xB, 0.0f, 1.0f);
+#pragma unroll
+            for (int i = 1; i <= L; ++i) a[i - 1] = fmaf(pB, fminf(xc, float(i) / L), a[i - 1]);
+          }
+        }
+        d[iA] = (gA + pA) * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xA)));
+        d[iB] = (gB + pB) * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xB)));
       } else {
         d[iA] = gA * lut_slope(lut, cc, xA, clamp01x(xA, 0.0f, 1.0f));
         d[iB] = gB * lut_slope(lut, cc, xB, clamp01x(xB, 0.0f, 1.0f));
