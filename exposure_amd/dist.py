@@ -102,6 +102,7 @@ class GradBucket:
     self.numel = sum(p.numel() for p in self.params)
     self.flat = None
     self.on_ready = on_ready
+    self.launched = False  # set by the owner once this step's all-reduce has been issued
     self._arrived = 0
     self._hooks = []
 
@@ -139,6 +140,7 @@ class GradBucket:
     else:
       self.flat.zero_()
     self._arrived = 0
+    self.launched = False
 
   def _arrive(self, _param):
     self._arrived += 1

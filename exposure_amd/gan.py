@@ -123,7 +123,7 @@ class GAN(nn.Module):
   def _bucket_ready(self, bucket):
     """Backward hook (exposure_amd.dist.GradBucket): the bucket's last gradient has just been accumulated
     -- start its all-reduce now, on RCCL's stream, while autograd keeps running the rest of the backward."""
-    if self._collectives() and not getattr(bucket, 'launched', False):
+    if self._collectives() and not bucket.launched:
       bucket.launched = True
       self._pending.append(bucket.all_reduce_mean(self.process_group, async_op=True, force=self.force_collectives))
 
@@ -134,7 +134,6 @@ class GAN(nn.Module):
     for name in names:
       b = self.buckets[name]
       b.zero()
-      b.launched = False
       params += b.params
     loss.backward(inputs=params, retain_graph=retain_graph)
     for name in names:  # a bucket whose hook could not fire (a parameter outside the graph): reduce it now
