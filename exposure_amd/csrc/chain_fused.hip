@@ -1,12 +1,14 @@
 // chain_fused.hip -- the fused multi-step forward of the high-resolution inference path
 // (expo_chain_fused_fwd; /root/reference/net.py:796-821, BASELINE config 5), in its own translation unit
-// because it is compiled with -fno-slp-vectorize: this kernel is VALU-bound (8 filter bodies back to
+// because it is compiled with -fno-slp-vectorize: this kernel is compute-heavy (8 filter bodies back to
 // back on values that stay in registers), and clang's SLP vectoriser turns pairs of independent fp32
-// operations into v_pk_mul_f32 / v_pk_fma_f32 plus the v_mov's that assemble their operand pairs.  On
-// gfx950 a packed fp32 instruction issues at HALF the rate of a scalar one (same flops per cycle), so
-// the packing buys nothing and the moves cost: 1 203 VALU with 216 v_mov -> 24.6 us, against 1 262
-// scalar VALU with 102 v_mov -> 22.7 us at 16x512x512x3 fp16 (gpurun r02p5).  The streaming kernels of
-// exposure_hip.hip are not VALU-bound and keep the default (-0.8 % for the chain with the flag).
+// operations into v_pk_mul_f32 / v_pk_fma_f32 plus the v_mov's that assemble their operand pairs.  The
+// packed forms issue at the scalar rate on gfx950 (tools/valubench), but the kernel is bound by its
+// dependent chains, not by issue slots (SQ counters, profiles/r02_experiments.md r02p18/19), so the
+// packing buys nothing and the moves cost: 1 203 VALU with 216 v_mov -> 24.6 us, against 1 262
+// scalar VALU with 102 v_mov -> 22.7 us at 16x512x512x3 fp16 (gpurun r02p5); a hand-paired build with
+// 963 VALU measured the same as this one.  The streaming kernels of exposure_hip.hip keep the default
+// (-0.8 % for the chain with the flag).
 // -fno-honor-nans drops the canonicalising v_max_f32 x, x, x in front of every min / max / med3 whose
 // operand comes from memory or LDS (1 218 -> 1 171 VALU): a NaN pixel is not a defined input of the
 // inference path (the result for such a pixel is unspecified; every other pixel is unaffected).
