@@ -189,6 +189,63 @@ def test_dispatch_rows_are_fully_written_without_a_fill(gpu_device):
     assert_param_grad_close(dp_h[i:i + 1, :npar], rdp, scale, 'dispatch row %d (filter %d)' % (i, fid))
 
 
+def test_dispatch_backward_on_streaming_sized_tensors_and_in_a_graph(gpu_device):
+  """Tensors >= 8 MiB take the nt / sc1 instantiations of the light / curve launch pair.  Every image must
+  equal the per-filter backward of that image bit for bit (dx) / to summation order (dparams), back-to-back
+  calls must not see each other's records, and a hipGraph capture of the call replays to the same bits."""
+  dev = gpu_device
+  n = 10
+  shape = (n, 512, 512, 3)
+  rng = np.random.default_rng(5)
+  ids = np.array([7, 0, 4, 3, -1, 7, 5, 4, 1, 6], dtype=np.int32)
+  p24 = np.zeros((n, 24), dtype=np.float32)
+  for i, fid in enumerate(ids):
+    if fid >= 0:
+      p24[i, :fnp.NUM_PARAMS[fid]] = synthetic.make_params(rng, int(fid), 1)[0]
+  g = torch.Generator(device=dev).manual_seed(3)
+  tx = (torch.rand(shape, device=dev, generator=g)**2.2 * 1.1).half()
+  tdy = torch.randn(shape, device=dev, generator=g).half()
+  tids, tp24 = torch.from_numpy(ids).to(dev), torch.from_numpy(p24).to(dev)
+  assert tx.numel() * 2 >= 8 << 20
+  dx = torch.empty_like(tx)
+  dp = torch.full((n, 24), float('nan'), device=dev)
+  for _ in range(3):  # back to back
+    dx.fill_(float('nan'))
+    _cabi.dispatch_bwd(tids, tx, tdy, dx, tp24, dp, None)
+  torch.cuda.synchronize()
+  for i, fid in enumerate(ids):
+    if fid < 0:
+      assert float(dx[i].abs().max()) == 0.0 and float(dp[i].abs().max()) == 0.0
+      continue
+    npar = fnp.NUM_PARAMS[fid]
+    rdx = torch.empty_like(tx[i:i + 1])
+    rdp = torch.empty((1, npar), device=dev)
+    _cabi.filter_bwd(int(fid), tx[i:i + 1], tdy[i:i + 1], rdx, tp24[i:i + 1, :npar].contiguous(), rdp)
+    assert torch.equal(dx[i:i + 1], rdx), 'dx of image %d (filter %d)' % (i, fid)
+    scale = float(tdy[i].float().abs().sum()) * 4
+    assert_param_grad_close(dp[i:i + 1, :npar].cpu().numpy(), rdp.cpu().numpy().astype(np.float64), scale,
+                            'dparams of image %d (filter %d)' % (i, fid))
+    assert npar == 24 or float(dp[i, npar:].abs().max()) == 0.0
+  # the same call replayed from a hipGraph
+  dx_g = torch.empty_like(tx)
+  dp_g = torch.full((n, 24), float('nan'), device=dev)
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    _cabi.dispatch_bwd(tids, tx, tdy, dx_g, tp24, dp_g, None)
+  torch.cuda.current_stream().wait_stream(side)
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    _cabi.dispatch_bwd(tids, tx, tdy, dx_g, tp24, dp_g, None)
+  for _ in range(3):
+    dx_g.fill_(float('nan'))
+    dp_g.fill_(float('nan'))
+    graph.replay()
+  torch.cuda.synchronize()
+  assert torch.equal(dx_g, dx) and torch.equal(dp_g, dp)
+
+
 @pytest.mark.parametrize('shape', [(3, 8, 8, 3), (1, 2048, 2048, 3), (70, 40, 40, 3)])
 def test_stats_and_penalty_single_launch(shape, gpu_device):
   """critic statistics are finished by the image's last block (no separate finish kernel, no fill)."""
