@@ -155,18 +155,37 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
     }
   };
   if constexpr (!VEC) stage_lut();
+  // fused penalty of the curve filters on the vector path: the forward is re-evaluated through the per-wave
+  // segment table of the forward kernels (5 VALU + one LDS read per element instead of 16 VALU), and not at all
+  // for an image whose curve cannot exceed 1 (curve_can_exceed_one -- every image under the reference's ranges)
+  constexpr bool kPenTab = PEN && VEC && F::kLutFloats > 0;
+  constexpr int kNC = kPenTab ? F::NP / kCurveSteps : 1;
+  __shared__ float2_lut ptab[kPenTab ? kWaves : 1][32];
+  float2_lut* const tab = ptab[kPenTab ? (threadIdx.x >> 6) : 0];
+  bool pen_live = PEN;
+  if constexpr (kPenTab) {
+    pen_live = curve_can_exceed_one<kNC>(prm);
+    if (pen_live) curve_lut_build<kNC>(prm[(threadIdx.x & 63) % F::NP], tab);
+  }
   float acc[F::NACC];
 #pragma unroll
   for (int j = 0; j < F::NACC; ++j) acc[j] = 0.f;
   const int stride = gridDim.x * kThreads;
   auto compute = [&](float* v, float* d, int g) {
+    if constexpr (kPenTab) {
+      if (!pen_live) {  // block-uniform
+        F::template bwd_group<PPL, kF16X, false>(q, lut, v, d, acc, nullptr);
+        return;
+      }
+    }
     float pen[PEN ? PPL * 3 : 1];
     if constexpr (PEN) {
       // fused over-exposure penalty: dy += 2 max(y-1,0) * dpen / (H W 3)
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         float y[3];
-        F::fwd(q, v + 3 * k, y);
+        if constexpr (kPenTab) curve_lut_pixel<kNC>(tab, v + 3 * k, y);
+        else F::fwd(q, v + 3 * k, y);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {  // padding pixels: y = f(0) <= 1 -> no contribution
           pen[3 * k + c] = fmaxf(y[c] - 1.0f, 0.0f) * pen_scale;
@@ -237,12 +256,19 @@ __global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict
   const typename F::Prm q = F::load(params + n * F::NP);
   const MaskPrm mk = MaskPrm::load(mask_params + n * 6, sharp, min_strength, h, w);
   const int stride = gridDim.x * kThreads;
+  // curve filters on the vector path: per-wave segment table, as in filter_fwd_kernel
+  constexpr bool kCurveTab = VEC && F::kLutFloats > 0;
+  constexpr int kNC = kCurveTab ? F::NP / kCurveSteps : 1;
+  __shared__ float2_lut ftab[kCurveTab ? kWaves : 1][32];
+  float2_lut* const tab = ftab[kCurveTab ? (threadIdx.x >> 6) : 0];
+  if constexpr (kCurveTab) curve_lut_build<kNC>(params[n * F::NP + (threadIdx.x & 63) % F::NP], tab);
   auto compute = [&](float* v, int g) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       float p[3];
-      F::fwd(q, v + 3 * k, p);
+      if constexpr (kCurveTab) curve_lut_pixel<kNC>(tab, v + 3 * k, p);
+      else F::fwd(q, v + 3 * k, p);
       const MaskPrm::Eval e = mk.eval(pixel_index<T, VEC>(g, k, lane), v + 3 * k);
 #pragma unroll
       for (int c = 0; c < 3; ++c) v[3 * k + c] = fmaf(e.m, p[c] - v[3 * k + c], v[3 * k + c]);
@@ -282,6 +308,12 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
     F::stage(prm, lut);
     __syncthreads();
   }
+  // curve filters on the vector path: the forward re-evaluation goes through the per-wave segment table
+  constexpr bool kCurveTab = VEC && F::kLutFloats > 0;
+  constexpr int kNC = kCurveTab ? F::NP / kCurveSteps : 1;
+  __shared__ float2_lut ftab[kCurveTab ? kWaves : 1][32];
+  float2_lut* const tab = ftab[kCurveTab ? (threadIdx.x >> 6) : 0];
+  if constexpr (kCurveTab) curve_lut_build<kNC>(prm[(threadIdx.x & 63) % F::NP], tab);
   // filter accumulators and the 6 mask-parameter accumulators share ONE per-block record
   float acc[F::NACC + 6];
   float* const macc = acc + F::NACC;
@@ -295,7 +327,8 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
       const float* xv = v + 3 * k;
       float* dv = d + 3 * k;
       float p[3], gp[3], dxf[3];
-      F::fwd(q, xv, p);
+      if constexpr (kCurveTab) curve_lut_pixel<kNC>(tab, xv, p);
+      else F::fwd(q, xv, p);
       const MaskPrm::Eval e = mk.eval(pixel_index<T, VEC>(g, k, lane), xv);
       const float dm = dv[0] * (p[0] - xv[0]) + dv[1] * (p[1] - xv[1]) + dv[2] * (p[2] - xv[2]);
       const float gsig = dm * mk.S * e.sg * (1.0f - e.sg);  // dL/d(inp)

@@ -132,6 +132,40 @@ __device__ __forceinline__ void curve_lut_apply(float* v, const float2_lut* tab)
     }
   }
 }
+// One pixel through the table (the backward kernels that re-evaluate the forward: fused penalty, masked apply).
+template <int NC>
+__device__ __forceinline__ void curve_lut_pixel(const float2_lut* tab, const float x[3], float y[3]) {
+  constexpr int L = kCurveSteps;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float xc = clamp01x(x[c], 0.0f, 1.0f);
+    const float2_lut e = tab[(NC == 1 ? 0 : c * (L + 1)) + int(xc * float(L))];
+    y[c] = fmaf(xc, e.x, e.y);
+  }
+}
+// Block-uniform: can the curve exceed 1 + 1e-6 anywhere on [0, 1]?  It is piecewise linear, so its maximum sits
+// on a knot: T(i/L) = (sum_{m<i} k_m) / S.  With the reference's parameter ranges (k > 0: tone 0.5..2, colour
+// 0.9..1.1, config_example.py:40-42) it never can, and the fused over-exposure penalty max(y - 1, 0) of such an
+// image is identically zero (below 1e-6 at most) -- the backward then skips re-evaluating the forward.
+template <int NC>
+__device__ __forceinline__ bool curve_can_exceed_one(const float* __restrict__ p) {
+  constexpr int L = kCurveSteps;
+  bool r = false;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float S = 0.f;
+#pragma unroll
+    for (int i = 0; i < L; ++i) S += p[c * L + i];
+    const float inv = 1.0f / (S + 1e-30f);
+    float pre = 0.f;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      pre += p[c * L + i];
+      r = r || !(pre * inv <= 1.0f + 1e-6f);  // !(<=) also catches NaN parameters
+    }
+  }
+  return r;
+}
 template <int NC, int NPIX>
 __device__ __forceinline__ void curve_fwd_lut(float* v, float klane, float2_lut* tab) {
   curve_lut_build<NC>(klane, tab);
