@@ -79,6 +79,45 @@ def test_dispatch_matches_oracle(dtype, shape, with_pen, gpu_device):
   assert float(dp[torch.from_numpy(sel).to(dev)].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [(6, 64, 64, 3), (5, 9, 7, 3)])
+def test_dispatch_penalty_of_curves_that_exceed_one(dtype, shape, gpu_device):
+  """Tone / Color curves outside the reference's parameter ranges (falling tail -> T(x) > 1 in the middle):
+  the fused penalty's gradient is live for those images and the backward must re-evaluate the forward
+  (vector path: segment table; element-wise path: telescoped chain); a curve that stays below 1 beside
+  them takes the skip."""
+  dev = gpu_device
+  x, dy, ids, p24, dpen = dispatch_case(31, shape, NP_DT[dtype])
+  rng = np.random.default_rng(2)
+  hump = np.array([2.0, 2.0, 2.0, 2.0, -0.5, -1.0, -1.0, -0.5], dtype=np.float32)  # T(1/2) = 8/3
+  ids[:] = [4, 7, 7, 4, 7, 4][:shape[0]]
+  p24[:] = 0
+  p24[0, :8] = hump
+  p24[1, :24] = np.concatenate([hump, synthetic.make_params(rng, 4, 1)[0], hump[::-1].copy() + 1.2])
+  p24[2, :24] = synthetic.make_params(rng, 7, 1)[0]  # reference range: cannot exceed 1
+  p24[3, :8] = synthetic.make_params(rng, 4, 1)[0]
+  p24[4, :24] = np.tile(hump, 3) * np.float32(0.7)
+  if shape[0] > 5:
+    p24[5, :8] = hump * np.float32(3.0)
+  tx, tdy = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+  tid, tp = torch.from_numpy(ids).to(dev), torch.from_numpy(p24).to(dev)
+  y = torch.empty_like(tx)
+  pen = torch.empty((shape[0],), device=dev)
+  _cabi.dispatch_fwd(tid, tx, y, tp, pen)
+  dx = torch.empty_like(tx)
+  dp = torch.empty_like(tp)
+  _cabi.dispatch_bwd(tid, tx, tdy, dx, tp, dp, torch.from_numpy(dpen).to(dev))
+  ry, rpen, rdx, rdp = dispatch_oracle(x, dy, ids, p24, dpen)
+  assert rpen[0] > 1e-3 and rpen[1] > 1e-3 and rpen[4] > 1e-3, 'the case must exercise the live penalty'
+  assert_image_close(y.float().cpu().numpy(), ry, NP_DT[dtype], 'dispatch y')
+  assert_image_close(dx.float().cpu().numpy(), rdx, NP_DT[dtype], 'dispatch dx')
+  np.testing.assert_allclose(pen.cpu().numpy(), rpen, rtol=2e-4, atol=1e-7)
+  g_eff = np.abs(dy.astype(np.float64)) + 2.0 * np.maximum(ry - 1, 0) * np.abs(dpen)[:, None, None, None] / (
+      shape[1] * shape[2] * 3)
+  scale = g_eff.reshape(shape[0], -1).sum(axis=1, keepdims=True) * 4 + 50.0
+  assert_param_grad_close(dp.cpu().numpy(), rdp, np.broadcast_to(scale, rdp.shape), 'dispatch dparams')
+
+
 def test_dispatch_autograd_matches_per_filter(gpu_device):
   dev = gpu_device
   x, dy, ids, p24, _ = dispatch_case(23, (9, 32, 32, 3), np.float32)
