@@ -173,10 +173,11 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   const int stride = gridDim.x * kThreads;
   auto compute = [&](float* v, float* d, int g) {
     if constexpr (kPenTab) {
-      if (!pen_live) {  // block-uniform
-        F::template bwd_group<PPL, kF16X, false>(q, lut, v, d, acc, nullptr);
-        return;
-      }
+      // plain group backward on dy, then the penalty's share as a fix-up (block-uniform: only for an image whose
+      // curve can exceed 1; element-wise: only where y > 1)
+      F::template bwd_group<PPL, kF16X, false>(q, lut, v, d, acc, nullptr);
+      if (pen_live) F::template bwd_pen_fixup<PPL, kF16X>(lut, tab, v, d, acc, pen_scale);
+      return;
     }
     float pen[PEN ? PPL * 3 : 1];
     if constexpr (PEN) {
@@ -184,8 +185,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         float y[3];
-        if constexpr (kPenTab) curve_lut_pixel<kNC>(tab, v + 3 * k, y);
-        else F::fwd(q, v + 3 * k, y);
+        F::fwd(q, v + 3 * k, y);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {  // padding pixels: y = f(0) <= 1 -> no contribution
           pen[3 * k + c] = fmaxf(y[c] - 1.0f, 0.0f) * pen_scale;

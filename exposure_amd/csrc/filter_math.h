@@ -407,6 +407,30 @@ struct CurveF {
       }
     }
   }
+  // Fused over-exposure penalty as a FIX-UP after the plain group backward (everything is linear in the upstream
+  // gradient): y through the per-wave segment table `tab` (kernel_common.h: curve_lut_build), addend
+  // pe = max(y - 1, 0) * pen_scale; where it is non-zero (rare), dx += pe * slope and Q_i += pe * min(x^, i/L) in
+  // fp32.  Keeping the addend out of the main pass keeps its registers out of the kernel's budget.
+  template <int PPL, bool F16X>
+  __device__ static void bwd_pen_fixup(const float* lut, const float2_lut* tab, const float* x, float* d,
+                                       float acc[NACC], float pen_scale) {
+#pragma unroll
+    for (int e = 0; e < PPL * 3; ++e) {
+      const int cc = (NC == 1) ? 0 : (e % 3);
+      const float xc = clamp01x(x[e], 0.0f, 1.0f);
+      const float2_lut seg = tab[cc * (L + 1) + int(xc * float(L))];
+      const float pe = fmaxf(fmaf(xc, seg.x, seg.y) - 1.0f, 0.0f) * pen_scale;
+      if (pe != 0.f) {
+        float sl;
+        if constexpr (F16X) sl = slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(x[e])));
+        else sl = lut_slope(lut, cc, x[e], xc);
+        d[e] = fmaf(pe, sl, d[e]);
+        float* a = acc + cc * L;
+#pragma unroll
+        for (int i = 1; i <= L; ++i) a[i - 1] = fmaf(pe, fminf(xc, float(i) / L), a[i - 1]);
+      }
+    }
+  }
   // a[] per curve: Q_1..Q_L.  B = (L/S) sum_m (k_{m-1} - k_m) Q_m;  dk_i = (L/S)(Q_{i+1} - Q_i) - B/S
   __device__ static float finish_one(const float* __restrict__ p, const float* a, int j) {
     const int c = j / L, i = j % L;
