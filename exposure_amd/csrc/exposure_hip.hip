@@ -33,22 +33,12 @@
 #include "kernel_common.h"
 #include "host_common.h"
 
-// forward launches give every wave exactly one chunk (EXPO_FWD_GROUPS_PER_THREAD = 1), so a
-// prefetch stage would only cost registers there
-#ifndef EXPO_FWD_PREFETCH
-#define EXPO_FWD_PREFETCH 0
-#endif
-#ifndef EXPO_CURVE_PREFETCH
-#define EXPO_CURVE_PREFETCH 1
-#endif
-// chunk -> wave mapping of the backward kernels: 1 = a block's k-th chunk group is blockIdx.x + k * gridDim.x
-// (block-strided), 2 = every wave walks adjacent 3 KiB chunks (block-contiguous; tools/membench rpol4 map2)
-#ifndef EXPO_BWD_MAP
-#define EXPO_BWD_MAP 1
-#endif
-#ifndef EXPO_FWD_LATE_PARAMS
-#define EXPO_FWD_LATE_PARAMS 1
-#endif
+// Compile-time structure of the streaming kernels (each alternative was measured and rejected, see
+// profiles/r02_experiments.md): forward waves own exactly one chunk and do not prefetch; backward waves walk
+// block-strided chunks with a one-deep software prefetch; the forward's per-image constants are fetched after
+// the first chunk's loads have been issued.
+constexpr bool kFwdPrefetch = false;
+constexpr bool kBwdPrefetch = true;
 
 
 namespace expo {
@@ -63,7 +53,7 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   // (stream_groups' prologue): the dependent scalar loads (kernel argument -> parameter -> exp2) otherwise sit
   // in front of the image loads of every wave, and a forward wave lives for exactly one chunk.
   typename F::Prm q;
-  if constexpr (!VEC || !EXPO_FWD_LATE_PARAMS) q = F::load(prm);
+  if constexpr (!VEC) q = F::load(prm);
   float pen = 0.f;
   const int stride = gridDim.x * kThreads;
   // Tone / Color on the vector path (all lanes of a wave alive): segment table instead of the
@@ -102,11 +92,11 @@ __device__ __forceinline__ void fwd_body(const T* __restrict__ xi, T* __restrict
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, EXPO_FWD_PREFETCH != 0, IO>(
+    stream_groups<T, 1, true, kFwdPrefetch, IO>(
         ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
         [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); },
         [&]() {
-          if constexpr (EXPO_FWD_LATE_PARAMS) q = F::load(prm);
+          q = F::load(prm);
           if constexpr (kCurveTab) curve_lut_build<kNC>(prm[(threadIdx.x & 63) % F::NP], tab);
         });
   } else {
@@ -170,6 +160,17 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   float acc[F::NACC];
 #pragma unroll
   for (int j = 0; j < F::NACC; ++j) acc[j] = 0.f;
+  // element-wise filters: the pixels of a group feed EXPO_ACC_PARTS independent partial sums, so a group's 24
+  // accumulator updates are not one dependent chain (Exposure / Gamma / S+ / Contrast / WNB keep ONE accumulator)
+#ifndef EXPO_ACC_PARTS
+#define EXPO_ACC_PARTS 4
+#endif
+  constexpr int kParts = F::kHasGroupBwd ? 1 : (EXPO_ACC_PARTS < PPL ? EXPO_ACC_PARTS : PPL);
+  float part[kParts > 1 ? kParts - 1 : 1][F::NACC];
+#pragma unroll
+  for (int p = 0; p < (kParts > 1 ? kParts - 1 : 1); ++p)
+#pragma unroll
+    for (int j = 0; j < F::NACC; ++j) part[p][j] = 0.f;
   const int stride = gridDim.x * kThreads;
   auto compute = [&](float* v, float* d, int g) {
     if constexpr (kPenTab) {
@@ -199,7 +200,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         float dx[3];
-        F::bwd(q, lut, v + 3 * k, d + 3 * k, dx, acc, MODE);
+        F::bwd(q, lut, v + 3 * k, d + 3 * k, dx, (k % kParts == 0) ? acc : part[(k % kParts + kParts - 1) % kParts], MODE);
 #pragma unroll
         for (int c = 0; c < 3; ++c) d[3 * k + c] = dx[c];
       }
@@ -207,16 +208,9 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   };
   if constexpr (VEC) {
     const T* const ins[2] = {xi, dyi};
-    constexpr bool kPF = (F::kLutFloats > 0 ? EXPO_CURVE_PREFETCH : EXPO_PREFETCH) != 0;
-#if EXPO_BWD_MAP == 2
-    const int iters = (groups + stride - 1) / stride;  // chunks per wave
-    stream_groups<T, 2, HAS_DX, kPF, IO>(ins, dxi, hw, (blockIdx.x * kWaves + (threadIdx.x >> 6)) * 64 * iters, 64,
-                                         [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); }, stage_lut,
-                                         iters);
-#else
-    stream_groups<T, 2, HAS_DX, kPF, IO>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                         [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); }, stage_lut);
-#endif
+    stream_groups<T, 2, HAS_DX, kBwdPrefetch, IO>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                                  [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); },
+                                                  stage_lut);
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3], d[PPL * 3];
@@ -225,6 +219,12 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
       compute(v, d, g);
       if constexpr (HAS_DX) store_slow<T>(dxi, g, hw, d);
     }
+  }
+  if constexpr (kParts > 1) {
+#pragma unroll
+    for (int p = 0; p < kParts - 1; ++p)
+#pragma unroll
+      for (int j = 0; j < F::NACC; ++j) acc[j] += part[p][j];
   }
   block_reduce_record<F::NACC>(acc, rec);  // finish_kernel applies F::finish_one to the image totals
 }

@@ -39,9 +39,6 @@ template <> struct PixTraits<float> { static constexpr int PPL = 4; };
 #ifndef EXPO_FP16_OVFL
 #define EXPO_FP16_OVFL 1
 #endif
-#ifndef EXPO_PREFETCH
-#define EXPO_PREFETCH 1
-#endif
 
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 
@@ -164,11 +161,9 @@ template <> __device__ __forceinline__ RawGroup pack<float>(const float* in) {
 // them: block-wide set-up that must not delay the first loads (the curve backward stages its LDS
 // slope table there, including the __syncthreads -- every wave calls it, also one without work).
 struct NoPrologue { __device__ void operator()() const {} };
-// `count` bounds the number of chunks a wave walks (block-contiguous mapping); the default walks to
-// the end of the image with the given stride.
 template <typename T, int NIN, bool HAS_OUT, bool PF, class IO, class Fn, class Pre = NoPrologue>
 __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out, int hw, int first_gw,
-                                              int stride, Fn&& fn, Pre&& pre = Pre(), int count = 0x7fffffff) {
+                                              int stride, Fn&& fn, Pre&& pre = Pre()) {
   constexpr int PPL = PixTraits<T>::PPL;
   const int lane = threadIdx.x & 63;
 #if EXPO_FP16_OVFL
@@ -195,7 +190,7 @@ __device__ __forceinline__ void stream_groups(const T* const (&in)[NIN], T* out,
   // on the chain and cost ~30 VGPRs on the light backward kernels; gpurun r02p5.)
   while (true) {
     const int gn = gw + stride;
-    const bool more = (--count > 0) && gn * PPL < hw;  // wave-uniform
+    const bool more = gn * PPL < hw;  // wave-uniform
     RawGroup nxt[NIN];
 #pragma unroll
     for (int s = 0; s < NIN; ++s) nxt[s] = cur[s];
