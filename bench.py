@@ -61,7 +61,6 @@ def parse():
   ap.add_argument('--cold-shape', default='256,512,512',
                   help="chain workload: also time the dominant kernel on tensors of this shape (384 MiB each, beyond "
                   "the 256 MiB Infinity Cache) for roofline.hbm_cold; 'none' disables")
-  ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                   help='replay the 17 launches of a step from one hipGraph (auto = on; off: eager C-ABI calls)')
   return ap.parse_args()
@@ -219,23 +218,35 @@ def _cpu_chain_rates(name, threads, budget_s=4.0):
   return best
 
 
-def cpu_worker(spec):
-  """`bench.py --cpu-worker NAME:THREADS`: one configuration in its own process (so that a pathological
-  one -- every logical CPU of a 256-thread host oversubscribing torch's intra-op pool -- can be timed
-  out and killed by the parent instead of stalling the whole benchmark)."""
-  name, threads = spec.split(':')
-  print(json.dumps(_cpu_chain_rates(name, int(threads), budget_s=3.0)))
+def _c_port_rates(name, threads, budget_s=3.0):
+  """Best-of-5-after-2-warm-ups rate (Mpixels/s, fwd+bwd) of the C / OpenMP restatement (oracle/filters_c.c,
+  float32 -- the reference's dtype -- one fused pass per step and direction) on SHAPES[name]."""
+  from oracle import filters_c as fc
+  shape = synthetic.SHAPES[name]
+  x, dy, params = synthetic.make_case(1234, shape, np.float16)
+  fc.set_threads(threads)
+  chain = fc.Chain(x.astype(np.float32), dy.astype(np.float32), params)
+  times, t_cfg = [], time.perf_counter()
+  for _ in range(7):
+    t0 = time.perf_counter()
+    chain.run()
+    times.append(time.perf_counter() - t0)
+    if time.perf_counter() - t_cfg > budget_s and len(times) >= 2:  # a slow configuration is cut short
+      break
+  return shape[0] * shape[1] * shape[2] / min(times[min(2, len(times) - 1):]) / 1e6
 
 
 def cpu_baseline():
-  """the torch-CPU fp32 op-by-op restatement (oracle/filters_torch.py, autograd
-  backward -- the granularity at which TF-1 executes the reference graph) timed on the host cores on the
-  same synthetic workload: shapes A (64x64x64x3) and B (16x512x512x3), chain fwd-only and fwd+bwd, best of
-  5 after 2 warm-ups, for a small sweep of thread counts, plus the all-logical-CPUs run of the plan
-  (torch.set_num_threads(os.cpu_count())) in a child process with a 12 s limit -- on a 256-thread host
-  torch's intra-op pool oversubscribes badly for this op mix (one pass took > 70 s).  `value` = the best
-  fwd+bwd rate on shape B; ~15-30 s of CPU work in total."""
-  import subprocess
+  """The CPU side of the comparison, on the host cores, same synthetic workload, best of 5 after 2 warm-ups
+  (BASELINE.md section 3), two restatements (both `kind: "port"` -- TF-1 itself cannot run here):
+
+  * `value`: the C / OpenMP restatement oracle/filters_c.c in float32 (the reference's dtype), one fused pass per
+    step and direction like the HIP chain, swept over thread counts up to every logical CPU -- what a tuned CPU
+    implementation of this path does on this host;
+  * `op_by_op`: the torch-CPU fp32 op-by-op restatement (oracle/filters_torch.py, autograd backward) -- the
+    granularity at which TF-1 executes the reference graph (one pass over the image per elementwise op) -- on
+    shapes A (64x64x64x3) and B (16x512x512x3).
+  ~20-30 s of CPU work in total."""
   ncpu = os.cpu_count() or 1
   model = ''
   try:
@@ -245,17 +256,30 @@ def cpu_baseline():
         break
   except OSError:
     pass
-  sweep = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)})
   t_start = time.perf_counter()
+  # ---- C / OpenMP port
+  c_sweep = sorted({t for t in (ncpu // 8, ncpu // 4, ncpu // 2, ncpu) if t >= 1})
+  c_port = {'B': {}, 'A': {}}
+  try:
+    for threads in c_sweep:
+      c_port['B'][str(threads)] = _c_port_rates('B', threads)
+      print('cpu_baseline: C port, shape B, %d threads: %.0f Mpixels/s fwd+bwd' % (threads, c_port['B'][str(threads)]),
+            file=sys.stderr)
+    best_c = int(max(c_port['B'], key=c_port['B'].get))
+    c_port['A'][str(best_c)] = _c_port_rates('A', best_c)
+  except (OSError, RuntimeError) as e:  # the oracle's library is missing: report the op-by-op figure only
+    print('cpu_baseline: C port unavailable (%s)' % e, file=sys.stderr)
+    c_port, best_c = None, None
+  # ---- torch op-by-op
+  sweep = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)})
   by_shape = {}
   for name in ('A', 'B'):
-    # shape A (0.26 Mpixel) sweeps every thread count; shape B (4.2 Mpixel, ~1.5 s per pass) only the two best
-    # of A -- the whole leg stays within ~25 s
+    # shape A (0.26 Mpixel) sweeps every thread count; shape B (4.2 Mpixel, ~1.5 s per pass) only the two best of A
     counts = sweep if name == 'A' else sorted(by_shape['A']['sweep_fwd_bwd'], key=by_shape['A']['sweep_fwd_bwd'].get)[-2:]
     rows = {}
     for threads in [int(t) for t in counts]:
-      rows[threads] = _cpu_chain_rates(name, threads, budget_s=2.0 if name == 'B' else 4.0)
-      print('cpu_baseline: shape %s, %d threads: %.1f Mpixels/s fwd+bwd (%.1f s so far)' %
+      rows[threads] = _cpu_chain_rates(name, threads, budget_s=2.0 if name == 'B' else 3.0)
+      print('cpu_baseline: op-by-op, shape %s, %d threads: %.1f Mpixels/s fwd+bwd (%.1f s so far)' %
             (name, threads, rows[threads]['fwd_bwd'], time.perf_counter() - t_start), file=sys.stderr)
     bt = max(rows, key=lambda t: rows[t]['fwd_bwd'])
     by_shape[name] = {
@@ -265,31 +289,26 @@ def cpu_baseline():
         'fwd_Mpixels_per_s': rows[bt]['fwd'],
         'sweep_fwd_bwd': {str(t): r['fwd_bwd'] for t, r in rows.items()},
     }
-  # the plan's all-core run (shape B), in a child that can be killed
-  all_cores = {'threads': ncpu, 'fwd_bwd_Mpixels_per_s': None, 'note': ''}
-  if ncpu in sweep:
-    all_cores['fwd_bwd_Mpixels_per_s'] = by_shape['B']['sweep_fwd_bwd'][str(ncpu)]
-  else:
-    try:
-      out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', 'B:%d' % ncpu],
-                           capture_output=True, text=True, timeout=12)
-      all_cores['fwd_bwd_Mpixels_per_s'] = json.loads(out.stdout.strip().splitlines()[-1])['fwd_bwd']
-    except subprocess.TimeoutExpired:
-      all_cores['note'] = 'killed after 12 s: torch intra-op pool oversubscribed at %d threads' % ncpu
-    except (ValueError, IndexError, KeyError):
-      all_cores['note'] = 'worker failed'
   b = by_shape['B']
+  host = '%s with %d logical CPUs' % (model or 'unknown CPU', ncpu)
+  if c_port is None:
+    value, cores = b['fwd_bwd_Mpixels_per_s'], b['best_threads']
+    sample = ('torch fp32 op-by-op restatement (autograd backward; never TF1) on host %s: 8-step chain fwd+bwd on '
+              '16x512x512x3, best of 5 after 2 warm-ups, best thread count of %s' % (host, sweep))
+  else:
+    value, cores = c_port['B'][str(best_c)], best_c
+    sample = ('C / OpenMP restatement oracle/filters_c.c (float32, one fused pass per step and direction; never TF1) on '
+              'host %s: 8-step chain fwd+bwd on 16x512x512x3 (4.19 Mpixel per pass), best of 5 after 2 warm-ups, best '
+              'thread count of %s = %d; op_by_op = the torch fp32 op-by-op restatement (TF-1\'s execution granularity) '
+              'on 64x64x64x3 and 16x512x512x3' % (host, c_sweep, best_c))
   return {
-      'value': b['fwd_bwd_Mpixels_per_s'],
+      'value': value,
       'unit': 'Mpixels/s',
-      'cores': b['best_threads'],
+      'cores': cores,
       'kind': 'port',
-      'sample': 'CPU restatement (torch fp32 op-by-op, autograd backward; never TF1) on host %s with %d logical CPUs: '
-                '8-step chain fwd+bwd on 16x512x512x3 (4.19 Mpixel per pass), best of 5 after 2 warm-ups, best '
-                'thread count of %s = %d; by_shape also holds 64x64x64x3 and fwd-only; all_cores = the %d-thread run' %
-                (model or 'unknown CPU', ncpu, sweep, b['best_threads'], ncpu),
-      'by_shape': by_shape,
-      'all_cores': all_cores,
+      'sample': sample,
+      'c_port_sweep': c_port,
+      'op_by_op': by_shape,
       'seconds': time.perf_counter() - t_start,
   }
 
@@ -634,8 +653,6 @@ def time_cold(args, dev, dom, ids):
 
 def main():
   args = parse()
-  if args.cpu_worker:
-    return cpu_worker(args.cpu_worker)
   if args.gpus > 1 and 'LOCAL_RANK' not in os.environ and 'RANK' not in os.environ:
     raise SystemExit(self_launch(args))
   world = int(os.environ.get('WORLD_SIZE', '1'))

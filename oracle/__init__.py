@@ -9,8 +9,10 @@ tests, golden vectors or fixtures, and cannot be imported in this image (no
 tensorflow / cv2; ``util.py:658`` is a SyntaxError on Python >= 3.7).  The
 restatement is therefore pinned by (i) closed-form identities of the reference
 code, (ii) hand-computed points, (iii) float64 finite differences, and (iv)
-agreement of two independently written restatements (``filters_np`` with
-hand-derived backward, ``filters_torch`` with autograd), and (v) for the two
+agreement of three independently written restatements (``filters_np`` with
+hand-derived backward, ``filters_torch`` with autograd, and since round 2
+``filters_c.c``: plain C following the reference's formulas literally, also
+the CPU baseline of ``bench.py``), and (v) for the two
 TensorFlow image ops the reference calls but does not contain
 (``tf.image.rgb_to_hsv`` / ``hsv_to_rgb``, tensorflow 1.x), the check TensorFlow's
 own unit test applies to them: agreement with Python's ``colorsys`` tuple by

@@ -1,0 +1,110 @@
+"""ctypes binding of the C restatement ``oracle/filters_c.c`` (built by ``oracle/build_c.sh``).
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``): the float64 build is a third, independently written
+checker beside ``filters_np`` / ``filters_torch``; the float32 + OpenMP build is what ``bench.py`` times as the
+CPU baseline (``cpu_baseline.kind = "port"``).  Same packed-parameter convention as ``filters_np``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24)
+
+
+class OracleCMissing(RuntimeError):
+  pass
+
+
+def lib_path(dtype):
+  return os.path.join(_HERE, 'liboracle_c_f64.so' if np.dtype(dtype) == np.float64 else 'liboracle_c_f32.so')
+
+
+def load(dtype=np.float64):
+  dt = np.dtype(dtype)
+  if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+    raise ValueError('the C oracle is built for float64 and float32')
+  if dt not in _LIBS:
+    path = lib_path(dt)
+    if not os.path.exists(path):
+      raise OracleCMissing('%s is missing: run oracle/build_c.sh (or __graft_entry__.build())' % path)
+    lib = ctypes.CDLL(path)
+    real_p = ctypes.POINTER(ctypes.c_double if dt == np.float64 else ctypes.c_float)
+    lib.oracle_c_real_bytes.restype = ctypes.c_int
+    assert lib.oracle_c_real_bytes() == dt.itemsize
+    lib.oracle_c_process.argtypes = [ctypes.c_int, real_p, real_p, real_p, ctypes.c_long, ctypes.c_long]
+    lib.oracle_c_process.restype = None
+    lib.oracle_c_backward.argtypes = [ctypes.c_int, real_p, real_p, real_p, real_p, real_p, ctypes.c_long,
+                                      ctypes.c_long]
+    lib.oracle_c_backward.restype = None
+    pp = ctypes.POINTER(real_p)
+    lib.oracle_c_chain.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, pp, pp, real_p, real_p, real_p, pp,
+                                   ctypes.c_long, ctypes.c_long]
+    lib.oracle_c_chain.restype = None
+    lib.oracle_c_set_threads.argtypes = [ctypes.c_int]
+    lib.oracle_c_set_threads.restype = ctypes.c_int
+    _LIBS[dt] = (lib, real_p)
+  return _LIBS[dt]
+
+
+def _prep(a, dt):
+  return np.ascontiguousarray(a, dtype=dt)
+
+
+def process_packed(fid, img, packed, dtype=np.float64):
+  """y = filter ``fid`` applied to NHWC ``img`` with packed parameters (N, P)."""
+  lib, real_p = load(dtype)
+  x = _prep(img, dtype)
+  p = _prep(packed, dtype).reshape(x.shape[0], NUM_PARAMS[fid])
+  y = np.empty_like(x)
+  n, hw = x.shape[0], x.shape[1] * x.shape[2]
+  lib.oracle_c_process(fid, x.ctypes.data_as(real_p), p.ctypes.data_as(real_p), y.ctypes.data_as(real_p), n, hw)
+  return y
+
+
+def backward_packed(fid, img, packed, dy, dtype=np.float64):
+  """(dx, dpacked) -- the TF-1-faithful gradient (no gradient through the HSV round trip)."""
+  lib, real_p = load(dtype)
+  x, g = _prep(img, dtype), _prep(dy, dtype)
+  p = _prep(packed, dtype).reshape(x.shape[0], NUM_PARAMS[fid])
+  dx = np.empty_like(x)
+  dp = np.empty_like(p)
+  n, hw = x.shape[0], x.shape[1] * x.shape[2]
+  lib.oracle_c_backward(fid, x.ctypes.data_as(real_p), p.ctypes.data_as(real_p), g.ctypes.data_as(real_p),
+                        dx.ctypes.data_as(real_p), dp.ctypes.data_as(real_p), n, hw)
+  return dx, dp
+
+
+def set_threads(n, dtype=np.float32):
+  """OpenMP threads of the float32 build (0 = leave unchanged); returns the count in effect."""
+  return load(dtype)[0].oracle_c_set_threads(int(n))
+
+
+class Chain:
+  """Buffers + one call for the 8-step benchmark chain (forward, then backward with every step's parameter
+  gradients), float32 + OpenMP: the CPU baseline of bench.py."""
+
+  def __init__(self, x, dy, params, ids=tuple(range(8)), dtype=np.float32):
+    self.lib, self.real_p = load(dtype)
+    self.ids = list(ids)
+    steps = len(self.ids)
+    self.acts = [_prep(x, dtype)] + [np.empty(x.shape, dtype=dtype) for _ in range(steps)]
+    self.dy = _prep(dy, dtype)
+    self.g = [np.empty(x.shape, dtype=dtype) for _ in range(2)]
+    self.params = [_prep(params[i], dtype).reshape(x.shape[0], NUM_PARAMS[i]) for i in self.ids]
+    self.dparams = [np.empty_like(p) for p in self.params]
+    self.n, self.hw = x.shape[0], x.shape[1] * x.shape[2]
+    arr = lambda bufs: (self.real_p * len(bufs))(*[b.ctypes.data_as(self.real_p) for b in bufs])
+    self._acts, self._params, self._dparams = arr(self.acts), arr(self.params), arr(self.dparams)
+    self._ids = (ctypes.c_int * steps)(*self.ids)
+
+  def run(self):
+    self.lib.oracle_c_chain(self._ids, len(self.ids), self._acts, self._params, self.dy.ctypes.data_as(self.real_p),
+                            self.g[0].ctypes.data_as(self.real_p), self.g[1].ctypes.data_as(self.real_p),
+                            self._dparams, self.n, self.hw)
+
+  @property
+  def dx(self):
+    return self.g[0]  # step 0 writes the even buffer

@@ -1,0 +1,102 @@
+"""The C restatement (oracle/filters_c.c) against the NumPy restatement and the committed golden vectors:
+three independently written oracles (NumPy hand-derived backward, torch autograd, plain C) must agree."""
+import os
+
+import numpy as np
+import pytest
+
+from exposure_amd import synthetic
+from oracle import filters_c as fc
+from oracle import filters_np as fnp
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _built():
+  if not (os.path.exists(fc.lib_path(np.float64)) and os.path.exists(fc.lib_path(np.float32))):
+    import subprocess
+    subprocess.check_call(['bash', os.path.join(os.path.dirname(fc.__file__), 'build_c.sh')])
+
+
+def _case(seed, shape, scale=1.0):
+  rng = np.random.default_rng(seed)
+  x = synthetic.make_images(rng, shape, np.float64) * scale
+  dy = synthetic.make_grad(rng, shape, np.float64)
+  return rng, x, dy
+
+
+@pytest.mark.parametrize('fid', range(8))
+@pytest.mark.parametrize('shape,scale', [((3, 16, 12, 3), 1.0), ((2, 9, 7, 3), 1.5), ((1, 1, 1, 3), 1.0)])
+def test_c_matches_numpy_float64(fid, shape, scale):
+  rng, x, dy = _case(100 + fid, shape, scale)
+  p = synthetic.make_params(rng, fid, shape[0]).astype(np.float64)
+  y_np = fnp.process_packed(fid, x, p)
+  y_c = fc.process_packed(fid, x, p)
+  np.testing.assert_allclose(y_c, y_np, rtol=1e-12, atol=1e-13)
+  dx_np, dp_np = fnp.backward_packed(fid, x, p, dy)
+  dx_c, dp_c = fc.backward_packed(fid, x, p, dy)
+  np.testing.assert_allclose(dx_c, dx_np, rtol=1e-11, atol=1e-12)
+  np.testing.assert_allclose(dp_c, dp_np, rtol=1e-9, atol=1e-10 * max(1.0, np.abs(dy).sum()))
+
+
+@pytest.mark.parametrize('fid', [4, 7])
+def test_c_matches_numpy_on_the_knots(fid):
+  """x exactly on the knots i/8, at 0, at 1 and outside [0, 1]: TF's inclusive clip gradient (both neighbours)."""
+  vals = np.array([-0.25, 0.0, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75, 0.875, 1.0, 1.25, 0.3])
+  x = np.stack([vals, vals[::-1], np.roll(vals, 3)], axis=-1).reshape(1, 3, 4, 3).copy()
+  rng = np.random.default_rng(3)
+  dy = rng.standard_normal(x.shape)
+  p = synthetic.make_params(rng, fid, 1).astype(np.float64)
+  dx_np, dp_np = fnp.backward_packed(fid, x, p, dy)
+  dx_c, dp_c = fc.backward_packed(fid, x, p, dy)
+  np.testing.assert_allclose(dx_c, dx_np, rtol=1e-12, atol=1e-13)
+  np.testing.assert_allclose(dp_c, dp_np, rtol=1e-10, atol=1e-12)
+
+
+def test_tie_conventions_of_max_min():
+  """Gamma: x == 0.001 passes the gradient; S+: x == 1 passes, x > 1 does not; Contrast: lum == 0 and == 1 pass."""
+  x = np.array([[[[0.001, 0.0005, 0.5], [1.0, 1.5, 0.2], [0.0, 0.0, 0.0], [1 / 0.27 * 0.27, 1.0, 1.0]]]])
+  dy = np.ones_like(x)
+  for fid in (1, 3, 5):
+    p = synthetic.make_params(np.random.default_rng(fid), fid, 1).astype(np.float64)
+    dx_np, dp_np = fnp.backward_packed(fid, x, p, dy)
+    dx_c, dp_c = fc.backward_packed(fid, x, p, dy)
+    np.testing.assert_allclose(dx_c, dx_np, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dp_c, dp_np, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', ['filters_small.npz', 'filters_ragged.npz', 'filters_proxy.npz'])
+def test_c_reproduces_the_golden_vectors(name):
+  """tests/golden/*.npz hold fp16 inputs, float32 parameters and float64-computed outputs stored as float32
+  (tests/golden/make_golden.py); samples sit exactly on knots / clip edges for the curve filters."""
+  z = np.load(os.path.join(GOLDEN, name))
+  for fid in range(8):
+    x, dy = z['x_%d' % fid].astype(np.float64), z['dy_%d' % fid].astype(np.float64)
+    p = z['p_%d' % fid].astype(np.float64)
+    y = fc.process_packed(fid, x, p)
+    np.testing.assert_allclose(y, z['y_%d' % fid], rtol=2e-7, atol=1e-7)  # float32 storage of the expected values
+    dx, dp = fc.backward_packed(fid, x, p, dy)
+    np.testing.assert_allclose(dx, z['dx_%d' % fid], rtol=2e-7, atol=1e-6)
+    np.testing.assert_allclose(dp, z['dp_%d' % fid], rtol=1e-6, atol=1e-6 * max(1.0, np.abs(dy).sum()))
+
+
+def test_float32_openmp_chain_matches_the_float64_chain():
+  """The build bench.py times: 8 steps forward + backward in float32 with OpenMP, against step-by-step float64."""
+  rng, x, dy = _case(7, (4, 32, 24, 3))
+  params = [synthetic.make_params(rng, fid, 4) for fid in range(8)]
+  ch = fc.Chain(x, dy, params)
+  ch.run()
+  ch.run()  # twice: buffers are reusable, results identical
+  a = x
+  acts = [a]
+  for fid in range(8):
+    a = fc.process_packed(fid, a, params[fid])
+    acts.append(a)
+  np.testing.assert_allclose(ch.acts[8], acts[8], rtol=2e-4, atol=2e-5)
+  g = dy
+  for fid in reversed(range(8)):
+    g, dp = fc.backward_packed(fid, acts[fid], params[fid], g)
+    scale = max(1.0, float(np.abs(dp).max()))
+    np.testing.assert_allclose(ch.dparams[fid], dp, rtol=5e-3, atol=5e-3 * scale)
+  np.testing.assert_allclose(ch.dx, g, rtol=5e-3, atol=5e-3 * float(np.abs(g).max()))
