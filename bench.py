@@ -220,20 +220,17 @@ def _cpu_chain_rates(name, threads, budget_s=4.0):
 
 def _c_port_rates(name, threads, budget_s=3.0):
   """Best-of-5-after-2-warm-ups rate (Mpixels/s, fwd+bwd) of the C / OpenMP restatement (oracle/filters_c.c,
-  float32 -- the reference's dtype -- one fused pass per step and direction) on SHAPES[name]."""
-  from oracle import filters_c as fc
-  shape = synthetic.SHAPES[name]
-  x, dy, params = synthetic.make_case(1234, shape, np.float16)
-  fc.set_threads(threads)
-  chain = fc.Chain(x.astype(np.float32), dy.astype(np.float32), params)
-  times, t_cfg = [], time.perf_counter()
-  for _ in range(7):
-    t0 = time.perf_counter()
-    chain.run()
-    times.append(time.perf_counter() - t0)
-    if time.perf_counter() - t_cfg > budget_s and len(times) >= 2:  # a slow configuration is cut short
-      break
-  return shape[0] * shape[1] * shape[2] / min(times[min(2, len(times) - 1):]) / 1e6
+  float32 -- the reference's dtype -- one fused pass per step and direction) on SHAPES[name], in its own
+  process (`python -m oracle.filters_c`): the OpenMP runtime is configured through the environment before it
+  starts, and a team left spinning by one thread count cannot disturb the next."""
+  import subprocess
+  env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY='passive', OMP_PROC_BIND='spread',
+             OMP_PLACES='cores' if threads <= (os.cpu_count() or 1) // 2 else 'threads', PYTHONPATH=ROOT)
+  out = subprocess.run([sys.executable, '-m', 'oracle.filters_c', name, str(threads), str(budget_s)], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=60)
+  if out.returncode != 0:
+    raise RuntimeError('oracle.filters_c worker failed: %s' % out.stderr.strip()[-300:])
+  return json.loads(out.stdout.strip().splitlines()[-1])['Mpixels_per_s']
 
 
 def cpu_baseline():
@@ -247,7 +244,11 @@ def cpu_baseline():
     granularity at which TF-1 executes the reference graph (one pass over the image per elementwise op) -- on
     shapes A (64x64x64x3) and B (16x512x512x3).
   ~20-30 s of CPU work in total."""
-  ncpu = os.cpu_count() or 1
+  import subprocess
+  try:
+    ncpu = len(os.sched_getaffinity(0))  # the CPUs this process may run on, not the host's total
+  except (AttributeError, OSError):
+    ncpu = os.cpu_count() or 1
   model = ''
   try:
     for line in open('/proc/cpuinfo'):
@@ -267,7 +268,7 @@ def cpu_baseline():
             file=sys.stderr)
     best_c = int(max(c_port['B'], key=c_port['B'].get))
     c_port['A'][str(best_c)] = _c_port_rates('A', best_c)
-  except (OSError, RuntimeError) as e:  # the oracle's library is missing: report the op-by-op figure only
+  except (OSError, RuntimeError, ValueError, subprocess.SubprocessError) as e:  # no C oracle: op-by-op figure only
     print('cpu_baseline: C port unavailable (%s)' % e, file=sys.stderr)
     c_port, best_c = None, None
   # ---- torch op-by-op

@@ -108,3 +108,33 @@ class Chain:
   @property
   def dx(self):
     return self.g[0]  # step 0 writes the even buffer
+
+
+def _worker(argv):
+  """``python -m oracle.filters_c SHAPE_NAME THREADS [BUDGET_S]``: best-of-5-after-2-warm-ups rate (Mpixels/s,
+  8-step chain fwd+bwd, float32) of one thread count, as one JSON line.  bench.py's cpu_baseline leg runs every
+  thread count in its own process with OMP_NUM_THREADS / OMP_WAIT_POLICY=passive / OMP_PROC_BIND set before
+  libgomp starts: spinning worker teams of a previous, different thread count otherwise wreck the next one."""
+  import json
+  import time
+  from exposure_amd import synthetic
+  name, threads = argv[0], int(argv[1])
+  budget_s = float(argv[2]) if len(argv) > 2 else 3.0
+  shape = synthetic.SHAPES[name]
+  x, dy, params = synthetic.make_case(1234, shape, np.float16)
+  got = set_threads(threads)
+  chain = Chain(x.astype(np.float32), dy.astype(np.float32), params)
+  times, t_cfg = [], time.perf_counter()
+  for _ in range(7):
+    t0 = time.perf_counter()
+    chain.run()
+    times.append(time.perf_counter() - t0)
+    if time.perf_counter() - t_cfg > budget_s and len(times) >= 2:  # a slow configuration is cut short
+      break
+  rate = shape[0] * shape[1] * shape[2] / min(times[min(2, len(times) - 1):]) / 1e6
+  print(json.dumps({'Mpixels_per_s': rate, 'threads': got, 'runs': len(times)}))
+
+
+if __name__ == '__main__':
+  import sys
+  _worker(sys.argv[1:])
