@@ -49,7 +49,7 @@ static const int kNumParams[8] = {1, 1, 3, 1, 8, 1, 1, 24};
 
 int oracle_c_num_params(int fid) { return (fid >= 0 && fid < 8) ? kNumParams[fid] : -1; }
 int oracle_c_real_bytes(void) { return (int)sizeof(real); }
-/* threads of the OpenMP build (the double build is serial): sets when n > 0, returns the count in effect */
+/* OpenMP threads: sets when n > 0, returns the count in effect (results do not depend on it: fixed-order sums) */
 int oracle_c_set_threads(int n) {
 #ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);

@@ -78,7 +78,8 @@ def backward_packed(fid, img, packed, dy, dtype=np.float64):
 
 
 def set_threads(n, dtype=np.float32):
-  """OpenMP threads of the float32 build (0 = leave unchanged); returns the count in effect."""
+  """OpenMP threads of one build (0 = leave unchanged); returns the count in effect.  Results do not depend on
+  the count (per-block partial sums added in a fixed order)."""
   return load(dtype)[0].oracle_c_set_threads(int(n))
 
 

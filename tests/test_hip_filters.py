@@ -1,5 +1,7 @@
 """GPU parity: every HIP filter kernel (through the C-ABI) vs the float64 oracle on the same
 fp16/fp32-quantised inputs; edge cases; size-independent properties at full size."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -302,6 +304,44 @@ def test_full_size_properties(shape_name, gpu_device):
       _, rdp = fnp.backward_packed(fid, xi, p[i:i + 1].cpu().numpy().astype(np.float64), gi)
       assert_param_grad_close(dp1[i:i + 1].cpu().numpy(), rdp, np.abs(gi).sum() * 4,
                               'full-size dparams filter %d image %d' % (fid, i))
+
+
+def test_full_size_chain_every_pixel_against_the_c_oracle(gpu_device):
+  """BASELINE's metric shape, 64x512x512x3 fp16, all 8 steps forward and backward: EVERY output value of every
+  launch is compared with the float64 C restatement (oracle/filters_c.c, OpenMP) evaluated on the very inputs that
+  launch read -- not a sample, not a property."""
+  from oracle import filters_c as fc
+  dev = gpu_device
+  shape = synthetic.SHAPES['C']
+  try:
+    ncpu = len(os.sched_getaffinity(0))
+  except (AttributeError, OSError):
+    ncpu = os.cpu_count() or 1
+  fc.set_threads(max(1, min(64, ncpu // 2)), np.float64)
+  x, dy, params = synthetic.make_case(4242, shape, np.float16)
+  ids = list(range(8))
+  acts = [torch.from_numpy(x).to(dev)] + [torch.empty(shape, dtype=torch.float16, device=dev) for _ in ids]
+  prm = [torch.from_numpy(p).to(dev) for p in params]
+  grads = [torch.empty(shape, dtype=torch.float16, device=dev) for _ in ids] + [torch.from_numpy(dy).to(dev)]
+  dprm = [torch.empty_like(p) for p in prm]
+  _cabi.chain_fwd(ids, acts, prm)
+  _cabi.chain_bwd(ids, acts, grads, prm, dprm)
+  torch.cuda.synchronize()
+
+  def check(got16, ref, what):
+    np.clip(ref, -65504.0, 65504.0, out=ref)  # fp16 stores saturate
+    assert_image_close(got16.cpu().numpy(), ref, np.float16, what)
+
+  for i in ids:
+    xin = acts[i].cpu().numpy().astype(np.float64)
+    p64 = params[i].astype(np.float64)
+    check(acts[i + 1], fc.process_packed(i, xin, p64), 'forward of step %d' % i)
+    gin = grads[i + 1].cpu().numpy().astype(np.float64)
+    rdx, rdp = fc.backward_packed(i, xin, p64, gin)
+    check(grads[i], rdx, 'dx of step %d' % i)
+    scale = np.abs(gin).reshape(shape[0], -1).sum(axis=1, keepdims=True) * 4 + 50.0
+    assert_param_grad_close(dprm[i].cpu().numpy(), rdp, np.broadcast_to(scale, rdp.shape), 'dparams of step %d' % i)
+    del xin, gin, rdx
 
 
 def test_bwd_accumulate(gpu_device):
