@@ -305,6 +305,42 @@ def test_fused_chain_matches_oracle(dtype, shape, gpu_device):
   assert float(y[1].abs().max()) >= 0.0
 
 
+def test_fused_chain_at_config5_size_every_pixel_against_the_c_oracle(gpu_device):
+  """BASELINE config 5's kernel at 16x512x512x3 fp16: all 8 filters in registers, one read and one write; EVERY
+  output value against the float64 C restatement applied step by step (no fp16 rounding between steps on either
+  side).  Image 3 runs the sequence backwards."""
+  import os
+  from oracle import filters_c as fc
+  dev = gpu_device
+  shape = synthetic.SHAPES['B']
+  n = shape[0]
+  try:
+    ncpu = len(os.sched_getaffinity(0))
+  except (AttributeError, OSError):
+    ncpu = os.cpu_count() or 1
+  fc.set_threads(max(1, min(64, ncpu // 2)), np.float64)
+  rng = np.random.default_rng(77)
+  x = synthetic.make_images(rng, shape, np.float16)
+  ids = np.tile(np.arange(8, dtype=np.int32), (n, 1))
+  ids[3] = ids[3, ::-1]
+  p = np.zeros((n, 8, 24), dtype=np.float32)
+  for i in range(n):
+    for st in range(8):
+      fid = int(ids[i, st])
+      p[i, st, :fnp.NUM_PARAMS[fid]] = synthetic.make_params(rng, fid, 1)[0]
+  ref = x.astype(np.float64)
+  for st in range(8):
+    nxt = np.empty_like(ref)
+    for fid in np.unique(ids[:, st]):
+      sel = np.nonzero(ids[:, st] == fid)[0]
+      nxt[sel] = fc.process_packed(int(fid), ref[sel], p[sel, st, :fnp.NUM_PARAMS[fid]].astype(np.float64))
+    ref = nxt
+  y = torch.empty(shape, dtype=torch.float16, device=dev)
+  _cabi.chain_fused_fwd(torch.from_numpy(ids).to(dev), torch.from_numpy(p).to(dev), torch.from_numpy(x).to(dev), y)
+  np.clip(ref, -65504.0, 65504.0, out=ref)
+  assert_image_close(y.cpu().numpy(), ref, np.float16, 'fused chain at 16x512x512')
+
+
 def test_retouch_fused_equals_stepwise_on_gpu(gpu_device):
   from exposure_amd import evaluate
   dev = gpu_device
