@@ -118,6 +118,55 @@ def test_dispatch_penalty_of_curves_that_exceed_one(dtype, shape, gpu_device):
   assert_param_grad_close(dp.cpu().numpy(), rdp, np.broadcast_to(scale, rdp.shape), 'dispatch dparams')
 
 
+def test_dispatch_at_config5_size_every_pixel_against_the_c_oracle(gpu_device):
+  """The agent's per-step kernels (one-hot select + fused over-exposure penalty, forward and backward) at
+  16x512x512x3 fp16 -- streaming instantiations, light / curve launch pair -- with EVERY value of y and dx, the
+  penalty and every parameter gradient checked against the float64 C restatement."""
+  import os
+  from oracle import filters_c as fc
+  dev = gpu_device
+  shape = synthetic.SHAPES['B']
+  n, cnt = shape[0], shape[1] * shape[2] * 3
+  try:
+    ncpu = len(os.sched_getaffinity(0))
+  except (AttributeError, OSError):
+    ncpu = os.cpu_count() or 1
+  fc.set_threads(max(1, min(64, ncpu // 2)), np.float64)
+  rng = np.random.default_rng(91)
+  x = synthetic.make_images(rng, shape, np.float16)
+  x *= np.float16(1.6)
+  dy = synthetic.make_grad(rng, shape, np.float16)
+  ids = (np.arange(n) % 9 - 1).astype(np.int32)  # -1, 0..7, -1, 0..6
+  p24 = np.zeros((n, 24), dtype=np.float32)
+  for i, fid in enumerate(ids):
+    if fid >= 0:
+      p24[i, :fnp.NUM_PARAMS[fid]] = synthetic.make_params(rng, int(fid), 1)[0]
+  dpen = (rng.standard_normal(n) * 50.0).astype(np.float32)
+  tx, tdy = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+  tid, tp = torch.from_numpy(ids).to(dev), torch.from_numpy(p24).to(dev)
+  y, dx = torch.empty_like(tx), torch.empty_like(tx)
+  pen = torch.empty(n, device=dev)
+  dp = torch.full_like(tp, float('nan'))
+  _cabi.dispatch_fwd(tid, tx, y, tp, pen)
+  _cabi.dispatch_bwd(tid, tx, tdy, dx, tp, dp, torch.from_numpy(dpen).to(dev))
+  x64, dy64 = x.astype(np.float64), dy.astype(np.float64)
+  ry, rdx, rdp = np.zeros_like(x64), np.zeros_like(x64), np.zeros((n, 24))
+  for fid in range(8):
+    sel = np.nonzero(ids == fid)[0]
+    npar = fnp.NUM_PARAMS[fid]
+    pp = p24[sel, :npar].astype(np.float64)
+    ry[sel] = fc.process_packed(fid, x64[sel], pp)
+    g = dy64[sel] + 2.0 * np.maximum(ry[sel] - 1, 0) * dpen[sel].astype(np.float64)[:, None, None, None] / cnt
+    rdx[sel], rdp[sel, :npar] = fc.backward_packed(fid, x64[sel], pp, g)
+  rpen = np.mean(np.maximum(ry - 1, 0)**2, axis=(1, 2, 3))
+  assert (rpen[ids >= 0] > 1e-4).any(), 'the case must exercise the penalty'
+  np.testing.assert_allclose(pen.cpu().numpy(), rpen, rtol=2e-4, atol=1e-7)
+  assert_image_close(y.cpu().numpy(), np.clip(ry, -65504.0, 65504.0), np.float16, 'dispatch y')
+  assert_image_close(dx.cpu().numpy(), np.clip(rdx, -65504.0, 65504.0), np.float16, 'dispatch dx')
+  scale = np.abs(dy64).reshape(n, -1).sum(axis=1, keepdims=True) * 4 + 50.0
+  assert_param_grad_close(dp.cpu().numpy(), rdp, np.broadcast_to(scale, rdp.shape), 'dispatch dparams')
+
+
 def test_dispatch_autograd_matches_per_filter(gpu_device):
   dev = gpu_device
   x, dy, ids, p24, _ = dispatch_case(23, (9, 32, 32, 3), np.float32)
