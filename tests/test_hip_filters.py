@@ -306,31 +306,34 @@ def test_full_size_properties(shape_name, gpu_device):
                               'full-size dparams filter %d image %d' % (fid, i))
 
 
-def test_full_size_chain_every_pixel_against_the_c_oracle(gpu_device):
-  """BASELINE's metric shape, 64x512x512x3 fp16, all 8 steps forward and backward: EVERY output value of every
-  launch is compared with the float64 C restatement (oracle/filters_c.c, OpenMP) evaluated on the very inputs that
-  launch read -- not a sample, not a property."""
+@pytest.mark.parametrize('shape_name,dtype', [('C', torch.float16), ('B', torch.float32)])
+def test_full_size_chain_every_pixel_against_the_c_oracle(shape_name, dtype, gpu_device):
+  """BASELINE's metric shape, 64x512x512x3 fp16 (and 16x512x512x3 in the reference's own fp32 storage), all 8
+  steps forward and backward: EVERY output value of every launch is compared with the float64 C restatement
+  (oracle/filters_c.c, OpenMP) evaluated on the very inputs that launch read -- not a sample, not a property."""
   from oracle import filters_c as fc
   dev = gpu_device
-  shape = synthetic.SHAPES['C']
+  shape = synthetic.SHAPES[shape_name]
+  np_dt = NP_DT[dtype]
   try:
     ncpu = len(os.sched_getaffinity(0))
   except (AttributeError, OSError):
     ncpu = os.cpu_count() or 1
   fc.set_threads(max(1, min(64, ncpu // 2)), np.float64)
-  x, dy, params = synthetic.make_case(4242, shape, np.float16)
+  x, dy, params = synthetic.make_case(4242, shape, np_dt)
   ids = list(range(8))
-  acts = [torch.from_numpy(x).to(dev)] + [torch.empty(shape, dtype=torch.float16, device=dev) for _ in ids]
+  acts = [torch.from_numpy(x).to(dev)] + [torch.empty(shape, dtype=dtype, device=dev) for _ in ids]
   prm = [torch.from_numpy(p).to(dev) for p in params]
-  grads = [torch.empty(shape, dtype=torch.float16, device=dev) for _ in ids] + [torch.from_numpy(dy).to(dev)]
+  grads = [torch.empty(shape, dtype=dtype, device=dev) for _ in ids] + [torch.from_numpy(dy).to(dev)]
   dprm = [torch.empty_like(p) for p in prm]
   _cabi.chain_fwd(ids, acts, prm)
   _cabi.chain_bwd(ids, acts, grads, prm, dprm)
   torch.cuda.synchronize()
 
-  def check(got16, ref, what):
-    np.clip(ref, -65504.0, 65504.0, out=ref)  # fp16 stores saturate
-    assert_image_close(got16.cpu().numpy(), ref, np.float16, what)
+  def check(got, ref, what):
+    if np_dt == np.float16:
+      np.clip(ref, -65504.0, 65504.0, out=ref)  # fp16 stores saturate
+    assert_image_close(got.cpu().numpy(), ref, np_dt, what)
 
   for i in ids:
     xin = acts[i].cpu().numpy().astype(np.float64)
