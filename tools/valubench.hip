@@ -21,7 +21,7 @@ constexpr int ITER = 4096;
     typedef float f2 __attribute__((ext_vector_type(2)));                                        \
     f2 p[16];                                                                                    \
     unsigned h[16];                                                                              \
-    f2 s2 = {s, t}; float tv = t + threadIdx.x * 0.f; unsigned long long mask = __ballot(threadIdx.x & 1); unsigned three = 3 + (threadIdx.x >> 10), zero = threadIdx.x >> 10; __shared__ float lds[2048]; lds[threadIdx.x] = s; __syncthreads(); unsigned ldsaddr = (threadIdx.x & 255) * 8;                                                                           \
+    f2 s2 = {s, t}; float tv = t + threadIdx.x * 0.f; unsigned long long mask = __ballot(threadIdx.x & 1); unsigned three = 3 + (threadIdx.x >> 10), zero = threadIdx.x >> 10; __shared__ float lds[4096]; lds[threadIdx.x] = s; __syncthreads(); unsigned ldsaddr = (threadIdx.x & 255) * 8; unsigned ldsaddr4 = (threadIdx.x & 255) * 4;                                                                           \
     for (int i = 0; i < 16; ++i) {                                                               \
       a[i] = threadIdx.x * 1e-3f + i;                                                            \
       p[i] = f2{a[i], a[i] + 0.5f};                                                              \
@@ -76,6 +76,8 @@ constexpr int ITER = 4096;
 #define OP_CMPSDWA(i) asm volatile("v_cmp_eq_u32_sdwa vcc, %0, %1 src0_sel:BYTE_0 src1_sel:DWORD" : : "v"(h[i]), "v"(zero) : "vcc");
 #define OP_DSREAD(i) asm volatile("ds_read_b64 %0, %1" : "=v"(p[i]) : "v"(ldsaddr));
 #define OP_DSREADW(i) asm volatile("ds_read_b64 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(p[i]) : "v"(ldsaddr));
+#define OP_DSADD(i) asm volatile("ds_add_f32 %0, %1 offset:" #i "*1024" : : "v"(ldsaddr4), "v"(a[i]) : "memory");
+#define OP_DSWRITE(i) asm volatile("ds_write_b32 %0, %1 offset:" #i "*1024" : : "v"(ldsaddr4), "v"(a[i]) : "memory");
 #define OP_PKMOV(i) asm volatile("v_pk_mov_b32 %0, %1, %1" : "=v"(p[i]) : "v"(p[(i + 1) & 15]));
 // a mixed pair: one scalar fma + one transcendental (do they overlap?)
 #define OP_FMAEXP(i) asm volatile("v_fma_f32 %0, %0, %2, %3\n v_exp_f32 %1, %1" : "+v"(a[i]), "+v"(p[i].x) : "s"(s), "v"(tv));
@@ -123,6 +125,8 @@ KERNEL(k_cmpsdwa, REP16(OP_CMPSDWA))
 KERNEL(k_dsread, REP16(OP_DSREAD) asm volatile("s_waitcnt lgkmcnt(0)");)
 KERNEL(k_dsreadw, REP16(OP_DSREADW))
 KERNEL(k_pkmov, REP16(OP_PKMOV))
+KERNEL(k_dsadd, REP16(OP_DSADD) asm volatile("s_waitcnt lgkmcnt(0)");)
+KERNEL(k_dswrite, REP16(OP_DSWRITE) asm volatile("s_waitcnt lgkmcnt(0)");)
 
 typedef void (*kern_t)(float*, float, float);
 struct Entry { const char* name; kern_t k; int per_rep; };
@@ -155,6 +159,7 @@ int main(int argc, char** argv) {
       {"v_add_f32", k_add, 16}, {"v_lshlrev_b32_sdwa", k_lshlsdwa, 16}, {"v_cmp_eq_u32_sdwa", k_cmpsdwa, 16},
       {"ds_read_b64 (16 in flight)", k_dsread, 16}, {"ds_read_b64 + wait", k_dsreadw, 16},
       {"v_pk_mov_b32", k_pkmov, 16},
+      {"ds_add_f32 (no return, lane-private)", k_dsadd, 16}, {"ds_write_b32", k_dswrite, 16},
   };
   printf("device %s, %d CUs, %.3f GHz (hipDeviceProp clockRate), %d wave(s) per SIMD, %d x 16 instructions per wave\n",
          prop.name, cus, ghz, waves_per_simd, ITER);
