@@ -369,13 +369,21 @@ struct CurveF {
       if constexpr (F16X) {
         const half2_t x2 = {_Float16(xA), _Float16(xB)};  // exact: values came from fp16 storage
         const half2_t g2 = {_Float16(gA), _Float16(gB)};
-        const half2_t z2 = {_Float16(0.f), _Float16(0.f)};
-        const half2_t xp = __builtin_elementwise_max(x2, z2);
+        // x^ = clamp(x, 0, 1) of both halves: ONE v_pk_max_f16 x, x clamp (it also canonicalises, so the seven
+        // v_pk_min below need no quieting first); E_8 = min(x^, 1) = x^ needs no min at all
+        half2_t xp;
+        asm("v_pk_max_f16 %0, %1, 0 clamp" : "=v"(xp) : "v"(x2));  // max(-0, +0) = +0: the bit-pattern order below needs it
+        // x^ and the thresholds are non-negative fp16 values, whose order is the order of their bit patterns:
+        // the seven minima run as v_pk_min_u16 (an integer op is never preceded by a quieting v_pk_max)
+        typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+        const ushort2_t xb = __builtin_bit_cast(ushort2_t, xp);
 #pragma unroll
-        for (int i = 1; i <= L; ++i) {
-          const half2_t t2 = {_Float16(float(i) / L), _Float16(float(i) / L)};
-          a[i - 1] = __builtin_amdgcn_fdot2(g2, __builtin_elementwise_min(xp, t2), a[i - 1], false);
+        for (int i = 1; i < L; ++i) {
+          const unsigned short tb = __builtin_bit_cast(unsigned short, _Float16(float(i) / L));
+          const ushort2_t mb = __builtin_elementwise_min(xb, ushort2_t{tb, tb});
+          a[i - 1] = __builtin_amdgcn_fdot2(g2, __builtin_bit_cast(half2_t, mb), a[i - 1], false);
         }
+        a[L - 1] = __builtin_amdgcn_fdot2(g2, xp, a[L - 1], false);
       } else {
         const float xcA = clamp01x(xA, 0.0f, 1.0f), xcB = clamp01x(xB, 0.0f, 1.0f);
 #pragma unroll
@@ -399,8 +407,12 @@ struct CurveF {
             for (int i = 1; i <= L; ++i) a[i - 1] = fmaf(pB, fminf(xc, float(i) / L), a[i - 1]);
           }
         }
-        d[iA] = (gA + pA) * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xA)));
-        d[iB] = (gB + pB) * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xB)));
+        if constexpr (HAS_PEN) {  // (x + 0.0f is not a no-op for the compiler: -0 + 0 = +0)
+          gA += pA;
+          gB += pB;
+        }
+        d[iA] = gA * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xA)));
+        d[iB] = gB * slope16(lut, cc, __builtin_bit_cast(unsigned short, _Float16(xB)));
       } else {
         d[iA] = gA * lut_slope(lut, cc, xA, clamp01x(xA, 0.0f, 1.0f));
         d[iB] = gB * lut_slope(lut, cc, xB, clamp01x(xB, 0.0f, 1.0f));

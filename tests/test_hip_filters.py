@@ -583,6 +583,28 @@ def test_curve_backward_on_every_fp16_value(fid, gpu_device):
   assert not bad.any(), 'dx wrong for x = %r (got %r, want %r)' % (x[bad][:8], dx[bad][:8], rdx[bad][:8])
 
 
+@pytest.mark.parametrize('fid', [4, 7])
+@pytest.mark.parametrize('value', [-0.0, 0.0, -1.0, 1.0, 2.0, float('inf'), -float('inf')])
+def test_curve_backward_accumulators_at_the_clamp_edges(fid, value, gpu_device):
+  """Images made of ONE value at / beyond the ends of [0, 1] (fp16 storage: the packed accumulation clamps with
+  one v_pk_max ... clamp and takes its minima on the bit patterns, which must see -0.0 as +0): the parameter
+  gradients must be the oracle's -- exactly zero for x <= 0."""
+  dev = gpu_device
+  shape = (2, 16, 24, 3)
+  x = np.full(shape, value, dtype=np.float16)
+  rng = np.random.default_rng(11)
+  dy = synthetic.make_grad(rng, shape, np.float16)
+  p = synthetic.make_params(rng, fid, shape[0])
+  _, dx, dp = run_fwd_bwd(fid, x, dy, p, torch.float16, dev)
+  xo = np.clip(x.astype(np.float64), -1e30, 1e30)
+  rdx, rdp = fnp.backward_packed(fid, xo, p.astype(np.float64), dy.astype(np.float64))
+  assert_image_close(dx, rdx, np.float16, 'dx')
+  if value <= 0:
+    assert np.abs(rdp).max() == 0.0 and np.abs(dp).max() == 0.0, dp
+  else:
+    assert_param_grad_close(dp, rdp, np.abs(dy.astype(np.float64)).reshape(2, -1).sum(axis=1, keepdims=True), 'dparams')
+
+
 def test_dispatch_streaming_policy_equals_cached_policy(gpu_device):
   """Same check for the per-image dispatch (the agent's one-hot select): 10 images x 512x512 (15.7 MB,
   streaming kernels) against the same images in two 5-image calls (7.9 MB, cached kernels); every
