@@ -540,6 +540,7 @@ struct FinishStep {
   const int32_t* ids;     // dispatch: per-image filter ids
   int kind, filter_id, accumulate;
   float scale;            // stats: 1 / (H W); penalty: 1 / (H W 3)
+  int bx;                 // records per image (the streaming kernel's gridDim.x)
 };
 constexpr int kMaxFinishSteps = 12;
 struct FinishArgs { FinishStep s[kMaxFinishSteps]; };
@@ -554,8 +555,9 @@ __device__ __forceinline__ void finish_filter(const FinishStep& st, const float*
 }
 
 constexpr int kFinishThreads = 256;
-__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const FinishArgs args, int bx) {
+__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const FinishArgs args) {
   const FinishStep st = args.s[blockIdx.y];
+  const int bx = st.bx;
   const int n = blockIdx.x, lane = threadIdx.x & 63;
   __shared__ float part[kFinishThreads / kWsSlots][kWsSlots];
   __shared__ float tot[kWsSlots];
@@ -673,8 +675,21 @@ static int ws_check(void* workspace, size_t workspace_bytes, int n, int blocks_x
   return EXPO_OK;
 }
 
-static int launch_finish(const FinishArgs& args, int steps, int n, int bx, hipStream_t s) {
-  hipLaunchKernelGGL(finish_kernel, dim3(n, steps), dim3(kFinishThreads), 0, s, args, bx);
+static int geom_bx(int kind, int n, int h, int w, int dtype) {
+  return dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}, kind).blocks_x : make_geom<float>(n, h, w, {}, kind).blocks_x;
+}
+// the largest per-image record count any reducing entry point uses: the stride of a chain's per-step slices
+static int geom_bx_max(int n, int h, int w, int dtype) {
+  int bx = 1;
+  for (int kind = kGeomReduce; kind < kNumGeomKinds; ++kind) {
+    const int b = geom_bx(kind, n, h, w, dtype);
+    if (b > bx) bx = b;
+  }
+  return bx;
+}
+
+static int launch_finish(const FinishArgs& args, int steps, int n, hipStream_t s) {
+  hipLaunchKernelGGL(finish_kernel, dim3(n, steps), dim3(kFinishThreads), 0, s, args);
   HIP_TRY(hipGetLastError(), "finish launch");
   return EXPO_OK;
 }
@@ -696,7 +711,8 @@ static int launch_fwd(const void* x, void* y, const float* params, int n, int h,
 template <class F, typename T>
 static int launch_bwd(const void* x, const void* dy, void* dx, const float* params, float* records, int n,
                       int h, int w, int mode, hipStream_t s, int rev) {
-  const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
+  constexpr int kKind = F::kLutFloats > 0 ? (F::NP == kCurveSteps ? kGeomReduceTone : kGeomReduceColor) : kGeomReduce;
+  const Geom g = make_geom<T>(n, h, w, {x, dy, dx}, kKind);
   const dim3 grid(g.blocks_x, n), block(kThreads);
 #define EXPO_LIO(VEC, HAS_DX, MODE, IO)                                                                  \
   hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, HAS_DX, MODE, IO>), grid, block, 0, s, (const T*)x, \
@@ -779,7 +795,7 @@ static int launch_apply_fwd(const void* x, void* y, const float* params, const f
 template <class F, typename T>
 static int launch_apply_bwd(const void* x, const void* dy, void* dx, const float* params, const float* mp,
                             float* records, float sharp, float ms, int n, int h, int w, int mode, hipStream_t s) {
-  const Geom g = make_geom<T>(n, h, w, {x, dy, dx});
+  const Geom g = make_geom<T>(n, h, w, {x, dy, dx}, kGeomApply);
   const dim3 grid(g.blocks_x, n), block(kThreads);
 #define EXPO_L(VEC, HAS_DX, MODE)                                                                          \
   hipLaunchKernelGGL((apply_bwd_kernel<F, T, VEC, HAS_DX, MODE>), grid, block, 0, s, (const T*)x,          \
@@ -860,8 +876,8 @@ static int dispatch_fwd_t(const int32_t* ids, const void* x, void* y, const floa
   HIP_TRY(hipGetLastError(), "dispatch_fwd launch");
   if (penalty) {
     FinishArgs fa{};
-    fa.s[0] = FinishStep{nullptr, penalty, nullptr, records, ids, kFinPenalty, 0, 0, 1.0f / (float(g.hw) * 3.0f)};
-    return launch_finish(fa, 1, n, g.blocks_x, s);
+    fa.s[0] = FinishStep{nullptr, penalty, nullptr, records, ids, kFinPenalty, 0, 0, 1.0f / (float(g.hw) * 3.0f), g.blocks_x};
+    return launch_finish(fa, 1, n, s);
   }
   return EXPO_OK;
 }
@@ -908,8 +924,8 @@ static int dispatch_bwd_t(const int32_t* ids, const void* x, const void* dy, voi
 #undef EXPO_L2
   HIP_TRY(hipGetLastError(), "dispatch_bwd launch");
   FinishArgs fa{};
-  fa.s[0] = FinishStep{params, dparams, nullptr, records, ids, kFinDispatch, 0, 0, 0.f};
-  return launch_finish(fa, 1, n, g.blocks_x, s);
+  fa.s[0] = FinishStep{params, dparams, nullptr, records, ids, kFinDispatch, 0, 0, 0.f, g.blocks_x};
+  return launch_finish(fa, 1, n, s);
 }
 
 template <typename T>
@@ -924,8 +940,8 @@ static int stats_t(const void* x, float* stats, int n, int h, int w, void* works
   else hipLaunchKernelGGL((stats_kernel<T, false, IoCached>), grid, block, 0, s, (const T*)x, records, g.hw, g.groups);
   HIP_TRY(hipGetLastError(), "stats launch");
   FinishArgs fa{};
-  fa.s[0] = FinishStep{nullptr, stats, nullptr, records, nullptr, kFinStats, 0, 0, 1.0f / float(g.hw)};
-  return launch_finish(fa, 1, n, g.blocks_x, s);
+  fa.s[0] = FinishStep{nullptr, stats, nullptr, records, nullptr, kFinStats, 0, 0, 1.0f / float(g.hw), g.blocks_x};
+  return launch_finish(fa, 1, n, s);
 }
 
 template <typename T>
@@ -940,8 +956,8 @@ static int penalty_t(const void* y, float* pen, int n, int h, int w, void* works
   else hipLaunchKernelGGL((penalty_kernel<T, false, IoCached>), grid, block, 0, s, (const T*)y, records, g.hw, g.groups);
   HIP_TRY(hipGetLastError(), "penalty launch");
   FinishArgs fa{};
-  fa.s[0] = FinishStep{nullptr, pen, nullptr, records, nullptr, kFinPenalty, 0, 0, 1.0f / (float(g.hw) * 3.0f)};
-  return launch_finish(fa, 1, n, g.blocks_x, s);
+  fa.s[0] = FinishStep{nullptr, pen, nullptr, records, nullptr, kFinPenalty, 0, 0, 1.0f / (float(g.hw) * 3.0f), g.blocks_x};
+  return launch_finish(fa, 1, n, s);
 }
 
 }  // namespace expo
@@ -978,11 +994,7 @@ int expo_num_filter_params(int filter_id) {
 
 size_t expo_workspace_bytes(int n, int h, int w, int dtype) {
   if (check_common(n, h, w, dtype) != EXPO_OK || n == 0) return 0;
-  int bx = 1;
-  for (int kind : {int(kGeomReduce), int(kGeomReadReduce), int(kGeomDispatch)}) {
-    const Geom g = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}, kind) : make_geom<float>(n, h, w, {}, kind);
-    if (g.blocks_x > bx) bx = g.blocks_x;
-  }
+  const int bx = geom_bx_max(n, h, w, dtype);
   return ws_step_bytes(n, bx);
 }
 
@@ -1006,7 +1018,7 @@ static int filter_bwd_common(int filter_id, const void* x, const void* dy, void*
   if (n == 0) return EXPO_OK;
   if (!x || !dy || !params || !dparams) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int bx = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}).blocks_x : make_geom<float>(n, h, w, {}).blocks_x;
+  const int bx = geom_bx(bwd_geom_kind(filter_id), n, h, w, dtype);
   float* records;
   if (int rc = ws_check(workspace, workspace_bytes, n, bx, 1, &records)) return rc;
   const int rc = dtype == EXPO_F16
@@ -1014,8 +1026,8 @@ static int filter_bwd_common(int filter_id, const void* x, const void* dy, void*
                      : bwd_by_id<float>(filter_id, x, dy, dx, params, records, n, h, w, hsv_grad_mode, s);
   if (rc) return rc;
   FinishArgs fa{};
-  fa.s[0] = FinishStep{params, dparams, nullptr, records, nullptr, kFinFilter, filter_id, accum ? 1 : 0, 0.f};
-  return launch_finish(fa, 1, n, bx, s);
+  fa.s[0] = FinishStep{params, dparams, nullptr, records, nullptr, kFinFilter, filter_id, accum ? 1 : 0, 0.f, bx};
+  return launch_finish(fa, 1, n, s);
 }
 
 int expo_filter_bwd(int filter_id, const void* x, const void* dy, void* dx, const float* params, float* dparams,
@@ -1056,7 +1068,7 @@ int expo_filter_apply_bwd(int filter_id, const void* x, const void* dy, void* dx
   if (n == 0) return EXPO_OK;
   if (!x || !dy || !params || !dparams || !mask_params || !dmask_params) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int bx = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}).blocks_x : make_geom<float>(n, h, w, {}).blocks_x;
+  const int bx = geom_bx(kGeomApply, n, h, w, dtype);
   float* records;
   if (int rc = ws_check(workspace, workspace_bytes, n, bx, 1, &records)) return rc;
   const int rc = dtype == EXPO_F16
@@ -1066,8 +1078,8 @@ int expo_filter_apply_bwd(int filter_id, const void* x, const void* dy, void* dx
                                               minimum_strength, n, h, w, hsv_grad_mode, s);
   if (rc) return rc;
   FinishArgs fa{};
-  fa.s[0] = FinishStep{params, dparams, dmask_params, records, nullptr, kFinApply, filter_id, 0, 0.f};
-  return launch_finish(fa, 1, n, bx, s);
+  fa.s[0] = FinishStep{params, dparams, dmask_params, records, nullptr, kFinApply, filter_id, 0, 0.f, bx};
+  return launch_finish(fa, 1, n, s);
 }
 
 int expo_filter_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y, const float* params,
@@ -1123,7 +1135,7 @@ int expo_filter_bwd_records(int filter_id, const void* x, const void* dy, void* 
   if (n == 0) return EXPO_OK;
   if (!x || !dy || !params) return fail(EXPO_E_BADARG, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int bx = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}).blocks_x : make_geom<float>(n, h, w, {}).blocks_x;
+  const int bx = geom_bx(bwd_geom_kind(filter_id), n, h, w, dtype);
   float* rec;
   if (int rc = ws_check(records, records_bytes, n, bx, 1, &rec)) return rc;
   return dtype == EXPO_F16 ? bwd_by_id<half_t>(filter_id, x, dy, dx, params, rec, n, h, w, hsv_grad_mode, s)
@@ -1136,10 +1148,12 @@ int expo_finish_bwd(const int* filter_ids, int steps, const float* const* params
   if (int rc = check_common(n, h, w, dtype)) return rc;
   if (n == 0 || steps == 0) return EXPO_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int bx = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}).blocks_x : make_geom<float>(n, h, w, {}).blocks_x;
+  // a step's records sit at the start of its slice; slices are strided by the largest record count of any kernel,
+  // each step's kernel wrote (and this launch reads) the count of ITS geometry
+  const int bx_max = geom_bx_max(n, h, w, dtype);
   float* records;
-  if (int rc = ws_check(workspace, workspace_bytes, n, bx, steps, &records)) return rc;
-  const size_t step_floats = ws_step_bytes(n, bx) / sizeof(float);
+  if (int rc = ws_check(workspace, workspace_bytes, n, bx_max, steps, &records)) return rc;
+  const size_t step_floats = ws_step_bytes(n, bx_max) / sizeof(float);
   for (int i = 0; i < steps; ++i) {
     if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
     if (!params[i] || !dparams[i]) return fail(EXPO_E_BADARG, "null pointer");
@@ -1149,8 +1163,9 @@ int expo_finish_bwd(const int* filter_ids, int steps, const float* const* params
     FinishArgs fa{};
     for (int k = 0; k < cnt; ++k)
       fa.s[k] = FinishStep{params[i0 + k], dparams[i0 + k], nullptr, records + size_t(i0 + k) * step_floats, nullptr,
-                           kFinFilter, filter_ids[i0 + k], 0, 0.f};
-    if (int rc = launch_finish(fa, cnt, n, bx, s)) return rc;
+                           kFinFilter, filter_ids[i0 + k], 0, 0.f,
+                           geom_bx(bwd_geom_kind(filter_ids[i0 + k]), n, h, w, dtype)};
+    if (int rc = launch_finish(fa, cnt, n, s)) return rc;
   }
   return EXPO_OK;
 }
@@ -1170,10 +1185,10 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
   }
   // every step's kernel writes its block records into its own slice of the workspace; ONE finish launch
   // (per kMaxFinishSteps steps) then produces all the dparams
-  const int bx = dtype == EXPO_F16 ? make_geom<half_t>(n, h, w, {}).blocks_x : make_geom<float>(n, h, w, {}).blocks_x;
+  const int bx_max = geom_bx_max(n, h, w, dtype);
   float* records;
-  if (int rc = ws_check(workspace, workspace_bytes, n, bx, steps, &records)) return rc;
-  const size_t step_floats = ws_step_bytes(n, bx) / sizeof(float);
+  if (int rc = ws_check(workspace, workspace_bytes, n, bx_max, steps, &records)) return rc;
+  const size_t step_floats = ws_step_bytes(n, bx_max) / sizeof(float);
   for (int i = steps - 1; i >= 0; --i) {
     if (!acts[i] || !grads[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
     float* rec = records + size_t(i) * step_floats;

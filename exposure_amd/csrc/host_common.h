@@ -46,7 +46,18 @@ inline int env_int(const char* name, int dflt) {
 
 // a reducing kernel writes one workspace record per block: bound the records of one image
 constexpr int kMaxReduceBlocksX = 1024;
-enum GeomKind { kGeomMap = 0, kGeomReduce = 1, kGeomReadReduce = 2, kGeomDispatch = 3 };
+enum GeomKind {
+  kGeomMap = 0,         // forward kernels
+  kGeomReduce = 1,      // backward of the element-wise filters
+  kGeomReadReduce = 2,  // read-only reductions (statistics, penalty)
+  kGeomDispatch = 3,    // per-image dispatch backward
+  kGeomReduceTone = 4,  // backward of Tone / Color: every block first stages its image's slope table, so fewer,
+  kGeomReduceColor = 5, //   fatter blocks pay (Tone: 2 KB table, Color: 6 KB)
+  kGeomApply = 6,       // masked apply backward
+  kNumGeomKinds = 7
+};
+// geometry of the plain backward of one filter (expo_filter_bwd / _records / expo_chain_bwd / expo_finish_bwd)
+inline int bwd_geom_kind(int filter_id) { return filter_id == 4 ? kGeomReduceTone : filter_id == 7 ? kGeomReduceColor : kGeomReduce; }
 
 // groups of 48 bytes per image; blocks per image chosen so the whole grid is >= ~1024
 // blocks when the problem allows and each thread walks a few groups (amortises the
@@ -61,14 +72,20 @@ inline Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
   g.vec = (g.hw % VecTraits<T>::PPV) == 0;  // dwordx3 path: whole 12-byte vectors, 4-byte aligned
   for (const void* p : ptrs) g.vec = g.vec && (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 3) == 0);
   const int max_bx = (g.groups + kThreads - 1) / kThreads;
-  // groups each thread walks: kernels with a reduction epilogue (one workspace record per block) want
-  // fewer, fatter blocks; pure maps (forward) stream best with many blocks (tools/membench.hip)
-  static const int gpt_red = env_int("EXPO_BWD_GROUPS_PER_THREAD", 4);
-  static const int gpt_map = env_int("EXPO_FWD_GROUPS_PER_THREAD", 1);
-  static const int gpt_read = env_int("EXPO_RED_GROUPS_PER_THREAD", 4);  // read-only reductions (stats, penalty)
-  static const int gpt_disp = env_int("EXPO_DISPATCH_GROUPS_PER_THREAD", 4);  // per-image dispatch backward
-  const int gpt = kind == kGeomReduce ? gpt_red : kind == kGeomReadReduce ? gpt_read : kind == kGeomDispatch ? gpt_disp
-                                                                                                           : gpt_map;
+  // groups each thread walks (measured per kernel at 64x512x512, gpurun r02p35: the light backward kernels stream
+  // best with ONE group per thread like the forward kernels -- 45.6-46.2 vs 47.4-48.3 us at four --, while the
+  // curve kernels pay their per-block table staging: Tone 54.7 / 47.7 / 48.2 and Color 70.3 / 53.9 / 53.1 us
+  // at 1 / 2 / 4 groups per thread)
+  static const int gpt_kind[kNumGeomKinds] = {
+      env_int("EXPO_FWD_GROUPS_PER_THREAD", 1),       env_int("EXPO_BWD_GROUPS_PER_THREAD", 1),
+      env_int("EXPO_RED_GROUPS_PER_THREAD", 4),       env_int("EXPO_DISPATCH_GROUPS_PER_THREAD", 4),
+      env_int("EXPO_TONE_GROUPS_PER_THREAD", 2),      env_int("EXPO_COLOR_GROUPS_PER_THREAD", 4),
+      env_int("EXPO_APPLY_GROUPS_PER_THREAD", 4)};
+  int gpt = gpt_kind[kind >= 0 && kind < kNumGeomKinds ? kind : kGeomReduce];
+  // beyond the Infinity Cache (one tensor >= 256 MiB: HBM-cold streams, images walked in alternating order) the
+  // light backward kernels are back to four groups per thread: 2.556 vs 2.595 ms per chain step at 256x512x512
+  static const bool bwd_gpt_forced = getenv("EXPO_BWD_GROUPS_PER_THREAD") != nullptr;
+  if (kind == kGeomReduce && !bwd_gpt_forced && long(n) * g.hw * 3L * long(sizeof(T)) >= (256L << 20) && gpt < 4) gpt = 4;
   int bx = (g.groups + kThreads * gpt - 1) / (kThreads * gpt);
   const long want = 1024;
   if (long(bx) * n < want) bx = int((want + n - 1) / n);
