@@ -139,9 +139,15 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   // masked path scales dy -> generic path there.
   constexpr bool kF16X = std::is_same<T, half_t>::value;
   // staged AFTER the first chunk's loads are in flight on the vector path (stream_groups' prologue)
+  // fp16 vector path: the table is built from a per-lane copy of the parameters, fetched HERE -- before the first
+  // image loads are issued -- so that nothing in the staging waits behind them (CurveF::stage16_lanes)
+  constexpr bool kLaneStage = F::kLutFloats > 0 && kF16X && VEC;
+  float klane = 0.f;
+  if constexpr (kLaneStage) klane = prm[(threadIdx.x & 63) % F::NP];
   auto stage_lut = [&]() {
     if constexpr (F::kLutFloats > 0) {
-      F::template stage_for<kF16X>(prm, lut);
+      if constexpr (kLaneStage) F::stage16_lanes(klane, lut);
+      else F::template stage_for<kF16X>(prm, lut);
       __syncthreads();
     }
   };

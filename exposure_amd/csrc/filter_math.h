@@ -322,6 +322,37 @@ struct CurveF {
       lut[t * 2 + 1] = slope_closed(k, scale, x_ex);
     }
   }
+  // The same table from a PER-LANE copy of the parameters (lane l < NC*L of every wave holds k[l], fetched by ONE
+  // vector load issued before the image loads), indexed through wave shuffles: staging then has no dependent
+  // global loads queued behind the first image chunk (vector loads return in order), which was most of its
+  // latency.  All 64 lanes of every wave must be active; bit-identical to stage16 (same summation order).
+  __device__ static float slope_closed_lanes(float klane, int c, float scale, float x) {
+    const float u = x * float(L);
+    const bool in = (u >= 0.0f && u <= float(L));
+    const float jf = floorf(in ? u : 0.0f);
+    const int j = int(jf);  // 0..L
+    const float kj = __shfl(klane, c * L + (j < L ? j : L - 1));
+    const float kp = __shfl(klane, c * L + (j >= 1 ? j - 1 : 0));
+    float sl = (j < L) ? kj : 0.0f;
+    if (jf == u && j >= 1) sl = kp + sl;
+    return in ? scale * sl : 0.0f;
+  }
+  __device__ static void stage16_lanes(float klane, float* lut) {
+    typedef _Float16 half_s;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {  // entries t = c * 256 + threadIdx.x (blockDim.x == 256)
+      float S = 0.f;
+#pragma unroll
+      for (int i = 0; i < L; ++i) S += __shfl(klane, c * L + i);
+      S += 1e-30f;
+      const float scale = float(L) / S;
+      const int h = threadIdx.x & 255, t = c * 256 + h;
+      const unsigned short b_in = (unsigned short)((h << 8) | 1), b_ex = (unsigned short)(h << 8);
+      const float x_in = float(__builtin_bit_cast(half_s, b_in)), x_ex = float(__builtin_bit_cast(half_s, b_ex));
+      lut[t * 2 + 0] = slope_closed_lanes(klane, c, scale, x_in);
+      lut[t * 2 + 1] = slope_closed_lanes(klane, c, scale, x_ex);
+    }
+  }
   __device__ static float slope16(const float* lut, int cc, unsigned short bits) {
     const float2_lut e = *reinterpret_cast<const float2_lut*>(lut + (cc * 256 + (bits >> 8)) * 2);
     return (bits & 0xFF) ? e.x : e.y;

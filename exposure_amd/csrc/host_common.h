@@ -79,7 +79,7 @@ inline Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
   static const int gpt_kind[kNumGeomKinds] = {
       env_int("EXPO_FWD_GROUPS_PER_THREAD", 1),       env_int("EXPO_BWD_GROUPS_PER_THREAD", 1),
       env_int("EXPO_RED_GROUPS_PER_THREAD", 4),       env_int("EXPO_DISPATCH_GROUPS_PER_THREAD", 4),
-      env_int("EXPO_TONE_GROUPS_PER_THREAD", 2),      env_int("EXPO_COLOR_GROUPS_PER_THREAD", 4),
+      env_int("EXPO_TONE_GROUPS_PER_THREAD", 2),      env_int("EXPO_COLOR_GROUPS_PER_THREAD", 2),
       env_int("EXPO_APPLY_GROUPS_PER_THREAD", 4)};
   int gpt = gpt_kind[kind >= 0 && kind < kNumGeomKinds ? kind : kGeomReduce];
   // beyond the Infinity Cache (one tensor >= 256 MiB: HBM-cold streams, images walked in alternating order) the
