@@ -269,6 +269,72 @@ __global__ __launch_bounds__(256) void cpol2(const uint32_t* __restrict__ a, uin
 }
 
 
+// cpol3: what kind of work between a wave's loads and stores costs the copy skeleton its ~3 us?  KIND 0: COUNT
+// integer xors per dword; 1: COUNT dependent fp32 fmas per dword; 2: COUNT fp16 -> fp32 -> fp16 round trips per
+// dword; 3: no arithmetic, COUNT x s_sleep 1 (64 clocks each) between the last load's return and the stores;
+// 4: like 0 but ALL four rows are processed before the first store (the shape of the real kernels);
+// 5: batched stores, ONE xor per row on its first dword only (cpol's work); 6: batched stores, no work.
+template <int KIND, int COUNT>
+__global__ __launch_bounds__(256) void cpol3(const uint32_t* __restrict__ a, uint32_t* __restrict__ b, size_t nrows,
+                                             int nbytes, float scale) {
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, nbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, nbytes, 0x00020000);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (size_t r = (size_t(blockIdx.x) * 4 + wave) * 4; r < nrows; r += size_t(gridDim.x) * 16) {
+    u32x3 v[4];
+    const int off = int(r) * 768 + lane * 12;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b96(ra, off + j * 768, 0, 2);
+    auto work = [&](int j) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        uint32_t w = v[j][e];
+        if constexpr (KIND == 0 || KIND == 4) {
+#pragma unroll
+          for (int k = 0; k < COUNT; ++k) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(w) : "v"(uint32_t(k + 1)));
+        } else if constexpr (KIND == 1) {
+          float f = __builtin_bit_cast(float, w);
+#pragma unroll
+          for (int k = 0; k < COUNT; ++k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f) : "v"(scale));
+          w = __builtin_bit_cast(uint32_t, f);
+        } else if constexpr (KIND == 2) {
+#pragma unroll
+          for (int k = 0; k < COUNT; ++k) {
+            float lo, hi;
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(lo) : "v"(w));
+            asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(hi) : "v"(w));
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
+          }
+        }
+        v[j][e] = w;
+      }
+    };
+    if constexpr (KIND == 3) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < COUNT; ++k) __builtin_amdgcn_s_sleep(1);
+    }
+    if constexpr (KIND == 5) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j].x ^= 1u;
+    }
+    if constexpr (KIND >= 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if constexpr (KIND == 4) work(j);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b96(v[j], rb, off + j * 768, 0, 16);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (KIND != 3) work(j);
+        __builtin_amdgcn_raw_buffer_store_b96(v[j], rb, off + j * 768, 0, 16);
+      }
+    }
+  }
+}
+
 // rpol3: read-read-write with nt loads + sc1 stores, moved towards a real backward kernel:
 // LDSKB limits the occupancy (160 KiB LDS per CU / LDSKB blocks), PF prefetches the next chunk pair.
 template <int LDSKB, bool PF>
@@ -352,7 +418,18 @@ int main(int argc, char** argv) {
   const int reps = argc > 3 ? atoi(argv[3]) : 40;
   const bool pol_only = argc > 4;  // any 4th argument: cache-policy sweep only (PMC calibration runs)
   std::vector<u32x4*> buf(nbuf);
-  for (auto& p : buf) { CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 1, bytes)); }
+  const bool random_fill = argc > 5;  // any 5th argument: pseudo-random buffer contents instead of 0x01 bytes
+  for (auto& p : buf) {
+    CK(hipMalloc(&p, bytes));
+    CK(hipMemset(p, 1, bytes));
+    if (random_fill) {
+      std::vector<uint32_t> h(bytes / 4);
+      uint32_t x = 2463534242u;
+      for (auto& w : h) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; w = x & 0x3bff3bffu; }  // two fp16 values in [0, 1)
+      CK(hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice));
+    }
+  }
+  printf("buffer contents: %s\n", random_fill ? "pseudo-random fp16 pairs" : "0x01 bytes");
   const size_t n16 = bytes / 16, ngroups = bytes / 48;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -403,6 +480,19 @@ int main(int argc, char** argv) {
 #undef CPOL2
     }
 
+    if (grid == 8192 && argc > 4 && argv[4][0] == 'w') {  // "work" sweep only
+#define CPOL3(K, C) run("cpol3 kind" #K " count" #C, 2, [&](int i) { cpol3<K, C><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes), 1.0f); });
+      run("cpol L2 S16 (reference)", 2, [&](int i) { cpol<2, 16><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes)); });
+      CPOL3(5, 0) CPOL3(6, 0)
+      run("cpol L2 S16 (reference)", 2, [&](int i) { cpol<2, 16><<<grid, 256>>>((const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes)); });
+      CPOL3(0, 0) CPOL3(0, 1) CPOL3(0, 4) CPOL3(0, 16) CPOL3(0, 64)
+      CPOL3(1, 1) CPOL3(1, 4) CPOL3(1, 16) CPOL3(1, 64)
+      CPOL3(2, 1) CPOL3(2, 4) CPOL3(2, 16)
+      CPOL3(3, 1) CPOL3(3, 4) CPOL3(3, 16)
+      CPOL3(4, 1) CPOL3(4, 16) CPOL3(5, 0) CPOL3(6, 0)
+#undef CPOL3
+      continue;
+    }
     if (grid <= 8192) {
 #define RPOL3(K, P) run("rpol3 lds" #K " pf" #P, 3, [&](int i) { rpol3<K, P><<<grid, 256>>>((const uint32_t*)buf[(i + 4) % nbuf], (const uint32_t*)buf[i % nbuf], (uint32_t*)buf[(i + 1) % nbuf], bytes / 768, int(bytes)); });
       RPOL3(1, 0) RPOL3(1, 1) RPOL3(26, 0) RPOL3(26, 1) RPOL3(32, 0) RPOL3(32, 1) RPOL3(40, 0) RPOL3(40, 1)
