@@ -100,3 +100,27 @@ def test_float32_openmp_chain_matches_the_float64_chain():
     scale = max(1.0, float(np.abs(dp).max()))
     np.testing.assert_allclose(ch.dparams[fid], dp, rtol=5e-3, atol=5e-3 * scale)
   np.testing.assert_allclose(ch.dx, g, rtol=5e-3, atol=5e-3 * float(np.abs(g).max()))
+
+
+def test_cpu_baseline_worker_protocol():
+  """bench.py times the float32 / OpenMP build through `python -m oracle.filters_c SHAPE THREADS [BUDGET]` (one
+  process per thread count): one JSON line with the rate, the thread count in effect and the number of runs."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, OMP_NUM_THREADS='2', OMP_WAIT_POLICY='passive', PYTHONPATH=root)
+  out = subprocess.run([sys.executable, '-m', 'oracle.filters_c', 'A', '2', '0.5'], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=120)
+  assert out.returncode == 0, out.stderr
+  rec = json.loads(out.stdout.strip().splitlines()[-1])
+  assert rec['threads'] == 2 and rec['runs'] >= 2 and rec['Mpixels_per_s'] > 0
+
+
+def test_bench_c_port_rate_runs_the_worker():
+  import importlib
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  bench = importlib.import_module('bench')
+  assert bench._c_port_rates('A', 1, budget_s=0.5) > 0
