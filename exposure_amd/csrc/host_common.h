@@ -63,7 +63,7 @@ inline int bwd_geom_kind(int filter_id) { return filter_id == 4 ? kGeomReduceTon
 // blocks when the problem allows and each thread walks a few groups (amortises the
 // reduction epilogue); capped at 2048-ish total blocks (grid-stride the rest).
 template <typename T>
-inline Geom make_geom(int n, int h, int w, std::initializer_list<const void*> ptrs, int kind = kGeomReduce) {
+inline Geom make_geom(int n, int h, int w, std::initializer_list<const void*> ptrs, int kind) {
   const bool reduces = kind != kGeomMap;
   constexpr int PPL = PixTraits<T>::PPL;
   Geom g;
