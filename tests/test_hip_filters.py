@@ -400,6 +400,36 @@ def test_masked_apply_matches_oracle(fid, shape, gpu_device):
   assert_param_grad_close(traw.grad.cpu().numpy(), rdraw.numpy(), np.broadcast_to(scale, raw.shape), 'masked dmask')
 
 
+@pytest.mark.parametrize('fid', [0, 3, 4, 5, 7])
+def test_masked_apply_fp16_storage_every_value(fid, gpu_device):
+  """The fp16 instantiations of the masked kernels (vector path; Tone / Color re-evaluate their forward through the
+  per-wave segment table) on 2x256x256x3: every value of y and dx, the parameter and the mask-parameter gradients
+  against the float64 torch restatement."""
+  from oracle import filters_torch as ft
+  from exposure_amd.util import tanh_range
+  dev = gpu_device
+  shape = (2, 256, 256, 3)
+  rng = np.random.default_rng(900 + fid)
+  x, dy, _ = synthetic.make_case(910 + fid, shape, np.float16)
+  p = synthetic.make_params(rng, fid, shape[0])
+  raw = rng.standard_normal((shape[0], 6)).astype(np.float32)
+  sharp, ms = 1.0, 0.3
+  ry, rdx, rdp, rdraw = ft.apply_masked_backward(fid, torch.from_numpy(x).double(), torch.from_numpy(p).double(),
+                                                 torch.from_numpy(raw).double(), torch.from_numpy(dy).double(), sharp, ms)
+  tx = torch.from_numpy(x).to(dev).requires_grad_(True)
+  tp = torch.from_numpy(p).to(dev).requires_grad_(True)
+  traw = torch.from_numpy(raw).to(dev).requires_grad_(True)
+  mp = tanh_range(-5, 5, initial=0)(traw)
+  y = filters._MaskedApplyFunction.apply(tx, tp, mp, fid, sharp, ms, 0)
+  assert y.dtype == torch.float16
+  y.backward(torch.from_numpy(dy).to(dev))
+  assert_image_close(y.detach().float().cpu().numpy(), ry.numpy(), np.float16, 'masked y')
+  assert_image_close(tx.grad.float().cpu().numpy(), rdx.numpy(), np.float16, 'masked dx')
+  scale = np.abs(dy.astype(np.float64)).reshape(shape[0], -1).sum(axis=1, keepdims=True) * 4
+  assert_param_grad_close(tp.grad.cpu().numpy(), rdp.numpy(), np.broadcast_to(scale, p.shape), 'masked dparams')
+  assert_param_grad_close(traw.grad.cpu().numpy(), rdraw.numpy(), np.broadcast_to(scale, raw.shape), 'masked dmask')
+
+
 def test_filter_apply_with_masking_enabled(gpu_device):
   from oracle import filters_torch as ft
   dev = gpu_device
