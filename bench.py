@@ -61,6 +61,10 @@ def parse():
   ap.add_argument('--cold-shape', default='256,512,512',
                   help="chain workload: also time the dominant kernel on tensors of this shape (384 MiB each, beyond "
                   "the 256 MiB Infinity Cache) for roofline.hbm_cold; 'none' disables")
+  ap.add_argument('--miopen-find', default='on', choices=['on', 'off'],
+                  help="train workload: MIOpen's benchmark ('find') kernel selection (on: ~10 %% faster iterations; the "
+                  "library default is off -- EXPO_MIOPEN_FIND -- because find-mode trial kernels faulted once inside a "
+                  "380-test process, gpurun r03p9; a benchmark runs in a fresh process)")
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                   help='replay the 17 launches of a step from one hipGraph (auto = on; off: eager C-ABI calls)')
   return ap.parse_args()
@@ -355,6 +359,7 @@ def run_train(args, world, rank, dev, dist):
   from exposure_amd.gan import GAN
   cfg = make_cfg()
   torch.manual_seed(args.seed)  # identical initial weights on every rank
+  os.environ.setdefault('EXPO_MIOPEN_FIND', '1' if args.miopen_find == 'on' else '0')
   gan = GAN(cfg, device=dev, use_graphs=(args.graph != 'off'))
   # weak: cfg.batch_size (64) images per GPU; strong: the reference's global batch of 64 split image-wise
   n = local_shape((cfg.batch_size,), world, args.scaling)[0]
@@ -424,6 +429,7 @@ def run_train(args, world, rank, dev, dist):
             'parallelism': 'dp%d image-sharded; flat gradient buckets (theta_g heads / trunks, theta_v, theta_c) '
                            'all-reduced over RCCL from backward hooks' % world,
             'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
+            'miopen_find': bool(torch.backends.cudnn.benchmark),
             'reference_note': 'README.md:43: ~0.30 s/iteration on a GTX 1080 Ti (whole run ~100 min / 20000 it)',
         },
     }), flush=True)

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # never a non-HIP implementation.
 LIB_PATH = os.environ.get('EXPO_HIP_LIB') or os.path.join(_HERE, 'libexposure_hip.so')
 
-EXPO_ABI_VERSION = 2
+EXPO_ABI_VERSION = 3
 EXPO_F16, EXPO_F32 = 0, 1
 EXPO_MAX_PARAMS = 24
 NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24, 2)  # ids 0..7 = cfg.filters order, 8 = LevelFilter
@@ -47,6 +47,12 @@ SIGNATURES = {
     'expo_chain_fused_fwd': (_i, [_vp, _fp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'expo_critic_stats': (_i, [_vp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_overexposure_penalty': (_i, [_vp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_overexposure_penalty_bwd': (_i, [_vp, _fp, _vp, _i, _i, _i, _i, _vp]),
+    'expo_critic_stats_bwd': (_i, [_vp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
+    'expo_critic_stats_jvp': (_i, [_vp, _fp, _vp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_critic_stats_hvp': (_i, [_vp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'expo_bias_lrelu_fwd': (_i, [_fp, _fp, _fp, _sz, _i, _f, _vp]),
+    'expo_lrelu_bwd': (_i, [_fp, _fp, _fp, _sz, _f, _vp]),
 }
 
 _lib = None
@@ -378,3 +384,84 @@ def overexposure_penalty(y, penalty, workspace=None):
     wsp, wsb = _ws(y, workspace)
     _check(lib.expo_overexposure_penalty(_ptr(y), _ptr(penalty), n, h, w, _dtype_code(y), wsp, wsb, _stream()),
            'expo_overexposure_penalty')
+
+
+def overexposure_penalty_bwd(y, dpenalty, dy):
+  lib = load()
+  _img(y, 'y'), _img(dy, 'dy')
+  n, h, w, _ = y.shape
+  assert dy.shape == y.shape and dy.dtype == y.dtype
+  _f32(dpenalty, 'dpenalty', (n,))
+  with torch.cuda.device(y.device):
+    _check(lib.expo_overexposure_penalty_bwd(_ptr(y), _ptr(dpenalty), _ptr(dy), n, h, w, _dtype_code(y), _stream()),
+           'expo_overexposure_penalty_bwd')
+
+
+def critic_stats_bwd(x, stats, dstats, dx):
+  """dx = J^T dstats (first derivative of the critic statistics)."""
+  lib = load()
+  _img(x, 'x'), _img(dx, 'dx')
+  n, h, w, _ = x.shape
+  assert dx.shape == x.shape and dx.dtype == x.dtype
+  _f32(stats, 'stats', (n, 3)), _f32(dstats, 'dstats', (n, 3))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_critic_stats_bwd(_ptr(x), _ptr(stats), _ptr(dstats), _ptr(dx), n, h, w, _dtype_code(x), _stream()),
+           'expo_critic_stats_bwd')
+
+
+def critic_stats_jvp(x, stats, v, jv, workspace=None):
+  """jv = J v (N, 3): the derivative of <critic_stats_bwd(x, g), v> with respect to g."""
+  lib = load()
+  _img(x, 'x'), _img(v, 'v')
+  n, h, w, _ = x.shape
+  assert v.shape == x.shape and v.dtype == x.dtype
+  _f32(stats, 'stats', (n, 3)), _f32(jv, 'jv', (n, 3))
+  with torch.cuda.device(x.device):
+    wsp, wsb = _ws(x, workspace)
+    _check(lib.expo_critic_stats_jvp(_ptr(x), _ptr(stats), _ptr(v), _ptr(jv), n, h, w, _dtype_code(x), wsp, wsb,
+                                     _stream()), 'expo_critic_stats_jvp')
+
+
+def critic_stats_hvp(x, dstats, jv, v, out):
+  """out = d <critic_stats_bwd(x, dstats), v> / dx (jv = critic_stats_jvp(x, stats, v))."""
+  lib = load()
+  _img(x, 'x'), _img(v, 'v'), _img(out, 'out')
+  n, h, w, _ = x.shape
+  assert v.shape == x.shape and v.dtype == x.dtype and out.shape == x.shape and out.dtype == x.dtype
+  _f32(dstats, 'dstats', (n, 3)), _f32(jv, 'jv', (n, 3))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_critic_stats_hvp(_ptr(x), _ptr(dstats), _ptr(jv), _ptr(v), _ptr(out), n, h, w, _dtype_code(x),
+                                     _stream()), 'expo_critic_stats_hvp')
+
+
+def _dense_f32(t, name):
+  if not isinstance(t, torch.Tensor) or not t.is_cuda:
+    raise ExposureHipError('exposure_amd: %s must be a tensor on a ROCm device (HIP path only, no CPU fallback)' %
+                           name)
+  if t.dtype != torch.float32 or not t.is_contiguous():
+    raise ExposureHipError('exposure_amd: %s must be a contiguous float32 tensor, got %s' % (name, t.dtype))
+  return t
+
+
+def bias_lrelu_fwd(y, bias, z, leak=0.2):
+  """z = lrelu(y + bias) with the channel as the LAST dimension of y (bias may be None)."""
+  lib = load()
+  _dense_f32(y, 'y'), _dense_f32(z, 'z')
+  assert z.shape == y.shape
+  channels = 1
+  if bias is not None:
+    _dense_f32(bias, 'bias')
+    channels = int(y.shape[-1])
+    assert bias.numel() == channels
+  with torch.cuda.device(y.device):
+    _check(lib.expo_bias_lrelu_fwd(_ptr(y), _ptr(bias), _ptr(z), y.numel(), channels, float(leak), _stream()),
+           'expo_bias_lrelu_fwd')
+
+
+def lrelu_bwd(z, dz, dy, leak=0.2):
+  """dy = dz * lrelu'(.) with the slope read from the activation's OUTPUT z."""
+  lib = load()
+  _dense_f32(z, 'z'), _dense_f32(dz, 'dz'), _dense_f32(dy, 'dy')
+  assert dz.shape == z.shape and dy.shape == z.shape
+  with torch.cuda.device(z.device):
+    _check(lib.expo_lrelu_bwd(_ptr(z), _ptr(dz), _ptr(dy), z.numel(), float(leak), _stream()), 'expo_lrelu_bwd')

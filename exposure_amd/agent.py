@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from . import filters as F
+from .nn_ops import bias_lrelu, conv2d_nhwc
 from .util import (STATE_DROPOUT_BEGIN, STATE_REWARD_DIM, STATE_STEP_DIM, STATE_STOPPED_DIM,
                    enrich_image_input, lrelu)
 
@@ -63,11 +64,11 @@ class FeatureExtractor(nn.Module):
     self.to(memory_format=torch.channels_last)
 
   def forward(self, net_nhwc, dropout_mask=None):
-    # NHWC storage viewed as NCHW/channels_last: no copy, MIOpen picks its NHWC kernels
-    net = (net_nhwc.float() - 0.5).permute(0, 3, 1, 2)
+    # NHWC end to end (the convolutions see channels_last views: no copy, MIOpen picks its NHWC kernels)
+    net = net_nhwc.float() - 0.5
     for conv in self.convs:
-      net = lrelu(conv(net))
-    net = net.permute(0, 2, 3, 1).reshape(net.shape[0], self.output_dim)  # TF reshape order (H,W,C)
+      net = bias_lrelu(conv2d_nhwc(net, conv.weight), conv.bias)
+    net = net.reshape(net.shape[0], self.output_dim)  # TF reshape order (H,W,C)
     if dropout_mask is None:
       dropout_mask = (torch.rand_like(net) < self.keep_prob).to(net.dtype)
     # tf.nn.dropout: x / keep_prob * mask

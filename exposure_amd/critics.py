@@ -4,37 +4,78 @@
 as constant feature planes (+ optional state planes) -> ``cnn`` (critics.py:6-38: ``x - 0.5``,
 four conv4x4/s2 + lrelu, no norm) -> FC128 lrelu -> FC1.
 
-The statistics are computed with differentiable torch ops inside the training graph (the
-gradient-penalty term needs a double backward through everything the critic does to its input,
-net.py:174-194); :func:`critic_stats` is the fused HIP reduction (``expo_critic_stats``) for
-inference-side callers.  ``lrelu`` (``util.py:225-229``: ``0.6 x + 0.4 |x|``) is one fused forward kernel with a
-differentiable backward (``exposure_amd.util._Lrelu``), so the double backward exists.
+The statistics are HIP reductions INSIDE the training graph (:func:`stat_features`): forward
+``expo_critic_stats``, first derivative ``expo_critic_stats_bwd`` (the generator's reward flows through
+``critic(fake_output)``, net.py:68-90), and the derivative of that derivative -- the gradient-penalty term
+differentiates ``D(x^)`` with respect to ``x^`` and then with respect to the critic's weights
+(net.py:174-194) -- ``expo_critic_stats_jvp`` / ``expo_critic_stats_hvp``.  ~15 torch element-wise /
+reduction launches forward, ~30 backward and ~60 in the double backward become 2 + 1 + 3.
+``lrelu`` (``util.py:225-229``: ``0.6 x + 0.4 |x|``) is one fused forward kernel with a differentiable
+backward (``exposure_amd.util._Lrelu``), so the double backward exists there too.
 """
 import torch
 from torch import nn
+from torch.autograd.function import once_differentiable
 
 from . import _cabi
+from .nn_ops import bias_lrelu, conv2d_nhwc
 from .util import lrelu
 
 
+class _CriticStatsGrad(torch.autograd.Function):
+  """dx = J^T g for the statistics' Jacobian J (``expo_critic_stats_bwd``); its own backward -- the double
+  backward of the WGAN-GP term -- is J v for g (``expo_critic_stats_jvp``: the path to the critic's weights)
+  and the second-order term d<J^T g, v>/dx for the image (``expo_critic_stats_hvp``)."""
+
+  @staticmethod
+  def forward(ctx, x, g, stats):
+    g = g.contiguous().float()
+    dx = torch.empty_like(x)
+    _cabi.critic_stats_bwd(x, stats, g, dx)
+    ctx.save_for_backward(x, g, stats)
+    return dx
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, v):
+    x, g, stats = ctx.saved_tensors
+    v = v.contiguous().to(x.dtype)
+    jv = torch.empty_like(g)
+    _cabi.critic_stats_jvp(x, stats, v, jv)
+    gx = None
+    if ctx.needs_input_grad[0]:
+      gx = torch.empty_like(x)
+      _cabi.critic_stats_hvp(x, g, jv, v, gx)
+    return gx, jv, None
+
+
+class _CriticStats(torch.autograd.Function):
+  """stats = [mean lum, var lum, mean saturation] per image (``expo_critic_stats``), twice differentiable."""
+
+  @staticmethod
+  def forward(ctx, x):
+    stats = torch.empty((x.shape[0], 3), dtype=torch.float32, device=x.device)
+    _cabi.critic_stats(x, stats)
+    ctx.save_for_backward(x, stats)
+    return stats
+
+  @staticmethod
+  def backward(ctx, g):
+    x, stats = ctx.saved_tensors
+    # the mean the first derivative reads is a function of x too: expo_critic_stats_hvp carries that dependence,
+    # so `stats` enters as a constant here
+    return _CriticStatsGrad.apply(x, g, stats.detach())
+
+
 def stat_features(images):
-  """critics.py:48-73 on NHWC ``images`` -> (N, 3) [mean lum, var lum, mean saturation]."""
-  images = images.float()
-  lum = images[:, :, :, 0] * 0.27 + images[:, :, :, 1] * 0.67 + images[:, :, :, 2] * 0.06 + 1e-5
-  luminance = lum.mean(dim=(1, 2))
-  contrast = lum.var(dim=(1, 2), unbiased=False)  # tf.nn.moments: population variance
-  clipped = images.clamp(0.0, 1.0)
-  # amax/amin split the gradient evenly between tied maxima, like tf.reduce_max/min
-  i_max = clipped.amax(dim=3)
-  i_min = clipped.amin(dim=3)
-  a, b = i_max + i_min, 2.0 - i_max - i_min
-  sat = (i_max - i_min) / (torch.where(a <= b, a, b) + 1e-2)  # tf.minimum(x, y): ties go to x
-  saturation = sat.mean(dim=(1, 2))
-  return torch.stack([luminance, contrast, saturation], dim=1)
+  """critics.py:48-73 on NHWC ``images`` -> (N, 3) [mean lum, var lum, mean saturation], through the HIP
+  reductions, differentiable twice.  The gradients are O(1 / (H W)) per pixel, far below fp16's normal range,
+  so the image enters as float32 (the reference's dtype)."""
+  return _CriticStats.apply(images.float().contiguous())
 
 
 def critic_stats(images):
-  """Same three statistics through the HIP reduction kernel (no autograd)."""
+  """The same three statistics without autograd, on the image's own dtype (inference-side callers)."""
   stats = torch.empty((images.shape[0], 3), dtype=torch.float32, device=images.device)
   _cabi.critic_stats(images.contiguous(), stats)
   return stats
@@ -76,10 +117,10 @@ class Critic(nn.Module):
     n, h, w, _ = images.shape
     planes = states[:, None, None, :].expand(n, h, w, states.shape[1])
     net = torch.cat([images, planes], dim=3)
-    net = (net - 0.5).permute(0, 3, 1, 2)  # NHWC storage, channels_last view
+    net = net - 0.5  # NHWC; the convolutions see channels_last views
     for conv in self.convs:
-      net = lrelu(conv(net))
-    net = net.permute(0, 2, 3, 1).reshape(n, self.flat)
+      net = bias_lrelu(conv2d_nhwc(net, conv.weight), conv.bias)
+    net = net.reshape(n, self.flat)
     net = lrelu(self.fc1(net))
     return self.fc2(net)
 

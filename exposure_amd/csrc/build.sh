@@ -1,7 +1,8 @@
 #!/bin/bash
 # Build libexposure_hip.so for gfx950 in-tree (the .so is git-ignored but travels with gpurun).
-# Two translation units: the streaming kernels (default flags) and the VALU-bound fused inference
-# kernel (-fno-slp-vectorize -fno-honor-nans, see chain_fused.hip); extra arguments go to both compile steps.
+# Three translation units: the streaming kernels (default flags), the VALU-bound fused inference kernel
+# (-fno-slp-vectorize -fno-honor-nans, see chain_fused.hip) and the convnets' activation (nn_ops.hip); extra
+# arguments go to every compile step.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${EXPO_LIB_OUT:-$HERE/../libexposure_hip.so}"
@@ -10,7 +11,14 @@ TMP="$(mktemp -d)"
 trap 'rm -rf "$TMP"' EXIT
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC)
 "$HIPCC" "${FLAGS[@]}" "$@" -c "$HERE/exposure_hip.hip" -o "$TMP/exposure_hip.o" &
+p1=$!
 "$HIPCC" "${FLAGS[@]}" -fno-slp-vectorize -fno-honor-nans "$@" -c "$HERE/chain_fused.hip" -o "$TMP/chain_fused.o" &
-wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$TMP/exposure_hip.o" "$TMP/chain_fused.o" -o "$OUT"
+p2=$!
+"$HIPCC" "${FLAGS[@]}" "$@" -c "$HERE/nn_ops.hip" -o "$TMP/nn_ops.o" &
+p3=$!
+# (a bare `wait` returns 0 whatever the jobs did: wait for each PID so a failed compile stops the script here)
+wait $p1
+wait $p2
+wait $p3
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$TMP/exposure_hip.o" "$TMP/chain_fused.o" "$TMP/nn_ops.o" -o "$OUT"
 echo "built $OUT"

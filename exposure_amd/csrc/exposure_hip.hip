@@ -533,11 +533,205 @@ __global__ __launch_bounds__(kThreads) void penalty_kernel(const T* __restrict__
   block_reduce_record<1>(acc, records + size_t(n) * gridDim.x * kWsSlots);
 }
 
+// d penalty / d y (agent.py:249-251): dy = 2 max(y - 1, 0) dpenalty[n] / (H W 3).  A map, 12 B/px.
+template <typename T, bool VEC, class IO>
+__global__ __launch_bounds__(kThreads) void penalty_bwd_kernel(const T* __restrict__ y, const float* __restrict__ dpen,
+                                                               T* __restrict__ dy, int hw, int groups, float inv_count) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  const float sc = 2.0f * inv_count * dpen[n];
+  const int stride = gridDim.x * kThreads;
+  auto compute = [&](float* v) {
+#pragma unroll
+    for (int j = 0; j < PPL * 3; ++j) v[j] = fmaxf(v[j] - 1.0f, 0.0f) * sc;
+  };
+  if constexpr (VEC) {
+    const T* const ins[1] = {y + off};
+    stream_groups<T, 1, true, false, IO>(ins, dy + off, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                         [&](float (&v)[1][PPL * 3], int) { compute(v[0]); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3];
+      load_slow<T>(y + off, g, hw, v);
+      compute(v);
+      store_slow<T>(dy + off, g, hw, v);
+    }
+  }
+}
+
+// ---------------------------------------------- critic statistics: first and second derivatives
+// The critic's three statistics sit INSIDE the training graph: the generator's reward flows through
+// critic(fake_output) (net.py:68-90), and the WGAN-GP term differentiates D(x^) with respect to x^ and then that
+// gradient with respect to theta_c (net.py:174-194) -- a double backward through everything the critic does to its
+// input, the statistics planes included.  Three kernels cover it (stats = S(x), J = dS/dx, per image):
+//   stats_bwd   dx      = J^T g                      (g = dL/dstats, [N][3])              map, 12 B/px
+//   stats_jvp   jv      = J v                        (v an image; = d<dx, v>/dg)          read-only reduction, 12 B/px
+//   stats_hvp   out     = d<J^T g, v>/dx             (the second-order term in x)         map, 18 B/px
+// Conventions (oracle/nets_np.py::stat_features_backward): tf.nn.moments is the population variance (its mean is
+// a stop_gradient in TF, which leaves the first derivative unchanged); reduce_max / reduce_min split the gradient
+// evenly between tied channels; clip_by_value passes on 0 <= x <= 1 inclusive; tf.minimum(x=a, y=b) sends ties to a.
+struct SatPix {
+  float a[3], b[3];       // d max / d x_j and d min / d x_j
+  float fmx, fmn;         // d sat / d max, d sat / d min
+  float hxx, hxn, hnn;    // second derivatives of sat in (max, min)   (HESS only)
+};
+template <bool HESS>
+__device__ __forceinline__ SatPix sat_pix(const float p[3]) {
+  SatPix s;
+  float c[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c[j] = clamp01x(p[j], 0.f, 1.f);
+  const float mx = fmaxf(fmaxf(c[0], c[1]), c[2]), mn = fminf(fminf(c[0], c[1]), c[2]);
+  const int nmax = (c[0] == mx) + (c[1] == mx) + (c[2] == mx), nmin = (c[0] == mn) + (c[1] == mn) + (c[2] == mn);
+  const float imax = nmax == 1 ? 1.0f : (nmax == 2 ? 0.5f : 1.0f / 3.0f);
+  const float imin = nmin == 1 ? 1.0f : (nmin == 2 ? 0.5f : 1.0f / 3.0f);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const bool in = p[j] >= 0.f && p[j] <= 1.f;
+    s.a[j] = (in && c[j] == mx) ? imax : 0.f;
+    s.b[j] = (in && c[j] == mn) ? imin : 0.f;
+  }
+  const float sa = mx + mn, sb = 2.0f - mx - mn;
+  const bool use_a = sa <= sb;
+  const float sg = use_a ? 1.0f : -1.0f;
+  const float r = fast_rcp((use_a ? sa : sb) + 1e-2f);  // denominator >= 1e-2
+  const float num = mx - mn;
+  const float t = num * sg * r * r;
+  s.fmx = r - t;
+  s.fmn = -r - t;
+  if constexpr (HESS) {
+    const float q = 2.0f * num * r * r * r, e = 2.0f * sg * r * r;
+    s.hxx = q - e;
+    s.hxn = q;
+    s.hnn = q + e;
+  }
+  return s;
+}
+
+template <typename T, bool VEC, class IO>
+__global__ __launch_bounds__(kThreads) void stats_bwd_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                             const float* __restrict__ dstats, T* __restrict__ dx,
+                                                             int hw, int groups, float inv_hw) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  const float mean = stats[n * 3];
+  const float g0 = dstats[n * 3] * inv_hw, g1 = dstats[n * 3 + 1] * 2.0f * inv_hw, g2 = dstats[n * 3 + 2] * inv_hw;
+  const int stride = gridDim.x * kThreads;
+  auto compute = [&](float* v) {
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      float* p = v + 3 * k;
+      const float l = (p[0] * kLumR + p[1] * kLumG) + p[2] * kLumB + 1e-5f;
+      const float dl = fmaf(g1, l - mean, g0);
+      const SatPix s = sat_pix<false>(p);
+      p[0] = fmaf(kLumR, dl, g2 * (s.fmx * s.a[0] + s.fmn * s.b[0]));
+      p[1] = fmaf(kLumG, dl, g2 * (s.fmx * s.a[1] + s.fmn * s.b[1]));
+      p[2] = fmaf(kLumB, dl, g2 * (s.fmx * s.a[2] + s.fmn * s.b[2]));
+    }
+  };
+  if constexpr (VEC) {
+    const T* const ins[1] = {x + off};
+    stream_groups<T, 1, true, false, IO>(ins, dx + off, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                         [&](float (&v)[1][PPL * 3], int) { compute(v[0]); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3];
+      load_slow<T>(x + off, g, hw, v);
+      compute(v);
+      store_slow<T>(dx + off, g, hw, v);
+    }
+  }
+}
+
+template <typename T, bool VEC, class IO>
+__global__ __launch_bounds__(kThreads) void stats_jvp_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                             const T* __restrict__ vimg, float* __restrict__ records,
+                                                             int hw, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  const float mean = stats[n * 3];
+  float acc[3] = {0.f, 0.f, 0.f};
+  const int stride = gridDim.x * kThreads;
+  auto compute = [&](const float* xv, const float* vv) {  // padding pixels carry v = 0 and add nothing
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      const float* p = xv + 3 * k;
+      const float* d = vv + 3 * k;
+      const float l = (p[0] * kLumR + p[1] * kLumG) + p[2] * kLumB + 1e-5f;
+      const float wv = (d[0] * kLumR + d[1] * kLumG) + d[2] * kLumB;
+      acc[0] += wv;
+      acc[1] = fmaf(l - mean, wv, acc[1]);
+      const SatPix s = sat_pix<false>(p);
+      const float vm = s.a[0] * d[0] + s.a[1] * d[1] + s.a[2] * d[2];
+      const float vn = s.b[0] * d[0] + s.b[1] * d[1] + s.b[2] * d[2];
+      acc[2] += s.fmx * vm + s.fmn * vn;
+    }
+  };
+  if constexpr (VEC) {
+    const T* const ins[2] = {x + off, vimg + off};
+    stream_groups<T, 2, false, true, IO>(ins, (T*)nullptr, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                         [&](float (&v)[2][PPL * 3], int) { compute(v[0], v[1]); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3], d[PPL * 3];
+      load_slow<T>(x + off, g, hw, v);
+      load_slow<T>(vimg + off, g, hw, d);
+      compute(v, d);
+    }
+  }
+  acc[1] *= 2.0f;
+  block_reduce_record<3>(acc, records + size_t(n) * gridDim.x * kWsSlots);
+}
+
+template <typename T, bool VEC, class IO>
+__global__ __launch_bounds__(kThreads) void stats_hvp_kernel(const T* __restrict__ x, const float* __restrict__ dstats,
+                                                             const float* __restrict__ jv, const T* __restrict__ vimg,
+                                                             T* __restrict__ out, int hw, int groups, float inv_hw) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * hw * 3;
+  const float jv0 = jv[n * 3];  // mean over the image of w . v
+  const float g1 = dstats[n * 3 + 1] * 2.0f * inv_hw, g2 = dstats[n * 3 + 2] * inv_hw;
+  const int stride = gridDim.x * kThreads;
+  auto compute = [&](const float* xv, float* d) {
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      const float* p = xv + 3 * k;
+      float* q = d + 3 * k;
+      const float wv = (q[0] * kLumR + q[1] * kLumG) + q[2] * kLumB;
+      const float dv = g1 * (wv - jv0);  // variance: d/dx of (2/HW) sum (l - mean)(w . v)
+      const SatPix s = sat_pix<true>(p);
+      const float vm = s.a[0] * q[0] + s.a[1] * q[1] + s.a[2] * q[2];
+      const float vn = s.b[0] * q[0] + s.b[1] * q[1] + s.b[2] * q[2];
+      const float dfx = g2 * (s.hxx * vm + s.hxn * vn), dfn = g2 * (s.hxn * vm + s.hnn * vn);
+      q[0] = fmaf(kLumR, dv, s.a[0] * dfx + s.b[0] * dfn);
+      q[1] = fmaf(kLumG, dv, s.a[1] * dfx + s.b[1] * dfn);
+      q[2] = fmaf(kLumB, dv, s.a[2] * dfx + s.b[2] * dfn);
+    }
+  };
+  if constexpr (VEC) {
+    const T* const ins[2] = {x + off, vimg + off};
+    stream_groups<T, 2, true, false, IO>(ins, out + off, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                         [&](float (&v)[2][PPL * 3], int) { compute(v[0], v[1]); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3], d[PPL * 3];
+      load_slow<T>(x + off, g, hw, v);
+      load_slow<T>(vimg + off, g, hw, d);
+      compute(v, d);
+      store_slow<T>(out + off, g, hw, d);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------- finish
 // One wave per (image, step): adds the image's bx block records in a fixed order and writes the final
 // per-image values.  Steps of a chain (or the single step of any other entry point) are described by
 // value in the kernel arguments.
-enum FinishKind : int { kFinFilter = 0, kFinDispatch = 1, kFinApply = 2, kFinStats = 3, kFinPenalty = 4 };
+enum FinishKind : int { kFinFilter = 0, kFinDispatch = 1, kFinApply = 2, kFinStats = 3, kFinPenalty = 4, kFinScaled = 5 };
 struct FinishStep {
   const float* params;    // [n][P] (filter / apply), [n][EXPO_MAX_PARAMS] (dispatch)
   float* out;             // dparams [n][P] | [n][24]; stats [n][3]; penalty [n]
@@ -608,6 +802,9 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const FinishArgs
     } break;
     case kFinPenalty:  // agent.py:249-251 (also the fused penalty of the dispatch forward; id -1 -> 0)
       if (lane == 0) st.out[n] = nothing ? 0.0f : tot[0] * st.scale;
+      break;
+    case kFinScaled:  // out[n][0..filter_id) = totals * scale (the statistics' Jacobian-vector product)
+      if (lane < st.filter_id) st.out[n * st.filter_id + lane] = tot[lane] * st.scale;
       break;
     default: {
       const bool disp = st.kind == kFinDispatch;
@@ -968,6 +1165,64 @@ static int penalty_t(const void* y, float* pen, int n, int h, int w, void* works
   return launch_finish(fa, 1, n, s);
 }
 
+template <typename T>
+static int penalty_bwd_t(const void* y, const float* dpen, void* dy, int n, int h, int w, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {y, dy}, kGeomMap);
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  const float inv_count = 1.0f / (float(g.hw) * 3.0f);
+#define EXPO_L(VEC, IO) \
+  hipLaunchKernelGGL((penalty_bwd_kernel<T, VEC, IO>), grid, block, 0, s, (const T*)y, dpen, (T*)dy, g.hw, g.groups, inv_count)
+  if (g.stream) EXPO_L(true, IoStream); else if (g.vec) EXPO_L(true, IoCached); else EXPO_L(false, IoCached);
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "penalty_bwd launch");
+  return EXPO_OK;
+}
+
+template <typename T>
+static int stats_bwd_t(const void* x, const float* stats, const float* dstats, void* dx, int n, int h, int w,
+                       hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, dx}, kGeomMap);
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  const float inv_hw = 1.0f / float(g.hw);
+#define EXPO_L(VEC, IO) \
+  hipLaunchKernelGGL((stats_bwd_kernel<T, VEC, IO>), grid, block, 0, s, (const T*)x, stats, dstats, (T*)dx, g.hw, g.groups, inv_hw)
+  if (g.stream) EXPO_L(true, IoStream); else if (g.vec) EXPO_L(true, IoCached); else EXPO_L(false, IoCached);
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "stats_bwd launch");
+  return EXPO_OK;
+}
+
+template <typename T>
+static int stats_jvp_t(const void* x, const float* stats, const void* v, float* jv, int n, int h, int w,
+                       void* workspace, size_t workspace_bytes, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, v}, kGeomReadReduce);
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  float* records;
+  if (int rc = ws_check(workspace, workspace_bytes, n, g.blocks_x, 1, &records)) return rc;
+#define EXPO_L(VEC, IO) \
+  hipLaunchKernelGGL((stats_jvp_kernel<T, VEC, IO>), grid, block, 0, s, (const T*)x, stats, (const T*)v, records, g.hw, g.groups)
+  if (g.stream) EXPO_L(true, IoStream); else if (g.vec) EXPO_L(true, IoCached); else EXPO_L(false, IoCached);
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "stats_jvp launch");
+  FinishArgs fa{};
+  fa.s[0] = FinishStep{nullptr, jv, nullptr, records, nullptr, kFinScaled, 3, 0, 1.0f / float(g.hw), g.blocks_x};
+  return launch_finish(fa, 1, n, s);
+}
+
+template <typename T>
+static int stats_hvp_t(const void* x, const float* dstats, const float* jv, const void* v, void* out, int n, int h,
+                       int w, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, v, out}, kGeomMap);
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  const float inv_hw = 1.0f / float(g.hw);
+#define EXPO_L(VEC, IO) \
+  hipLaunchKernelGGL((stats_hvp_kernel<T, VEC, IO>), grid, block, 0, s, (const T*)x, dstats, jv, (const T*)v, (T*)out, g.hw, g.groups, inv_hw)
+  if (g.stream) EXPO_L(true, IoStream); else if (g.vec) EXPO_L(true, IoCached); else EXPO_L(false, IoCached);
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "stats_hvp launch");
+  return EXPO_OK;
+}
+
 }  // namespace expo
 
 // ======================================================================== C-ABI
@@ -1230,6 +1485,46 @@ int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == EXPO_F16 ? penalty_t<half_t>(y, penalty, n, h, w, workspace, workspace_bytes, s)
                            : penalty_t<float>(y, penalty, n, h, w, workspace, workspace_bytes, s);
+}
+
+int expo_overexposure_penalty_bwd(const void* y, const float* dpenalty, void* dy, int n, int h, int w, int dtype,
+                                  void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!y || !dpenalty || !dy) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? penalty_bwd_t<half_t>(y, dpenalty, dy, n, h, w, s)
+                           : penalty_bwd_t<float>(y, dpenalty, dy, n, h, w, s);
+}
+
+int expo_critic_stats_bwd(const void* x, const float* stats, const float* dstats, void* dx, int n, int h, int w,
+                          int dtype, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!x || !stats || !dstats || !dx) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? stats_bwd_t<half_t>(x, stats, dstats, dx, n, h, w, s)
+                           : stats_bwd_t<float>(x, stats, dstats, dx, n, h, w, s);
+}
+
+int expo_critic_stats_jvp(const void* x, const float* stats, const void* v, float* jv, int n, int h, int w, int dtype,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!x || !stats || !v || !jv) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? stats_jvp_t<half_t>(x, stats, v, jv, n, h, w, workspace, workspace_bytes, s)
+                           : stats_jvp_t<float>(x, stats, v, jv, n, h, w, workspace, workspace_bytes, s);
+}
+
+int expo_critic_stats_hvp(const void* x, const float* dstats, const float* jv, const void* v, void* out, int n, int h,
+                          int w, int dtype, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!x || !dstats || !jv || !v || !out) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? stats_hvp_t<half_t>(x, dstats, jv, v, out, n, h, w, s)
+                           : stats_hvp_t<float>(x, dstats, jv, v, out, n, h, w, s);
 }
 
 }  // extern "C"

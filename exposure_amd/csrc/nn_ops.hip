@@ -1,0 +1,113 @@
+// nn_ops.hip -- the activation of the convnets that drive the filter path: lrelu (util.py:225-229) fused with the
+// bias add in front of it, and its gradient (feature_extractor agent.py:21-32, cnn critics.py:13-35, the FC heads
+// filters.py:31-42, agent.py:87-99, critics.py:94-97).  The GEMMs / convolutions themselves stay with MIOpen /
+// hipBLASLt (MFMA); what sits between them is element-wise fp32 work that torch issues as 3 launches forward
+// (bias add, leaky_relu) and 4 per backward (sign, mul, add, mul) -- at the 64x64 proxy resolution every one of
+// them is launch-bound, and a training iteration runs ~100 of each.  One launch each here.
+//   z  = lrelu(y + bias[c])              channel = fastest dimension (NHWC conv outputs, (N, C) FC outputs)
+//   dy = dz * (z > 0 ? 1 : z < 0 ? leak : (1 + leak) / 2)
+// The slope is read from the OUTPUT z: lrelu keeps the sign (and the zero) of its argument.  At exactly 0 the
+// reference's formula f1 x + f2 |x| has TF's sub-gradient f1 = (1 + leak) / 2 (tf.abs has gradient 0 there), not
+// leaky_relu's `leak`.  The gradient is linear in dz, so the same kernel is its own double backward (the WGAN-GP
+// term differentiates the critic's input gradient again, net.py:174-194).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/exposure_hip.h"
+#include "host_common.h"
+
+namespace expo {
+
+__device__ __forceinline__ float lrelu1(float v, float leak) { return v > 0.f ? v : v * leak; }
+__device__ __forceinline__ float lrelu_slope(float z, float leak) {
+  return z > 0.f ? 1.0f : (z < 0.f ? leak : 0.5f * (1.0f + leak));
+}
+
+// VEC: count % 4 == 0, channels % 4 == 0 (or no bias), 16-byte aligned pointers -> one float4 per thread iteration
+template <bool VEC, bool BIAS>
+__global__ __launch_bounds__(256) void bias_lrelu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                             float* __restrict__ z, size_t count, int channels,
+                                                             float leak) {
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  if constexpr (VEC) {
+    const size_t n4 = count / 4;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      float4 v = reinterpret_cast<const float4*>(y)[i];
+      if constexpr (BIAS) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + (i * 4) % size_t(channels));
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      v.x = lrelu1(v.x, leak); v.y = lrelu1(v.y, leak); v.z = lrelu1(v.z, leak); v.w = lrelu1(v.w, leak);
+      reinterpret_cast<float4*>(z)[i] = v;
+    }
+  } else {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride) {
+      float v = y[i];
+      if constexpr (BIAS) v += bias[i % size_t(channels)];
+      z[i] = lrelu1(v, leak);
+    }
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dz,
+                                                        float* __restrict__ dy, size_t count, float leak) {
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  if constexpr (VEC) {
+    const size_t n4 = count / 4;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const float4 a = reinterpret_cast<const float4*>(z)[i];
+      float4 g = reinterpret_cast<const float4*>(dz)[i];
+      g.x *= lrelu_slope(a.x, leak); g.y *= lrelu_slope(a.y, leak);
+      g.z *= lrelu_slope(a.z, leak); g.w *= lrelu_slope(a.w, leak);
+      reinterpret_cast<float4*>(dy)[i] = g;
+    }
+  } else {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride)
+      dy[i] = dz[i] * lrelu_slope(z[i], leak);
+  }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int grid_for(size_t items) {
+  const size_t blocks = (items + 255) / 256;
+  return int(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));  // grid-stride beyond 1 M items
+}
+
+}  // namespace expo
+
+using namespace expo;
+
+extern "C" {
+
+int expo_bias_lrelu_fwd(const float* y, const float* bias, float* z, size_t count, int channels, float leak,
+                        void* stream) {
+  if (count == 0) return EXPO_OK;
+  if (!y || !z) return fail(EXPO_E_BADARG, "null pointer");
+  if (bias && (channels < 1 || count % size_t(channels) != 0))
+    return fail(EXPO_E_BADARG, "count must be a multiple of channels");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = count % 4 == 0 && aligned16(y) && aligned16(z) && (!bias || (channels % 4 == 0 && aligned16(bias)));
+  const int grid = grid_for(vec ? count / 4 : count);
+#define EXPO_L(VEC, BIAS) \
+  hipLaunchKernelGGL((bias_lrelu_fwd_kernel<VEC, BIAS>), dim3(grid), dim3(256), 0, s, y, bias, z, count, channels, leak)
+  if (vec) { if (bias) EXPO_L(true, true); else EXPO_L(true, false); }
+  else { if (bias) EXPO_L(false, true); else EXPO_L(false, false); }
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "bias_lrelu_fwd launch");
+  return EXPO_OK;
+}
+
+int expo_lrelu_bwd(const float* z, const float* dz, float* dy, size_t count, float leak, void* stream) {
+  if (count == 0) return EXPO_OK;
+  if (!z || !dz || !dy) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = count % 4 == 0 && aligned16(z) && aligned16(dz) && aligned16(dy);
+  const int grid = grid_for(vec ? count / 4 : count);
+  if (vec) hipLaunchKernelGGL((lrelu_bwd_kernel<true>), dim3(grid), dim3(256), 0, s, z, dz, dy, count, leak);
+  else hipLaunchKernelGGL((lrelu_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, z, dz, dy, count, leak);
+  HIP_TRY(hipGetLastError(), "lrelu_bwd launch");
+  return EXPO_OK;
+}
+
+}  // extern "C"

@@ -26,9 +26,15 @@ class GAN(nn.Module):
     self.cfg = cfg
     self.use_graphs = bool(use_graphs)
     self._graphs = {}
-    # MIOpen's default heuristic picks a 2 ms kernel for the double-backward convolutions of the
-    # gradient penalty; its benchmark ("find") mode settles on one 2.7x faster (tools/conv_probe.py)
-    torch.backends.cudnn.benchmark = True
+    # MIOpen kernel selection: EXPO_MIOPEN_FIND=1 switches on its benchmark ("find") mode, 0 keeps the immediate-mode
+    # heuristic.  (Rounds 1-2 needed find mode: torch's generic double backward of the gradient penalty runs forward
+    # convolutions with batch and channels swapped, for which the heuristic picked a 2 ms kernel.  Those convolutions
+    # are gone -- exposure_amd/nn_ops.py keeps every derivative on the native forward / data / weight kernels.)
+    # Default off: find mode TRIES every applicable solver on each new problem shape, and one of those trial kernels
+    # faulted (GPU memory access fault, process abort) on gfx950 / ROCm 7.2 deep inside the 380-test gpu suite --
+    # reproducible there, never in a fresh process (gpurun r03p8-12).  bench.py --workload train switches it on
+    # (14.7 vs 16.2 ms per iteration).
+    torch.backends.cudnn.benchmark = os.environ.get('EXPO_MIOPEN_FIND', '0') == '1'
     self.generator = Agent(cfg)
     self.critic = Critic(cfg, num_state_dim=0)
     self.value = Critic(cfg, num_state_dim=cfg.num_state_dim)

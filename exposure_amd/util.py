@@ -31,32 +31,15 @@ class Dict(dict):
     del self[key]
 
 
-class _Lrelu(torch.autograd.Function):
-  """``f1*x + f2*|x|`` (util.py:225-229) as ONE forward kernel, with TF's gradient: d/dx = f1 + f2*sign(x),
-  i.e. 1 for x > 0, ``leak`` for x < 0 and f1 = (1+leak)/2 exactly AT x == 0 (``tf.abs`` has gradient
-  sign(0) = 0 there; ``leaky_relu``'s own backward would give ``leak``).  The backward is written in
-  differentiable torch ops, so the double backward the WGAN-GP term needs (net.py:174-194) exists: the
-  slope does not depend on x almost everywhere, only grad_output carries second-order terms."""
-
-  @staticmethod
-  def forward(ctx, x, leak):
-    ctx.save_for_backward(x)
-    ctx.leak = leak
-    return torch.nn.functional.leaky_relu(x, negative_slope=leak)
-
-  @staticmethod
-  def backward(ctx, grad):
-    x, = ctx.saved_tensors
-    f1, f2 = 0.5 * (1 + ctx.leak), 0.5 * (1 - ctx.leak)
-    slope = torch.add(torch.sign(x).mul_(f2), f1)  # constant w.r.t. x (sign has zero gradient)
-    return grad * slope, None
-
-
 def lrelu(x, leak=0.2):
   """util.py:225-229: ``f1*x + f2*|x|`` with f1 = (1+leak)/2, f2 = (1-leak)/2, i.e. the leaky ReLU
-  ``x if x > 0 else leak*x`` evaluated as one fused kernel (agrees with the literal formula to 1 ulp:
-  0.6x + 0.4x vs x), with the reference's sub-gradient f1 at x == 0 (:class:`_Lrelu`)."""
-  return _Lrelu.apply(x, leak)
+  ``x if x > 0 else leak*x`` (agrees with the literal formula to 1 ulp: 0.6x + 0.4x vs x), with the reference's
+  sub-gradient f1 at x == 0 (``tf.abs`` has gradient sign(0) = 0 there; ``leaky_relu``'s own backward would give
+  ``leak``).  One HIP launch forward and one per backward (``exposure_amd.nn_ops``: ``expo_bias_lrelu_fwd`` /
+  ``expo_lrelu_bwd``); the backward is linear in the incoming gradient and differentiable again, so the double
+  backward the WGAN-GP term needs (net.py:174-194) exists."""
+  from .nn_ops import bias_lrelu
+  return bias_lrelu(x, None, leak)
 
 
 def rgb2lum(image):

@@ -48,7 +48,8 @@
 extern "C" {
 #endif
 
-#define EXPO_ABI_VERSION 2 /* 2: caller-owned reduction workspace (no float atomics, no fills) */
+#define EXPO_ABI_VERSION 3 /* 2: caller-owned reduction workspace (no float atomics, no fills); 3: derivatives of the
+                              critic statistics and of the penalty */
 
 #define EXPO_OK 0
 #define EXPO_E_BADARG (-1)
@@ -246,6 +247,52 @@ int expo_critic_stats(const void* x, float* stats, int n, int h, int w, int dtyp
  */
 int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w,
                               int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * d penalty / d y of expo_overexposure_penalty (what tf.gradients produces for agent.py:249-251 when the
+ * penalty is NOT taken from the fused dispatch pass -- cfg.masking or cfg.clamp, agent.py:240-241):
+ *   dy[n] = 2 * max(y[n] - 1, 0) * dpenalty[n] / (H*W*3).      dy: [N][H][W][3] dtype, overwritten.
+ */
+int expo_overexposure_penalty_bwd(const void* y, const float* dpenalty, void* dy, int n, int h, int w,
+                                  int dtype, void* stream);
+
+/*
+ * Derivatives of expo_critic_stats.  The statistics sit inside the training graph of the reference: the
+ * generator's reward flows through critic(fake_output) (net.py:68-90) and the WGAN-GP term takes
+ * tf.gradients(inte_logit, [interpolated]) and then differentiates THAT with respect to the critic's weights
+ * (net.py:174-194), i.e. a double backward through critics.py:48-73.  With S = the three statistics of one
+ * image and J = dS/dx (3 x H*W*3):
+ *   expo_critic_stats_bwd   dx  = J^T dstats              first derivative (tf.gradients of critics.py:48-62)
+ *   expo_critic_stats_jvp   jv  = J v                     d <dx, v> / d dstats: the path of the double backward
+ *                                                         that reaches the critic's weights
+ *   expo_critic_stats_hvp   out = d <J^T dstats, v> / dx  the second-order term in the image itself
+ * stats: float32 [N][3] as written by expo_critic_stats for the SAME x (the mean luminance is read from it);
+ * dstats, jv: float32 [N][3]; v, dx, out: images of x's dtype (the gradients are O(1/(H*W)): use EXPO_F32 images
+ * when the values matter -- exposure_amd/critics.py always does).  TF conventions: population variance
+ * (tf.nn.moments), reduce_max / reduce_min split the gradient evenly between tied channels, clip_by_value
+ * passes on 0 <= x <= 1 inclusive, tf.minimum(x, y) sends ties to x.
+ */
+int expo_critic_stats_bwd(const void* x, const float* stats, const float* dstats, void* dx, int n, int h,
+                          int w, int dtype, void* stream);
+int expo_critic_stats_jvp(const void* x, const float* stats, const void* v, float* jv, int n, int h, int w,
+                          int dtype, void* workspace, size_t workspace_bytes, void* stream);
+int expo_critic_stats_hvp(const void* x, const float* dstats, const float* jv, const void* v, void* out,
+                          int n, int h, int w, int dtype, void* stream);
+
+/*
+ * The activation of the convnets around the filter path -- lrelu(x) = f1*x + f2*|x| with leak 0.2 (util.py:225-229),
+ * used after every ly.conv2d / ly.fully_connected of feature_extractor (agent.py:21-32), cnn (critics.py:13-35) and
+ * the FC heads (filters.py:31-42, agent.py:87-99, critics.py:94-97) -- fused with the bias add in front of it.
+ *   expo_bias_lrelu_fwd   z[i] = lrelu(y[i] + bias[i % channels])     bias may be NULL (then channels is ignored)
+ *   expo_lrelu_bwd        dy[i] = dz[i] * (z[i] > 0 ? 1 : z[i] < 0 ? leak : (1 + leak) / 2)
+ * float32, `count` contiguous elements, the channel is the fastest dimension (NHWC conv outputs, (N, C) FC
+ * outputs); z may alias y, dy may alias dz.  The slope is taken from the OUTPUT z (lrelu keeps sign and zero);
+ * exactly at 0 it is TF's sub-gradient f1 (tf.abs has gradient 0 at 0).  expo_lrelu_bwd is linear in dz and
+ * therefore its own double backward (net.py:174-194).
+ */
+int expo_bias_lrelu_fwd(const float* y, const float* bias, float* z, size_t count, int channels, float leak,
+                        void* stream);
+int expo_lrelu_bwd(const float* z, const float* dz, float* dy, size_t count, float leak, void* stream);
 
 #ifdef __cplusplus
 }

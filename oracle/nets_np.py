@@ -252,6 +252,53 @@ def stat_features_backward(cache, dstats):
   return dimg + np.where(inside, d_clip, 0.0)
 
 
+def _sat_partials(cache):
+  """Per pixel: d sat/d max, d sat/d min, their second derivatives, and the tie-split selectors
+  a_j = d max / d x_j, b_j = d min / d x_j (0 outside the inclusive clip range)."""
+  images, clipped = cache['images'], cache['clipped']
+  i_max, i_min, denom = cache['i_max'], cache['i_min'], cache['denom']
+  num = i_max - i_min
+  sg = np.where(cache['a'] <= cache['b'], 1.0, -1.0)  # d denom / d max = d denom / d min
+  f_mx = 1.0 / denom - num * sg / denom**2
+  f_mn = -1.0 / denom - num * sg / denom**2
+  q = 2.0 * num / denom**3
+  e = 2.0 * sg / denom**2
+  is_max = clipped == i_max[..., None]
+  is_min = clipped == i_min[..., None]
+  inside = (images >= 0.0) & (images <= 1.0)
+  a = np.where(inside, is_max / is_max.sum(axis=3, keepdims=True), 0.0)
+  b = np.where(inside, is_min / is_min.sum(axis=3, keepdims=True), 0.0)
+  return f_mx, f_mn, q - e, q, q + e, a, b
+
+
+def stat_features_jvp(cache, v):
+  """J v with J = d stats / d images: (N, 3).  It is also d <stat_features_backward(cache, g), v> / d g -- the
+  path by which the double backward of the gradient penalty reaches the critic's weights (net.py:174-194)."""
+  n, h, w, _ = v.shape
+  hw = float(h * w)
+  wv = v @ np.array([0.27, 0.67, 0.06])
+  f_mx, f_mn, _, _, _, a, b = _sat_partials(cache)
+  vm, vn = (a * v).sum(axis=3), (b * v).sum(axis=3)
+  j0 = wv.sum(axis=(1, 2)) / hw
+  j1 = (2.0 * (cache['lumpix'] - cache['lum'][:, None, None]) * wv).sum(axis=(1, 2)) / hw
+  j2 = (f_mx * vm + f_mn * vn).sum(axis=(1, 2)) / hw
+  return np.stack([j0, j1, j2], axis=1)
+
+
+def stat_features_hvp(cache, dstats, v):
+  """d <stat_features_backward(cache, dstats), v> / d images (tie selectors and clip masks locally constant)."""
+  n, h, w, _ = v.shape
+  hw = float(h * w)
+  lw = np.array([0.27, 0.67, 0.06])
+  wv = v @ lw
+  g_con, g_sat = dstats[:, 1], dstats[:, 2]
+  out = (g_con[:, None, None] * 2.0 / hw * (wv - wv.mean(axis=(1, 2), keepdims=True)))[..., None] * lw
+  _, _, hxx, hxn, hnn, a, b = _sat_partials(cache)
+  vm, vn = (a * v).sum(axis=3), (b * v).sum(axis=3)
+  gs = g_sat[:, None, None] / hw
+  return out + a * (gs * (hxx * vm + hxn * vn))[..., None] + b * (gs * (hxn * vm + hnn * vn))[..., None]
+
+
 def critic_forward(images, cfg, weights, prefix, states=None):
   """critics.py:42-98.  ``prefix``: 'critic/' or 'rl_value/critic/'.  Returns (outputs (N,1), cache)."""
   stats, scache = stat_features(images)

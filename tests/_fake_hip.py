@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from oracle import agent_np
+from oracle import nets_np
 from oracle import filters_torch as ft
 
 NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24, 2)
@@ -105,6 +106,38 @@ def _stats(x, stats):
   stats.copy_(torch.from_numpy(agent_np.critic_stats(x.double().numpy())).float())
 
 
+def _stats_cache(x):
+  return nets_np.stat_features(x.detach().double().numpy())[1]
+
+
+def _stats_bwd(x, stats, dstats, dx):
+  dx.copy_(torch.from_numpy(nets_np.stat_features_backward(_stats_cache(x), dstats.detach().double().numpy())).to(dx.dtype))
+
+
+def _stats_jvp(x, stats, v, jv, workspace=None):
+  jv.copy_(torch.from_numpy(nets_np.stat_features_jvp(_stats_cache(x), v.detach().double().numpy())).float())
+
+
+def _stats_hvp(x, dstats, jv, v, out):
+  out.copy_(torch.from_numpy(nets_np.stat_features_hvp(_stats_cache(x), dstats.detach().double().numpy(),
+                                                       v.detach().double().numpy())).to(out.dtype))
+
+
+def _penalty_bwd(y, dpen, dy):
+  cnt = y.shape[1] * y.shape[2] * 3
+  dy.copy_((2.0 * (y.double() - 1).clamp_min(0) * dpen.double()[:, None, None, None] / cnt).to(dy.dtype))
+
+
+def _bias_lrelu_fwd(y, bias, z, leak=0.2):
+  v = y if bias is None else y + bias
+  z.copy_(torch.where(v > 0, v, v * leak))
+
+
+def _lrelu_bwd(z, dz, dy, leak=0.2):
+  f1 = 0.5 * (1 + leak)
+  dy.copy_(dz * torch.where(z > 0, torch.ones_like(z), torch.where(z < 0, torch.full_like(z, leak), torch.full_like(z, f1))))
+
+
 def _penalty(y, pen):
   pen.copy_(torch.from_numpy(agent_np.overexposure_penalty(y.double().numpy())).float())
 
@@ -113,5 +146,7 @@ def _penalty(y, pen):
 def fake_hip():
   with mock.patch.multiple('exposure_amd._cabi', filter_fwd=_fwd, filter_bwd=_bwd, dispatch_fwd=_dispatch_fwd,
                            dispatch_bwd=_dispatch_bwd, critic_stats=_stats, overexposure_penalty=_penalty,
+                           critic_stats_bwd=_stats_bwd, critic_stats_jvp=_stats_jvp, critic_stats_hvp=_stats_hvp,
+                           overexposure_penalty_bwd=_penalty_bwd, bias_lrelu_fwd=_bias_lrelu_fwd, lrelu_bwd=_lrelu_bwd,
                            chain_fused_fwd=_chain_fused_fwd, apply_fwd=_apply_fwd, apply_bwd=_apply_bwd):
     yield

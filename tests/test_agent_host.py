@@ -104,7 +104,7 @@ def test_agent_step_matches_oracle(is_train):
   ids = dbg['selected_filter_ids'].numpy()
   assert ids.dtype == np.int32
   # recompute the selection from the selector logits with the numpy restatement
-  with torch.no_grad():
+  with fake_hip(), torch.no_grad():
     enriched = xagent.enrich_image_input(cfg, t(img), t(states))
     sel = ag.selector_features(enriched, t(masks[1]))
     logits = ag.selector_fc2(xagent.lrelu(ag.selector_fc1(sel))).numpy()

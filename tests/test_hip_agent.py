@@ -190,7 +190,7 @@ def test_critic_stats_and_penalty(dtype, shape, gpu_device):
   stats = critics.critic_stats(tx)
   ref = agent_np.critic_stats(x.astype(np.float64))
   np.testing.assert_allclose(stats.cpu().numpy(), ref, rtol=2e-4, atol=2e-6)
-  # the differentiable torch statistics the critic uses in training agree too
+  # the autograd entry the critic uses in training (same kernel, float32 image)
   np.testing.assert_allclose(critics.stat_features(tx).cpu().numpy(), ref, rtol=2e-4, atol=2e-6)
   pen = torch.empty(shape[0], device=dev)
   _cabi.overexposure_penalty(tx, pen)

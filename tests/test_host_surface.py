@@ -92,9 +92,10 @@ def test_vignet_filter_matches_oracle(masking):
   v = filters.VignetFilter((1, 10, 14, 3), cfg)
   img = torch.rand(2, 10, 14, 3)
   feats = torch.randn(2, cfg.feature_extractor_dims)
-  low, high, dbg = v.apply(img, img_features=feats, high_res=torch.rand(2, 20, 12, 3))
-  with torch.no_grad():
-    _, mraw = v.extract_parameters(feats)
+  with fake_hip():
+    low, high, dbg = v.apply(img, img_features=feats, high_res=torch.rand(2, 20, 12, 3))
+    with torch.no_grad():
+      _, mraw = v.extract_parameters(feats)
   assert mraw.shape == (2, 5)
   ref = fnp.vignet_apply(img.numpy().astype(np.float64), mraw.numpy().astype(np.float64), cfg.maximum_sharpness,
                          masking)
@@ -122,12 +123,12 @@ def test_agent_masking_path_matches_oracle_and_gives_mask_gradients():
                                                       dropout_masks=masks)
     out.sum().backward()
   ids = dbg['selected_filter_ids'].numpy()
-  with torch.no_grad():
+  with fake_hip(), torch.no_grad():
     feats = ag.filter_features(xagent.enrich_image_input(cfg, img, states), masks[0])
   for i in range(n):
     j = int(ids[i])
     filt = ag.filters[j]
-    with torch.no_grad():
+    with fake_hip(), torch.no_grad():
       f, mraw = filt.extract_parameters(feats[i:i + 1])
       packed = filt.pack(filt.filter_param_regressor(f)).numpy().astype(np.float64)
     ref = fnp.apply_masked(filt.filter_id, img[i:i + 1].numpy().astype(np.float64), packed,

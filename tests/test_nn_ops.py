@@ -1,0 +1,120 @@
+"""exposure_amd/nn_ops.py: the convolution family (forward / data gradient / weight gradient, closed under
+differentiation) against torch's own conv2d autograd, and the fused bias + lrelu against the reference formula
+(util.py:225-229) with TF's sub-gradient at 0.  CPU tests run the library-call structure in float64 (gradcheck /
+gradgradcheck); the -m gpu tests run the HIP activation kernels and MIOpen's kernels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from exposure_amd import nn_ops
+from tests._fake_hip import fake_hip
+
+
+def ref_conv(x_nhwc, w):
+  return F.conv2d(x_nhwc.permute(0, 3, 1, 2), w, None, stride=2, padding=1).permute(0, 2, 3, 1)
+
+
+def test_conv_family_first_and_second_derivatives_cpu_float64():
+  torch.manual_seed(0)
+  x = torch.randn(2, 8, 6, 3, dtype=torch.float64, requires_grad=True)
+  w = torch.randn(5, 3, 4, 4, dtype=torch.float64, requires_grad=True)
+  assert torch.allclose(nn_ops.conv2d_nhwc(x, w), ref_conv(x, w), atol=1e-12)
+  assert torch.autograd.gradcheck(nn_ops.conv2d_nhwc, (x, w), atol=1e-8)
+  assert torch.autograd.gradgradcheck(nn_ops.conv2d_nhwc, (x, w), atol=1e-8)
+
+
+def test_conv_family_matches_torch_double_backward_cpu():
+  """The gradient-penalty pattern: d/dW of || d sum(conv(x, W) * c) / dx ||^2, ours vs torch's conv2d."""
+  torch.manual_seed(1)
+  x0 = torch.randn(3, 16, 16, 6, dtype=torch.float64)
+  w0 = torch.randn(8, 6, 4, 4, dtype=torch.float64)
+  c = torch.randn(3, 8, 8, 8, dtype=torch.float64)
+  out = []
+  for conv in (nn_ops.conv2d_nhwc, ref_conv):
+    x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    gx, = torch.autograd.grad((conv(x, w) * c).sum(), x, create_graph=True)
+    out.append(torch.autograd.grad((gx**2).sum(), [w]))
+  assert torch.allclose(out[0][0], out[1][0], rtol=1e-10, atol=1e-10)
+
+
+def lrelu_formula(x, leak=0.2):
+  f1, f2 = 0.5 * (1 + leak), 0.5 * (1 - leak)
+  return f1 * x + f2 * np.abs(x)
+
+
+def lrelu_slope(x, leak=0.2):
+  return np.where(x > 0, 1.0, np.where(x < 0, leak, 0.5 * (1 + leak)))
+
+
+def test_bias_lrelu_autograd_wiring_cpu():
+  """_BiasLrelu / _LreluGrad with the two C-ABI calls mocked: values, first derivative (incl. the bias reduction) and
+  the second derivative with respect to the incoming gradient."""
+  rng = np.random.default_rng(0)
+  y = rng.standard_normal((3, 4, 5, 8)).astype(np.float32)
+  b = rng.standard_normal(8).astype(np.float32)
+  y[0, 0, 0, :] = -b  # pre-activation exactly 0: TF's sub-gradient f1 = 0.6
+  ty, tb = torch.tensor(y, requires_grad=True), torch.tensor(b, requires_grad=True)
+  g = torch.tensor(rng.standard_normal(y.shape).astype(np.float32), requires_grad=True)
+  with fake_hip():
+    z = nn_ops.bias_lrelu(ty, tb)
+    gy, gb = torch.autograd.grad(z, [ty, tb], g, create_graph=True)
+    v = torch.tensor(rng.standard_normal(y.shape).astype(np.float32))
+    gg, = torch.autograd.grad(gy, g, v)
+  pre = y + b
+  np.testing.assert_allclose(z.detach().numpy(), lrelu_formula(pre), rtol=1e-6, atol=1e-7)
+  np.testing.assert_allclose(gy.detach().numpy(), g.detach().numpy() * lrelu_slope(pre), rtol=1e-6)
+  assert np.allclose(gy.detach().numpy()[0, 0, 0], 0.6 * g.detach().numpy()[0, 0, 0])
+  np.testing.assert_allclose(gb.detach().numpy(), (g.detach().numpy() * lrelu_slope(pre)).reshape(-1, 8).sum(0),
+                             rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(gg.numpy(), v.numpy() * lrelu_slope(pre), rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(64, 32, 32, 32), (5, 128), (3, 7, 5, 6), (1, 3)])
+def test_bias_lrelu_kernels_match_formula(shape, gpu_device):
+  dev = gpu_device
+  rng = np.random.default_rng(1)
+  y = rng.standard_normal(shape).astype(np.float32)
+  b = rng.standard_normal(shape[-1]).astype(np.float32)
+  y.reshape(-1, shape[-1])[0] = -b  # exact zeros after the bias add
+  for bias in (b, None):
+    ty = torch.from_numpy(y).to(dev).requires_grad_(True)
+    tb = torch.from_numpy(bias).to(dev).requires_grad_(True) if bias is not None else None
+    g = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(dev).requires_grad_(True)
+    v = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(dev)
+    z = nn_ops.bias_lrelu(ty, tb)
+    pre = y + (bias if bias is not None else 0.0)
+    # x if x > 0 else 0.2 x: within 1 ulp of the literal 0.6 x + 0.4 |x|
+    np.testing.assert_allclose(z.detach().cpu().numpy(), lrelu_formula(pre.astype(np.float64)), rtol=3e-7, atol=1e-30)
+    ins = [ty] + ([tb] if tb is not None else [])
+    grads = torch.autograd.grad(z, ins, g, create_graph=True)
+    ref_gy = g.detach().cpu().numpy() * lrelu_slope(pre).astype(np.float32)
+    assert np.array_equal(grads[0].detach().cpu().numpy(), ref_gy)  # one multiply per element: exact
+    if tb is not None:
+      np.testing.assert_allclose(grads[1].detach().cpu().numpy(), ref_gy.astype(np.float64).reshape(-1, shape[-1]).sum(0),
+                                 rtol=1e-4, atol=1e-4)
+    gg, = torch.autograd.grad(grads[0], g, v)
+    assert np.array_equal(gg.cpu().numpy(), v.cpu().numpy() * lrelu_slope(pre).astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,cout,size,n', [(6, 32, 64, 16), (17, 32, 64, 8), (32, 64, 32, 8), (128, 256, 8, 8)])
+def test_conv_family_matches_torch_on_gpu(cin, cout, size, n, gpu_device):
+  """Values, first derivatives and the gradient-penalty double backward of conv2d_nhwc (MIOpen forward / data-gradient
+  / weight-gradient kernels) against torch's conv2d autograd on the same device (its generic double backward)."""
+  dev = gpu_device
+  torch.manual_seed(2)
+  x0 = torch.randn(n, size, size, cin, device=dev)
+  w0 = (torch.randn(cout, cin, 4, 4, device=dev) * (cin * 16)**-0.5).contiguous(memory_format=torch.channels_last)
+  c = torch.randn(n, size // 2, size // 2, cout, device=dev)
+  res = []
+  for conv in (nn_ops.conv2d_nhwc, ref_conv):
+    x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    y = conv(x, w)
+    gx, gw = torch.autograd.grad((y * c).sum(), [x, w], create_graph=True)
+    ggw, = torch.autograd.grad((gx**2).sum(), [w])
+    res.append((y.detach(), gx.detach(), gw.detach(), ggw))
+  for a, b, what in zip(res[0], res[1], ('y', 'dx', 'dW', 'd/dW |dx|^2')):
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-6, (what, float((a - b).abs().max()), scale)

@@ -96,6 +96,53 @@ def test_stat_features_backward_matches_finite_differences():
     assert abs(fd - got[idx]) < 1e-6 * max(1.0, abs(fd)), idx
 
 
+def _stats_case(seed=5):
+  rng = np.random.default_rng(seed)
+  img = rng.random((2, 6, 5, 3)) * 1.5 - 0.2  # values below 0 and above 1 (clip masks)
+  return img, rng.normal(size=(2, 3)), rng.normal(size=img.shape)
+
+
+def test_stat_features_jvp_matches_finite_differences():
+  """J v (the path of the gradient penalty's double backward to the critic's weights) two ways: central
+  differences of the statistics along v, and the adjoint identity <J^T g, v> == <g, J v>."""
+  img, dstats, v = _stats_case()
+  _, cache = nn_np.stat_features(img)
+  jv = nn_np.stat_features_jvp(cache, v)
+  fd = (nn_np.stat_features(img + 1e-6 * v)[0] - nn_np.stat_features(img - 1e-6 * v)[0]) / 2e-6
+  assert np.abs(fd - jv).max() < 1e-8
+  back = nn_np.stat_features_backward(cache, dstats)
+  assert np.abs((back * v).sum(axis=(1, 2, 3)) - (jv * dstats).sum(axis=1)).max() < 1e-14
+
+
+def test_stat_features_hvp_matches_finite_differences():
+  img, dstats, v = _stats_case(6)
+  _, cache = nn_np.stat_features(img)
+  got = nn_np.stat_features_hvp(cache, dstats, v)
+  f = lambda a: float((nn_np.stat_features_backward(nn_np.stat_features(a)[1], dstats) * v).sum())
+  for idx in np.ndindex(*img.shape):
+    e = np.zeros_like(img)
+    e[idx] = 1e-6
+    fd = (f(img + e) - f(img - e)) / 2e-6
+    assert abs(fd - got[idx]) < 1e-7 * max(1.0, abs(fd)), idx
+  assert np.abs(got).max() > 1e-2
+
+
+def test_torch_stats_restatement_agrees_with_numpy_incl_second_order():
+  """oracle/stats_torch.py (autograd) vs oracle/nets_np.py (hand-written): values, J^T g, and the double backward."""
+  from oracle import stats_torch
+  img, dstats, v = _stats_case(7)
+  x = torch.tensor(img, requires_grad=True)
+  g = torch.tensor(dstats, requires_grad=True)
+  st = stats_torch.stat_features(x)
+  ref, cache = nn_np.stat_features(img)
+  assert np.abs(st.detach().numpy() - ref).max() < 1e-14
+  dx, = torch.autograd.grad(st, x, g, create_graph=True)
+  assert np.abs(dx.detach().numpy() - nn_np.stat_features_backward(cache, dstats)).max() < 1e-14
+  gx, gg = torch.autograd.grad(dx, [x, g], torch.tensor(v))
+  assert np.abs(gg.numpy() - nn_np.stat_features_jvp(cache, v)).max() < 1e-13
+  assert np.abs(gx.numpy() - nn_np.stat_features_hvp(cache, dstats, v)).max() < 1e-13
+
+
 @pytest.mark.parametrize('with_states', [False, True])
 def test_critic_input_grad_matches_finite_differences(with_states):
   cfg = small_cfg()
@@ -212,3 +259,33 @@ def test_torch_nets_and_losses_match_oracle_cpu():
   with fake_hip():
     res = compare_gan_with_oracle(gan, torch.device('cpu'))
   assert res['gradient_norm'] > 1e-3
+
+
+def test_gradient_penalty_double_backward_wiring_cpu(monkeypatch):
+  """The autograd wiring of the HIP statistics (exposure_amd/critics.py: _CriticStats -> _CriticStatsGrad, with
+  the C-ABI calls mocked by the NumPy oracle): the critic-weight gradients of c_loss -- a double backward through
+  the statistics planes -- must equal those of the same graph with torch-autograd statistics."""
+  from exposure_amd import critics
+  from oracle import stats_torch
+  torch.manual_seed(1)
+  gan = GAN(make_cfg())
+  with torch.no_grad():
+    for p in gan.parameters():
+      if p.dim() == 1:
+        p.normal_(0.0, 0.05)
+    gan.critic.fc2.weight.mul_(40.0)
+  fake_input, real, states, z, masks, alpha = make_batch(3, 5)
+  t = torch.from_numpy
+
+  def grads():
+    out = gan.critic_losses(t(real), t(fake_input), t(alpha))
+    return float(out['gradient_penalty']), torch.autograd.grad(out['c_loss'], list(gan.critic.parameters()))
+
+  with fake_hip():
+    pen_a, g_a = grads()
+  monkeypatch.setattr(critics, 'stat_features', lambda im: stats_torch.stat_features(im.float()))
+  with fake_hip():  # (the activation kernels stay mocked; only the statistics switch to torch autograd)
+    pen_b, g_b = grads()
+  assert pen_a > 1e-3 and abs(pen_a - pen_b) <= 1e-4 * pen_b
+  for a, b in zip(g_a, g_b):
+    assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-8
