@@ -124,12 +124,13 @@ class Chain:
       self.launch()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    try:
-      import torch.distributed as _dist
-      if _dist.is_available() and _dist.is_initialized():
-        time.sleep(0.35)  # let ProcessGroupNCCL's watchdog reap earlier works before a capture (GAN._replay)
-    except ImportError:
-      pass
+    # The chain contains no collective, so RCCL's stream never joins this capture and the NCCL watchdog's event
+    # polls stay legal under capture_error_mode='thread_local'; draining it first (exposure_amd.dist) is cheap
+    # insurance against a collective of the timing bracket still sitting in its list.
+    import torch.distributed as _dist
+    if _dist.is_available() and _dist.is_initialized():
+      from exposure_amd import dist as xdist
+      xdist.drain_before_capture()
     self.graph = torch.cuda.CUDAGraph()
     # thread_local: with a process group alive, RCCL's watchdog thread may poll events while this
     # thread captures; under the default "global" mode such a call aborts the process
@@ -360,7 +361,7 @@ def run_train(args, world, rank, dev, dist):
   cfg = make_cfg()
   torch.manual_seed(args.seed)  # identical initial weights on every rank
   os.environ.setdefault('EXPO_MIOPEN_FIND', '1' if args.miopen_find == 'on' else '0')
-  gan = GAN(cfg, device=dev, use_graphs=(args.graph != 'off'))
+  gan = GAN(cfg, device=dev, use_graphs=(args.graph != 'off'), seed=args.seed)
   # weak: cfg.batch_size (64) images per GPU; strong: the reference's global batch of 64 split image-wise
   n = local_shape((cfg.batch_size,), world, args.scaling)[0]
   from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
@@ -430,6 +431,7 @@ def run_train(args, world, rank, dev, dist):
                            'all-reduced over RCCL from backward hooks' % world,
             'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
             'miopen_find': bool(torch.backends.cudnn.benchmark),
+            'capture_drain_verified': getattr(gan, 'capture_drain_verified', None),
             'reference_note': 'README.md:43: ~0.30 s/iteration on a GTX 1080 Ti (whole run ~100 min / 20000 it)',
         },
     }), flush=True)
@@ -676,6 +678,8 @@ def main():
   dist = None
   if world > 1 or 'LOCAL_RANK' in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
     import torch.distributed as dist
+    # the NCCL flight recorder lets exposure_amd.dist verify the watchdog drain in front of a hipGraph capture
+    os.environ.setdefault('TORCH_FR_BUFFER_SIZE', '2000')  # (TORCH_NCCL_TRACE_BUFFER_SIZE before torch 2.8)
     dist.init_process_group('nccl', device_id=dev)
   if args.gpus != world and rank == 0:
     print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)

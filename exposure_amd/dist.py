@@ -42,12 +42,78 @@ def shard(t, group=None):
   return t[lo:hi]
 
 
-def per_image_generator(seed, global_index, device):
-  """RNG stream keyed by the GLOBAL image index so dropout / alpha / z do not depend on how the
-  batch is partitioned."""
-  g = torch.Generator(device=device)
-  g.manual_seed(int(seed) * 1000003 + int(global_index))
-  return g
+class GlobalBatchRng:
+  """Per-step random inputs (dropout masks, the gradient penalty's alpha) that do NOT depend on how the global
+  minibatch is partitioned: every rank holds a generator with the SAME seed, draws the tensor
+  for the GLOBAL batch -- row i belongs to global image i -- and keeps the rows of its own image shard.  The streams
+  advance in lock step on every rank, so a run on p ranks consumes exactly the numbers of the single-process run
+  (tests/test_dist_gloo.py: two ranks == one process with nothing but the seed in common).  The redundant draw is
+  world_size x (N x 4096) uniform numbers per step: negligible next to one convolution."""
+
+  def __init__(self, seed, device):
+    self.device = torch.device(device)
+    self.gen = torch.Generator(device=self.device)
+    self.gen.manual_seed(int(seed))
+
+  def uniform(self, n_local, tail, group=None):
+    """(n_local, *tail) uniform [0, 1) numbers: this rank's rows of the (n_local * world, *tail) global draw."""
+    p, r = world_size(group), rank(group)
+    full = torch.rand((n_local * p,) + tuple(tail), generator=self.gen, device=self.device)
+    return full[r * n_local:(r + 1) * n_local]
+
+
+def nccl_works_retired(timeout_s=5.0, poll_s=0.01):
+  """Block until ProcessGroupNCCL's watchdog has RETIRED every collective issued so far (removed it from its work
+  list), i.e. until it holds no work whose end event it would still poll.  Needed before a hipGraph capture that
+  pulls RCCL's stream in: a watchdog poll (hipEventQuery) of an earlier eager work's event while that stream is
+  capturing fails with hipErrorCapturedEvent, the watchdog throws in its own thread and the process aborts
+  (profiles/r02_rccl_graph_soak.txt).  The watchdog reaps completed works every ~100 ms; instead of sleeping for
+  "long enough", this reads the NCCL flight recorder (every collective is logged with the `retired` flag the
+  watchdog sets when it drops the work) and returns True once no un-retired entry is left.  Returns False when the
+  recorder is unavailable or disabled (TORCH_FR_BUFFER_SIZE=0) or the deadline passes: the caller then
+  must not rely on the drain."""
+  import pickle
+  import time
+  try:
+    from torch._C._distributed_c10d import _dump_nccl_trace
+  except ImportError:
+    return False
+  deadline = time.monotonic() + timeout_s
+  seen_any = False
+  while True:
+    try:
+      dump = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False))
+    except Exception:  # recorder compiled out / API drift: undetermined
+      return False
+    entries = dump.get('entries', []) if isinstance(dump, dict) else []
+    seen_any = seen_any or bool(entries)
+    if not entries:
+      return False  # nothing recorded although collectives were issued: the recorder is off
+    if all(e.get('retired', False) for e in entries):
+      return True
+    if time.monotonic() > deadline:
+      return False
+    time.sleep(poll_s)
+
+
+def drain_before_capture(works=(), issued_collectives=True):
+  """Make it safe to start a hipGraph capture that will contain RCCL collectives: wait for the given Work handles,
+  drain the device, and wait until the watchdog has retired every earlier collective.  Returns True when the drain
+  is VERIFIED (flight recorder), False when it could only wait a grace period (EXPO_CAPTURE_GRACE_S, default
+  0.35 s = 3.5 watchdog periods) -- callers treat the latter as "not proven"."""
+  import os
+  import time
+  for w in works:
+    if w is not None:
+      w.wait()
+  if torch.cuda.is_available():
+    torch.cuda.synchronize()
+  if not issued_collectives:
+    return True
+  if nccl_works_retired():
+    return True
+  time.sleep(float(os.environ.get('EXPO_CAPTURE_GRACE_S', '0.35')))
+  return False
 
 
 def all_reduce_mean_(t, group=None, force=False):
@@ -104,6 +170,7 @@ class GradBucket:
     self.on_ready = on_ready
     self.launched = False  # set by the owner once this step's all-reduce has been issued
     self._arrived = 0
+    self._armed = False  # zero() arms the hook counting for ONE backward pass; on_ready / disarm() ends it
     self._hooks = []
 
   def attach(self):
@@ -129,7 +196,10 @@ class GradBucket:
     off = 0
     for p in self.params:
       g = p.grad
-      if g is None or g.data_ptr() != self.flat.data_ptr() + 4 * off:
+      # same storage slot AND the parameter's own layout (fused Adam walks both in lock step): a later
+      # .to(memory_format=...) of the module leaves stale views behind -> re-attach
+      if g is None or g.data_ptr() != self.flat.data_ptr() + 4 * off or g.stride() != p.stride() or \
+          g.size() != p.size():
         return False
       off += p.numel()
     return True
@@ -140,11 +210,21 @@ class GradBucket:
     else:
       self.flat.zero_()
     self._arrived = 0
+    self._armed = True
     self.launched = False
 
+  def disarm(self):
+    """End of the backward pass this bucket was zero()ed for: gradient hooks fired by any OTHER backward (user
+    code, a pre-training loop, a test) must not count towards -- or trigger -- this bucket's all-reduce: a
+    collective issued by one rank only, or in a different order, is a mismatch or a hang."""
+    self._armed = False
+
   def _arrive(self, _param):
+    if not self._armed:
+      return
     self._arrived += 1
     if self._arrived == len(self.params) and self.on_ready is not None:
+      self._armed = False
       self.on_ready(self)
 
   def all_reduce_mean(self, group=None, async_op=False, force=False):

@@ -8,7 +8,6 @@ HIP library.
 gradients are all-reduced in flat buckets (``exposure_amd.dist``) before the optimiser steps.
 """
 import os
-import time
 
 import torch
 from torch import nn
@@ -21,7 +20,7 @@ from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
 
 class GAN(nn.Module):
 
-  def __init__(self, cfg, device=None, process_group=None, use_graphs=False):
+  def __init__(self, cfg, device=None, process_group=None, use_graphs=False, seed=0):
     super().__init__()
     self.cfg = cfg
     self.use_graphs = bool(use_graphs)
@@ -55,6 +54,9 @@ class GAN(nn.Module):
     self.opt_c = torch.optim.Adam(self.critic.parameters(), lr=lr(cfg.lr_c(0)), **adam)
     self.process_group = process_group
     self.world_size = xdist.world_size(process_group)
+    # dropout masks and the gradient penalty's alpha: drawn for the GLOBAL batch from a generator every rank seeds
+    # identically, each rank keeping its image shard's rows -- results do not depend on the partition
+    self.rng = xdist.GlobalBatchRng(seed, device if device is not None else 'cpu')
     # EXPO_FORCE_COLLECTIVES=1: issue the gradient all-reduces even in a one-rank group, so the RCCL
     # path (and its hipGraph capture) can be exercised on a single GPU
     self.force_collectives = os.environ.get('EXPO_FORCE_COLLECTIVES', '0') == '1'
@@ -62,8 +64,12 @@ class GAN(nn.Module):
     # stream-ordered kernels); EXPO_GRAPH_COLLECTIVES=0 falls back to eager launches for multi-rank runs.
     # (Round 1 kept this opt-in because ~1 run in 15 aborted; the cause -- the NCCL watchdog polling an
     # eager work's event while RCCL's stream was being captured -- is handled in _replay.)
+    # EXPO_GRAPH_COLLECTIVES: 'auto' (default) captures them once the watchdog drain in front of the capture is
+    # VERIFIED (exposure_amd.dist.drain_before_capture) and otherwise keeps multi-rank steps eager; '1' captures after
+    # the unverified grace period too; '0' never captures a step that contains collectives.
     collectives = self.world_size > 1 or self.force_collectives
-    self._replay_steps = self.use_graphs and (not collectives or os.environ.get('EXPO_GRAPH_COLLECTIVES', '1') == '1')
+    self._graph_collectives = os.environ.get('EXPO_GRAPH_COLLECTIVES', 'auto')
+    self._replay_steps = self.use_graphs and (not collectives or self._graph_collectives != '0')
     # Flat gradient buckets (p.grad are views into them).  theta_g is split where the backward pass splits
     # in time: the FC heads (8 x fc1/fc2 + the selector FCs, 19 MB) receive their gradients first, the two
     # conv trunks (5.6 MB) last -- so the heads' all-reduce runs under the trunks' backward, and theta_v's
@@ -143,6 +149,7 @@ class GAN(nn.Module):
       params += b.params
     loss.backward(inputs=params, retain_graph=retain_graph)
     for name in names:  # a bucket whose hook could not fire (a parameter outside the graph): reduce it now
+      self.buckets[name].disarm()
       self._bucket_ready(self.buckets[name])
 
   def _finish_collectives(self):
@@ -162,18 +169,24 @@ class GAN(nn.Module):
     self.opt_v.step()
     return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
-  def _draw_masks(self, n, device):
+  def _draw_masks(self, n, device=None):
+    """The two always-on dropout masks of feature_extractor (agent.py:36), partition-invariant (self.rng)."""
     keep = self.cfg.dropout_keep_prob
-    return [(torch.rand((n, self.cfg.feature_extractor_dims), device=device) < keep).float() for _ in range(2)]
+    return [(self.rng.uniform(n, (self.cfg.feature_extractor_dims,), self.process_group) < keep).float()
+            for _ in range(2)]
+
+  def _draw_alpha(self, n):
+    """net.py:170-172: alpha ~ U(0, 1) per image for the interpolation of the gradient penalty."""
+    return self.rng.uniform(n, (1, 1, 1), self.process_group)
 
   def generator_step(self, fake_input, z, states, progress, it=1, dropout_masks=None):
     """opt_g on g_loss w.r.t. theta_g and opt_v on v_loss w.r.t. theta_v (net.py:222-241)."""
     self.set_lrs(it, zero_g=(it == 0))
+    masks = dropout_masks or self._draw_masks(fake_input.shape[0])
     if self._replay_steps:
-      masks = dropout_masks or self._draw_masks(fake_input.shape[0], fake_input.device)
       prog = torch.as_tensor(float(progress), device=fake_input.device)
       return self._replay('g', self._generator_body_graph, (fake_input, z, states, prog, masks[0], masks[1]))
-    return self._generator_body(fake_input, z, states, progress, dropout_masks)
+    return self._generator_body(fake_input, z, states, progress, masks)
 
   def _generator_body_graph(self, fake_input, z, states, progress, m0, m1):
     return self._generator_body(fake_input, z, states, progress, [m0, m1])
@@ -195,16 +208,22 @@ class GAN(nn.Module):
       # (with a process group the gradient all-reduces are captured too: RCCL collectives are
       # stream-ordered kernels, and the eager first call has already initialised the communicator)
       static_in = [t.clone() for t in inputs]
-      torch.cuda.synchronize()
-      if self._collectives():
-        # ROOT CAUSE of round 1's "one run in ~15 aborts" (gpurun r02soak, 3 of 28 runs): the eager first call
-        # left WorkNCCL entries in ProcessGroupNCCL's watchdog list; they are complete, but the watchdog only
-        # reaps its list every ~100 ms.  If it polls (hipEventQuery on the work's end event) AFTER this thread
-        # has pulled RCCL's stream into the capture, HIP answers hipErrorCapturedEvent ("operation not permitted
-        # on an event last recorded in a capturing stream") for an event that belongs to a now-capturing stream,
-        # the watchdog thread throws, and the process aborts.  Works issued DURING capture are never enqueued
-        # (ProcessGroupNCCL checks the capture status), so it is enough to let the watchdog drain first.
-        time.sleep(float(os.environ.get('EXPO_CAPTURE_GRACE_S', '0.35')))
+      # ROOT CAUSE of round 1's "one run in ~15 aborts" (gpurun r02soak, 3 of 28 runs): the eager first call left
+      # WorkNCCL entries in ProcessGroupNCCL's watchdog list; they are complete, but the watchdog only reaps its list
+      # every ~100 ms.  If it polls (hipEventQuery on the work's end event) AFTER this thread has pulled RCCL's stream
+      # into the capture, HIP answers hipErrorCapturedEvent for an event that belongs to a now-capturing stream, the
+      # watchdog thread throws, and the process aborts.  Works issued DURING capture are never enqueued, so the list
+      # only has to be EMPTY when the capture starts: drain_before_capture waits until the flight recorder shows every
+      # earlier collective retired (deterministic); when it cannot verify that (recorder off) a multi-rank step
+      # stays eager unless EXPO_GRAPH_COLLECTIVES=1 accepts the timed grace period of round 2.
+      verified = xdist.drain_before_capture(issued_collectives=self._collectives())
+      if not verified and self.world_size > 1 and self._graph_collectives != '1':
+        import warnings
+        warnings.warn('exposure_amd: the NCCL watchdog drain could not be verified (flight recorder off?); steps with '
+                      'collectives stay eager (set TORCH_FR_BUFFER_SIZE>0, or EXPO_GRAPH_COLLECTIVES=1)')
+        self.use_graphs = self._replay_steps = False
+        return body(*inputs)
+      self.capture_drain_verified = verified
       graph = torch.cuda.CUDAGraph()
       # thread_local: RCCL's watchdog thread polls events while this thread captures; under the
       # default "global" mode such a call from another thread aborts the process
@@ -241,7 +260,7 @@ class GAN(nn.Module):
     real_logit, fake_logit = logits[:n], logits[n:]
     c_loss = (fake_logit - real_logit).mean()
     if alpha is None:
-      alpha = torch.rand((real_data.shape[0], 1, 1, 1), device=real_data.device)
+      alpha = self._draw_alpha(real_data.shape[0])
     interpolated = (real_data + alpha * (fake_output - real_data)).requires_grad_(True)
     inte_logit = self.critic(interpolated)
     gradients, = torch.autograd.grad(inte_logit.sum(), interpolated, create_graph=True)
@@ -265,9 +284,9 @@ class GAN(nn.Module):
 
   def critic_step(self, real_data, fake_output, it=1, alpha=None):
     self.set_lrs(it)
+    if alpha is None:
+      alpha = self._draw_alpha(real_data.shape[0])
     if self._replay_steps:
-      if alpha is None:
-        alpha = torch.rand((real_data.shape[0], 1, 1, 1), device=real_data.device)
       out = dict(self._replay('c', self._critic_body, (real_data, fake_output, alpha)))
     else:
       out = self._critic_body(real_data, fake_output, alpha)

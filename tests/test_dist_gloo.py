@@ -36,11 +36,13 @@ def _inputs(n=4, s=64):
   return img, real, states, z, masks, alpha
 
 
-def _run_steps(gan, img, real, states, z, masks, alpha):
+def _run_steps(gan, img, real, states, z):
+  """Dropout masks and alpha are NOT passed in: the GAN draws them itself (exposure_amd.dist.GlobalBatchRng), keyed by
+  global image index, so the only things a rank is handed are its shard of the data and the common seed."""
   from tests._fake_hip import fake_hip
   with fake_hip():
-    g = gan.generator_step(img, z, states, progress=0.1, it=7, dropout_masks=masks)
-    c = gan.critic_step(real, g['fake_output'], it=7, alpha=alpha)
+    g = gan.generator_step(img, z, states, progress=0.1, it=7)
+    c = gan.critic_step(real, g['fake_output'], it=7)
   return g, c
 
 
@@ -54,10 +56,10 @@ def _worker(rank, world, port, out_dir):
   from exposure_amd.config import make_cfg
   from exposure_amd.gan import GAN
   torch.manual_seed(123)  # identical initial weights on every rank
-  gan = GAN(make_cfg())
-  img, real, states, z, masks, alpha = _inputs()
-  sh = xdist.shard
-  _run_steps(gan, sh(img), sh(real), sh(states), sh(z), [sh(m) for m in masks], sh(alpha))
+  gan = GAN(make_cfg(), seed=77)
+  img, real, states, z, _masks, _alpha = _inputs()
+  sh = xdist.shard  # this rank's images of the global batch (data, not random state)
+  _run_steps(gan, sh(img), sh(real), sh(states), sh(z))
   torch.save({'params': [p.detach().clone() for p in gan.parameters()],
               'grads': [p.grad.detach().clone() for p in gan.parameters()]}, os.path.join(out_dir, 'rank%d.pt' % rank))
   dist.barrier()
@@ -69,8 +71,8 @@ def test_two_rank_step_matches_single_process(tmp_path):
   from exposure_amd.config import make_cfg
   from exposure_amd.gan import GAN
   torch.manual_seed(123)
-  ref = GAN(make_cfg())
-  _run_steps(ref, *_inputs())
+  ref = GAN(make_cfg(), seed=77)
+  _run_steps(ref, *_inputs()[:4])
   port = _free_port()
   mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
   r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
@@ -114,8 +116,32 @@ def test_shard_helpers_single_process():
   before = b.flat.clone()
   b.all_reduce_mean(None)  # one rank: no collective, scale 1
   assert torch.equal(b.flat, before)
+  # hooks only count while the bucket is armed for a backward pass (zero() .. on_ready / disarm())
+  loss2 = conv(x).sum() + lin(torch.randn(3, 5)).sum()
+  loss2.backward(inputs=b.params)  # a backward nobody armed the bucket for: no callback, no counting
+  assert ready == [b] and b._arrived == len(b.params)
   b.zero()
   assert float(b.flat.abs().max()) == 0.0 and all(float(p.grad.abs().max()) == 0.0 for p in b.params)
-  g1 = xdist.per_image_generator(1, 5, 'cpu')
-  g2 = xdist.per_image_generator(1, 5, 'cpu')
-  assert torch.equal(torch.rand(4, generator=g1), torch.rand(4, generator=g2))
+  assert b._arrived == 0
+  b.disarm()
+  (conv(x).sum() + lin(torch.randn(3, 5)).sum()).backward(inputs=b.params)
+  assert ready == [b]
+  # a layout change of the module invalidates the views: attached() notices and zero() re-attaches
+  conv.to(memory_format=torch.contiguous_format)
+  assert not b.attached()
+  b.zero()
+  assert b.attached() and all(p.grad.stride() == p.stride() for p in b.params)
+
+
+def test_global_batch_rng_is_partition_invariant():
+  """Rank r's rows of the global draw == rows [r n, (r+1) n) of the single-process draw, call after call."""
+  from exposure_amd import dist as xdist
+  one = xdist.GlobalBatchRng(5, 'cpu')
+  a, b = one.uniform(6, (7,)), one.uniform(6, (1, 1, 1))
+
+  import unittest.mock as mock
+  for r in range(3):
+    rng = xdist.GlobalBatchRng(5, 'cpu')
+    with mock.patch.object(xdist, 'world_size', lambda g=None: 3), mock.patch.object(xdist, 'rank', lambda g=None, r=r: r):
+      ar, br = rng.uniform(2, (7,)), rng.uniform(2, (1, 1, 1))
+    assert torch.equal(ar, a[2 * r:2 * r + 2]) and torch.equal(br, b[2 * r:2 * r + 2])

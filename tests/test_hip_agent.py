@@ -426,7 +426,7 @@ def test_training_step_graph_captures_rccl_collectives(gpu_device):
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   env = dict(os.environ, EXPO_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-  env.pop('EXPO_GRAPH_COLLECTIVES', None)  # default: on
+  env.pop('EXPO_GRAPH_COLLECTIVES', None)  # default 'auto': capture once the watchdog drain is verified
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
          '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'), '--gpus', '1', '--workload', 'train',
          '--steps', '3', '--warmup', '2']
@@ -437,3 +437,5 @@ def test_training_step_graph_captures_rccl_collectives(gpu_device):
   assert 'hipGraph' in d['config']['launch'], d['config']
   assert d['value'] > 0
   assert 'hipGraph capture of' not in last.stderr  # the eager fallback of GAN._replay was not taken
+  # the drain in front of the capture was VERIFIED through the NCCL flight recorder (no timed grace period)
+  assert d['config']['capture_drain_verified'] is True, d['config']
