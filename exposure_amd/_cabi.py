@@ -51,6 +51,8 @@ SIGNATURES = {
     'expo_critic_stats_bwd': (_i, [_vp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     'expo_critic_stats_jvp': (_i, [_vp, _fp, _vp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_critic_stats_hvp': (_i, [_vp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'expo_vignet_apply_fwd': (_i, [_vp, _vp, _fp, _f, _i, _i, _i, _i, _i, _vp]),
+    'expo_vignet_apply_bwd': (_i, [_vp, _vp, _vp, _fp, _fp, _f, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_bias_lrelu_fwd': (_i, [_fp, _fp, _fp, _sz, _i, _f, _vp]),
     'expo_lrelu_bwd': (_i, [_fp, _fp, _fp, _sz, _f, _vp]),
 }
@@ -137,6 +139,7 @@ def num_filter_params(fid):
 _WORKSPACES = {}
 _RETIRED = []
 _MIN_WORKSPACE = 4 << 20
+_WS_STREAM = {}  # device index -> the torch stream that last used the device's shared workspace
 
 
 def workspace_bytes(n, h, w, dtype_code, steps=1):
@@ -163,11 +166,30 @@ def reserve_workspace(device, nbytes):
   return ws
 
 
+def _order_shared_workspace(device):
+  """The shared workspace serves one stream at a time.  When a call arrives on a DIFFERENT stream than the previous
+  user's, make it wait for everything that stream has enqueued (the earlier call's records are consumed by its own
+  finish launch, so stream order is all that is needed) instead of silently racing on the block records.  No cost
+  while the stream does not change; skipped under hipGraph capture (a captured region runs on one stream, and a
+  cross-stream wait on a non-capturing stream is not capturable) -- concurrent streams pass their own
+  ``workspace=`` tensors."""
+  key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+  cur = torch.cuda.current_stream(key)
+  prev = _WS_STREAM.get(key)
+  if prev is not None and prev != cur and not torch.cuda.is_current_stream_capturing():
+    cur.wait_stream(prev)
+  _WS_STREAM[key] = cur
+
+
 def _ws(x, workspace, steps=1):
   """(pointer, size) of the workspace for an image tensor ``x``."""
   n, h, w, _ = x.shape
   need = workspace_bytes(n, h, w, _dtype_code(x), steps)
-  ws = workspace if workspace is not None else reserve_workspace(x.device, need)
+  if workspace is None:
+    ws = reserve_workspace(x.device, need)
+    _order_shared_workspace(x.device)
+  else:
+    ws = workspace
   if not ws.is_cuda or ws.device != x.device or ws.numel() * ws.element_size() < need:
     raise ExposureHipError('exposure_amd: workspace must be a device tensor of at least %d bytes on %s' %
                            (need, x.device))
@@ -465,3 +487,29 @@ def lrelu_bwd(z, dz, dy, leak=0.2):
   assert dz.shape == z.shape and dy.shape == z.shape
   with torch.cuda.device(z.device):
     _check(lib.expo_lrelu_bwd(_ptr(z), _ptr(dz), _ptr(dy), z.numel(), float(leak), _stream()), 'expo_lrelu_bwd')
+
+
+def vignet_apply_fwd(x, y, mask_params, maximum_sharpness, masking):
+  lib = load()
+  _img(x, 'x'), _img(y, 'y')
+  n, h, w, _ = x.shape
+  assert y.shape == x.shape and y.dtype == x.dtype
+  _f32(mask_params, 'mask_params', (n, 5))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_vignet_apply_fwd(_ptr(x), _ptr(y), _ptr(mask_params), float(maximum_sharpness), int(bool(masking)),
+                                     n, h, w, _dtype_code(x), _stream()), 'expo_vignet_apply_fwd')
+
+
+def vignet_apply_bwd(x, dy, dx, mask_params, dmask_params, maximum_sharpness, masking, workspace=None):
+  lib = load()
+  _img(x, 'x'), _img(dy, 'dy')
+  n, h, w, _ = x.shape
+  if dx is not None:
+    _img(dx, 'dx')
+  _f32(mask_params, 'mask_params', (n, 5))
+  _f32(dmask_params, 'dmask_params', (n, 5))
+  with torch.cuda.device(x.device):
+    wsp, wsb = _ws(x, workspace)
+    _check(lib.expo_vignet_apply_bwd(_ptr(x), _ptr(dy), _ptr(dx), _ptr(mask_params), _ptr(dmask_params),
+                                     float(maximum_sharpness), int(bool(masking)), n, h, w, _dtype_code(x), wsp, wsb,
+                                     _stream()), 'expo_vignet_apply_bwd')

@@ -217,7 +217,7 @@ class Agent(nn.Module):
     high_res_output = None
     if cfg.masking:
       out = self._apply_masked(net, params, mask_params, filter_one_hot)
-      overexposure = (torch.clamp_min(out.float() - 1.0, 0.0)**2).mean(dim=(1, 2, 3))
+      overexposure = F.overexposure_penalty(out)
       if high_res is not None:
         high_res_output = self._apply_masked(high_res, params, mask_params, filter_one_hot)
     else:
@@ -256,7 +256,7 @@ class Agent(nn.Module):
       # the reference -- high_res_output is not.  64x64 images: one tiny torch op, not a kernel.
       out = torch.clamp(out, 0.0, 5.0)
       # the penalty of agent.py:249-251 is taken on the CLIPPED image in the reference
-      overexposure = (torch.clamp_min(out.float() - 1.0, 0.0)**2).mean(dim=(1, 2, 3))
+      overexposure = F.overexposure_penalty(out)
 
     entropy_penalty = (1.0 - progress) * cfg.exploration_penalty * (-entropy + math.log(k))
     # Will be subtracted from the reward (agent.py:247-252)

@@ -369,6 +369,84 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
   block_reduce_record<F::NACC + 6>(acc, records + size_t(n) * gridDim.x * kWsSlots);
 }
 
+// ------------------------------------------------------------ VignetFilter.apply (filters.py:341-396)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void vignet_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                              const float* __restrict__ mask_params, float sharp,
+                                                              int masking, int h, int w, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y, hw = h * w;
+  const size_t off = size_t(n) * hw * 3;
+  const VignetPrm mk = VignetPrm::load(mask_params + n * 5, sharp, masking, h, w);
+  const int stride = gridDim.x * kThreads;
+  auto compute = [&](float* v, int g) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      const float keep = 1.0f - mk.eval(pixel_index<T, VEC>(g, k, lane)).m;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[3 * k + c] *= keep;
+    }
+  };
+  if constexpr (VEC) {
+    const T* const ins[1] = {x + off};
+    stream_groups<T, 1, true, true, IoCached>(ins, y + off, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                              [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3];
+      load_slow<T>(x + off, g, hw, v);
+      compute(v, g);
+      store_slow<T>(y + off, g, hw, v);
+    }
+  }
+}
+
+template <typename T, bool VEC, bool HAS_DX>
+__global__ __launch_bounds__(kThreads) void vignet_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                              T* __restrict__ dx, const float* __restrict__ mask_params,
+                                                              float* __restrict__ records, float sharp, int masking,
+                                                              int h, int w, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  const int n = blockIdx.y, hw = h * w;
+  const size_t off = size_t(n) * hw * 3;
+  const VignetPrm mk = VignetPrm::load(mask_params + n * 5, sharp, masking, h, w);
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int stride = gridDim.x * kThreads;
+  auto compute = [&](const float* xv, float* d, int g) {  // padding pixels: x = dy = 0 -> t = 0
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      const VignetPrm::Eval e = mk.eval(pixel_index<T, VEC>(g, k, lane));
+      const float t = -(xv[3 * k] * d[3 * k] + xv[3 * k + 1] * d[3 * k + 1] + xv[3 * k + 2] * d[3 * k + 2]);
+      const float ts = t * e.sg * (1.0f - e.sg);
+      acc[0] = fmaf(ts, e.gx2, acc[0]);
+      acc[1] = fmaf(ts, e.gy2, acc[1]);
+      acc[2] += ts;
+      acc[3] = fmaf(ts, e.u, acc[3]);
+      acc[4] = fmaf(t, e.sg, acc[4]);
+      const float keep = 1.0f - e.m;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d[3 * k + c] *= keep;
+    }
+  };
+  if constexpr (VEC) {
+    const T* const ins[2] = {x + off, dy + off};
+    stream_groups<T, 2, HAS_DX, true, IoCached>(ins, HAS_DX ? dx + off : nullptr, hw,
+                                                blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                                [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
+      float v[PPL * 3], d[PPL * 3];
+      load_slow<T>(x + off, g, hw, v);
+      load_slow<T>(dy + off, g, hw, d);
+      compute(v, d, g);
+      if constexpr (HAS_DX) store_slow<T>(dx + off, g, hw, d);
+    }
+  }
+  block_reduce_record<5>(acc, records + size_t(n) * gridDim.x * kWsSlots);
+}
+
 // --------------------------------------------------- per-image dispatch (one-hot select)
 template <typename T, bool VEC, class IO = IoCached>
 __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int groups) {
@@ -731,7 +809,7 @@ __global__ __launch_bounds__(kThreads) void stats_hvp_kernel(const T* __restrict
 // One wave per (image, step): adds the image's bx block records in a fixed order and writes the final
 // per-image values.  Steps of a chain (or the single step of any other entry point) are described by
 // value in the kernel arguments.
-enum FinishKind : int { kFinFilter = 0, kFinDispatch = 1, kFinApply = 2, kFinStats = 3, kFinPenalty = 4, kFinScaled = 5 };
+enum FinishKind : int { kFinFilter = 0, kFinDispatch = 1, kFinApply = 2, kFinStats = 3, kFinPenalty = 4, kFinScaled = 5, kFinVignet = 6 };
 struct FinishStep {
   const float* params;    // [n][P] (filter / apply), [n][EXPO_MAX_PARAMS] (dispatch)
   float* out;             // dparams [n][P] | [n][24]; stats [n][3]; penalty [n]
@@ -802,6 +880,9 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const FinishArgs
     } break;
     case kFinPenalty:  // agent.py:249-251 (also the fused penalty of the dispatch forward; id -1 -> 0)
       if (lane == 0) st.out[n] = nothing ? 0.0f : tot[0] * st.scale;
+      break;
+    case kFinVignet:  // d mask parameters of VignetFilter.apply (scale = maximum_sharpness; masking off -> 0)
+      if (lane < 5) st.out[n * 5 + lane] = st.accumulate ? VignetPrm::finish_one(st.params + n * 5, st.scale, tot, lane) : 0.0f;
       break;
     case kFinScaled:  // out[n][0..filter_id) = totals * scale (the statistics' Jacobian-vector product)
       if (lane < st.filter_id) st.out[n * st.filter_id + lane] = tot[lane] * st.scale;
@@ -1166,6 +1247,36 @@ static int penalty_t(const void* y, float* pen, int n, int h, int w, void* works
 }
 
 template <typename T>
+static int vignet_fwd_t(const void* x, void* y, const float* mp, float sharp, int masking, int n, int h, int w,
+                        hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  if (g.vec) hipLaunchKernelGGL((vignet_fwd_kernel<T, true>), grid, block, 0, s, (const T*)x, (T*)y, mp, sharp, masking, h, w, g.groups);
+  else hipLaunchKernelGGL((vignet_fwd_kernel<T, false>), grid, block, 0, s, (const T*)x, (T*)y, mp, sharp, masking, h, w, g.groups);
+  HIP_TRY(hipGetLastError(), "vignet_fwd launch");
+  return EXPO_OK;
+}
+
+template <typename T>
+static int vignet_bwd_t(const void* x, const void* dy, void* dx, const float* mp, float* dmp, float sharp, int masking,
+                        int n, int h, int w, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, dy, dx}, kGeomApply);
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  float* records;
+  if (int rc = ws_check(workspace, workspace_bytes, n, g.blocks_x, 1, &records)) return rc;
+#define EXPO_L(VEC, HAS_DX) \
+  hipLaunchKernelGGL((vignet_bwd_kernel<T, VEC, HAS_DX>), grid, block, 0, s, (const T*)x, (const T*)dy, (T*)dx, mp, records, sharp, masking, h, w, g.groups)
+  if (g.vec) { if (dx) EXPO_L(true, true); else EXPO_L(true, false); }
+  else { if (dx) EXPO_L(false, true); else EXPO_L(false, false); }
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "vignet_bwd launch");
+  FinishArgs fa{};
+  // `accumulate` carries the masking flag: with masking off the mask is the constant 1 and its parameters get 0
+  fa.s[0] = FinishStep{mp, dmp, nullptr, records, nullptr, kFinVignet, 0, masking ? 1 : 0, sharp, g.blocks_x};
+  return launch_finish(fa, 1, n, s);
+}
+
+template <typename T>
 static int penalty_bwd_t(const void* y, const float* dpen, void* dy, int n, int h, int w, hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {y, dy}, kGeomMap);
   const dim3 grid(g.blocks_x, n), block(kThreads);
@@ -1377,9 +1488,12 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
   if (int rc = check_common(n, h, w, dtype)) return rc;
   if (n == 0) return EXPO_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // validate EVERYTHING before the first launch: an error means nothing was enqueued
   for (int i = 0; i < steps; ++i) {
     if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
     if (!acts[i] || !acts[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
+  }
+  for (int i = 0; i < steps; ++i) {
     const int rev = chain_snake(n, h, w, dtype) ? (i & 1) : 0;
     const int rc = dtype == EXPO_F16
                        ? fwd_by_id<half_t>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, rev)
@@ -1442,9 +1556,10 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
   if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
   if (n == 0 || steps == 0) return EXPO_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // validate EVERYTHING before the first launch: an error means nothing was enqueued and no gradient was touched
   for (int i = 0; i < steps; ++i) {
     if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
-    if (!dparams[i]) return fail(EXPO_E_BADARG, "null pointer");
+    if (!dparams[i] || !acts[i] || !grads[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
   }
   // every step's kernel writes its block records into its own slice of the workspace; ONE finish launch
   // (per kMaxFinishSteps steps) then produces all the dparams
@@ -1453,7 +1568,6 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
   if (int rc = ws_check(workspace, workspace_bytes, n, bx_max, steps, &records)) return rc;
   const size_t step_floats = ws_step_bytes(n, bx_max) / sizeof(float);
   for (int i = steps - 1; i >= 0; --i) {
-    if (!acts[i] || !grads[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
     float* rec = records + size_t(i) * step_floats;
     // the forward chain ended descending (or ascending) on step steps-1; the backward starts where it ended
     const int rev = chain_snake(n, h, w, dtype) ? ((steps - i) & 1) : 0;
@@ -1485,6 +1599,29 @@ int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == EXPO_F16 ? penalty_t<half_t>(y, penalty, n, h, w, workspace, workspace_bytes, s)
                            : penalty_t<float>(y, penalty, n, h, w, workspace, workspace_bytes, s);
+}
+
+int expo_vignet_apply_fwd(const void* x, void* y, const float* mask_params, float maximum_sharpness, int masking, int n,
+                          int h, int w, int dtype, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!x || !y || !mask_params) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? vignet_fwd_t<half_t>(x, y, mask_params, maximum_sharpness, masking, n, h, w, s)
+                           : vignet_fwd_t<float>(x, y, mask_params, maximum_sharpness, masking, n, h, w, s);
+}
+
+int expo_vignet_apply_bwd(const void* x, const void* dy, void* dx, const float* mask_params, float* dmask_params,
+                          float maximum_sharpness, int masking, int n, int h, int w, int dtype, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!x || !dy || !mask_params || !dmask_params) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? vignet_bwd_t<half_t>(x, dy, dx, mask_params, dmask_params, maximum_sharpness, masking, n, h,
+                                                  w, workspace, workspace_bytes, s)
+                           : vignet_bwd_t<float>(x, dy, dx, mask_params, dmask_params, maximum_sharpness, masking, n, h,
+                                                 w, workspace, workspace_bytes, s);
 }
 
 int expo_overexposure_penalty_bwd(const void* y, const float* dpenalty, void* dy, int n, int h, int w, int dtype,

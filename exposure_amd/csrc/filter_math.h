@@ -649,4 +649,67 @@ struct MaskPrm {
   }
 };
 
+// ---------------------------------------------------------------------------------
+// VignetFilter   filters.py:341-396.  process() is img * 0 (the additive term is commented out, filters.py:351-352),
+// so Filter.apply = lerp(img, 0, mask) = img (1 - mask) with the elliptical mask
+//   mp = tanh_range(-5, 5)(mask_parameters)            (done by the caller, differentiably; 5 parameters)
+//   u = (gx mp0)^2 + (gy mp1)^2 + mp2 - 5;  inp = u sharp mp3 / 5;  mask = sigmoid(inp) (mp4/5 * .5 + .5)
+// on the same constant grid as MaskPrm; with cfg.masking off the reference forces mask = 1 (out = 0).
+// The mask does not depend on the image.  Backward accumulators (5), with t = -sum_c x_c dy_c per pixel:
+//   t s' gx^2, t s' gy^2, t s', t s' u, t s      (s = sigmoid(inp), s' = s (1 - s)); finish_vignet scales them.
+// ---------------------------------------------------------------------------------
+struct VignetPrm {
+  float a, b, c5, k, S;  // c5 = mp2 - 5; k = sharp mp3 / 5; S = mp4/5 * .5 + .5
+  float inv_se, oi, oj, inv_w;
+  int w;
+  bool small, masking;
+  __device__ static VignetPrm load(const float* __restrict__ mp, float sharp, int masking, int h, int w) {
+    VignetPrm m;
+    m.a = mp[0]; m.b = mp[1]; m.c5 = mp[2] - 5.0f;
+    m.k = sharp * mp[3] / 5.0f;
+    m.S = mp[4] / 5.0f * 0.5f + 0.5f;
+    const int se = h < w ? h : w;
+    m.inv_se = 1.0f / float(se);
+    m.oi = float(se - h) * 0.5f;
+    m.oj = float(se - w) * 0.5f;
+    m.w = w;
+    m.inv_w = 1.0f / float(w);
+    m.small = long(h) * long(w) < (1L << 22);
+    m.masking = masking != 0;
+    return m;
+  }
+  struct Eval { float m, sg, u, gx2, gy2; };
+  __device__ Eval eval(int px) const {
+    Eval e;
+    int row;
+    if (small) {  // one multiply by 1/w and a +-1 correction instead of an integer division (see MaskPrm::eval)
+      row = int(float(px) * inv_w);
+      const int r = px - row * w;
+      row += (r >= w) ? 1 : 0;
+      row -= (r < 0) ? 1 : 0;
+    } else {
+      row = px / w;
+    }
+    const int col = px - row * w;
+    const float gx = (float(row) + oi) * inv_se - 0.5f, gy = (float(col) + oj) * inv_se - 0.5f;
+    e.gx2 = gx * gx;
+    e.gy2 = gy * gy;
+    e.u = (gx * a) * (gx * a) + (gy * b) * (gy * b) + c5;
+    e.sg = fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * (e.u * k)));
+    e.m = masking ? e.sg * S : 1.0f;
+    return e;
+  }
+  // d mask / d mp_j from the image totals of the five accumulators
+  __device__ static float finish_one(const float* __restrict__ mp, float sharp, const float* a, int j) {
+    const float k = sharp * mp[3] / 5.0f, S = mp[4] / 5.0f * 0.5f + 0.5f;
+    switch (j) {
+      case 0: return S * k * 2.0f * mp[0] * a[0];
+      case 1: return S * k * 2.0f * mp[1] * a[1];
+      case 2: return S * k * a[2];
+      case 3: return S * (sharp / 5.0f) * a[3];
+      default: return 0.1f * a[4];
+    }
+  }
+};
+
 }  // namespace expo

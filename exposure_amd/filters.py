@@ -50,6 +50,70 @@ class _PixelFilterFunction(torch.autograd.Function):
     return dx, dparams, None, None
 
 
+class _PixelFilterPairFunction(torch.autograd.Function):
+  """One filter, one parameter tensor, TWO images: the 64x64 proxy and the full-resolution image of
+  ``Filter.apply(img, ..., high_res=...)`` (filters.py:88-96).  As one autograd node the parameter gradient is
+  produced ONCE: the proxy's pass overwrites it and the full-resolution pass adds to it in the finish launch
+  (``expo_filter_bwd_accumulate``) -- instead of two nodes whose (N, P) results autograd adds afterwards."""
+
+  @staticmethod
+  def forward(ctx, img, high, packed, fid, hsv_grad_mode):
+    img, high = img.contiguous(), high.contiguous()
+    packed = packed.contiguous().float()
+    y, yh = torch.empty_like(img), torch.empty_like(high)
+    _cabi.filter_fwd(fid, img, y, packed)
+    _cabi.filter_fwd(fid, high, yh, packed)
+    ctx.save_for_backward(img, high, packed)
+    ctx.fid = fid
+    ctx.hsv_grad_mode = hsv_grad_mode
+    ctx.set_materialize_grads(False)  # an output nobody differentiates costs no launch
+    return y, yh
+
+  @staticmethod
+  def backward(ctx, dy, dyh):
+    img, high, packed = ctx.saved_tensors
+    dparams = None
+    grads = []
+    for x, g, need in ((img, dy, ctx.needs_input_grad[0]), (high, dyh, ctx.needs_input_grad[1])):
+      if g is None:
+        grads.append(None)
+        continue
+      g = g.contiguous().to(x.dtype)
+      dx = torch.empty_like(x) if need else None
+      first = dparams is None
+      if first:
+        dparams = torch.empty_like(packed)
+      _cabi.filter_bwd(ctx.fid, x, g, dx, packed, dparams, ctx.hsv_grad_mode, accumulate=not first)
+      grads.append(dx)
+    return grads[0], grads[1], dparams, None, None
+
+
+class _OverexposurePenaltyFunction(torch.autograd.Function):
+  """mean_{h,w,c} max(y - 1, 0)^2 per image (agent.py:249-251) -- expo_overexposure_penalty / _bwd.  The agent's
+  default path gets this from the fused dispatch pass; this node serves the paths that cannot (cfg.masking,
+  cfg.clamp: the penalty is then taken on an image no dispatch kernel produced)."""
+
+  @staticmethod
+  def forward(ctx, y):
+    y = y.contiguous()
+    pen = torch.empty((y.shape[0],), dtype=torch.float32, device=y.device)
+    _cabi.overexposure_penalty(y, pen)
+    ctx.save_for_backward(y)
+    return pen
+
+  @staticmethod
+  def backward(ctx, dpen):
+    y, = ctx.saved_tensors
+    dy = torch.empty_like(y)
+    _cabi.overexposure_penalty_bwd(y, dpen.contiguous().float(), dy)
+    return dy
+
+
+def overexposure_penalty(y):
+  """(N,) float32: ``reduce_mean(maximum(net - 1, 0)**2, axis=(1, 2, 3))`` of agent.py:249-251, differentiable."""
+  return _OverexposurePenaltyFunction.apply(y)
+
+
 class _MaskedApplyFunction(torch.autograd.Function):
   """out = lerp(img, process(img, packed), mask(img, mask_params)) -- expo_filter_apply_fwd/bwd."""
 
@@ -181,6 +245,12 @@ class Filter(nn.Module):
       # lerp(img, process(img, p), ones(1,1,1,1)) == process(img, p): the constant-one mask of the
       # shipped configs (cfg.masking = False) is folded away instead of spending two more passes.
       apply_one = lambda im: self.process(im, filter_parameters)
+      if high_res is not None and not self.no_high_res():
+        # proxy + full-resolution image share the parameters: ONE autograd node, ONE parameter gradient
+        hsv_mode = int(self.cfg.get('hsv_grad_mode', 0)) if hasattr(self.cfg, 'get') else 0
+        low_res_output, high_res_output = _PixelFilterPairFunction.apply(img, high_res, self.pack(filter_parameters),
+                                                                         self.filter_id, hsv_mode)
+        return low_res_output, high_res_output, debug_info
     else:
       # masking on: mask evaluation, process() and the lerp are ONE kernel (expo_filter_apply_fwd)
       mp = tanh_range(-5, 5, initial=0)(mask_parameters)  # filters.py:121-123
@@ -368,12 +438,37 @@ class LevelFilter(Filter):
     return torch.sigmoid(features)
 
 
+class _VignetApplyFunction(torch.autograd.Function):
+  """out = img * (1 - mask(mask_params)) -- expo_vignet_apply_fwd/bwd (VignetFilter.apply, filters.py:341-396)."""
+
+  @staticmethod
+  def forward(ctx, img, mask_params, sharp, masking):
+    img = img.contiguous()
+    mask_params = mask_params.contiguous().float()
+    y = torch.empty_like(img)
+    _cabi.vignet_apply_fwd(img, y, mask_params, sharp, masking)
+    ctx.save_for_backward(img, mask_params)
+    ctx.args = (sharp, masking)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    img, mask_params = ctx.saved_tensors
+    sharp, masking = ctx.args
+    dy = dy.contiguous().to(img.dtype)
+    dx = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+    dmask = torch.empty_like(mask_params)
+    _cabi.vignet_apply_bwd(img, dy, dx, mask_params, dmask, sharp, masking)
+    return dx, dmask, None, None
+
+
 class VignetFilter(Filter):
-  """filters.py:341-401.  In the reference ``process`` is ``img * 0`` (the additive term is commented
-  out, filters.py:351-352) and the class is in no config, so ``apply`` = ``lerp(img, 0, mask)`` =
-  ``img * (1 - mask)`` with the elliptical mask of filters.py:360-396 (5 mask parameters; with masking
-  off the mask is forced to 1 and the output is 0).  No HIP kernel backs it: it is a two-op tensor
-  expression on whatever device ``img`` lives on, kept so the ``Filter`` surface is complete."""
+  """filters.py:341-401.  In the reference ``process`` is ``img * 0`` (the additive term is commented out,
+  filters.py:351-352) and the class is in no config, so ``apply`` = ``lerp(img, 0, mask)`` = ``img * (1 - mask)``
+  with the elliptical mask of filters.py:360-396 (5 mask parameters; with masking off the mask is forced to 1 and
+  the output is 0).  ``apply`` is ONE HIP kernel (``expo_vignet_apply_fwd``: mask evaluation + lerp), its backward
+  one more (``expo_vignet_apply_bwd``: image gradient + the 5 mask-parameter gradients); the filter's own parameter
+  (``sigmoid(features)``) reaches nothing, exactly as in the reference."""
   filter_id = None
 
   def __init__(self, net, cfg):
@@ -386,13 +481,16 @@ class VignetFilter(Filter):
     return torch.sigmoid(features)
 
   def process(self, img, param):
-    return img * 0  # + param[:, None, None, :]
+    """filters.py:351-352: ``img * 0`` -- a zero mask makes expo_vignet_apply_fwd exactly that (mask forced to 1)."""
+    zeros = torch.zeros((img.shape[0], self.get_num_mask_parameters()), dtype=torch.float32, device=img.device)
+    return _VignetApplyFunction.apply(img, zeros, float(self.cfg.maximum_sharpness), False)
 
   def get_num_mask_parameters(self):
     return 5
 
   def get_mask(self, img, mask_parameters):
-    """filters.py:360-396: sigmoid(((gx A)^2 + (gy B)^2 + C - 5) * sharp * D / 5) * (E / 5 * .5 + .5)."""
+    """filters.py:360-396: sigmoid(((gx A)^2 + (gy B)^2 + C - 5) * sharp * D / 5) * (E / 5 * .5 + .5), as a tensor
+    for debug_info / visualisers only -- ``apply`` evaluates the mask inside the kernel."""
     filter_input_range = 5
     assert mask_parameters.shape[1] == self.get_num_mask_parameters()
     mp = tanh_range(-filter_input_range, filter_input_range, initial=0)(mask_parameters)
@@ -420,17 +518,20 @@ class VignetFilter(Filter):
     else:
       assert not self.use_masking()
       filter_parameters = specified_parameter
-      mask_parameters = torch.zeros((1, self.get_num_mask_parameters()), dtype=torch.float32, device=img.device)
-    from .util import lerp
+      mask_parameters = torch.zeros((img.shape[0], self.get_num_mask_parameters()), dtype=torch.float32,
+                                    device=img.device)
     debug_info = {'filter_parameters': filter_parameters[0]}
     self.mask_parameters = mask_parameters
-    self.mask = self.get_mask(img, mask_parameters)
+    with torch.no_grad():  # debug output (first image) only
+      self.mask = self.get_mask(img[:1], mask_parameters[:1])
     debug_info['mask'] = self.mask[0]
-    low = lerp(img.float(), self.process(img.float(), filter_parameters), self.mask).to(img.dtype)
-    high = None
-    if high_res is not None:
-      hmask = self.get_mask(high_res, mask_parameters)
-      high = lerp(high_res.float(), self.process(high_res.float(), filter_parameters), hmask).to(high_res.dtype)
+    mp = tanh_range(-5, 5, initial=0)(mask_parameters)  # filters.py:366-368
+    if mp.shape[0] == 1 and img.shape[0] > 1:
+      mp = mp.expand(img.shape[0], mp.shape[1])
+    apply_one = lambda im: _VignetApplyFunction.apply(im, mp, float(self.cfg.maximum_sharpness),
+                                                      bool(self.use_masking()))
+    low = apply_one(img)
+    high = apply_one(high_res) if high_res is not None else None
     return low, high, debug_info
 
 

@@ -49,7 +49,7 @@ extern "C" {
 #endif
 
 #define EXPO_ABI_VERSION 3 /* 2: caller-owned reduction workspace (no float atomics, no fills); 3: derivatives of the
-                              critic statistics and of the penalty */
+                              critic statistics and of the penalty, VignetFilter, bias + lrelu */
 
 #define EXPO_OK 0
 #define EXPO_E_BADARG (-1)
@@ -247,6 +247,21 @@ int expo_critic_stats(const void* x, float* stats, int n, int h, int w, int dtyp
  */
 int expo_overexposure_penalty(const void* y, float* penalty, int n, int h, int w,
                               int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * VignetFilter.apply (filters.py:341-396; defined by the reference, in no cfg.filters).  process() is img * 0
+ * (filters.py:351-352), so the filter IS its mask:  y = x * (1 - mask),
+ *   mask = sigmoid(((gx*m0)^2 + (gy*m1)^2 + m2 - 5) * maximum_sharpness * m3 / 5) * (m4/5 * .5 + .5)
+ * with gx, gy the constant coordinate grid of filters.py:371-380 (the one expo_filter_apply_fwd uses).
+ * mask_params: float32 [N][5] = tanh_range(-5, 5)(raw mask parameters) (the squashing stays with the caller, as
+ * for expo_filter_apply_fwd).  masking = 0 reproduces cfg.masking = False: mask forced to 1 (filters.py:390-392),
+ * i.e. y = 0, dx = 0, dmask_params = 0.  The backward overwrites dx (nullable) and dmask_params [N][5].
+ */
+int expo_vignet_apply_fwd(const void* x, void* y, const float* mask_params, float maximum_sharpness, int masking,
+                          int n, int h, int w, int dtype, void* stream);
+int expo_vignet_apply_bwd(const void* x, const void* dy, void* dx, const float* mask_params,
+                          float* dmask_params, float maximum_sharpness, int masking, int n, int h, int w,
+                          int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * d penalty / d y of expo_overexposure_penalty (what tf.gradients produces for agent.py:249-251 when the

@@ -168,6 +168,28 @@ def get_mask(img, mask_parameters, maximum_sharpness=1, minimum_strength=0.3):
   return mask
 
 
+def vignet_mask(img, mask_parameters, maximum_sharpness=1, masking=True):
+  """VignetFilter.get_mask (filters.py:360-396); mask_parameters RAW (N,5)."""
+  filter_input_range = 5
+  mp = tanh_range(-filter_input_range, filter_input_range, initial=0)(mask_parameters)
+  h, w = img.shape[1], img.shape[2]
+  se = min(h, w)
+  gi = ((torch.arange(h, dtype=torch.float64) + (se - h) / 2.0) / se - 0.5).float().to(img.dtype)
+  gj = ((torch.arange(w, dtype=torch.float64) + (se - w) / 2.0) / se - 0.5).float().to(img.dtype)
+  inp = (gi[None, :, None, None] * mp[:, None, None, 0, None])**2 + \
+      (gj[None, None, :, None] * mp[:, None, None, 1, None])**2 + mp[:, None, None, 2, None] - filter_input_range
+  inp = inp * (maximum_sharpness * mp[:, None, None, 3, None] / filter_input_range)
+  mask = torch.sigmoid(inp) * (mp[:, None, None, 4, None] / filter_input_range * 0.5 + 0.5)
+  if not masking:
+    mask = mask * 0 + 1  # filters.py:390-392
+  return mask
+
+
+def vignet_apply(img, mask_parameters, maximum_sharpness=1, masking=True):
+  """VignetFilter.apply: process = img * 0 (filters.py:351-352), out = lerp(img, 0, mask) (filters.py:86-88)."""
+  return lerp(img, img * 0, vignet_mask(img, mask_parameters, maximum_sharpness, masking))
+
+
 def apply_masked(fid, img, packed, mask_parameters, maximum_sharpness=1, minimum_strength=0.3, hsv_grad_mode=0):
   """Filter.apply with cfg.masking = True (filters.py:86-88)."""
   mask = get_mask(img, mask_parameters, maximum_sharpness, minimum_strength)

@@ -102,6 +102,21 @@ def _apply_bwd(fid, x, dy, dx, params, dparams, mask_params, dmask_params, maxim
   dmask_params.copy_(gm.float())
 
 
+def _vignet_fwd(x, y, mask_params, maximum_sharpness, masking):
+  y.copy_(ft.vignet_apply(x.double(), _raw_mask(mask_params), maximum_sharpness, bool(masking)).to(y.dtype))
+
+
+def _vignet_bwd(x, dy, dx, mask_params, dmask_params, maximum_sharpness, masking):
+  with torch.enable_grad():
+    mp = mask_params.double().detach().clone().requires_grad_(True)
+    xi = x.double().detach().clone().requires_grad_(True)
+    out = ft.vignet_apply(xi, torch.atanh((mp / 5.0).clamp(-1 + 1e-15, 1 - 1e-15)), maximum_sharpness, bool(masking))
+    gx, gm = torch.autograd.grad(out, [xi, mp], dy.double(), allow_unused=True)
+  if dx is not None:
+    dx.copy_(gx.to(dx.dtype))
+  dmask_params.copy_(gm.float() if gm is not None else torch.zeros_like(dmask_params))
+
+
 def _stats(x, stats):
   stats.copy_(torch.from_numpy(agent_np.critic_stats(x.double().numpy())).float())
 
@@ -148,5 +163,6 @@ def fake_hip():
                            dispatch_bwd=_dispatch_bwd, critic_stats=_stats, overexposure_penalty=_penalty,
                            critic_stats_bwd=_stats_bwd, critic_stats_jvp=_stats_jvp, critic_stats_hvp=_stats_hvp,
                            overexposure_penalty_bwd=_penalty_bwd, bias_lrelu_fwd=_bias_lrelu_fwd, lrelu_bwd=_lrelu_bwd,
+                           vignet_apply_fwd=_vignet_fwd, vignet_apply_bwd=_vignet_bwd,
                            chain_fused_fwd=_chain_fused_fwd, apply_fwd=_apply_fwd, apply_bwd=_apply_bwd):
     yield

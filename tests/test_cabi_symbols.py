@@ -53,6 +53,27 @@ def test_argument_validation_without_gpu():
   assert lib.expo_filter_fwd(0, None, None, None, 1, 40000, 40000, 0, None) == -1  # image >= 2 GiB
   assert b'2 GiB' in lib.expo_last_error()
   assert lib.expo_chain_fwd(None, 1, None, None, 1, 1, 1, 0, None) == -1
+  # a bad entry in the LAST step is found before anything is enqueued (so this is safe without a GPU): the chain
+  # entry points validate every step first
+  vp = ctypes.c_void_p
+  ids = (ctypes.c_int * 3)(0, 1, 2)
+  fake = 0x1000  # never dereferenced on the host
+  acts = (vp * 4)(fake, fake, fake, fake)
+  grads = (vp * 4)(fake, fake, fake, fake)
+  prm = (vp * 3)(fake, fake, None)
+  dprm = (vp * 3)(fake, fake, fake)
+  assert lib.expo_chain_fwd(ids, 3, acts, prm, 1, 4, 4, 0, None) == -1 and b'null' in lib.expo_last_error()
+  assert lib.expo_chain_bwd(ids, 3, acts, grads, prm, dprm, 1, 4, 4, 0, 0, vp(fake), 1 << 20, None) == -1
+  assert b'null' in lib.expo_last_error()
+  bad_ids = (ctypes.c_int * 3)(0, 1, 9)
+  prm_ok = (vp * 3)(fake, fake, fake)
+  assert lib.expo_chain_fwd(bad_ids, 3, acts, prm_ok, 1, 4, 4, 0, None) == -1 and b'filter_id' in lib.expo_last_error()
+  # the new entry points validate the same way
+  assert lib.expo_critic_stats_bwd(None, None, None, None, 1, 4, 4, 0, None) == -1
+  assert lib.expo_critic_stats_jvp(None, None, None, None, 0, 4, 4, 0, None, 0, None) == 0
+  assert lib.expo_vignet_apply_fwd(None, None, None, 1.0, 1, 1, 4, 4, 5, None) == -2
+  assert lib.expo_bias_lrelu_fwd(None, None, None, 0, 1, 0.2, None) == 0
+  assert lib.expo_bias_lrelu_fwd(None, None, None, 8, 1, 0.2, None) == -1
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -192,6 +192,32 @@ def test_high_res_uses_same_parameters(gpu_device):
   assert_image_close(high.detach().float().cpu().numpy(), fnp.process_packed(4, hi.astype(np.float64), packed), np.float16)
 
 
+@pytest.mark.parametrize('fid', [0, 4, 7])
+def test_low_plus_high_res_node_accumulates_the_parameter_gradient_once(fid, gpu_device):
+  """filters.py:88-96: the proxy and the full-resolution image go through the SAME parameters.  The pair node
+  (expo_filter_bwd then expo_filter_bwd_accumulate) must give the image gradients of the two single applications
+  and a parameter gradient equal to the float64 sum of theirs; an output nobody differentiates costs nothing."""
+  dev = gpu_device
+  lo, dlo, p = synthetic.make_case(8, (3, 64, 64, 3), np.float16)
+  hi, dhi, _ = synthetic.make_case(9, (3, 96, 128, 3), np.float16)
+  t = lambda a: torch.from_numpy(a).to(dev)
+  packed = t(p[fid]).requires_grad_(True)
+  xl, xh = t(lo).requires_grad_(True), t(hi).requires_grad_(True)
+  yl, yh = filters._PixelFilterPairFunction.apply(xl, xh, packed, fid, 0)
+  gl, gh, gp = torch.autograd.grad([yl, yh], [xl, xh, packed], [t(dlo), t(dhi)])
+  rl = fnp.backward_packed(fid, lo.astype(np.float64), p[fid].astype(np.float64), dlo.astype(np.float64))
+  rh = fnp.backward_packed(fid, hi.astype(np.float64), p[fid].astype(np.float64), dhi.astype(np.float64))
+  assert_image_close(gl.float().cpu().numpy(), rl[0], np.float16, 'pair dx low')
+  assert_image_close(gh.float().cpu().numpy(), rh[0], np.float16, 'pair dx high')
+  scale = np.abs(dlo.astype(np.float64)).reshape(3, -1).sum(axis=1, keepdims=True) * 4 + \
+      np.abs(dhi.astype(np.float64)).reshape(3, -1).sum(axis=1, keepdims=True) * 4
+  assert_param_grad_close(gp.cpu().numpy(), rl[1] + rh[1], scale, 'pair dparams')
+  # only the full-resolution output is differentiated: the proxy's pass is skipped, the gradient is the high one
+  yl, yh = filters._PixelFilterPairFunction.apply(xl, xh, packed, fid, 0)
+  gp_h, = torch.autograd.grad(yh, packed, t(dhi))
+  assert_param_grad_close(gp_h.cpu().numpy(), rh[1], scale, 'pair dparams (high only)')
+
+
 def test_chain_matches_stepwise_oracle(gpu_device):
   """Config 2 of BASELINE.json: full 8-filter chain fwd+bwd at 64x64x64x3 fp16, per-step check
   (each step's oracle input is the previous fp16 GPU output, so the bound stays per-pixel)."""

@@ -101,6 +101,9 @@ def test_vignet_filter_matches_oracle(masking):
                          masking)
   assert np.abs(low.detach().numpy() - ref).max() < 1e-6
   assert high.shape == (2, 20, 12, 3)
+  with fake_hip():
+    (low.sum() + high.sum()).backward()
+  assert (float(v.fc2.weight.grad[1:].abs().max()) > 0.0) == masking  # the 5 mask rows of fc2
   if not masking:
     assert float(low.detach().abs().max()) == 0.0  # mask forced to 1, process = img * 0
 
