@@ -40,6 +40,7 @@ SIGNATURES = {
                                    _vp]),
     'expo_filter_dispatch_fwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_filter_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_chain_streams': (_i, [_i, _i, _i, _i]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
                             _vp]),
     'expo_chain_bwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
@@ -513,3 +514,8 @@ def vignet_apply_bwd(x, dy, dx, mask_params, dmask_params, maximum_sharpness, ma
     _check(lib.expo_vignet_apply_bwd(_ptr(x), _ptr(dy), _ptr(dx), _ptr(mask_params), _ptr(dmask_params),
                                      float(maximum_sharpness), int(bool(masking)), n, h, w, _dtype_code(x), wsp, wsb,
                                      _stream()), 'expo_vignet_apply_bwd')
+
+
+def chain_streams(n, h, w, dtype_code):
+  """1 or 2: how many streams expo_chain_fwd / _bwd use for a batch of this shape."""
+  return int(load().expo_chain_streams(int(n), int(h), int(w), int(dtype_code)))

@@ -21,6 +21,10 @@
 #include "kernel_common.h"
 #include "host_common.h"
 
+#ifndef EXPO_FUSED_MIN_WAVES
+#define EXPO_FUSED_MIN_WAVES  // e.g. -DEXPO_FUSED_MIN_WAVES=,8 : register budget for 8 waves per SIMD (probe builds)
+#endif
+
 namespace expo {
 
 // ------------------------------------------------------- fused multi-step forward (inference)
@@ -32,7 +36,7 @@ namespace expo {
 // Each wave owns exactly one 3 KiB chunk, so the per-step parameters are fetched once per wave
 // through scalar loads; the step loop is rolled (block-uniform switch per step).
 template <typename T, bool VEC, class IO>
-__global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t* __restrict__ ids,
+__global__ __launch_bounds__(kThreads EXPO_FUSED_MIN_WAVES) void chain_fused_fwd_kernel(const int32_t* __restrict__ ids,
                                                                    const float* __restrict__ params, int steps,
                                                                    const T* __restrict__ x, T* __restrict__ y,
                                                                    int hw, int groups) {
@@ -46,59 +50,81 @@ __global__ __launch_bounds__(kThreads) void chain_fused_fwd_kernel(const int32_t
   __shared__ float2_lut curve_tab[kWaves][32];
   float2_lut* const tab = curve_tab[threadIdx.x >> 6];
   const int plane = (threadIdx.x & 63) % EXPO_MAX_PARAMS;  // which parameter this lane mirrors
-  auto run = [&](float* v) {
-    // software-pipelined parameter fetch: step st+1's id and 24 parameters (wave-uniform -> scalar
-    // loads into SGPRs) are requested before step st computes, hiding the scalar-load latency;
-    // `klane` is a per-lane copy (lane l <-> parameter l) for the curve table of curve_fwd_lut
-    float cur[EXPO_MAX_PARAMS], nxt[EXPO_MAX_PARAMS];
-    float klane = 0.f, klane_next = 0.f;
-    int id = -1, id_next = -1;
-    if (steps > 0) {
-      id = idn[0];
-      klane = prn[plane];
-#pragma unroll
-      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = prn[j];
-    }
-#pragma unroll 1
-    for (int st = 0; st < steps; ++st) {
-      const int sn = (st + 1 < steps) ? st + 1 : st;
-      id_next = idn[sn];
-      klane_next = prn[sn * EXPO_MAX_PARAMS + plane];
-#pragma unroll
-      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) nxt[j] = prn[sn * EXPO_MAX_PARAMS + j];
-      const float* prm = cur;
+  // One step, OUT OF PLACE (in -> out).  The step loop below runs two steps per trip with the two pixel arrays (and
+  // the two parameter sets) swapping roles, so no loop-carried value is ever copied: the rolled one-step loop paid 24
+  // v_mov + 24 s_mov per step for its loop PHIs (the coupled filters cannot update a pixel in place), ~17 % of the
+  // instructions a wave issued for an 8-step sequence.
+  auto apply = [&](int id, const float* prm, float klane, const float* in, float* out) {
 #define EXPO_CASE(ID, F)                              \
   case ID: {                                          \
     const typename F::Prm q = F::load(prm);           \
-    _Pragma("unroll") for (int k = 0; k < PPL; ++k) { \
-      float o[3];                                     \
-      F::fwd(q, v + 3 * k, o);                        \
-      v[3 * k] = o[0];                                \
-      v[3 * k + 1] = o[1];                            \
-      v[3 * k + 2] = o[2];                            \
-    }                                                 \
+    _Pragma("unroll") for (int k = 0; k < PPL; ++k) F::fwd(q, in + 3 * k, out + 3 * k); \
   } break;
-      switch (id) {
-        EXPO_CASE(0, ExposureF)
-        EXPO_CASE(1, GammaF)
-        EXPO_CASE(2, WhiteBalanceF)
-        EXPO_CASE(3, SatPlusF)
-        case 4: curve_fwd_lut<1, PPL>(v, klane, tab); break;
-        EXPO_CASE(5, ContrastF)
-        EXPO_CASE(6, WnbF)
-        case 7: curve_fwd_lut<3, PPL>(v, klane, tab); break;
-        EXPO_CASE(8, LevelF)
-        default:  // id -1: the all-zero one-hot selects nothing -> the image becomes 0
+    switch (id) {
+      EXPO_CASE(0, ExposureF)
+      EXPO_CASE(1, GammaF)
+      EXPO_CASE(2, WhiteBalanceF)
+      EXPO_CASE(3, SatPlusF)
+      case 4:
+        curve_lut_build<1>(klane, tab);
+        curve_lut_map<1, PPL>(in, out, tab);
+        __builtin_amdgcn_wave_barrier();  // the next curve step of this wave rewrites the table
+        break;
+      EXPO_CASE(5, ContrastF)
+      EXPO_CASE(6, WnbF)
+      case 7:
+        curve_lut_build<3>(klane, tab);
+        curve_lut_map<3, PPL>(in, out, tab);
+        __builtin_amdgcn_wave_barrier();
+        break;
+      EXPO_CASE(8, LevelF)
+      default:  // id -1 (the all-zero one-hot selects nothing) -> the image becomes 0.  Written as arithmetic (clamp,
+        // then x * 0 + 0: exactly +0 for every input incl. inf / NaN) rather than as 24 constant moves: those the
+        // compiler executes speculatively in front of the neighbouring case (Exposure) on EVERY step.  (No
+        // __builtin_unreachable() for ids outside [-1, 8] either: with it hipcc 7.2 drops the first two values of the
+        // fp32 kernel's first pixel row -- found by the fp32 parity test, gpurun r03p17.)
 #pragma unroll
-          for (int j = 0; j < PPL * 3; ++j) v[j] = 0.f;
-          break;
-      }
-#undef EXPO_CASE
-      id = id_next;
-      klane = klane_next;
-#pragma unroll
-      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) cur[j] = nxt[j];
+        for (int j = 0; j < PPL * 3; ++j) out[j] = fmaf(clamp01x(in[j], -65504.0f, 65504.0f), 0.0f, 0.0f);
+        break;
     }
+#undef EXPO_CASE
+  };
+  auto run = [&](float* v) {
+    // software-pipelined parameter fetch: a step's id and 24 parameters (wave-uniform -> scalar loads into SGPRs)
+    // are requested one step ahead, hiding the scalar-load latency; `k*` is a per-lane copy (lane l <-> parameter l)
+    // for the curve table.  Two parameter sets alternate like the pixel arrays.
+    float pa[EXPO_MAX_PARAMS], pb[EXPO_MAX_PARAMS];
+    float ka = 0.f, kb = 0.f;
+    int ia = 0, ib = 0;
+    // a step past the end (the second half of the last trip of an odd-length sequence) is the identity: Exposure with
+    // 0 EV, x * 2^0 = x exactly -- no extra case in the switch
+    auto fetch = [&](int st, float* p, float& kl, int& id) {
+      const bool live = st < steps;
+      const int sn = live ? st : steps - 1;  // (past the end: any valid row)
+      id = live ? idn[sn] : 0;
+      kl = prn[sn * EXPO_MAX_PARAMS + plane];
+#pragma unroll
+      for (int j = 0; j < EXPO_MAX_PARAMS; ++j) p[j] = prn[sn * EXPO_MAX_PARAMS + j];
+      if (!live) p[0] = 0.0f;
+    };
+    if (steps <= 0) return;
+    // (the pixel arrays are locals, copied in and out -- free in SSA form.  Running the loop directly on the caller's
+    // array made hipcc 7.2 allocate the fp32 kernel's store ADDRESS register inside the 96-bit data tuple of the first
+    // pixel row: R and G of every 64th pixel wrong.  Caught by the fp32 parity tests, gpurun r03p17;
+    // tests/test_isa_sanity.py now scans every kernel's ISA for that overlap.)
+    float a[PPL * 3], w[PPL * 3];
+#pragma unroll
+    for (int j = 0; j < PPL * 3; ++j) a[j] = v[j];
+    fetch(0, pa, ka, ia);
+#pragma unroll 1
+    for (int st = 0; st < steps; st += 2) {
+      fetch(st + 1, pb, kb, ib);
+      apply(ia, pa, ka, a, w);
+      fetch(st + 2, pa, ka, ia);
+      apply(ib, pb, kb, w, a);
+    }
+#pragma unroll
+    for (int j = 0; j < PPL * 3; ++j) v[j] = a[j];
   };
   const int stride = gridDim.x * kThreads;
   if constexpr (VEC) {

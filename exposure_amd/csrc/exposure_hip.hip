@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 #include <string>
 #include <type_traits>
 
@@ -37,6 +38,9 @@
 // profiles/r02_experiments.md): forward waves own exactly one chunk and do not prefetch; backward waves walk
 // block-strided chunks with a one-deep software prefetch; the forward's per-image constants are fetched after
 // the first chunk's loads have been issued.
+#ifndef EXPO_BWD_MIN_WAVES
+#define EXPO_BWD_MIN_WAVES  // e.g. -DEXPO_BWD_MIN_WAVES=,5 : a register budget for 5 waves per SIMD (probe builds)
+#endif
 constexpr bool kFwdPrefetch = false;
 constexpr bool kBwdPrefetch = true;
 constexpr int kAccParts = 4;  // partial sums per thread in the element-wise backward (1 / 2 / 4 measured, r02p27)
@@ -234,7 +238,7 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
 }
 
 template <class F, typename T, bool VEC, bool HAS_DX, int MODE, class IO>
-__global__ __launch_bounds__(kThreads) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(kThreads EXPO_BWD_MIN_WAVES) void filter_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                               T* __restrict__ dx,
                                                               const float* __restrict__ params,
                                                               float* __restrict__ records, int hw, int groups,
@@ -979,8 +983,11 @@ static int launch_finish(const FinishArgs& args, int steps, int n, hipStream_t s
 }
 
 template <class F, typename T>
-static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s, int rev) {
-  const Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
+static int launch_fwd(const void* x, void* y, const float* params, int n, int h, int w, hipStream_t s, int rev,
+                      int n_geom) {
+  // n_geom: the batch size the launch geometry (blocks per image, cache policy) is chosen for -- the whole batch when
+  // a chain runs its two halves on two streams, so both halves and the finish launch agree on the record count
+  const Geom g = make_geom<T>(n_geom, h, w, {x, y}, kGeomMap);
   const dim3 grid(g.blocks_x, n), block(kThreads);
   if (g.stream)
     hipLaunchKernelGGL((filter_fwd_kernel<F, T, true, IoStream>), grid, block, 0, s, (const T*)x, (T*)y, params, g.hw, g.groups, rev);
@@ -994,9 +1001,9 @@ static int launch_fwd(const void* x, void* y, const float* params, int n, int h,
 
 template <class F, typename T>
 static int launch_bwd(const void* x, const void* dy, void* dx, const float* params, float* records, int n,
-                      int h, int w, int mode, hipStream_t s, int rev) {
+                      int h, int w, int mode, hipStream_t s, int rev, int n_geom) {
   constexpr int kKind = F::kLutFloats > 0 ? (F::NP == kCurveSteps ? kGeomReduceTone : kGeomReduceColor) : kGeomReduce;
-  const Geom g = make_geom<T>(n, h, w, {x, dy, dx}, kKind);
+  const Geom g = make_geom<T>(n_geom, h, w, {x, dy, dx}, kKind);
   const dim3 grid(g.blocks_x, n), block(kThreads);
 #define EXPO_LIO(VEC, HAS_DX, MODE, IO)                                                                  \
   hipLaunchKernelGGL((filter_bwd_kernel<F, T, VEC, HAS_DX, MODE, IO>), grid, block, 0, s, (const T*)x, \
@@ -1031,34 +1038,36 @@ static int launch_bwd(const void* x, const void* dy, void* dx, const float* para
 
 template <typename T>
 static int fwd_by_id(int id, const void* x, void* y, const float* p, int n, int h, int w, hipStream_t s,
-                     int rev = 0) {
+                     int rev = 0, int n_geom = -1) {
+  if (n_geom < 0) n_geom = n;
   switch (id) {
-    case 0: return launch_fwd<ExposureF, T>(x, y, p, n, h, w, s, rev);
-    case 1: return launch_fwd<GammaF, T>(x, y, p, n, h, w, s, rev);
-    case 2: return launch_fwd<WhiteBalanceF, T>(x, y, p, n, h, w, s, rev);
-    case 3: return launch_fwd<SatPlusF, T>(x, y, p, n, h, w, s, rev);
-    case 4: return launch_fwd<ToneF, T>(x, y, p, n, h, w, s, rev);
-    case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s, rev);
-    case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s, rev);
-    case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s, rev);
-    case 8: return launch_fwd<LevelF, T>(x, y, p, n, h, w, s, rev);
+    case 0: return launch_fwd<ExposureF, T>(x, y, p, n, h, w, s, rev, n_geom);
+    case 1: return launch_fwd<GammaF, T>(x, y, p, n, h, w, s, rev, n_geom);
+    case 2: return launch_fwd<WhiteBalanceF, T>(x, y, p, n, h, w, s, rev, n_geom);
+    case 3: return launch_fwd<SatPlusF, T>(x, y, p, n, h, w, s, rev, n_geom);
+    case 4: return launch_fwd<ToneF, T>(x, y, p, n, h, w, s, rev, n_geom);
+    case 5: return launch_fwd<ContrastF, T>(x, y, p, n, h, w, s, rev, n_geom);
+    case 6: return launch_fwd<WnbF, T>(x, y, p, n, h, w, s, rev, n_geom);
+    case 7: return launch_fwd<ColorF, T>(x, y, p, n, h, w, s, rev, n_geom);
+    case 8: return launch_fwd<LevelF, T>(x, y, p, n, h, w, s, rev, n_geom);
   }
   return fail(EXPO_E_BADARG, "filter_id out of range");
 }
 
 template <typename T>
 static int bwd_by_id(int id, const void* x, const void* dy, void* dx, const float* p, float* records, int n, int h,
-                     int w, int mode, hipStream_t s, int rev = 0) {
+                     int w, int mode, hipStream_t s, int rev = 0, int n_geom = -1) {
+  if (n_geom < 0) n_geom = n;
   switch (id) {
-    case 0: return launch_bwd<ExposureF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
-    case 1: return launch_bwd<GammaF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
-    case 2: return launch_bwd<WhiteBalanceF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
-    case 3: return launch_bwd<SatPlusF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
-    case 4: return launch_bwd<ToneF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
-    case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
-    case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
-    case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
-    case 8: return launch_bwd<LevelF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev);
+    case 0: return launch_bwd<ExposureF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev, n_geom);
+    case 1: return launch_bwd<GammaF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev, n_geom);
+    case 2: return launch_bwd<WhiteBalanceF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev, n_geom);
+    case 3: return launch_bwd<SatPlusF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev, n_geom);
+    case 4: return launch_bwd<ToneF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev, n_geom);
+    case 5: return launch_bwd<ContrastF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev, n_geom);
+    case 6: return launch_bwd<WnbF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev, n_geom);
+    case 7: return launch_bwd<ColorF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev, n_geom);
+    case 8: return launch_bwd<LevelF, T>(x, dy, dx, p, records, n, h, w, mode, s, rev, n_geom);
   }
   return fail(EXPO_E_BADARG, "filter_id out of range");
 }
@@ -1339,6 +1348,50 @@ static int stats_hvp_t(const void* x, const float* dstats, const float* jv, cons
 // ======================================================================== C-ABI
 using namespace expo;
 
+// ---- two half-batches on two streams inside a chain --------------------------------------------------------------
+// The 17 launches of a chain step depend on each other, so every kernel's ramp-up and tail (and the 1.7-1.9 us
+// boundary between two streaming kernels) is exposed.  Images are independent: the batch is split in two halves,
+// each half's launches go to its own stream (the caller's and a library-owned helper stream, forked and joined with
+// events inside the call -- the C-ABI contract "ordered only through `stream`" is unchanged, and the pattern is
+// capturable into a hipGraph as two parallel branches), and one half's kernels fill the other's bubbles.
+// Measured (gpurun r02p20, Python-level prototype): 64 images 0.613-0.622 -> 0.591-0.595 ms per chain step, 128
+// images 1.19-1.22 -> 1.18; a LOSS at 16 / 32 images (half a batch no longer fills 256 CUs) and beyond the Infinity
+// Cache (256 images: the two halves evict each other).  In the library itself (gpurun r03p15, ms per chain step off / on):
+// 16 images 0.184 / 0.185, 32 images 0.322 / 0.305, 64 images 0.600 / 0.579, 128 images 1.180 / 1.163, 64x64x64 0.046 / 0.09-0.14.
+// Hence the gate: on by default only when one tensor is in [40 MiB, 256 MiB); EXPO_CHAIN_STREAMS=1 / 2 forces it
+// off / on; expo_chain_streams() answers what a shape gets.
+struct ForkJoin {
+  hipStream_t helper = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+static ForkJoin* fork_join_for_device() {
+  static ForkJoin table[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  ForkJoin& f = table[dev];
+  if (!f.helper) {
+    hipStream_t st;
+    hipEvent_t e0, e1;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return nullptr;
+    f.helper = st;
+    f.fork = e0;
+    f.join = e1;
+  }
+  return &f;
+}
+static bool chain_split(int n, int h, int w, int dtype) {
+  static const int forced = getenv("EXPO_CHAIN_STREAMS") ? atoi(getenv("EXPO_CHAIN_STREAMS")) : 0;
+  if (n < 2) return false;
+  if (forced == 1) return false;
+  if (forced >= 2) return true;
+  const long bytes = long(n) * h * w * 3L * (dtype == EXPO_F16 ? 2L : 4L);
+  return bytes >= (40L << 20) && bytes < (256L << 20);
+}
+
 // Consecutive launches of a chain walk the images in alternating directions when ONE tensor is larger than
 // the 256 MiB Infinity Cache: each launch then starts on the images its predecessor touched last, which are
 // the ones still cached.  Measured on MI355X, 8-step chain fwd+bwd fp16 (gpurun r02p8, r02p11):
@@ -1482,6 +1535,11 @@ int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const voi
                                                    hsv_grad_mode, workspace, workspace_bytes, s);
 }
 
+int expo_chain_streams(int n, int h, int w, int dtype) {
+  if (check_common(n, h, w, dtype) != EXPO_OK) return 0;
+  return chain_split(n, h, w, dtype) ? 2 : 1;
+}
+
 int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const float* const* params, int n, int h,
                    int w, int dtype, void* stream) {
   if (steps < 0 || !filter_ids || !acts || !params) return fail(EXPO_E_BADARG, "bad chain arguments");
@@ -1493,12 +1551,30 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
     if (filter_ids[i] < 0 || filter_ids[i] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
     if (!acts[i] || !acts[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
   }
+  const size_t esz = dtype == EXPO_F16 ? 2 : 4;
+  ForkJoin* fj = chain_split(n, h, w, dtype) ? fork_join_for_device() : nullptr;
+  const int n0 = fj ? n / 2 : n;  // images [0, n0) on the caller's stream, [n0, n) on the helper stream
+  if (fj) {
+    HIP_TRY(hipEventRecord(fj->fork, s), "chain fork");
+    HIP_TRY(hipStreamWaitEvent(fj->helper, fj->fork, 0), "chain fork");
+  }
   for (int i = 0; i < steps; ++i) {
     const int rev = chain_snake(n, h, w, dtype) ? (i & 1) : 0;
-    const int rc = dtype == EXPO_F16
-                       ? fwd_by_id<half_t>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, rev)
-                       : fwd_by_id<float>(filter_ids[i], acts[i], acts[i + 1], params[i], n, h, w, s, rev);
-    if (rc) return rc;
+    for (int part = 0; part < (fj ? 2 : 1); ++part) {
+      const int nb = part ? n0 : 0, np = part ? n - n0 : n0;
+      const size_t ioff = size_t(nb) * h * w * 3 * esz;
+      const void* xin = static_cast<const char*>(acts[i]) + ioff;
+      void* yout = static_cast<char*>(acts[i + 1]) + ioff;
+      const float* prm = params[i] + size_t(nb) * kNumParams[filter_ids[i]];
+      hipStream_t sp = part ? fj->helper : s;
+      const int rc = dtype == EXPO_F16 ? fwd_by_id<half_t>(filter_ids[i], xin, yout, prm, np, h, w, sp, rev, n)
+                                       : fwd_by_id<float>(filter_ids[i], xin, yout, prm, np, h, w, sp, rev, n);
+      if (rc) return rc;
+    }
+  }
+  if (fj) {
+    HIP_TRY(hipEventRecord(fj->join, fj->helper), "chain join");
+    HIP_TRY(hipStreamWaitEvent(s, fj->join, 0), "chain join");
   }
   return EXPO_OK;
 }
@@ -1567,16 +1643,35 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
   float* records;
   if (int rc = ws_check(workspace, workspace_bytes, n, bx_max, steps, &records)) return rc;
   const size_t step_floats = ws_step_bytes(n, bx_max) / sizeof(float);
+  const size_t esz = dtype == EXPO_F16 ? 2 : 4;
+  ForkJoin* fj = chain_split(n, h, w, dtype) ? fork_join_for_device() : nullptr;
+  const int n0 = fj ? n / 2 : n;
+  if (fj) {
+    HIP_TRY(hipEventRecord(fj->fork, s), "chain fork");
+    HIP_TRY(hipStreamWaitEvent(fj->helper, fj->fork, 0), "chain fork");
+  }
   for (int i = steps - 1; i >= 0; --i) {
-    float* rec = records + size_t(i) * step_floats;
     // the forward chain ended descending (or ascending) on step steps-1; the backward starts where it ended
     const int rev = chain_snake(n, h, w, dtype) ? ((steps - i) & 1) : 0;
-    const int rc = dtype == EXPO_F16
-                       ? bwd_by_id<half_t>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], rec, n, h, w,
-                                           hsv_grad_mode, s, rev)
-                       : bwd_by_id<float>(filter_ids[i], acts[i], grads[i + 1], grads[i], params[i], rec, n, h, w,
-                                          hsv_grad_mode, s, rev);
-    if (rc) return rc;
+    const int bx = geom_bx(bwd_geom_kind(filter_ids[i]), n, h, w, dtype);  // records per image of this step's kernel
+    for (int part = 0; part < (fj ? 2 : 1); ++part) {
+      const int nb = part ? n0 : 0, np = part ? n - n0 : n0;
+      const size_t ioff = size_t(nb) * h * w * 3 * esz;
+      float* rec = records + size_t(i) * step_floats + size_t(nb) * bx * kWsSlots;
+      const void* xin = static_cast<const char*>(acts[i]) + ioff;
+      const void* gin = static_cast<const char*>(grads[i + 1]) + ioff;
+      void* gout = grads[i] ? static_cast<char*>(grads[i]) + ioff : nullptr;
+      const float* prm = params[i] + size_t(nb) * kNumParams[filter_ids[i]];
+      hipStream_t sp = part ? fj->helper : s;
+      const int rc = dtype == EXPO_F16
+                         ? bwd_by_id<half_t>(filter_ids[i], xin, gin, gout, prm, rec, np, h, w, hsv_grad_mode, sp, rev, n)
+                         : bwd_by_id<float>(filter_ids[i], xin, gin, gout, prm, rec, np, h, w, hsv_grad_mode, sp, rev, n);
+      if (rc) return rc;
+    }
+  }
+  if (fj) {
+    HIP_TRY(hipEventRecord(fj->join, fj->helper), "chain join");
+    HIP_TRY(hipStreamWaitEvent(s, fj->join, 0), "chain join");
   }
   return expo_finish_bwd(filter_ids, steps, params, dparams, n, h, w, dtype, workspace, workspace_bytes, stream);
 }

@@ -132,6 +132,21 @@ __device__ __forceinline__ void curve_lut_apply(float* v, const float2_lut* tab)
     }
   }
 }
+// Out-of-place form (the fused multi-step forward alternates between two pixel arrays).
+template <int NC, int NPIX>
+__device__ __forceinline__ void curve_lut_map(const float* in, float* out, const float2_lut* tab) {
+  constexpr int L = kCurveSteps;
+#pragma unroll
+  for (int k = 0; k < NPIX; ++k) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xc = clamp01x(in[3 * k + c], 0.0f, 1.0f);
+      const int seg = int(xc * float(L));  // 0..L; entry L == entry L-1
+      const float2_lut e = tab[(NC == 1 ? 0 : c * (L + 1)) + seg];
+      out[3 * k + c] = fmaf(xc, e.x, e.y);
+    }
+  }
+}
 // One pixel through the table (the backward kernels that re-evaluate the forward: fused penalty, masked apply).
 template <int NC>
 __device__ __forceinline__ void curve_lut_pixel(const float2_lut* tab, const float x[3], float y[3]) {

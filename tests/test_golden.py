@@ -11,7 +11,7 @@ from oracle import filters_np as fnp
 from tests._tol import assert_image_close, assert_param_grad_close
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['small', 'proxy', 'ragged']
+CASES = ['small', 'proxy', 'ragged', 'negative']
 
 
 def load(name):

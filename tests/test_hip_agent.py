@@ -329,15 +329,23 @@ def test_graphed_steps_match_eager(gpu_device):
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
 @pytest.mark.parametrize('shape', [(4, 96, 128, 3), (3, 7, 9, 3)])
-def test_fused_chain_matches_oracle(dtype, shape, gpu_device):
-  """expo_chain_fused_fwd: per-image filter sequences applied in registers == the float64 chain."""
+@pytest.mark.parametrize('steps', [8, 5, 1, 0])
+def test_fused_chain_matches_oracle(dtype, shape, steps, gpu_device):
+  """expo_chain_fused_fwd: per-image filter sequences applied in registers == the float64 chain.  The kernel runs
+  two steps per loop trip (two pixel arrays swapping roles), so odd lengths -- the reference's own 5 steps -- end on a
+  padding step; -1 (nothing selected) in the middle, at the start and at the end of a sequence; inf pixels through it."""
   dev = gpu_device
   rng = np.random.default_rng(31)
-  n, steps = shape[0], 8
+  n = shape[0]
   x = synthetic.make_images(rng, shape, NP_DT[dtype])
   ids = rng.integers(0, 9, (n, steps)).astype(np.int32)
-  ids[0] = np.arange(8)  # the cfg.filters order on image 0
-  ids[1, 3] = -1  # an all-zero one-hot in the middle of image 1's sequence
+  if steps == 8:
+    ids[0] = np.arange(8)  # the cfg.filters order on image 0
+    ids[1, 3] = -1  # an all-zero one-hot in the middle of image 1's sequence
+  if steps >= 1:
+    ids[2, 0] = -1
+    ids[1, steps - 1] = -1
+    x[2, 0, 0, :] = np.inf  # -1 must give exactly 0 whatever the pixel held
   p = np.zeros((n, steps, 24), dtype=np.float32)
   ref = x.astype(np.float64)
   for st in range(steps):
@@ -351,7 +359,10 @@ def test_fused_chain_matches_oracle(dtype, shape, gpu_device):
   from exposure_amd import evaluate
   y = evaluate.fused_chain(torch.from_numpy(x).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(p).to(dev))
   assert_image_close(y.float().cpu().numpy(), ref, NP_DT[dtype], 'fused chain')
-  assert float(y[1].abs().max()) >= 0.0
+  if steps >= 1:
+    assert float(y[1].abs().max()) == 0.0 and not bool(torch.signbit(y[1]).any())  # ends on -1: exactly +0
+  if steps == 0:
+    assert torch.equal(y, torch.from_numpy(x).to(dev))
 
 
 def test_fused_chain_at_config5_size_every_pixel_against_the_c_oracle(gpu_device):

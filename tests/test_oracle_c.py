@@ -66,7 +66,7 @@ def test_tie_conventions_of_max_min():
     np.testing.assert_allclose(dp_c, dp_np, rtol=1e-10, atol=1e-12)
 
 
-@pytest.mark.parametrize('name', ['filters_small.npz', 'filters_ragged.npz', 'filters_proxy.npz'])
+@pytest.mark.parametrize('name', ['filters_small.npz', 'filters_ragged.npz', 'filters_proxy.npz', 'filters_negative.npz'])
 def test_c_reproduces_the_golden_vectors(name):
   """tests/golden/*.npz hold fp16 inputs, float32 parameters and float64-computed outputs stored as float32
   (tests/golden/make_golden.py); samples sit exactly on knots / clip edges for the curve filters."""
