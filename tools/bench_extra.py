@@ -83,6 +83,24 @@ def main():
   res['critic_stats'] = {'ms': ms, 'GBps': gbps(6, ms)}
   ms = timeit(lambda: _cabi.overexposure_penalty(xs[nxt()], pen))
   res['overexposure_penalty'] = {'ms': ms, 'GBps': gbps(6, ms)}
+  # derivatives of the critic statistics (round 3): J^T g (map), J v (reduction), the second-order term (map)
+  g3 = torch.randn((n, 3), device=dev)
+  jv = torch.empty((n, 3), device=dev)
+  ms = timeit(lambda: _cabi.critic_stats_bwd(xs[nxt()], stats, g3, outs[k[0]]))
+  res['critic_stats_bwd'] = {'ms': ms, 'GBps': gbps(12, ms)}
+  ms = timeit(lambda: _cabi.critic_stats_jvp(xs[nxt()], stats, dy, jv))
+  res['critic_stats_jvp'] = {'ms': ms, 'GBps': gbps(12, ms)}
+  ms = timeit(lambda: _cabi.critic_stats_hvp(xs[nxt()], g3, jv, dy, outs[k[0]]))
+  res['critic_stats_hvp'] = {'ms': ms, 'GBps': gbps(18, ms)}
+  ms = timeit(lambda: _cabi.overexposure_penalty_bwd(xs[nxt()], dpen, outs[k[0]]))
+  res['overexposure_penalty_bwd'] = {'ms': ms, 'GBps': gbps(12, ms)}
+  # VignetFilter.apply (mask evaluation + lerp in one pass; backward with the 5 mask-parameter gradients)
+  vmp = torch.from_numpy(np.tanh(rng.standard_normal((n, 5))).astype(np.float32) * 5).to(dev)
+  dvmp = torch.empty_like(vmp)
+  ms = timeit(lambda: _cabi.vignet_apply_fwd(xs[nxt()], outs[k[0]], vmp, 1.0, True))
+  res['vignet_apply_fwd'] = {'ms': ms, 'GBps': gbps(12, ms)}
+  ms = timeit(lambda: _cabi.vignet_apply_bwd(xs[nxt()], dy, outs[k[0]], vmp, dvmp, 1.0, True))
+  res['vignet_apply_bwd'] = {'ms': ms, 'GBps': gbps(18, ms)}
   print(json.dumps({'shape': list(shape), 'dtype': 'f16', 'ids': args.ids, 'kernels': res}))
 
 

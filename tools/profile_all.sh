@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerates every measured artefact under profiles/ in ONE gpurun call:
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/profile_all.sh'
-# then, back in the container:  tools/collect_profiles.sh r02_final
+# then, back in the container:  tools/collect_profiles.sh r03_final
+# (an 8-GPU lease additionally runs tools/scale_all.sh: the section 8(e) scaling table)
 # rocprofv3 passes: --kernel-trace alone (durations) and one --pmc counter per pass (never combined
 # with sys/runtime tracing); the rocpd databases stay on the GPU box, only CSV summaries come back.
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -14,13 +15,16 @@ Q="--no-cpu-baseline --cold-shape none"
 
 python -m pytest $R/tests -x -q -m gpu 2>&1 | tail -2 > $OUT/pytest_gpu.txt
 python $R/bench.py > $OUT/bench_chain.json 2> $OUT/bench_chain.err
+EXPO_CHAIN_STREAMS=1 python $R/bench.py $Q > $OUT/bench_chain_1stream.json 2>/dev/null
 python $R/bench.py --shape A $Q > $OUT/bench_chain_A.json 2>/dev/null
 python $R/bench.py --shape B $Q > $OUT/bench_chain_B.json 2>/dev/null
 python $R/bench.py --dtype f32 $Q > $OUT/bench_chain_f32.json 2>/dev/null
 python $R/bench.py --shape $COLD $Q > $OUT/bench_chain_cold.json 2>/dev/null
 python $R/bench.py --workload infer --shape B > $OUT/bench_infer_B.json 2>/dev/null
 python $R/bench.py --workload infer --shape C > $OUT/bench_infer_C.json 2>/dev/null
-python $R/bench.py --workload train --no-cpu-baseline > $OUT/bench_train.json 2>/dev/null
+python $R/bench.py --workload train --steps 20 --warmup 3 > $OUT/bench_train.json 2>/dev/null
+python $R/bench.py --workload train --steps 20 --warmup 3 --miopen-find off > $OUT/bench_train_find_off.json 2>/dev/null
+python $R/bench.py --workload train --steps 10 --warmup 3 --graph off > $OUT/bench_train_eager.json 2>/dev/null
 python $R/tools/bench_extra.py > $OUT/bench_extra.json 2>/dev/null
 for sz in 96 512 1024; do
   reps=20; [ $sz -ge 512 ] && reps=8
@@ -35,13 +39,26 @@ kt() {  # name, command...
   rocprofv3 --kernel-trace -d /tmp/kt_$name -o kt -- "$@" > /tmp/kt_$name.log 2>&1
   python $R/tools/rocpd_stats.py "$(db /tmp/kt_$name)" > $OUT/kernel_stats_$name.csv
 }
-kt chain python $R/bench.py $Q
+# the chain: ONE run of the default command; its whole-batch launches (grid_y = 64: bench.py's per-kernel leg, what
+# roofline.* is quoted on) and the overlapping half-batch launches of the timed chain (grid_y = 32) in separate tables
+kt chain_all python $R/bench.py $Q
+python $R/tools/rocpd_stats.py "$(db /tmp/kt_chain_all)" grid_y=64,8 > $OUT/kernel_stats_chain.csv  # (8: the finish launch, grid (images, steps))
+python $R/tools/rocpd_stats.py "$(db /tmp/kt_chain_all)" grid_y=32 > $OUT/kernel_stats_chain_halves.csv
 kt cold python $R/bench.py --shape $COLD $Q
 kt chain_B python $R/bench.py --shape B $Q
 kt infer_B python $R/bench.py --workload infer --shape B
 kt infer_C python $R/bench.py --workload infer --shape C
 kt extra python $R/tools/bench_extra.py
 cp $OUT/kernel_stats_chain.csv $OUT/kernel_stats.csv
+# the training iteration (BASELINE config 3): the timed region only (tools/rocpd_window_stats.py)
+STEPS=10
+for mode in on off; do
+  rm -rf /tmp/kt_train_$mode
+  rocprofv3 --kernel-trace -d /tmp/kt_train_$mode -o kt -- python $R/bench.py --workload train --steps $STEPS --warmup 3 --graph $mode > $OUT/bench_train_profiled_$mode.json 2> /tmp/kt_train_$mode.log
+  ms=$(python -c "import json; print(json.load(open('$OUT/bench_train_profiled_$mode.json'))['ms_per_step'] * $STEPS)")
+  (cd $R/tools && python rocpd_window_stats.py "$(db /tmp/kt_train_$mode)" $ms $STEPS) > $OUT/kernel_stats_train_graph_$mode.csv
+done
+cp $OUT/kernel_stats_train_graph_on.csv $OUT/kernel_stats_train.csv
 
 # ---- HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, calibrated in the same run on membench
 pmc() {  # counter, name, command...
@@ -51,6 +68,7 @@ pmc() {  # counter, name, command...
   rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_${c}_$name -o pmc -- "$@" > /tmp/pmc_${c}_$name.log 2>&1
   python $R/tools/rocpd_pmc.py "$(db /tmp/pmc_${c}_$name)" > $OUT/pmc_${lc}_$name.csv
 }
+export EXPO_CHAIN_STREAMS=1  # whole-batch launches: bytes per launch are quoted per whole batch
 for c in FETCH_SIZE WRITE_SIZE; do
   lc=$(echo $c | tr 'A-Z' 'a-z')
   pmc $c chain python $R/bench.py $Q --no-per-kernel --steps 3 --warmup 1
@@ -61,5 +79,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc $c calibration_512 $R/tools/membench 512 9 2 pol
   cp $OUT/pmc_${lc}_chain.csv $OUT/pmc_${lc}.csv
 done
+unset EXPO_CHAIN_STREAMS
 cat $OUT/pytest_gpu.txt
 python $R/tools/show_bench.py $OUT/bench_chain.json
