@@ -61,10 +61,10 @@ def parse():
   ap.add_argument('--cold-shape', default='256,512,512',
                   help="chain workload: also time the dominant kernel on tensors of this shape (384 MiB each, beyond "
                   "the 256 MiB Infinity Cache) for roofline.hbm_cold; 'none' disables")
-  ap.add_argument('--miopen-find', default='on', choices=['on', 'off'],
-                  help="train workload: MIOpen's benchmark ('find') kernel selection (on: ~10 %% faster iterations; the "
-                  "library default is off -- EXPO_MIOPEN_FIND -- because find-mode trial kernels faulted once inside a "
-                  "380-test process, gpurun r03p9; a benchmark runs in a fresh process)")
+  ap.add_argument('--miopen-find', default='off', choices=['on', 'off'],
+                  help="train workload: MIOpen's benchmark ('find') kernel selection.  Off like the library default "
+                  "(EXPO_MIOPEN_FIND): a find-mode trial kernel faulted inside the 380-test gpu suite (gpurun r03p9), and "
+                  "what it buys varies by box (14.65 vs 16.2 ms per iteration on one, 14.30 vs 14.06 on another)")
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                   help='replay the 17 launches of a step from one hipGraph (auto = on; off: eager C-ABI calls)')
   return ap.parse_args()
@@ -229,6 +229,27 @@ def time_back_to_back(chain, name, reps=60):
   e1.record()
   torch.cuda.synchronize()
   return e0.elapsed_time(e1) / reps
+
+
+def event_pair_overhead_ms(dev, reps=200):
+  """What a HIP-event pair around ONE launch adds to the launch it brackets, measured on a 1-element kernel: the mean
+  of `reps` per-launch pairs minus the per-launch time of `reps` launches between one pair (same stream)."""
+  t = torch.zeros(1, device=dev)
+  for _ in range(20):
+    t.add_(1.0)
+  pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+  for a, b in pairs:
+    a.record()
+    t.add_(1.0)
+    b.record()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    t.add_(1.0)
+  e1.record()
+  torch.cuda.synchronize()
+  per_pair = sum(a.elapsed_time(b) for a, b in pairs) / reps
+  return max(per_pair - e0.elapsed_time(e1) / reps, 0.0)
 
 
 def rocprof_avg_us(kernel, prefix=None):
@@ -674,7 +695,8 @@ def run_infer(args, world, rank, dev, dist):
   # case bodies, 92 of them transcendental) at the issue cost tools/valubench measured on gfx950
   # (profiles/r02_valubench.txt: 4.5 clocks per wave instruction, 8.2 for v_exp / v_log / v_rcp / v_sin), 1024 SIMDs
   # at 2.4 GHz.  `achieved` / `peak` are in G wave-instructions/s.
-  valu_per_group, transc_per_group = 1083.0, 92.0
+  # (-60: the Level body, compiled in but not part of the 8-filter sequence)
+  valu_per_group, transc_per_group = 1083.0 - 60.0, 92.0
   clk_per_group = (valu_per_group - transc_per_group) * 4.5 + transc_per_group * 8.2
   groups = px / (8.0 if args.dtype == 'f16' else 4.0) / 64.0  # wave iterations
   peak_ginstr = 1024 * 2.4e9 / (clk_per_group / valu_per_group) / 1e9
@@ -904,10 +926,14 @@ def main():
     per = time_kernels(chain, args.kernel_reps)
     dom = max(per, key=per.get)
     bpp = (2 if dom.startswith('fwd') else 3) * 3 * esz  # algorithmic bytes per pixel per launch
-    # the dominant kernel's launch duration: back-to-back launches between ONE event pair (no per-launch event
-    # overhead; comparable with rocprofv3's kernel duration); the per-launch pair figure is kept beside it
+    # The dominant kernel's launch duration: the in-sequence HIP-event pair average (the kernel runs in the cache state
+    # it has inside the chain) MINUS the event pair's own cost, calibrated in this run on a 1-element kernel (a pair
+    # around every launch vs many launches between one pair).  Rounds 1-2 reported the raw pair figure, 2.3-4.3 us above
+    # rocprofv3's kernel duration depending on the box.
+    ev_over = event_pair_overhead_ms(dev)
+    launch_ms = max(per[dom] - ev_over, 1e-6)
     b2b = time_back_to_back(chain, dom)
-    achieved = bpp * px / (b2b * 1e-3) / 1e9
+    achieved = bpp * px / (launch_ms * 1e-3) / 1e9
     tensor_mib = px * 3 * esz / 2**20
     result['roofline'] = {
         'bound': 'hbm',
@@ -917,13 +943,16 @@ def main():
         'unit': 'GB/s',
         'frac': achieved / HBM_PEAK_GBPS,
         'traffic': load_traffic(dom, shape, args.dtype),
-        'avg_launch_ms': b2b,
-        'avg_launch_ms_method': 'mean of 60 back-to-back launches between one HIP-event pair on the launch stream, '
-                                'operands rotating through 3 buffer sets',
-        # the same kernel with an event pair around EVERY launch inside the chain sequence (round 1-2 method): reads
-        # the pair's own overhead on top, 2-4 us depending on the box
-        'avg_launch_ms_event_pair_per_launch': per[dom],
-        'event_pair_overhead_ms': per[dom] - b2b,
+        'avg_launch_ms': launch_ms,
+        'avg_launch_ms_method': 'HIP-event pair around every launch of the kernel inside the chain sequence (%d reps) on '
+                                'the launch stream, minus the event pair overhead measured in the same run' %
+                                args.kernel_reps,
+        'avg_launch_ms_event_pair_raw': per[dom],
+        'event_pair_overhead_ms': ev_over,
+        # the same kernel launched back to back between ONE event pair with its operands rotating through three buffer
+        # sets (0.86 GB: colder than inside the chain, where the upstream gradient was written by the previous launch
+        # and still sits in the 256 MiB Infinity Cache); includes the boundary between two dependent kernels
+        'avg_launch_ms_rotating_buffers': b2b,
         # what rocprofv3 --kernel-trace measured for this kernel on the same command (committed table)
         'rocprof_avg_us': rocprof_avg_us(dom),
         # 12 tensors of this size cycle through a 256 MiB Infinity Cache (MALL): below ~256 MiB per tensor the

@@ -23,7 +23,7 @@ python $R/bench.py --shape $COLD $Q > $OUT/bench_chain_cold.json 2>/dev/null
 python $R/bench.py --workload infer --shape B > $OUT/bench_infer_B.json 2>/dev/null
 python $R/bench.py --workload infer --shape C > $OUT/bench_infer_C.json 2>/dev/null
 python $R/bench.py --workload train --steps 20 --warmup 3 > $OUT/bench_train.json 2>/dev/null
-python $R/bench.py --workload train --steps 20 --warmup 3 --miopen-find off > $OUT/bench_train_find_off.json 2>/dev/null
+python $R/bench.py --workload train --steps 20 --warmup 3 --miopen-find on > $OUT/bench_train_find_on.json 2>/dev/null
 python $R/bench.py --workload train --steps 10 --warmup 3 --graph off > $OUT/bench_train_eager.json 2>/dev/null
 python $R/tools/bench_extra.py > $OUT/bench_extra.json 2>/dev/null
 for sz in 96 512 1024; do
