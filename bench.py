@@ -45,6 +45,9 @@ def parse():
   ap.add_argument('--kernel-reps', type=int, default=50, help='launches per kernel for the roofline timing')
   ap.add_argument('--prewarm-s', type=float, default=0.3, help='untimed clock warm-up before the W warm-up steps')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--rotating-probe', action='store_true',
+                  help='also time the dominant kernel back to back on operands rotating through three buffer sets '
+                  '(roofline.avg_launch_ms_rotating_buffers)')
   ap.add_argument('--no-per-kernel', action='store_true')
   ap.add_argument('--seed', type=int, default=1234)
   ap.add_argument('--order', default='0,1,2,3,4,5,6,7', help='filter ids of the chain steps (experiments only; the '
@@ -932,7 +935,8 @@ def main():
     # rocprofv3's kernel duration depending on the box.
     ev_over = event_pair_overhead_ms(dev)
     launch_ms = max(per[dom] - ev_over, 1e-6)
-    b2b = time_back_to_back(chain, dom)
+    # (optional extra leg; off by default so that the rocprofv3 table of the default command holds in-sequence launches only)
+    b2b = time_back_to_back(chain, dom) if args.rotating_probe else None
     achieved = bpp * px / (launch_ms * 1e-3) / 1e9
     tensor_mib = px * 3 * esz / 2**20
     result['roofline'] = {
