@@ -1383,6 +1383,22 @@ static ForkJoin* fork_join_for_device() {
   }
   return &f;
 }
+// fork: helper waits for everything `s` holds; join: `s` waits for everything the helper holds.  The event is shared by
+// all callers of a device, so record + wait must not interleave with another host thread's pair (its record would
+// replace the state this thread's wait is meant to see).
+static std::mutex g_fork_join_mu;
+static int chain_fork(ForkJoin* fj, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_fork_join_mu);
+  HIP_TRY(hipEventRecord(fj->fork, s), "chain fork");
+  HIP_TRY(hipStreamWaitEvent(fj->helper, fj->fork, 0), "chain fork");
+  return EXPO_OK;
+}
+static int chain_join(ForkJoin* fj, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_fork_join_mu);
+  HIP_TRY(hipEventRecord(fj->join, fj->helper), "chain join");
+  HIP_TRY(hipStreamWaitEvent(s, fj->join, 0), "chain join");
+  return EXPO_OK;
+}
 static bool chain_split(int n, int h, int w, int dtype) {
   static const int forced = getenv("EXPO_CHAIN_STREAMS") ? atoi(getenv("EXPO_CHAIN_STREAMS")) : 0;
   if (n < 2) return false;
@@ -1555,8 +1571,7 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
   ForkJoin* fj = chain_split(n, h, w, dtype) ? fork_join_for_device() : nullptr;
   const int n0 = fj ? n / 2 : n;  // images [0, n0) on the caller's stream, [n0, n) on the helper stream
   if (fj) {
-    HIP_TRY(hipEventRecord(fj->fork, s), "chain fork");
-    HIP_TRY(hipStreamWaitEvent(fj->helper, fj->fork, 0), "chain fork");
+    if (int rc = chain_fork(fj, s)) return rc;
   }
   for (int i = 0; i < steps; ++i) {
     const int rev = chain_snake(n, h, w, dtype) ? (i & 1) : 0;
@@ -1573,8 +1588,7 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
     }
   }
   if (fj) {
-    HIP_TRY(hipEventRecord(fj->join, fj->helper), "chain join");
-    HIP_TRY(hipStreamWaitEvent(s, fj->join, 0), "chain join");
+    if (int rc = chain_join(fj, s)) return rc;
   }
   return EXPO_OK;
 }
@@ -1647,8 +1661,7 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
   ForkJoin* fj = chain_split(n, h, w, dtype) ? fork_join_for_device() : nullptr;
   const int n0 = fj ? n / 2 : n;
   if (fj) {
-    HIP_TRY(hipEventRecord(fj->fork, s), "chain fork");
-    HIP_TRY(hipStreamWaitEvent(fj->helper, fj->fork, 0), "chain fork");
+    if (int rc = chain_fork(fj, s)) return rc;
   }
   for (int i = steps - 1; i >= 0; --i) {
     // the forward chain ended descending (or ascending) on step steps-1; the backward starts where it ended
@@ -1670,8 +1683,7 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
     }
   }
   if (fj) {
-    HIP_TRY(hipEventRecord(fj->join, fj->helper), "chain join");
-    HIP_TRY(hipStreamWaitEvent(s, fj->join, 0), "chain join");
+    if (int rc = chain_join(fj, s)) return rc;
   }
   return expo_finish_bwd(filter_ids, steps, params, dparams, n, h, w, dtype, workspace, workspace_bytes, stream);
 }

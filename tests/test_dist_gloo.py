@@ -145,3 +145,19 @@ def test_global_batch_rng_is_partition_invariant():
     with mock.patch.object(xdist, 'world_size', lambda g=None: 3), mock.patch.object(xdist, 'rank', lambda g=None, r=r: r):
       ar, br = rng.uniform(2, (7,)), rng.uniform(2, (1, 1, 1))
     assert torch.equal(ar, a[2 * r:2 * r + 2]) and torch.equal(br, b[2 * r:2 * r + 2])
+
+
+def test_drain_before_capture_without_a_process_group():
+  """No NCCL group in this process: the flight recorder has nothing to show, so a drain can only be VERIFIED when the
+  caller knows no collective was issued; otherwise it falls back to the grace period and says so."""
+  import time
+  from exposure_amd import dist as xdist
+  assert xdist.nccl_works_retired(timeout_s=0.2) is False  # undetermined, not "retired"
+  assert xdist.drain_before_capture(issued_collectives=False) is True
+  os.environ['EXPO_CAPTURE_GRACE_S'] = '0.05'
+  try:
+    t0 = time.perf_counter()
+    assert xdist.drain_before_capture(issued_collectives=True) is False
+    assert 0.04 <= time.perf_counter() - t0 < 2.0
+  finally:
+    del os.environ['EXPO_CAPTURE_GRACE_S']

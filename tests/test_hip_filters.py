@@ -701,3 +701,51 @@ def test_dispatch_streaming_policy_equals_cached_policy(gpu_device):
     assert torch.allclose(pens, pen[sl], rtol=1e-4, atol=1e-7)
     scale = dps.abs().max().item() + 1.0
     assert (dps - dp[sl]).abs().max().item() <= 1e-3 * scale
+
+
+def test_chain_calls_on_two_user_streams_share_the_helper_stream(gpu_device):
+  """expo_chain_fwd / _bwd fork to ONE library-owned helper stream per device.  Two chains enqueued
+  from two user streams (own workspaces) must each be ordered only through their own stream: results bit-identical to
+  the same chains run one after the other, and the split must actually be on for this shape."""
+  dev = gpu_device
+  shape = (28, 512, 512, 3)  # 44 MB per tensor: inside the [40 MiB, 256 MiB) gate
+  assert _cabi.chain_streams(shape[0], shape[1], shape[2], _cabi.EXPO_F16) == 2
+  assert _cabi.chain_streams(16, 512, 512, _cabi.EXPO_F16) == 1 and _cabi.chain_streams(64, 64, 64, _cabi.EXPO_F16) == 1
+  ids = list(range(8))
+
+  def make(seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = (torch.rand(shape, device=dev, generator=g)**2.2).half()
+    dy = torch.randn(shape, device=dev, generator=g).half()
+    rng = np.random.default_rng(seed)
+    prm = [torch.from_numpy(synthetic.make_params(rng, f, shape[0])).to(dev) for f in ids]
+    acts = [x] + [torch.empty_like(x) for _ in ids]
+    grads = [torch.empty_like(x) for _ in ids] + [dy]
+    dprm = [torch.empty_like(p) for p in prm]
+    ws = _cabi.new_workspace(dev, _cabi.workspace_bytes(shape[0], shape[1], shape[2], _cabi.EXPO_F16, 8))
+    return acts, grads, prm, dprm, ws
+
+  def run(c):
+    acts, grads, prm, dprm, ws = c
+    _cabi.chain_fwd(ids, acts, prm)
+    _cabi.chain_bwd(ids, acts, grads, prm, dprm, workspace=ws)
+
+  a, b = make(1), make(2)
+  run(a), run(b)
+  torch.cuda.synchronize()
+  want = [[t.clone() for t in (c[0][8], c[1][0])] + [d.clone() for d in c[3]] for c in (a, b)]
+  for c in (a, b):  # scribble over the outputs
+    for t in c[0][1:] + c[1][:8] + c[3]:
+      t.fill_(7.0)
+  s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+  torch.cuda.synchronize()
+  for _ in range(3):  # interleave the two callers
+    with torch.cuda.stream(s1):
+      run(a)
+    with torch.cuda.stream(s2):
+      run(b)
+  torch.cuda.synchronize()
+  for c, w in zip((a, b), want):
+    got = [c[0][8], c[1][0]] + list(c[3])
+    for g, r in zip(got, w):
+      assert torch.equal(g, r)
