@@ -38,6 +38,9 @@ SIGNATURES = {
     'expo_filter_apply_fwd': (_i, [_i, _vp, _vp, _fp, _fp, _f, _f, _i, _i, _i, _i, _vp]),
     'expo_filter_apply_bwd': (_i, [_i, _vp, _vp, _vp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _i, _i, _vp, _sz,
                                    _vp]),
+    'expo_filter_apply_dispatch_fwd': (_i, [_vp, _vp, _vp, _fp, _fp, _f, _f, _i, _i, _i, _i, _vp]),
+    'expo_filter_apply_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _i, _i, _vp, _sz,
+                                            _vp]),
     'expo_filter_dispatch_fwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_filter_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_chain_streams': (_i, [_i, _i, _i, _i]),
@@ -519,3 +522,37 @@ def vignet_apply_bwd(x, dy, dx, mask_params, dmask_params, maximum_sharpness, ma
 def chain_streams(n, h, w, dtype_code):
   """1 or 2: how many streams expo_chain_fwd / _bwd use for a batch of this shape."""
   return int(load().expo_chain_streams(int(n), int(h), int(w), int(dtype_code)))
+
+
+def apply_dispatch_fwd(ids, x, y, params, mask_params, maximum_sharpness, minimum_strength):
+  """Per-image masked apply: image n goes through filter ids[n] with params[n] (N, 24) and mask_params[n] (N, 6)."""
+  lib = load()
+  _img(x, 'x'), _img(y, 'y')
+  n, h, w, _ = x.shape
+  _ids(ids, n)
+  _f32(params, 'params', (n, EXPO_MAX_PARAMS))
+  _f32(mask_params, 'mask_params', (n, 6))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_filter_apply_dispatch_fwd(_ptr(ids), _ptr(x), _ptr(y), _ptr(params), _ptr(mask_params),
+                                              float(maximum_sharpness), float(minimum_strength), n, h, w,
+                                              _dtype_code(x), _stream()), 'expo_filter_apply_dispatch_fwd')
+
+
+def apply_dispatch_bwd(ids, x, dy, dx, params, dparams, mask_params, dmask_params, maximum_sharpness, minimum_strength,
+                       hsv_grad_mode=0, workspace=None):
+  lib = load()
+  _img(x, 'x'), _img(dy, 'dy')
+  n, h, w, _ = x.shape
+  _ids(ids, n)
+  if dx is not None:
+    _img(dx, 'dx')
+  _f32(params, 'params', (n, EXPO_MAX_PARAMS))
+  _f32(dparams, 'dparams', (n, EXPO_MAX_PARAMS))
+  _f32(mask_params, 'mask_params', (n, 6))
+  _f32(dmask_params, 'dmask_params', (n, 6))
+  with torch.cuda.device(x.device):
+    wsp, wsb = _ws(x, workspace)
+    _check(lib.expo_filter_apply_dispatch_bwd(_ptr(ids), _ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams),
+                                              _ptr(mask_params), _ptr(dmask_params), float(maximum_sharpness),
+                                              float(minimum_strength), n, h, w, _dtype_code(x), hsv_grad_mode, wsp, wsb,
+                                              _stream()), 'expo_filter_apply_dispatch_bwd')

@@ -156,22 +156,15 @@ class Agent(nn.Module):
       mask_params.append(mp)
     return out, mask_params
 
-  def _apply_masked(self, net, params, mask_params, filter_one_hot):
-    """cfg.masking = True (off in both shipped configs): the reference's own schedule -- every filter's
-    masked ``apply`` on the whole batch (one fused HIP kernel each: mask + process + lerp,
-    ``expo_filter_apply_fwd``), stacked and reduced with the one-hot (agent.py:58-77, 119-125).  The
-    dispatch-by-id kernels carry no mask parameters, so this path trades the 8x image work back for
-    correct mask gradients; the proxies are 64x64."""
-    from .util import tanh_range
+  def _apply_masked(self, net, params24, mask6, abi_ids):
+    """cfg.masking = True (off in both shipped configs).  The reference runs every filter's masked ``apply`` on the
+    whole batch, stacks the 8 results and reduces with the one-hot (agent.py:58-77, 119-125); the one-hot zeroes seven
+    of them, so ONE HIP launch applies, per image, only the selected filter's mask + process + lerp
+    (``expo_filter_apply_dispatch_fwd``) -- the same restructuring as the unmasked path, with the selected filter's
+    6 mask parameters gathered like its filter parameters."""
     cfg = self.cfg
-    out = None
-    for j, (filt, p, mp) in enumerate(zip(self.filters, params, mask_params)):
-      yj = F._MaskedApplyFunction.apply(net, filt.pack(p), tanh_range(-5, 5, initial=0)(mp), filt.filter_id,
-                                        float(cfg.maximum_sharpness), float(cfg.minimum_strength),
-                                        int(cfg.get('hsv_grad_mode', 0)))
-      term = yj.float() * filter_one_hot[:, j, None, None, None]
-      out = term if out is None else out + term
-    return out.to(net.dtype)
+    return F.dispatch_masked_filters(net, params24, mask6, abi_ids, cfg.maximum_sharpness, cfg.minimum_strength,
+                                     int(cfg.get('hsv_grad_mode', 0)))
 
   def action_pdf(self, selector_features):
     """agent.py:87-107 -> (pdf, entropy)."""
@@ -216,10 +209,15 @@ class Agent(nn.Module):
                           torch.full_like(selected_filter_id, -1))
     high_res_output = None
     if cfg.masking:
-      out = self._apply_masked(net, params, mask_params, filter_one_hot)
+      from .util import tanh_range
+      # one-hot gather of the selected filter's squashed mask parameters -> (N, 6) (filters.py:121-123)
+      mask6 = net.new_zeros((n, 6), dtype=torch.float32)
+      for j, mp in enumerate(mask_params):
+        mask6 = mask6 + tanh_range(-5, 5, initial=0)(mp.float()) * filter_one_hot[:, j:j + 1]
+      out = self._apply_masked(net, params24, mask6, abi_ids)
       overexposure = F.overexposure_penalty(out)
       if high_res is not None:
-        high_res_output = self._apply_masked(high_res, params, mask_params, filter_one_hot)
+        high_res_output = self._apply_masked(high_res, params24, mask6, abi_ids)
     else:
       out, overexposure = F.dispatch_filters(net, params24, abi_ids, hsv_mode)
       if high_res is not None:

@@ -249,27 +249,41 @@ __global__ __launch_bounds__(kThreads EXPO_BWD_MIN_WAVES) void filter_bwd_kernel
                                                records + size_t(n) * gridDim.x * kWsSlots, hw, groups, 0.f);
 }
 
+// y = 0 for a whole image (filter id -1 in the per-image dispatch entry points)
+template <typename T, bool VEC, class IO = IoCached>
+__device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int groups) {
+  constexpr int PPL = PixTraits<T>::PPL;
+  float z[PPL * 3];
+#pragma unroll
+  for (int j = 0; j < PPL * 3; ++j) z[j] = 0.f;
+  const int stride = gridDim.x * kThreads;
+  if constexpr (VEC) {
+    const RawGroup rz = pack<T>(z);
+    const __amdgpu_buffer_rsrc_t ry = make_image_rsrc(yi, hw);
+    for (int gw = blockIdx.x * kThreads + (threadIdx.x & ~63); gw * PPL < hw; gw += stride)
+      store_raw<IO::kStore>(ry, chunk_byte_offset<T>(gw, threadIdx.x & 63), rz);
+  } else {
+    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) store_slow<T>(yi, g, hw, z);
+  }
+}
+
 // ------------------------------------------------ Filter.apply with a spatial mask (masking on)
 // out = (1 - mask) x + mask process(x), mask per pixel from MaskPrm (filters.py:86-88, 110-148).
 template <class F, typename T, bool VEC>
-__global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                             const float* __restrict__ params,
-                                                             const float* __restrict__ mask_params, float sharp,
-                                                             float min_strength, int h, int w, int groups) {
+__device__ __forceinline__ void apply_fwd_body(const T* __restrict__ xi, T* __restrict__ yi, const float* __restrict__ prm,
+                                               const float* __restrict__ mprm, float sharp, float min_strength, int h,
+                                               int w, int groups) {
   constexpr int PPL = PixTraits<T>::PPL;
-  const int n = blockIdx.y, hw = h * w;
-  const size_t off = size_t(n) * hw * 3;
-  const T* xi = x + off;
-  T* yi = y + off;
-  const typename F::Prm q = F::load(params + n * F::NP);
-  const MaskPrm mk = MaskPrm::load(mask_params + n * 6, sharp, min_strength, h, w);
+  const int hw = h * w;
+  const typename F::Prm q = F::load(prm);
+  const MaskPrm mk = MaskPrm::load(mprm, sharp, min_strength, h, w);
   const int stride = gridDim.x * kThreads;
   // curve filters on the vector path: per-wave segment table, as in filter_fwd_kernel
   constexpr bool kCurveTab = VEC && F::kLutFloats > 0;
   constexpr int kNC = kCurveTab ? F::NP / kCurveSteps : 1;
   __shared__ float2_lut ftab[kCurveTab ? kWaves : 1][32];
   float2_lut* const tab = ftab[kCurveTab ? (threadIdx.x >> 6) : 0];
-  if constexpr (kCurveTab) curve_lut_build<kNC>(params[n * F::NP + (threadIdx.x & 63) % F::NP], tab);
+  if constexpr (kCurveTab) curve_lut_build<kNC>(prm[(threadIdx.x & 63) % F::NP], tab);
   auto compute = [&](float* v, int g) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -296,21 +310,56 @@ __global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict
   }
 }
 
-template <class F, typename T, bool VEC, bool HAS_DX, int MODE>
-__global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                             T* __restrict__ dx, const float* __restrict__ params,
-                                                             const float* __restrict__ mask_params,
-                                                             float* __restrict__ records, float sharp,
+template <class F, typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                             const float* __restrict__ params,
+                                                             const float* __restrict__ mask_params, float sharp,
                                                              float min_strength, int h, int w, int groups) {
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * h * w * 3;
+  apply_fwd_body<F, T, VEC>(x + off, y + off, params + n * F::NP, mask_params + n * 6, sharp, min_strength, h, w, groups);
+}
+
+// Masked apply with a per-image filter choice: the agent's step with cfg.masking = True.  The reference applies EVERY
+// filter's masked apply to the whole batch and reduces with the one-hot (agent.py:58-77, 119-125); the one-hot zeroes the
+// seven others, so only the selected filter's kernel body runs per image here (block-uniform switch, as in
+// dispatch_fwd_kernel).  params: [N][EXPO_MAX_PARAMS], mask_params: [N][6] of the SELECTED filter; id -1 -> y = 0.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void apply_dispatch_fwd_kernel(const int32_t* __restrict__ ids,
+                                                                      const T* __restrict__ x, T* __restrict__ y,
+                                                                      const float* __restrict__ params,
+                                                                      const float* __restrict__ mask_params, float sharp,
+                                                                      float min_strength, int h, int w, int groups) {
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * h * w * 3;
+  const float* prm = params + n * EXPO_MAX_PARAMS;
+  const float* mp = mask_params + n * 6;
+#define EXPO_CASE(ID, F) \
+  case ID: apply_fwd_body<F, T, VEC>(x + off, y + off, prm, mp, sharp, min_strength, h, w, groups); break;
+  switch (ids[n]) {
+    EXPO_CASE(0, ExposureF)
+    EXPO_CASE(1, GammaF)
+    EXPO_CASE(2, WhiteBalanceF)
+    EXPO_CASE(3, SatPlusF)
+    EXPO_CASE(4, ToneF)
+    EXPO_CASE(5, ContrastF)
+    EXPO_CASE(6, WnbF)
+    EXPO_CASE(7, ColorF)
+    EXPO_CASE(8, LevelF)
+    default: zero_image<T, VEC, IoCached>(y + off, h * w, groups); break;
+  }
+#undef EXPO_CASE
+}
+
+template <class F, typename T, bool VEC, bool HAS_DX, int MODE>
+__device__ __forceinline__ void apply_bwd_body(const T* __restrict__ xi, const T* __restrict__ dyi, T* __restrict__ dxi,
+                                               const float* __restrict__ prm, const float* __restrict__ mprm,
+                                               float* __restrict__ rec, float sharp, float min_strength, int h, int w,
+                                               int groups) {
   constexpr int PPL = PixTraits<T>::PPL;
-  const int n = blockIdx.y, hw = h * w;
-  const size_t off = size_t(n) * hw * 3;
-  const T* xi = x + off;
-  const T* dyi = dy + off;
-  T* dxi = HAS_DX ? dx + off : nullptr;
-  const float* prm = params + n * F::NP;
+  const int hw = h * w;
   const typename F::Prm q = F::load(prm);
-  const MaskPrm mk = MaskPrm::load(mask_params + n * 6, sharp, min_strength, h, w);
+  const MaskPrm mk = MaskPrm::load(mprm, sharp, min_strength, h, w);
   __shared__ __attribute__((aligned(16))) float lut[F::kLutFloats > 0 ? F::kLutFloats : 4];
   if constexpr (F::kLutFloats > 0) {
     F::stage(prm, lut);
@@ -370,7 +419,58 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
     }
   }
   // record = [filter accumulators | 6 mask accumulators]; finish_kernel splits them
-  block_reduce_record<F::NACC + 6>(acc, records + size_t(n) * gridDim.x * kWsSlots);
+  block_reduce_record<F::NACC + 6>(acc, rec);
+}
+
+template <class F, typename T, bool VEC, bool HAS_DX, int MODE>
+__global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                             T* __restrict__ dx, const float* __restrict__ params,
+                                                             const float* __restrict__ mask_params,
+                                                             float* __restrict__ records, float sharp,
+                                                             float min_strength, int h, int w, int groups) {
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * h * w * 3;
+  apply_bwd_body<F, T, VEC, HAS_DX, MODE>(x + off, dy + off, HAS_DX ? dx + off : nullptr, params + n * F::NP,
+                                          mask_params + n * 6, records + size_t(n) * gridDim.x * kWsSlots, sharp,
+                                          min_strength, h, w, groups);
+}
+
+// Backward of apply_dispatch_fwd_kernel: the selected filter's masked-apply backward per image.  One launch for all
+// filters (it runs at the 64x64 proxy resolution, where every launch is latency-bound; the curve bodies set the register
+// budget).  Records: [filter accumulators | 6 mask accumulators] of the image's filter; id -1 writes none (finish_kernel
+// emits zero rows).
+template <typename T, bool VEC, bool HAS_DX, int MODE>
+__global__ __launch_bounds__(kThreads) void apply_dispatch_bwd_kernel(const int32_t* __restrict__ ids,
+                                                                      const T* __restrict__ x, const T* __restrict__ dy,
+                                                                      T* __restrict__ dx, const float* __restrict__ params,
+                                                                      const float* __restrict__ mask_params,
+                                                                      float* __restrict__ records, float sharp,
+                                                                      float min_strength, int h, int w, int groups) {
+  const int n = blockIdx.y;
+  const size_t off = size_t(n) * h * w * 3;
+  const float* prm = params + n * EXPO_MAX_PARAMS;
+  const float* mp = mask_params + n * 6;
+  float* rec = records + size_t(n) * gridDim.x * kWsSlots;
+  T* dxi = HAS_DX ? dx + off : nullptr;
+#define EXPO_CASE(ID, F)                                                                                              \
+  case ID:                                                                                                            \
+    apply_bwd_body<F, T, VEC, HAS_DX, MODE>(x + off, dy + off, dxi, prm, mp, rec, sharp, min_strength, h, w, groups); \
+    break;
+  switch (ids[n]) {
+    EXPO_CASE(0, ExposureF)
+    EXPO_CASE(1, GammaF)
+    EXPO_CASE(2, WhiteBalanceF)
+    EXPO_CASE(3, SatPlusF)
+    EXPO_CASE(4, ToneF)
+    EXPO_CASE(5, ContrastF)
+    EXPO_CASE(6, WnbF)
+    EXPO_CASE(7, ColorF)
+    EXPO_CASE(8, LevelF)
+    default:
+      if constexpr (HAS_DX) zero_image<T, VEC, IoCached>(dxi, h * w, groups);
+      break;
+  }
+#undef EXPO_CASE
 }
 
 // ------------------------------------------------------------ VignetFilter.apply (filters.py:341-396)
@@ -452,23 +552,6 @@ __global__ __launch_bounds__(kThreads) void vignet_bwd_kernel(const T* __restric
 }
 
 // --------------------------------------------------- per-image dispatch (one-hot select)
-template <typename T, bool VEC, class IO = IoCached>
-__device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int groups) {
-  constexpr int PPL = PixTraits<T>::PPL;
-  float z[PPL * 3];
-#pragma unroll
-  for (int j = 0; j < PPL * 3; ++j) z[j] = 0.f;
-  const int stride = gridDim.x * kThreads;
-  if constexpr (VEC) {
-    const RawGroup rz = pack<T>(z);
-    const __amdgpu_buffer_rsrc_t ry = make_image_rsrc(yi, hw);
-    for (int gw = blockIdx.x * kThreads + (threadIdx.x & ~63); gw * PPL < hw; gw += stride)
-      store_raw<IO::kStore>(ry, chunk_byte_offset<T>(gw, threadIdx.x & 63), rz);
-  } else {
-    for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) store_slow<T>(yi, g, hw, z);
-  }
-}
-
 // SET is a bit mask of the filter ids this launch handles (bit 15 = id -1).  The BACKWARD dispatch
 // is issued as two launches -- light filters and the register-heavy curve filters -- so each gets
 // its own VGPR budget / occupancy; blocks whose image selected a filter outside SET exit at once.
@@ -813,7 +896,7 @@ __global__ __launch_bounds__(kThreads) void stats_hvp_kernel(const T* __restrict
 // One wave per (image, step): adds the image's bx block records in a fixed order and writes the final
 // per-image values.  Steps of a chain (or the single step of any other entry point) are described by
 // value in the kernel arguments.
-enum FinishKind : int { kFinFilter = 0, kFinDispatch = 1, kFinApply = 2, kFinStats = 3, kFinPenalty = 4, kFinScaled = 5, kFinVignet = 6 };
+enum FinishKind : int { kFinFilter = 0, kFinDispatch = 1, kFinApply = 2, kFinStats = 3, kFinPenalty = 4, kFinScaled = 5, kFinVignet = 6, kFinApplyDispatch = 7 };
 struct FinishStep {
   const float* params;    // [n][P] (filter / apply), [n][EXPO_MAX_PARAMS] (dispatch)
   float* out;             // dparams [n][P] | [n][24]; stats [n][3]; penalty [n]
@@ -892,17 +975,19 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const FinishArgs
       if (lane < st.filter_id) st.out[n * st.filter_id + lane] = tot[lane] * st.scale;
       break;
     default: {
-      const bool disp = st.kind == kFinDispatch;
+      const bool disp = st.kind == kFinDispatch || st.kind == kFinApplyDispatch;
+      const bool masked = st.kind == kFinApply || st.kind == kFinApplyDispatch;
       const int stride = disp ? EXPO_MAX_PARAMS : 0;
       if (nothing) {
         if (lane < EXPO_MAX_PARAMS) st.out[n * EXPO_MAX_PARAMS + lane] = 0.0f;
+        if (masked && lane < 6) st.out2[n * 6 + lane] = 0.0f;
         break;
       }
 #define EXPO_FIN(ID, F)                                                                                        \
   case ID: {                                                                                                   \
     const int row = disp ? stride : F::NP;                                                                     \
     finish_filter<F>(st, st.params + size_t(n) * row, tot, st.out + size_t(n) * row, row, lane);               \
-    if (st.kind == kFinApply && lane < 6) st.out2[n * 6 + lane] = tot[F::NACC + lane];                        \
+    if (masked && lane < 6) st.out2[n * 6 + lane] = tot[F::NACC + lane];                                      \
   } break;
       switch (fid) {
         EXPO_FIN(0, ExposureF)
@@ -1142,6 +1227,48 @@ static int apply_bwd_by_id(int id, const void* x, const void* dy, void* dx, cons
     case 8: return launch_apply_bwd<LevelF, T>(x, dy, dx, p, mp, records, sharp, ms, n, h, w, mode, s);
   }
   return fail(EXPO_E_BADARG, "filter_id out of range");
+}
+
+template <typename T>
+static int apply_dispatch_fwd_t(const int32_t* ids, const void* x, void* y, const float* params, const float* mp,
+                                float sharp, float ms, int n, int h, int w, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  if (g.vec)
+    hipLaunchKernelGGL((apply_dispatch_fwd_kernel<T, true>), grid, block, 0, s, ids, (const T*)x, (T*)y, params, mp, sharp, ms, h, w, g.groups);
+  else
+    hipLaunchKernelGGL((apply_dispatch_fwd_kernel<T, false>), grid, block, 0, s, ids, (const T*)x, (T*)y, params, mp, sharp, ms, h, w, g.groups);
+  HIP_TRY(hipGetLastError(), "apply_dispatch_fwd launch");
+  return EXPO_OK;
+}
+
+template <typename T>
+static int apply_dispatch_bwd_t(const int32_t* ids, const void* x, const void* dy, void* dx, const float* params,
+                                float* dparams, const float* mp, float* dmp, float sharp, float ms, int n, int h, int w,
+                                int mode, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  const Geom g = make_geom<T>(n, h, w, {x, dy, dx}, kGeomApply);
+  const dim3 grid(g.blocks_x, n), block(kThreads);
+  float* records;
+  if (int rc = ws_check(workspace, workspace_bytes, n, g.blocks_x, 1, &records)) return rc;
+#define EXPO_L(VEC, HAS_DX, MODE)                                                                                   \
+  hipLaunchKernelGGL((apply_dispatch_bwd_kernel<T, VEC, HAS_DX, MODE>), grid, block, 0, s, ids, (const T*)x,         \
+                     (const T*)dy, (T*)dx, params, mp, records, sharp, ms, h, w, g.groups)
+  const int key = (g.vec ? 4 : 0) | (dx ? 2 : 0) | (mode == 1 ? 1 : 0);
+  switch (key) {
+    case 7: EXPO_L(true, true, 1); break;
+    case 6: EXPO_L(true, true, 0); break;
+    case 5: EXPO_L(true, false, 1); break;
+    case 4: EXPO_L(true, false, 0); break;
+    case 3: EXPO_L(false, true, 1); break;
+    case 2: EXPO_L(false, true, 0); break;
+    case 1: EXPO_L(false, false, 1); break;
+    default: EXPO_L(false, false, 0); break;
+  }
+#undef EXPO_L
+  HIP_TRY(hipGetLastError(), "apply_dispatch_bwd launch");
+  FinishArgs fa{};
+  fa.s[0] = FinishStep{params, dparams, dmp, records, ids, kFinApplyDispatch, 0, 0, 0.f, g.blocks_x};
+  return launch_finish(fa, 1, n, s);
 }
 
 template <typename T>
@@ -1523,6 +1650,38 @@ int expo_filter_apply_bwd(int filter_id, const void* x, const void* dy, void* dx
   FinishArgs fa{};
   fa.s[0] = FinishStep{params, dparams, dmask_params, records, nullptr, kFinApply, filter_id, 0, 0.f, bx};
   return launch_finish(fa, 1, n, s);
+}
+
+int expo_filter_apply_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y, const float* params,
+                                   const float* mask_params, float maximum_sharpness, float minimum_strength, int n,
+                                   int h, int w, int dtype, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!filter_ids || !x || !y || !params || !mask_params) return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16 ? apply_dispatch_fwd_t<half_t>(filter_ids, x, y, params, mask_params, maximum_sharpness,
+                                                          minimum_strength, n, h, w, s)
+                           : apply_dispatch_fwd_t<float>(filter_ids, x, y, params, mask_params, maximum_sharpness,
+                                                         minimum_strength, n, h, w, s);
+}
+
+int expo_filter_apply_dispatch_bwd(const int32_t* filter_ids, const void* x, const void* dy, void* dx,
+                                   const float* params, float* dparams, const float* mask_params, float* dmask_params,
+                                   float maximum_sharpness, float minimum_strength, int n, int h, int w, int dtype,
+                                   int hsv_grad_mode, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (hsv_grad_mode != 0 && hsv_grad_mode != 1) return fail(EXPO_E_BADARG, "hsv_grad_mode must be 0 or 1");
+  if (n == 0) return EXPO_OK;
+  if (!filter_ids || !x || !dy || !params || !dparams || !mask_params || !dmask_params)
+    return fail(EXPO_E_BADARG, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == EXPO_F16
+             ? apply_dispatch_bwd_t<half_t>(filter_ids, x, dy, dx, params, dparams, mask_params, dmask_params,
+                                            maximum_sharpness, minimum_strength, n, h, w, hsv_grad_mode, workspace,
+                                            workspace_bytes, s)
+             : apply_dispatch_bwd_t<float>(filter_ids, x, dy, dx, params, dparams, mask_params, dmask_params,
+                                           maximum_sharpness, minimum_strength, n, h, w, hsv_grad_mode, workspace,
+                                           workspace_bytes, s);
 }
 
 int expo_filter_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y, const float* params,

@@ -579,6 +579,43 @@ class _DispatchFunction(torch.autograd.Function):
     return dx, dparams, None, None
 
 
+class _MaskedDispatchFunction(torch.autograd.Function):
+  """Per-image masked apply (expo_filter_apply_dispatch_fwd/bwd): the agent's step with cfg.masking = True."""
+
+  @staticmethod
+  def forward(ctx, img, params24, mask6, filter_ids, sharp, min_strength, hsv_grad_mode):
+    img = img.contiguous()
+    params24 = params24.contiguous().float()
+    mask6 = mask6.contiguous().float()
+    filter_ids = filter_ids.contiguous().to(torch.int32)
+    y = torch.empty_like(img)
+    _cabi.apply_dispatch_fwd(filter_ids, img, y, params24, mask6, sharp, min_strength)
+    ctx.save_for_backward(img, params24, mask6, filter_ids)
+    ctx.args = (sharp, min_strength, hsv_grad_mode)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    img, params24, mask6, filter_ids = ctx.saved_tensors
+    sharp, min_strength, hsv_grad_mode = ctx.args
+    dy = dy.contiguous().to(img.dtype)
+    dx = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+    dparams = torch.empty_like(params24)
+    dmask = torch.empty_like(mask6)
+    _cabi.apply_dispatch_bwd(filter_ids, img, dy, dx, params24, dparams, mask6, dmask, sharp, min_strength,
+                             hsv_grad_mode)
+    return dx, dparams, dmask, None, None, None, None
+
+
+def dispatch_masked_filters(img, params24, mask6, filter_ids, maximum_sharpness, minimum_strength, hsv_grad_mode=0):
+  """cfg.masking = True counterpart of :func:`dispatch_filters`: image n goes through the masked apply
+  (filters.py:62-99, 110-148) of filter ``filter_ids[n]`` only.  mask6: (N, 6) = tanh_range(-5, 5)(raw mask parameters
+  of the selected filter).  The reference computes all 8 masked applies and reduces with the one-hot (agent.py:58-77,
+  119-125); values and gradients are identical because the one-hot zeroes the other seven."""
+  return _MaskedDispatchFunction.apply(img, params24, mask6, filter_ids, float(maximum_sharpness),
+                                       float(minimum_strength), hsv_grad_mode)
+
+
 def dispatch_filters(img, params24, filter_ids, hsv_grad_mode=0):
   """One launch pair instead of "run all 8 filters, stack, one-hot, reduce_sum" (agent.py:58-77,
   119-125).  params24: (N, 24) float32, row n = packed params of filter ``filter_ids[n]`` in its

@@ -49,7 +49,7 @@ extern "C" {
 #endif
 
 #define EXPO_ABI_VERSION 3 /* 2: caller-owned reduction workspace (no float atomics, no fills); 3: derivatives of the
-                              critic statistics and of the penalty, VignetFilter, bias + lrelu */
+                              critic statistics and of the penalty, VignetFilter, bias + lrelu, masked per-image dispatch */
 
 #define EXPO_OK 0
 #define EXPO_E_BADARG (-1)
@@ -149,6 +149,23 @@ int expo_filter_apply_bwd(int filter_id, const void* x, const void* dy, void* dx
                           float* dmask_params, float maximum_sharpness, float minimum_strength,
                           int n, int h, int w, int dtype, int hsv_grad_mode, void* workspace,
                           size_t workspace_bytes, void* stream);
+
+/*
+ * The agent's step with cfg.masking = True (agent.py:58-77, 119-125 around filters.py:62-99, 110-148): the reference runs
+ * EVERY filter's masked apply on the whole batch, stacks the 8 results and reduces with one_hot(selected_filter_id).
+ * The one-hot zeroes the seven others (values and gradients), so per image only the selected filter's masked apply runs:
+ *   y[n] = expo_filter_apply_fwd(filter_ids[n], x[n], params[n], mask_params[n])      filter_ids[n] = -1 -> y[n] = 0
+ * params / dparams: float32 [N][EXPO_MAX_PARAMS] (row = packed parameters of filter filter_ids[n], rest ignored / 0);
+ * mask_params / dmask_params: float32 [N][6] = tanh_range(-5, 5)(raw mask parameters of THAT filter).
+ */
+int expo_filter_apply_dispatch_fwd(const int32_t* filter_ids, const void* x, void* y, const float* params,
+                                   const float* mask_params, float maximum_sharpness, float minimum_strength,
+                                   int n, int h, int w, int dtype, void* stream);
+int expo_filter_apply_dispatch_bwd(const int32_t* filter_ids, const void* x, const void* dy, void* dx,
+                                   const float* params, float* dparams, const float* mask_params,
+                                   float* dmask_params, float maximum_sharpness, float minimum_strength, int n,
+                                   int h, int w, int dtype, int hsv_grad_mode, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /*
  * Per-image filter choice == the reference's "compute all 8 filters, stack, multiply

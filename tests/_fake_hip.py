@@ -121,6 +121,33 @@ def _stats(x, stats):
   stats.copy_(torch.from_numpy(agent_np.critic_stats(x.double().numpy())).float())
 
 
+def _apply_dispatch_fwd(ids, x, y, params, mask_params, maximum_sharpness, minimum_strength):
+  for n in range(x.shape[0]):
+    fid = int(ids[n])
+    if fid < 0:
+      y[n].zero_()
+    else:
+      _apply_fwd(fid, x[n:n + 1], y[n:n + 1], params[n:n + 1, :NUM_PARAMS[fid]].contiguous(), mask_params[n:n + 1],
+                 maximum_sharpness, minimum_strength)
+
+
+def _apply_dispatch_bwd(ids, x, dy, dx, params, dparams, mask_params, dmask_params, maximum_sharpness, minimum_strength,
+                        hsv_grad_mode=0):
+  dparams.zero_()
+  dmask_params.zero_()
+  for n in range(x.shape[0]):
+    fid = int(ids[n])
+    if fid < 0:
+      if dx is not None:
+        dx[n].zero_()
+      continue
+    dp = torch.empty((1, NUM_PARAMS[fid]))
+    _apply_bwd(fid, x[n:n + 1], dy[n:n + 1], dx[n:n + 1] if dx is not None else None,
+               params[n:n + 1, :NUM_PARAMS[fid]].contiguous(), dp, mask_params[n:n + 1], dmask_params[n:n + 1],
+               maximum_sharpness, minimum_strength, hsv_grad_mode)
+    dparams[n, :NUM_PARAMS[fid]] = dp[0]
+
+
 def _stats_cache(x):
   return nets_np.stat_features(x.detach().double().numpy())[1]
 
@@ -164,5 +191,6 @@ def fake_hip():
                            critic_stats_bwd=_stats_bwd, critic_stats_jvp=_stats_jvp, critic_stats_hvp=_stats_hvp,
                            overexposure_penalty_bwd=_penalty_bwd, bias_lrelu_fwd=_bias_lrelu_fwd, lrelu_bwd=_lrelu_bwd,
                            vignet_apply_fwd=_vignet_fwd, vignet_apply_bwd=_vignet_bwd,
+                           apply_dispatch_fwd=_apply_dispatch_fwd, apply_dispatch_bwd=_apply_dispatch_bwd,
                            chain_fused_fwd=_chain_fused_fwd, apply_fwd=_apply_fwd, apply_bwd=_apply_bwd):
     yield

@@ -450,3 +450,88 @@ def test_training_step_graph_captures_rccl_collectives(gpu_device):
   assert 'hipGraph capture of' not in last.stderr  # the eager fallback of GAN._replay was not taken
   # the drain in front of the capture was VERIFIED through the NCCL flight recorder (no timed grace period)
   assert d['config']['capture_drain_verified'] is True, d['config']
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [(12, 64, 64, 3), (10, 9, 7, 3)])
+def test_masked_dispatch_equals_per_filter_masked_apply(dtype, shape, gpu_device):
+  """expo_filter_apply_dispatch_fwd/bwd (the agent's step with cfg.masking = True: per image only the SELECTED filter's
+  mask + process + lerp) against the per-filter entry points image by image -- same kernel bodies, so bit-identical
+  images and parameter gradients -- and against the float64 restatement; id -1 gives zeros everywhere."""
+  from oracle import filters_torch as ft
+  dev = gpu_device
+  x, dy, ids, p24, _ = dispatch_case(23, shape, NP_DT[dtype])
+  ids[-1] = 8  # LevelFilter rides along (dispatch_case draws ids from -1..7)
+  rng = np.random.default_rng(5)
+  p24[-1] = 0
+  p24[-1, :2] = synthetic.make_params(rng, 8, 1)[0]
+  n = shape[0]
+  mp = (np.tanh(rng.standard_normal((n, 6))) * 5).astype(np.float32)
+  t = lambda a: torch.from_numpy(a).to(dev)
+  tx, tdy, tid, tp, tmp = t(x), t(dy), t(ids), t(p24), t(mp)
+  y = torch.empty_like(tx)
+  _cabi.apply_dispatch_fwd(tid, tx, y, tp, tmp, 1.0, 0.3)
+  dx = torch.empty_like(tx)
+  dp = torch.full_like(tp, float('nan'))
+  dm = torch.full_like(tmp, float('nan'))
+  _cabi.apply_dispatch_bwd(tid, tx, tdy, dx, tp, dp, tmp, dm, 1.0, 0.3)
+  for i in range(n):
+    fid = int(ids[i])
+    if fid < 0:
+      assert float(y[i].float().abs().max()) == 0.0 and float(dx[i].float().abs().max()) == 0.0
+      assert float(dp[i].abs().max()) == 0.0 and float(dm[i].abs().max()) == 0.0
+      continue
+    P = fnp.NUM_PARAMS[fid]
+    xi, gi = tx[i:i + 1].contiguous(), tdy[i:i + 1].contiguous()
+    pi, mi = tp[i:i + 1, :P].contiguous(), tmp[i:i + 1].contiguous()
+    yi, dxi = torch.empty_like(xi), torch.empty_like(xi)
+    dpi, dmi = torch.empty_like(pi), torch.empty_like(mi)
+    _cabi.apply_fwd(fid, xi, yi, pi, mi, 1.0, 0.3)
+    _cabi.apply_bwd(fid, xi, gi, dxi, pi, dpi, mi, dmi, 1.0, 0.3)
+    assert torch.equal(y[i:i + 1], yi) and torch.equal(dx[i:i + 1], dxi), (i, fid)
+    assert torch.equal(dp[i:i + 1, :P], dpi) and torch.equal(dm[i:i + 1], dmi), (i, fid)
+    assert float(dp[i, P:].abs().max()) == 0.0 if P < 24 else True
+    # and the float64 restatement (raw mask parameters that reproduce the float32 squashed ones)
+    raw = torch.atanh(torch.from_numpy(mp[i:i + 1].astype(np.float64)) / 5.0)
+    ref = ft.apply_masked(fid, torch.from_numpy(x[i:i + 1].astype(np.float64)),
+                          torch.from_numpy(p24[i:i + 1, :P].astype(np.float64)), raw, 1.0, 0.3).numpy()
+    assert_image_close(yi.float().cpu().numpy(), ref, NP_DT[dtype], 'masked dispatch image %d filter %d' % (i, fid))
+
+
+def test_agent_with_masking_on_gpu(gpu_device):
+  """Agent.forward with cfg.masking = True on the GPU: one masked-dispatch launch per step instead of eight masked
+  applies; output against the float64 restatement from the agent's own parameters, gradients reach the mask rows of the
+  selected filters' heads only."""
+  from oracle import filters_torch as ft
+  dev = gpu_device
+  cfg = make_cfg()
+  cfg.masking = True
+  torch.manual_seed(2)
+  ag = xagent.Agent(cfg).to(dev)
+  n = 6
+  rng = np.random.default_rng(3)
+  img = torch.from_numpy((rng.random((n, 64, 64, 3))**2.2).astype(np.float32)).to(dev)
+  states = torch.zeros(n, 11, device=dev)
+  z = torch.from_numpy(rng.random((n, 131)).astype(np.float32)).to(dev)
+  masks = [torch.from_numpy((rng.random((n, 4096)) < 0.5).astype(np.float32)).to(dev) for _ in range(2)]
+  (out, new_states, surrogate, penalty), dbg, _ = ag((img, z, states), is_train=1, progress=0.5, dropout_masks=masks)
+  out.sum().backward()
+  ids = dbg['selected_filter_ids'].cpu().numpy()
+  with torch.no_grad():
+    feats = ag.filter_features(xagent.enrich_image_input(cfg, img, states), masks[0])
+  for i in range(n):
+    j = int(ids[i])
+    filt = ag.filters[j]
+    with torch.no_grad():
+      f, mraw = filt.extract_parameters(feats[i:i + 1])
+      packed = filt.pack(filt.filter_param_regressor(f)).double().cpu()
+    ref = ft.apply_masked(filt.filter_id, img[i:i + 1].double().cpu(), packed, mraw.double().cpu(),
+                          cfg.maximum_sharpness, cfg.minimum_strength).numpy()
+    assert np.abs(out[i:i + 1].detach().cpu().numpy() - ref).max() < 5e-5
+  chosen = set(int(v) for v in ids)
+  for j, filt in enumerate(ag.filters):
+    p = filt.get_num_filter_parameters()
+    has = float(filt.fc2.weight.grad[p:].abs().max()) > 0.0
+    assert has == (j in chosen), (j, has)
+  ref_pen = (np.maximum(out.detach().cpu().numpy().astype(np.float64) - 1, 0)**2).mean(axis=(1, 2, 3))
+  assert np.abs(penalty.detach().cpu().numpy()[:, 0] - ref_pen).max() < 2.0  # contains the entropy / usage terms too
