@@ -749,3 +749,53 @@ def test_chain_calls_on_two_user_streams_share_the_helper_stream(gpu_device):
     got = [c[0][8], c[1][0]] + list(c[3])
     for g, r in zip(got, w):
       assert torch.equal(g, r)
+
+
+def test_split_chain_replayed_from_a_hipgraph_equals_eager(gpu_device):
+  """The fork / join of the two half-batch streams (one pair of library-owned events, re-recorded by every call) is
+  captured as parallel branches: a graph holding TWO chain steps must reproduce the eager results bit for bit, replay
+  after replay, and eager calls must keep working after the capture."""
+  dev = gpu_device
+  shape = (28, 512, 512, 3)
+  assert _cabi.chain_streams(shape[0], shape[1], shape[2], _cabi.EXPO_F16) == 2
+  ids = list(range(8))
+  g = torch.Generator(device=dev).manual_seed(9)
+  x = (torch.rand(shape, device=dev, generator=g)**2.2).half()
+  dy = torch.randn(shape, device=dev, generator=g).half()
+  rng = np.random.default_rng(9)
+  prm = [torch.from_numpy(synthetic.make_params(rng, f, shape[0])).to(dev) for f in ids]
+  acts = [x] + [torch.empty_like(x) for _ in ids]
+  grads = [torch.empty_like(x) for _ in ids] + [dy]
+  dprm = [torch.empty_like(p) for p in prm]
+  ws = _cabi.new_workspace(dev, _cabi.workspace_bytes(shape[0], shape[1], shape[2], _cabi.EXPO_F16, 8))
+
+  def step():
+    _cabi.chain_fwd(ids, acts, prm)
+    _cabi.chain_bwd(ids, acts, grads, prm, dprm, workspace=ws)
+
+  step()
+  torch.cuda.synchronize()
+  want = [acts[8].clone(), grads[0].clone()] + [d.clone() for d in dprm]
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    step()
+  torch.cuda.current_stream().wait_stream(side)
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    step()
+    step()
+  for _ in range(3):
+    for t in [acts[8], grads[0]] + dprm:
+      t.fill_(3.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    for got, ref in zip([acts[8], grads[0]] + dprm, want):
+      assert torch.equal(got, ref)
+  for t in [acts[8], grads[0]] + dprm:
+    t.fill_(3.0)
+  step()  # eager again, after the events were last recorded inside a capture
+  torch.cuda.synchronize()
+  for got, ref in zip([acts[8], grads[0]] + dprm, want):
+    assert torch.equal(got, ref)
