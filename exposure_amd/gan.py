@@ -15,6 +15,7 @@ from torch import nn
 from . import dist as xdist
 from .agent import Agent
 from .critics import Critic
+from .nn_ops import frozen_parameters, skip_parameter_gradients
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
 
 
@@ -109,11 +110,15 @@ class GAN(nn.Module):
     cfg = self.cfg
     (fake_output, new_states, surrogate, penalty), debug, _ = self.generator(
         (fake_input, z, states), is_train=is_train, progress=progress, dropout_masks=dropout_masks)
-    fake_logit = self.critic(fake_output)
+    # this step updates theta_g (through g_loss) and theta_v (through v_loss = f(old_value) only): the critic's and the
+    # value net's convolution parameters take no part in differentiating fake_logit / new_value
+    with frozen_parameters():
+      fake_logit = self.critic(fake_output)
     with torch.no_grad():
       fake_input_logit = self.critic(fake_input)
     old_value = self.value(fake_input, states)
-    new_value = self.value(fake_output, new_states)
+    with frozen_parameters():
+      new_value = self.value(fake_output, new_states)
     stopped = new_states[:, STATE_STOPPED_DIM:STATE_STOPPED_DIM + 1]
     clear_final = (new_states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1] > cfg.maximum_trajectory_length).float()
     new_value = new_value * (1.0 - clear_final)
@@ -263,7 +268,8 @@ class GAN(nn.Module):
       alpha = self._draw_alpha(real_data.shape[0])
     interpolated = (real_data + alpha * (fake_output - real_data)).requires_grad_(True)
     inte_logit = self.critic(interpolated)
-    gradients, = torch.autograd.grad(inte_logit.sum(), interpolated, create_graph=True)
+    with skip_parameter_gradients():  # only d D / d x^ is wanted here; theta_c is reached by the OUTER backward
+      gradients, = torch.autograd.grad(inte_logit.sum(), interpolated, create_graph=True)
     gradient_norm = torch.sqrt(1e-6 + (gradients**2).sum(dim=(1, 2, 3)))
     gradient_penalty = cfg.gradient_penalty_lambda * (torch.clamp_min(gradient_norm - 1.0, 0.0)**2).mean()
     total = c_loss + gradient_penalty if cfg.gradient_penalty_lambda > 0 else c_loss

@@ -22,6 +22,42 @@ from . import _cabi
 
 _STRIDE, _PAD, _DIL = [2, 2], [1, 1], [1, 1]
 
+# Python autograd Functions only know statically whether an input requires a gradient (ctx.needs_input_grad); they
+# cannot see -- as torch's built-in nodes can -- that the CURRENT backward pass does not need it.  Two places of the
+# training step differentiate through a convnet without wanting its parameter gradients, and would otherwise pay one
+# weight-gradient convolution and one bias reduction per layer for results autograd throws away:
+#   * the gradient penalty's inner `autograd.grad(D(x^), x^, create_graph=True)` (net.py:174-183)   -> _SKIP_PARAM_GRADS,
+#     read at BACKWARD time (the same forward nodes serve the outer backward, which does need them);
+#   * the generator step's passes through the critic and the value net, whose weights that step does not update
+#     (net.py:222-241)                                                                              -> _FROZEN, read at
+#     FORWARD time (the parameters enter the graph detached).
+_SKIP_PARAM_GRADS = False
+_FROZEN = False
+
+
+class skip_parameter_gradients:
+  """Context manager for a backward pass that only wants INPUT gradients (``torch.autograd.grad(y, x, ...)``)."""
+
+  def __enter__(self):
+    global _SKIP_PARAM_GRADS
+    self.prev, _SKIP_PARAM_GRADS = _SKIP_PARAM_GRADS, True
+
+  def __exit__(self, *exc):
+    global _SKIP_PARAM_GRADS
+    _SKIP_PARAM_GRADS = self.prev
+
+
+class frozen_parameters:
+  """Context manager for a forward pass whose convolution weights / biases take no part in the differentiation."""
+
+  def __enter__(self):
+    global _FROZEN
+    self.prev, _FROZEN = _FROZEN, True
+
+  def __exit__(self, *exc):
+    global _FROZEN
+    _FROZEN = self.prev
+
 
 def _nchw(x_nhwc):
   return x_nhwc.permute(0, 3, 1, 2)
@@ -45,7 +81,7 @@ class _ConvF(torch.autograd.Function):
     x, w = ctx.saved_tensors
     gy = gy.contiguous()
     gx = _ConvD.apply(gy, w) if ctx.needs_input_grad[0] else None
-    gw = _ConvG.apply(x, gy, w) if ctx.needs_input_grad[1] else None
+    gw = _ConvG.apply(x, gy, w) if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS else None
     return gx, gw
 
 
@@ -95,7 +131,7 @@ def conv2d_nhwc(x, weight):
   """``ly.conv2d(x, C_out, kernel_size=4, stride=2)`` without bias and activation: NHWC float32 ``x`` (even H, W),
   ``weight`` (C_out, C_in, 4, 4) as ``nn.Conv2d`` holds it.  Differentiable to any order through library kernels."""
   assert x.dim() == 4 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and tuple(weight.shape[2:]) == (4, 4)
-  return _ConvF.apply(x.contiguous(), weight)
+  return _ConvF.apply(x.contiguous(), weight.detach() if _FROZEN else weight)
 
 
 class _LreluGrad(torch.autograd.Function):
@@ -134,7 +170,7 @@ class _BiasLrelu(torch.autograd.Function):
     z, = ctx.saved_tensors
     gy = _LreluGrad.apply(z, gz, ctx.leak)
     gb = None
-    if ctx.has_bias and ctx.needs_input_grad[1]:
+    if ctx.has_bias and ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS:
       gb = gy.reshape(-1, gy.shape[-1]).sum(dim=0)
     return gy, gb, None
 
@@ -143,4 +179,6 @@ def bias_lrelu(y, bias=None, leak=0.2):
   """``lrelu(y + bias)`` with the channel as the last dimension of ``y`` (float32).  util.py:225-229:
   ``f1*x + f2*|x|``, f1 = (1+leak)/2, f2 = (1-leak)/2, i.e. ``x if x > 0 else leak*x`` (equal to the literal formula
   within 1 ulp: 0.6x + 0.4x vs x), with TF's sub-gradient f1 exactly at 0."""
+  if _FROZEN and bias is not None:
+    bias = bias.detach()
   return _BiasLrelu.apply(y, bias, leak)
