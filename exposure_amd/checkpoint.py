@@ -1,10 +1,10 @@
 """Weight import/export between the reference's TF-1 variable layout and this package's modules.
 
-The reference saves ``tf.train.Saver`` checkpoints (``net.py:271,380-384``); reading a ``.ckpt``
-needs TensorFlow, which this image does not have, and the pretrained ``models/`` submodule is empty
-(``.gitmodules``).  What CAN be fixed here is the layout contract, so that a checkpoint dumped to
-``{variable_name: ndarray}`` (e.g. ``np.savez`` of ``tf.train.load_checkpoint(...).get_tensor``)
-loads directly:
+The reference saves ``tf.train.Saver`` checkpoints (``net.py:271,380-384``) and ``evaluate.py:27-28``
+restores ``model.ckpt-20000``.  ``tf_bundle.py`` reads and writes that file format without TensorFlow;
+this module is the layout contract between the variables in such a checkpoint (or a
+``{variable_name: ndarray}`` dump of one) and the modules here, in both directions
+(``restore`` / ``save`` mirror ``GAN.restore(ckpt)`` / the ``saver.save`` call):
 
 * ``ly.conv2d`` kernels are HWIO -> ``nn.Conv2d`` OIHW;
 * ``ly.fully_connected`` weights are (in, out) -> ``nn.Linear`` (out, in); the 4096-d feature is
@@ -24,7 +24,9 @@ def _conv_names(prefix, n):
 
 
 def tf_name_map(gan):
-  """[(tf_variable_name, torch_parameter, kind)] with kind in {'conv_w', 'fc_w', 'bias'}."""
+  """[(tf_variable_name, torch_parameter, kind)] with kind in {'conv_w', 'fc_w', 'bias'}.  ``gan``: a ``GAN``
+  (generator + critic + value network) or an ``Agent`` alone (the generator's variables: all that
+  ``evaluate.py`` needs from a checkpoint)."""
   out = []
 
   def conv(prefix, convs):
@@ -36,7 +38,7 @@ def tf_name_map(gan):
     out.append((name + '/weights', m.weight, 'fc_w'))
     out.append((name + '/biases', m.bias, 'bias'))
 
-  g = gan.generator
+  g = getattr(gan, 'generator', gan)
   conv('generator/', g.filter_features.convs)
   for j, f in enumerate(g.filters):
     fc('generator/filter_%d/fc1' % j, f.fc1)
@@ -44,6 +46,8 @@ def tf_name_map(gan):
   conv('generator/action_selection/', g.selector_features.convs)
   fc('generator/action_selection/selector_fc1', g.selector_fc1)
   fc('generator/action_selection/selector_fc2', g.selector_fc2)
+  if g is gan:
+    return out
   for scope, net in (('critic/', gan.critic), ('rl_value/critic/', gan.value)):
     conv(scope, net.convs)
     fc(scope + 'fully_connected', net.fc1)
@@ -93,3 +97,33 @@ def load_tf_dict(gan, weights, strict=True):
 def load_tf_npz(gan, path, strict=True):
   with np.load(path) as z:
     return load_tf_dict(gan, {k: z[k] for k in z.files}, strict)
+
+
+def checkpoint_prefix(model_dir, ckpt):
+  """``net.py:406-407``: ``os.path.join(self.dir, "model.ckpt-%s" % ckpt)``."""
+  import os
+  return os.path.join(model_dir, 'model.ckpt-%s' % ckpt)
+
+
+def restore(gan, model_dir, ckpt=20000, strict=True):
+  """``GAN.restore(ckpt)`` (``net.py:405-407``; ``evaluate.py:28`` passes 20000) from the TF-1 checkpoint
+  ``<model_dir>/model.ckpt-<ckpt>.{index,data-*}``.  Whatever else the checkpoint holds (Adam slots, the
+  critic's moving averages, step counters) is ignored; returns the names that were missing."""
+  from . import tf_bundle
+  names = [n for n, _p, _k in tf_name_map(gan)]
+  return load_tf_dict(gan, tf_bundle.read_bundle(checkpoint_prefix(model_dir, ckpt), names=names), strict)
+
+
+def save(gan, model_dir, iteration):
+  """The ``saver.save(sess, <dir>/model.ckpt, global_step=iter)`` of ``net.py:380-384``: writes
+  ``model.ckpt-<iteration>.index / .data-00000-of-00001`` and the ``checkpoint`` state file TF keeps next to them,
+  readable by ``tf.train.Saver.restore`` of a graph that declares these variables (optimizer slots are not
+  written: a restoring graph that wants them must initialise them itself)."""
+  import os
+  from . import tf_bundle
+  prefix = checkpoint_prefix(model_dir, iteration)
+  tf_bundle.write_bundle(prefix, export_tf_dict(gan))
+  base = os.path.basename(prefix)
+  with open(os.path.join(model_dir, 'checkpoint'), 'w') as f:
+    f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
+  return prefix

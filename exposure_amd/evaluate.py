@@ -146,7 +146,7 @@ FILTER_BY_SHORT_NAME = {'E': 'ExposureFilter', 'G': 'GammaFilter', 'W': 'Improve
 
 
 def main(argv=None):
-  """``python -m exposure_amd.evaluate [--filters E,G] [--weights w.pt] [--out dir|file] img ...`` -- the
+  """``python -m exposure_amd.evaluate [--filters E,G] [--weights w.pt | --tf-checkpoint dir] [--out dir|file] img ...`` -- the
   tensor part of ``evaluate.py:8-31`` / ``GAN.eval`` (``net.py:711-821``): per image, load (16-bit TIFF or
   8-bit sRGB), 5 retouching steps on the GPU, write the linear result.  Returns one record per image."""
   import argparse
@@ -159,6 +159,10 @@ def main(argv=None):
   ap.add_argument('--weights', default=None,
                   help='torch state_dict of exposure_amd.agent.Agent, or the GAN state dict train.py --save writes '
                   '(random init if absent)')
+  ap.add_argument('--tf-checkpoint', default=None, metavar='MODEL_DIR',
+                  help="directory of a TF-1 checkpoint of the reference (models/<cfg>/<name>): restores "
+                  "MODEL_DIR/model.ckpt-<--ckpt> like evaluate.py:27-28 (no TensorFlow needed)")
+  ap.add_argument('--ckpt', default='20000', help='checkpoint iteration for --tf-checkpoint (evaluate.py:28: 20000)')
   ap.add_argument('--out', default=None, help='output file (one image) or directory; default <image>.retouched.npy')
   ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
   ap.add_argument('--filters', default=None,
@@ -175,8 +179,13 @@ def main(argv=None):
     flt = [getattr(F, FILTER_BY_SHORT_NAME[name.strip()]) for name in args.filters.split(',')]
   cfg = make_cfg(filters=flt)
   agent = Agent(cfg).to(dev)
+  if args.weights and args.tf_checkpoint:
+    ap.error('--weights and --tf-checkpoint are alternatives')
   if args.weights:
     load_agent_weights(agent, torch.load(args.weights, map_location=dev))
+  if args.tf_checkpoint:
+    from . import checkpoint
+    checkpoint.restore(agent, args.tf_checkpoint, args.ckpt)
   dt = torch.float16 if args.dtype == 'f16' else torch.float32
   records = []
   for path in args.images:

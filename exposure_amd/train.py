@@ -2,7 +2,8 @@
 ``train.py:9-14`` / ``GAN.train`` (``net.py:298-403``) on synthetic FiveK-shaped data: the G/V and
 critic alternation with the device-resident replay memory, one hipGraph replay per optimisation
 step.  Dataset loading, TensorBoard, PNG dashboards and checkpoints of the reference are out of scope
-(SURVEY.md section 2); ``--save`` writes a plain ``torch.save`` state dict.
+(SURVEY.md section 2); ``--save`` writes a plain ``torch.save`` state dict, ``--save-tf`` a TF-1 checkpoint
+(``checkpoint.py``, ``tf_bundle.py``).
 
 Note on the numbers it prints: with random-init weights the policy can chain Exposure (x11) and
 Gamma (power 3) steps, so pixel values -- and with them the over-exposure penalty, the critic logits
@@ -27,6 +28,9 @@ def main(argv=None):
   ap.add_argument('--log-every', type=int, default=10)
   ap.add_argument('--no-graphs', action='store_true')
   ap.add_argument('--save', default=None)
+  ap.add_argument('--save-tf', default=None, metavar='MODEL_DIR',
+                  help="also write MODEL_DIR/model.ckpt-<iters> in TensorFlow's checkpoint format, variable names and "
+                  "layouts as the reference's graph declares them (net.py:380-384)")
   ap.add_argument('--clamp', action='store_true', help='cfg.clamp = True (agent.py:240-241)')
   ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'], help='storage type of the image pool')
   args = ap.parse_args(argv)
@@ -47,6 +51,9 @@ def main(argv=None):
         (len(hist), dt))
   if args.save:
     torch.save(gan.state_dict(), args.save)
+  if args.save_tf:
+    from . import checkpoint
+    print('wrote', checkpoint.save(gan, args.save_tf, args.iters))
 
 
 if __name__ == '__main__':

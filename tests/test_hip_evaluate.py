@@ -95,3 +95,53 @@ def test_train_save_then_evaluate_round_trip(gpu_device, tmp_path):
   write_tiff(tif, raw)
   rec = evaluate.main(['--weights', w, '--seed', '1', '--out', str(tmp_path / 'o.npy'), tif])[0]
   assert np.isfinite(np.load(rec['output'])).all()
+
+
+def test_tf_checkpoint_round_trip_through_the_cli(gpu_device, tmp_path):
+  """f-4: train -> `saver.save`-format checkpoint (net.py:380-384) -> evaluate restoring it like evaluate.py:27-28
+  gives bit-for-bit the output of the torch state dict of the same weights; a checkpoint with the optimizer's slot
+  variables in it restores the same."""
+  from exposure_amd import checkpoint, tf_bundle, train
+  w = str(tmp_path / 'gan.pt')
+  model_dir = str(tmp_path / 'models' / 'example' / 'run')
+  train.main(['--iters', '1', '--no-graphs', '--clamp', '--save', w, '--save-tf', model_dir, '--log-every', '0'])
+  assert os.path.exists(os.path.join(model_dir, 'model.ckpt-1.index'))
+  raw = (np.random.default_rng(5).random((96, 64, 3)) * 30000).astype(np.uint16)
+  tif = str(tmp_path / 'd.tif')
+  write_tiff(tif, raw)
+  a = evaluate.main(['--weights', w, '--seed', '3', '--out', str(tmp_path / 'a.npy'), tif])[0]
+  b = evaluate.main(['--tf-checkpoint', model_dir, '--ckpt', '1', '--seed', '3', '--out', str(tmp_path / 'b.npy'), tif])[0]
+  assert a['filters'] == b['filters'] and a['states'] == b['states']
+  np.testing.assert_array_equal(a['params24'], b['params24'])
+  np.testing.assert_array_equal(np.load(a['output']), np.load(b['output']))
+  # what TF itself writes holds more than the trainable variables
+  d = tf_bundle.read_bundle(checkpoint.checkpoint_prefix(model_dir, 1))
+  extra = dict(d)
+  for k, v in d.items():
+    extra[k + '/Adam'] = np.zeros_like(v)
+    extra[k + '/Adam_1'] = np.zeros_like(v)
+  extra['beta1_power'] = np.float32(0.5)
+  tf_bundle.write_bundle(checkpoint.checkpoint_prefix(model_dir, 20000), extra)
+  c = evaluate.main(['--tf-checkpoint', model_dir, '--seed', '3', '--out', str(tmp_path / 'c.npy'), tif])[0]
+  np.testing.assert_array_equal(np.load(a['output']), np.load(c['output']))
+  with pytest.raises(SystemExit):
+    evaluate.main(['--tf-checkpoint', model_dir, '--weights', w, tif])
+
+
+def test_histogram_intersection_metric_on_device(gpu_device):
+  """histogram_intersection.py:11-31,62-76 on GPU tensors (fp16 storage, as the retouched images are) equals the
+  CPU evaluation of the same images, and retouched-vs-target behaves like a similarity."""
+  from exposure_amd import metrics
+  g = torch.Generator().manual_seed(4)
+  out = (torch.rand((256, 64, 64, 3), generator=g)**2.0).half()
+  tgt = (torch.rand((256, 64, 64, 3), generator=g)**0.7).half()
+  ints_cpu, avg_cpu = metrics.histogram_intersection(out, tgt)
+  ints_gpu, avg_gpu = metrics.histogram_intersection(out.to(gpu_device), tgt.to(gpu_device))
+  st_cpu, st_gpu = metrics.get_statistics(out), metrics.get_statistics(out.to(gpu_device)).cpu()
+  np.testing.assert_allclose(st_gpu.numpy(), st_cpu.numpy(), rtol=2e-5, atol=2e-6)
+  # a statistic within rounding of a bin edge may change bins between devices: at most one image per histogram
+  for a, b in zip(ints_cpu, ints_gpu):
+    assert abs(a - b) <= 2.0 / 256 + 1e-6
+  assert abs(avg_cpu - avg_gpu) <= 2.0 / 256 + 1e-6
+  same, avg_same = metrics.histogram_intersection(out.to(gpu_device), out.to(gpu_device))
+  assert all(abs(v - 1.0) < 1e-6 for v in same) and avg_gpu < avg_same
