@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W          (N > 1: re-launches itself as N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W                  (same thing, external launcher)
-  --workload chain|train|infer|allreduce   --scaling weak|strong        (SURVEY.md 8(e) scaling report rows)
+  --workload chain|train|infer|allreduce|chain_fused   --scaling weak|strong        (SURVEY.md 8(e) scaling report rows)
 
 One "step" = one pass of the hot path over one synthetic batch: the 8 filters of cfg.filters
 (E,G,W,S+,T,Ct,BW,C; /root/reference/config_example.py:22-25) applied sequentially, one HIP
@@ -52,7 +52,7 @@ def parse():
   ap.add_argument('--seed', type=int, default=1234)
   ap.add_argument('--order', default='0,1,2,3,4,5,6,7', help='filter ids of the chain steps (experiments only; the '
                   'metric is defined on the cfg.filters order 0..7)')
-  ap.add_argument('--workload', default='chain', choices=['chain', 'train', 'infer', 'allreduce'],
+  ap.add_argument('--workload', default='chain', choices=['chain', 'train', 'infer', 'allreduce', 'chain_fused'],
                   help="chain: the headline filter-chain metric; train: one reference training iteration "
                   "(1 generator/value step + cfg.citers critic steps, net.py:307-365) on 64 images per GPU")
   ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
@@ -743,6 +743,110 @@ def run_infer(args, world, rank, dev, dist):
     dist.destroy_process_group()
 
 
+def run_chain_fused(args, world, rank, dev, dist):
+  """A benchmark construct beside the headline, never instead of it: the same 8-step sequence forward + backward with
+  the parameters FIXED, so that each direction is ONE pass (expo_chain_fused_fwd: read x, write y; expo_chain_fused_bwd:
+  read x and dy, write dx, activations recomputed in registers) -- 30 B/pixel of HBM traffic instead of the 240 B/pixel
+  of the 16 per-step launches.  The reference has no caller for this (its step k+1 parameters depend on image k through
+  the CNN), which is why the headline stays the per-step chain.  Quoted against the same 240 B/pixel."""
+  shape = local_shape(parse_shape(args.shape or 'C'), world, args.scaling)
+  dtype = torch.float16 if args.dtype == 'f16' else torch.float32
+  esz = 2 if args.dtype == 'f16' else 4
+  x, dy, params = make_device_case(shape, dtype, dev, args.seed + rank)
+  n = shape[0]
+  px = shape[0] * shape[1] * shape[2]
+  ids = torch.arange(8, dtype=torch.int32, device=dev)[None, :].repeat(n, 1).contiguous()
+  p24 = torch.zeros((n, 8, 24), dtype=torch.float32, device=dev)
+  for fid in range(8):
+    p24[:, fid, :params[fid].shape[1]] = params[fid]
+  y, dx, dp24 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(p24)
+  ws = _cabi.reserve_workspace(dev, _cabi.workspace_bytes(n, shape[1], shape[2], 0 if args.dtype == 'f16' else 1, 8))
+
+  def step():
+    _cabi.chain_fused_fwd(ids, p24, x, y)
+    _cabi.chain_fused_bwd(ids, p24, x, dy, dx, dp24, workspace=ws)
+
+  def event_avg(fn, reps=50):
+    for _ in range(5):
+      fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+      fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+  for _ in range(args.warmup):
+    step()
+  torch.cuda.synchronize()
+  light_barrier(dist, dev)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  torch.cuda.synchronize()
+  light_barrier(dist, dev)
+  torch.cuda.synchronize()
+  el = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+  t_step = el / args.steps
+  t_fwd = event_avg(lambda: _cabi.chain_fused_fwd(ids, p24, x, y))
+  t_bwd = event_avg(lambda: _cabi.chain_fused_bwd(ids, p24, x, dy, dx, dp24, workspace=ws))
+  # the per-step construction on the same tensors (the headline's 16 launches + finish), for the ratio
+  acts = [x] + [torch.empty_like(x) for _ in range(8)]
+  grads = [torch.empty_like(x) for _ in range(8)] + [dy]
+  dprm = [torch.empty_like(q) for q in params]
+
+  def per_step():
+    _cabi.chain_fwd(list(range(8)), acts, params)
+    _cabi.chain_bwd(list(range(8)), acts, grads, params, dprm, workspace=ws)
+
+  t_per_step = event_avg(per_step, reps=20)
+  worst = 0.0
+  for fid in range(8):
+    a, b = dp24[:, fid, :params[fid].shape[1]], dprm[fid]
+    worst = max(worst, float(((a - b).abs() / (b.abs() + dy.float().abs().sum(dim=(1, 2, 3))[:, None] * 1e-3 + 1e-6)).max()))
+  if rank == 0:
+    actual = (2 + 3) * 3 * esz * px  # x, y | x, dy, dx
+    print(json.dumps({
+        'roofline': {
+            'bound': 'valu', 'kernel': 'chain_fused_bwd_kernel', 'avg_launch_ms': t_bwd * 1e3,
+            'achieved': 3 * 3 * esz * px / t_bwd / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'frac': 3 * 3 * esz * px / t_bwd / 1e9 / HBM_PEAK_GBPS, 'traffic': None,
+            'note': 'actual traffic of the one-pass backward (18 B/px at fp16) against HBM; the kernel is VALU-bound '
+                    '(8 forward + 8 backward filter bodies per pixel group), so this fraction is not a quality measure',
+        },
+        'metric': 'Mpixels/s through 8-step filter chain fwd+bwd, one pass each way (fixed parameters)',
+        'value': world * px / t_step / 1e6,
+        'unit': 'Mpixels/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': t_step * 1e3,
+        'higher_is_better': True,
+        'scaling': args.scaling,
+        'vs_baseline': None,
+        'dtype': args.dtype,
+        'data': 'synthetic',
+        'config': {
+            'workload': 'fused 8-step chain forward + backward (expo_chain_fused_fwd / _bwd), %dx%dx%dx3 %s per GPU; '
+                        'a benchmark construct beside the per-step headline' % (shape[0], shape[1], shape[2], args.dtype),
+            'fused_fwd_ms': t_fwd * 1e3, 'fused_bwd_ms': t_bwd * 1e3,
+            'per_step_chain_ms': t_per_step * 1e3, 'speedup_vs_per_step': t_per_step / (t_fwd + t_bwd),
+            'algorithmic_GBps_at_240B_per_pixel': 8 * 5 * 3 * esz * px / t_step / 1e9,
+            'actual_traffic_GBps': actual / t_step / 1e9,
+            'dparams_max_rel_diff_vs_per_step': worst,
+        },
+    }))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def self_launch(args):
   """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this same command
   (one process per GPU, `torch.distributed.run`, rendezvous on 127.0.0.1) and return their exit code.  Rank 0
@@ -854,6 +958,8 @@ def main():
     return run_infer(args, world, rank, dev, dist)
   if args.workload == 'allreduce':
     return run_allreduce(args, world, rank, dev, dist)
+  if args.workload == 'chain_fused':
+    return run_chain_fused(args, world, rank, dev, dist)
 
   gshape = parse_shape(args.shape or 'C')
   shape = local_shape(gshape, world, args.scaling)

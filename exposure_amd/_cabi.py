@@ -49,6 +49,7 @@ SIGNATURES = {
     'expo_chain_bwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                             ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_chain_fused_fwd': (_i, [_vp, _fp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'expo_chain_fused_bwd': (_i, [_vp, _fp, _i, _vp, _vp, _vp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_critic_stats': (_i, [_vp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_overexposure_penalty': (_i, [_vp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_overexposure_penalty_bwd': (_i, [_vp, _fp, _vp, _i, _i, _i, _i, _vp]),
@@ -388,6 +389,30 @@ def chain_fused_fwd(filter_ids, params, x, y):
   with torch.cuda.device(x.device):
     _check(lib.expo_chain_fused_fwd(_ptr(filter_ids), _ptr(params), steps, _ptr(x), _ptr(y), n, h, w,
                                     _dtype_code(x), _stream()), 'expo_chain_fused_fwd')
+
+
+FUSED_BWD_MAX_STEPS = 8  # EXPO_FUSED_BWD_MAX_STEPS
+
+
+def chain_fused_bwd(filter_ids, params, x, dy, dx, dparams, hsv_grad_mode=0, workspace=None):
+  """One-pass backward of the fixed per-image sequence of ``chain_fused_fwd``: filter_ids (N, steps) int32, params
+  and dparams (N, steps, 24) float32; x, dy -> dx (may alias dy).  steps <= FUSED_BWD_MAX_STEPS."""
+  lib = load()
+  _img(x, 'x'), _img(dy, 'dy'), _img(dx, 'dx')
+  n, h, w, _ = x.shape
+  steps = filter_ids.shape[1]
+  if dy.shape != x.shape or dx.shape != x.shape or dy.dtype != x.dtype or dx.dtype != x.dtype:
+    raise ExposureHipError('exposure_amd: x, dy, dx must agree in shape and dtype')
+  if not filter_ids.is_cuda or filter_ids.dtype != torch.int32 or not filter_ids.is_contiguous() or \
+      tuple(filter_ids.shape) != (n, steps):
+    raise ExposureHipError('exposure_amd: filter_ids must be a contiguous int32 device tensor of shape (N, steps)')
+  _f32(params, 'params', (n, steps, EXPO_MAX_PARAMS))
+  _f32(dparams, 'dparams', (n, steps, EXPO_MAX_PARAMS))
+  with torch.cuda.device(x.device):
+    wsp, wsb = _ws(x, workspace, max(steps, 1))
+    _check(lib.expo_chain_fused_bwd(_ptr(filter_ids), _ptr(params), steps, _ptr(x), _ptr(dy), _ptr(dx), _ptr(dparams),
+                                    n, h, w, _dtype_code(x), hsv_grad_mode, wsp, wsb, _stream()),
+           'expo_chain_fused_bwd')
 
 
 def critic_stats(x, stats, workspace=None):

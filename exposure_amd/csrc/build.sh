@@ -1,7 +1,8 @@
 #!/bin/bash
 # Build libexposure_hip.so for gfx950 in-tree (the .so is git-ignored but travels with gpurun).
-# Three translation units: the streaming kernels (default flags), the VALU-bound fused inference kernel
-# (-fno-slp-vectorize -fno-honor-nans, see chain_fused.hip) and the convnets' activation (nn_ops.hip); extra
+# Four translation units: the streaming kernels (default flags), the VALU-bound fused inference kernel
+# (-fno-slp-vectorize -fno-honor-nans, see chain_fused.hip), the convnets' activation (nn_ops.hip) and the one-pass
+# backward of a fixed sequence (chain_fused_bwd.hip; -fno-slp-vectorize: the packed-fp32 pairs cost it ~100 VGPRs); extra
 # arguments go to every compile step.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
@@ -16,9 +17,12 @@ p1=$!
 p2=$!
 "$HIPCC" "${FLAGS[@]}" "$@" -c "$HERE/nn_ops.hip" -o "$TMP/nn_ops.o" &
 p3=$!
+"$HIPCC" "${FLAGS[@]}" -fno-slp-vectorize "$@" -c "$HERE/chain_fused_bwd.hip" -o "$TMP/chain_fused_bwd.o" &
+p4=$!
 # (a bare `wait` returns 0 whatever the jobs did: wait for each PID so a failed compile stops the script here)
 wait $p1
 wait $p2
 wait $p3
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$TMP/exposure_hip.o" "$TMP/chain_fused.o" "$TMP/nn_ops.o" -o "$OUT"
+wait $p4
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$TMP/exposure_hip.o" "$TMP/chain_fused.o" "$TMP/nn_ops.o" "$TMP/chain_fused_bwd.o" -o "$OUT"
 echo "built $OUT"

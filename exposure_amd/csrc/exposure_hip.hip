@@ -896,14 +896,14 @@ __global__ __launch_bounds__(kThreads) void stats_hvp_kernel(const T* __restrict
 // One wave per (image, step): adds the image's bx block records in a fixed order and writes the final
 // per-image values.  Steps of a chain (or the single step of any other entry point) are described by
 // value in the kernel arguments.
-enum FinishKind : int { kFinFilter = 0, kFinDispatch = 1, kFinApply = 2, kFinStats = 3, kFinPenalty = 4, kFinScaled = 5, kFinVignet = 6, kFinApplyDispatch = 7 };
+enum FinishKind : int { kFinFilter = 0, kFinDispatch = 1, kFinApply = 2, kFinStats = 3, kFinPenalty = 4, kFinScaled = 5, kFinVignet = 6, kFinApplyDispatch = 7, kFinChainFused = 8 };
 struct FinishStep {
   const float* params;    // [n][P] (filter / apply), [n][EXPO_MAX_PARAMS] (dispatch)
   float* out;             // dparams [n][P] | [n][24]; stats [n][3]; penalty [n]
   float* out2;            // apply: dmask_params [n][6]
   const float* records;   // [n][bx][kWsSlots]
   const int32_t* ids;     // dispatch: per-image filter ids
-  int kind, filter_id, accumulate;
+  int kind, filter_id, accumulate;  // kFinChainFused: filter_id = steps of the sequence (row stride multiplier)
   float scale;            // stats: 1 / (H W); penalty: 1 / (H W 3)
   int bx;                 // records per image (the streaming kernel's gridDim.x)
 };
@@ -927,7 +927,9 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const FinishArgs
   __shared__ float part[kFinishThreads / kWsSlots][kWsSlots];
   __shared__ float tot[kWsSlots];
   int fid = st.filter_id;
-  if (st.ids) fid = st.ids[n];  // per-image choice (dispatch entry points)
+  // expo_chain_fused_bwd: ids [n][steps], params / dparams [n][steps][EXPO_MAX_PARAMS], this launch row = one step
+  const int seq = st.kind == kFinChainFused ? st.filter_id : 1;
+  if (st.ids) fid = st.ids[size_t(n) * seq];  // per-image choice (dispatch entry points)
   const bool nothing = st.ids && (fid < 0 || fid >= EXPO_NUM_FILTERS);  // id -1: the image wrote no records
   // fixed summation order: thread (g, j) adds the records b = g, g + 8, g + 16, ... of slot j (independent loads,
   // all in flight together -- the first version walked them in one dependent chain and took 5.3 us), then the 8
@@ -975,18 +977,19 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const FinishArgs
       if (lane < st.filter_id) st.out[n * st.filter_id + lane] = tot[lane] * st.scale;
       break;
     default: {
-      const bool disp = st.kind == kFinDispatch || st.kind == kFinApplyDispatch;
+      const bool disp = st.kind == kFinDispatch || st.kind == kFinApplyDispatch || st.kind == kFinChainFused;
       const bool masked = st.kind == kFinApply || st.kind == kFinApplyDispatch;
       const int stride = disp ? EXPO_MAX_PARAMS : 0;
       if (nothing) {
-        if (lane < EXPO_MAX_PARAMS) st.out[n * EXPO_MAX_PARAMS + lane] = 0.0f;
+        if (lane < EXPO_MAX_PARAMS) st.out[size_t(n) * seq * EXPO_MAX_PARAMS + lane] = 0.0f;
         if (masked && lane < 6) st.out2[n * 6 + lane] = 0.0f;
         break;
       }
 #define EXPO_FIN(ID, F)                                                                                        \
   case ID: {                                                                                                   \
     const int row = disp ? stride : F::NP;                                                                     \
-    finish_filter<F>(st, st.params + size_t(n) * row, tot, st.out + size_t(n) * row, row, lane);               \
+    const size_t at = size_t(n) * seq * row;                                                                   \
+    finish_filter<F>(st, st.params + at, tot, st.out + at, row, lane);                                         \
     if (masked && lane < 6) st.out2[n * 6 + lane] = tot[F::NACC + lane];                                      \
   } break;
       switch (fid) {
@@ -1065,6 +1068,23 @@ static int launch_finish(const FinishArgs& args, int steps, int n, hipStream_t s
   hipLaunchKernelGGL(finish_kernel, dim3(n, steps), dim3(kFinishThreads), 0, s, args);
   HIP_TRY(hipGetLastError(), "finish launch");
   return EXPO_OK;
+}
+
+// (declared in host_common.h for chain_fused_bwd.hip)
+int chain_records(void* workspace, size_t workspace_bytes, int n, int h, int w, int dtype, int steps, float** records,
+                  size_t* step_floats) {
+  const int bx_max = geom_bx_max(n, h, w, dtype);
+  *step_floats = ws_step_bytes(n, bx_max) / sizeof(float);
+  return ws_check(workspace, workspace_bytes, n, bx_max, steps, records);
+}
+int finish_chain_fused(const int32_t* ids, const float* params, float* dparams, const float* records,
+                       size_t step_floats, int steps, int n, int blocks_x, hipStream_t s) {
+  static_assert(EXPO_FUSED_BWD_MAX_STEPS <= kMaxFinishSteps, "one finish launch serves the whole sequence");
+  FinishArgs fa{};
+  for (int k = 0; k < steps; ++k)
+    fa.s[k] = FinishStep{params + size_t(k) * EXPO_MAX_PARAMS, dparams + size_t(k) * EXPO_MAX_PARAMS, nullptr,
+                         records + size_t(k) * step_floats, ids + k, kFinChainFused, steps, 0, 0.f, blocks_x};
+  return launch_finish(fa, steps, n, s);
 }
 
 template <class F, typename T>

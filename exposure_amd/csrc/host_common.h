@@ -54,7 +54,8 @@ enum GeomKind {
   kGeomReduceTone = 4,  // backward of Tone / Color: every block first stages its image's slope table, so fewer,
   kGeomReduceColor = 5, //   fatter blocks pay (Tone: 2 KB table, Color: 6 KB)
   kGeomApply = 6,       // masked apply backward
-  kNumGeomKinds = 7
+  kGeomFusedBwd = 7,    // one-pass backward of a whole sequence: per-block set-up of every step's tables, VALU-bound
+  kNumGeomKinds = 8
 };
 // geometry of the plain backward of one filter (expo_filter_bwd / _records / expo_chain_bwd / expo_finish_bwd)
 inline int bwd_geom_kind(int filter_id) { return filter_id == 4 ? kGeomReduceTone : filter_id == 7 ? kGeomReduceColor : kGeomReduce; }
@@ -80,7 +81,7 @@ inline Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
       env_int("EXPO_FWD_GROUPS_PER_THREAD", 1),       env_int("EXPO_BWD_GROUPS_PER_THREAD", 1),
       env_int("EXPO_RED_GROUPS_PER_THREAD", 4),       env_int("EXPO_DISPATCH_GROUPS_PER_THREAD", 4),
       env_int("EXPO_TONE_GROUPS_PER_THREAD", 2),      env_int("EXPO_COLOR_GROUPS_PER_THREAD", 2),
-      env_int("EXPO_APPLY_GROUPS_PER_THREAD", 4)};
+      env_int("EXPO_APPLY_GROUPS_PER_THREAD", 4),     env_int("EXPO_FUSED_BWD_GROUPS_PER_THREAD", 8)};
   int gpt = gpt_kind[kind >= 0 && kind < kNumGeomKinds ? kind : kGeomReduce];
   // beyond the Infinity Cache (one tensor >= 256 MiB: HBM-cold streams, images walked in alternating order) the
   // light backward kernels are back to four groups per thread: 2.556 vs 2.595 ms per chain step at 256x512x512
@@ -98,6 +99,13 @@ inline Geom make_geom(int n, int h, int w, std::initializer_list<const void*> pt
   g.stream = g.vec && long(n) * g.hw * 3L * long(sizeof(T)) >= stream_min;
   return g;
 }
+
+// defined in exposure_hip.hip (the finish kernel and the workspace layout live there), used by chain_fused_bwd.hip:
+// the per-step record slices of a chain's workspace, and the finish launch of expo_chain_fused_bwd
+int chain_records(void* workspace, size_t workspace_bytes, int n, int h, int w, int dtype, int steps, float** records,
+                  size_t* step_floats);
+int finish_chain_fused(const int32_t* ids, const float* params, float* dparams, const float* records,
+                       size_t step_floats, int steps, int n, int blocks_x, hipStream_t s);
 
 inline int check_common(int n, int h, int w, int dtype) {
   if (n < 0 || h < 1 || w < 1) return fail(EXPO_E_BADARG, "n >= 0, h >= 1, w >= 1 required");

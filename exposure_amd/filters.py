@@ -622,3 +622,39 @@ def dispatch_filters(img, params24, filter_ids, hsv_grad_mode=0):
   first P slots.  Returns (y, overexposure_penalty[N]) -- the latter is agent.py:249-251's
   ``reduce_mean(maximum(net - 1, 0)**2, axis=(1,2,3))``."""
   return _DispatchFunction.apply(img, params24, filter_ids, hsv_grad_mode)
+
+
+class _FusedSequenceFunction(torch.autograd.Function):
+  """A FIXED per-image filter sequence in one pass each way (expo_chain_fused_fwd / expo_chain_fused_bwd)."""
+
+  @staticmethod
+  def forward(ctx, img, params24, filter_ids, hsv_grad_mode):
+    img = img.contiguous()
+    params24 = params24.contiguous().float()
+    filter_ids = filter_ids.contiguous().to(torch.int32)
+    y = torch.empty_like(img)
+    _cabi.chain_fused_fwd(filter_ids, params24, img, y)
+    ctx.save_for_backward(img, params24, filter_ids)
+    ctx.hsv_grad_mode = hsv_grad_mode
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    img, params24, filter_ids = ctx.saved_tensors
+    dy = dy.contiguous().to(img.dtype)
+    dx = torch.empty_like(img)
+    dparams = torch.empty_like(params24)
+    _cabi.chain_fused_bwd(filter_ids, params24, img, dy, dx, dparams, ctx.hsv_grad_mode)
+    return dx, dparams, None, None
+
+
+def fused_sequence(img, params24, filter_ids, hsv_grad_mode=0):
+  """Apply ``filter_ids[n, 0], filter_ids[n, 1], ...`` (C-ABI ids, -1 = nothing selected) with parameters
+  ``params24[n, k, :P]`` to image n, differentiably, WITHOUT materialising the intermediate images: one read and
+  one write of the image forward, one read of img and dy and one write of dx backward (activations recomputed in
+  registers; at most ``_cabi.FUSED_BWD_MAX_STEPS`` steps when a gradient is needed).  Only for sequences that do
+  not depend on the intermediate images -- in the reference's agent each step's parameters are regressed from the
+  previous step's output (agent.py:30-125), which needs :func:`dispatch_filters` step by step; this serves the
+  replayed sequence of the high-resolution path (net.py:796-821) and the ``chain_fused`` benchmark."""
+  return _FusedSequenceFunction.apply(img, params24, filter_ids, hsv_grad_mode)
+

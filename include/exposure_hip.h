@@ -258,6 +258,27 @@ int expo_chain_fused_fwd(const int32_t* filter_ids, const float* params, int ste
                          const void* x, void* y, int n, int h, int w, int dtype, void* stream);
 
 /*
+ * One-pass backward of the same fixed per-image sequence: dx = d(loss)/dx and every step's parameter
+ * gradients from x and dy = d(loss)/dy alone -- ONE read of x and dy, ONE write of dx (18 B/pixel
+ * whatever the number of steps); the activations are recomputed in registers and no intermediate
+ * image exists.  A benchmark construct (bench.py --workload chain_fused): the reference has no caller
+ * for it, because there the parameters of step k+1 depend on the image after step k through the CNN
+ * (agent.py:30-125) and the backward has to be step by step (expo_chain_bwd / expo_filter_bwd).
+ * Each step is linearised at its input rounded to the storage dtype (exact for fp32 storage; for fp16
+ * storage the value the per-step chain stores between its launches); the gradient travels between the
+ * steps in fp32.  Tie conventions, hsv_grad_mode and id -1 (the image becomes 0: no gradient reaches
+ * the input or the earlier steps, that step's dparams row is 0) as in expo_filter_bwd / the dispatch.
+ *   filter_ids  device int32 [N][steps] in [-1, 8],  steps <= EXPO_FUSED_BWD_MAX_STEPS
+ *   params      device float32 [N][steps][EXPO_MAX_PARAMS]
+ *   dparams     device float32 [N][steps][EXPO_MAX_PARAMS], fully overwritten (unused tail of a row = 0)
+ *   dx may alias dy (not x).  workspace: expo_workspace_bytes(...) * steps, as for expo_chain_bwd.
+ */
+#define EXPO_FUSED_BWD_MAX_STEPS 8
+int expo_chain_fused_bwd(const int32_t* filter_ids, const float* params, int steps, const void* x,
+                         const void* dy, void* dx, float* dparams, int n, int h, int w, int dtype,
+                         int hsv_grad_mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Per-image statistics the critic appends as constant feature planes
  * (critics.py:48-62): stats[n] = { mean(lum), variance(lum), mean(sat) } with
  * lum = .27R + .67G + .06B + 1e-5 and

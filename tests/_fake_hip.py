@@ -77,6 +77,35 @@ def _chain_fused_fwd(ids, params, x, y):
   y.copy_(cur.to(y.dtype))
 
 
+def _chain_fused_bwd(ids, params, x, dy, dx, dparams, hsv_grad_mode=0, workspace=None):
+  dparams.zero_()
+  for n in range(x.shape[0]):
+    xi = x[n:n + 1].double().requires_grad_(True)
+    ps = []
+    cur = xi
+    alive = True
+    for st in range(ids.shape[1]):
+      fid = int(ids[n, st])
+      if fid < 0:
+        cur = cur * 0.0
+        ps.append(None)
+        continue
+      q = params[n:n + 1, st, :NUM_PARAMS[fid]].double().requires_grad_(True)
+      ps.append(q)
+      with torch.enable_grad():
+        cur = ft.process_packed(fid, cur, q, hsv_grad_mode)
+    live = [xi] + [q for q in ps if q is not None]
+    with torch.enable_grad():
+      grads = torch.autograd.grad(cur, live, dy[n:n + 1].double(), allow_unused=True)
+    dx[n:n + 1].copy_((grads[0] if grads[0] is not None else torch.zeros_like(xi)).to(dx.dtype))
+    it = iter(grads[1:])
+    for st, q in enumerate(ps):
+      if q is not None:
+        g = next(it)
+        if g is not None:
+          dparams[n, st, :q.shape[1]] = g[0].float()
+
+
 def _raw_mask(mp):
   """the C-ABI takes tanh_range(-5, 5)(raw) = 5 tanh(raw); the oracle takes raw"""
   return torch.atanh((mp.double() / 5.0).clamp(-1 + 1e-15, 1 - 1e-15))
@@ -192,5 +221,5 @@ def fake_hip():
                            overexposure_penalty_bwd=_penalty_bwd, bias_lrelu_fwd=_bias_lrelu_fwd, lrelu_bwd=_lrelu_bwd,
                            vignet_apply_fwd=_vignet_fwd, vignet_apply_bwd=_vignet_bwd,
                            apply_dispatch_fwd=_apply_dispatch_fwd, apply_dispatch_bwd=_apply_dispatch_bwd,
-                           chain_fused_fwd=_chain_fused_fwd, apply_fwd=_apply_fwd, apply_bwd=_apply_bwd):
+                           chain_fused_fwd=_chain_fused_fwd, chain_fused_bwd=_chain_fused_bwd, apply_fwd=_apply_fwd, apply_bwd=_apply_bwd):
     yield

@@ -141,3 +141,41 @@ def test_agent_masking_path_matches_oracle_and_gives_mask_gradients():
     filt = ag.filters[j]
     p = filt.get_num_filter_parameters()
     assert float(filt.fc2.weight.grad[p:].abs().max()) > 0.0  # the 6 mask rows
+
+
+def test_fused_sequence_host_op_matches_stepwise_composition():
+  """filters.fused_sequence (host side, the HIP calls replaced by the oracle): the value and the gradients of a fixed
+  per-image sequence equal those of the same filters applied one after the other through pixel_filter; id -1 zeroes
+  the image from its step on and blocks the gradient to earlier steps."""
+  from exposure_amd import filters as F
+  from exposure_amd import synthetic
+  rng = np.random.default_rng(3)
+  n, steps = 3, 4
+  x = torch.from_numpy(synthetic.make_images(rng, (n, 6, 5, 3), np.float32)).double()
+  ids = np.array([[0, 4, 3, 7], [5, 1, 2, 6], [1, -1, 0, 4]], dtype=np.int32)
+  p = np.zeros((n, steps, 24), dtype=np.float32)
+  for i in range(n):
+    for st in range(steps):
+      if ids[i, st] >= 0:
+        p[i, st, :F._cabi.NUM_PARAMS[ids[i, st]]] = synthetic.make_params(rng, int(ids[i, st]), 1)[0]
+  w = torch.from_numpy(rng.standard_normal((n, 6, 5, 3)))
+  with fake_hip():
+    xa = x.clone().requires_grad_(True)
+    pa = torch.from_numpy(p).requires_grad_(True)
+    ya = F.fused_sequence(xa, pa, torch.from_numpy(ids))
+    (ya * w).sum().backward()
+    xb = x.clone().requires_grad_(True)
+    pb = torch.from_numpy(p).requires_grad_(True)
+    rows = []
+    for i in range(n):
+      cur = xb[i:i + 1]
+      for st in range(steps):
+        fid = int(ids[i, st])
+        cur = cur * 0.0 if fid < 0 else F.pixel_filter(fid, cur, pb[i:i + 1, st, :F._cabi.NUM_PARAMS[fid]])
+      rows.append(cur)
+    yb = torch.cat(rows)
+    (yb * w).sum().backward()
+  np.testing.assert_allclose(ya.detach().numpy(), yb.detach().numpy(), rtol=1e-6, atol=1e-7)
+  np.testing.assert_allclose(xa.grad.numpy(), xb.grad.numpy(), rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(pa.grad.numpy(), pb.grad.numpy(), rtol=1e-4, atol=1e-5)
+  assert float(xa.grad[2].abs().max()) == 0.0 and float(pa.grad[2, :2].abs().max()) == 0.0

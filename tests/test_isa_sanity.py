@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'exposure_amd', 'csrc')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # (source, extra flags) exactly as exposure_amd/csrc/build.sh compiles them
-UNITS = [('exposure_hip.hip', []), ('chain_fused.hip', ['-fno-slp-vectorize', '-fno-honor-nans']), ('nn_ops.hip', [])]
+UNITS = [('exposure_hip.hip', []), ('chain_fused.hip', ['-fno-slp-vectorize', '-fno-honor-nans']), ('nn_ops.hip', []),
+         ('chain_fused_bwd.hip', ['-fno-slp-vectorize'])]
 
 
 def _listing(unit, tmp):

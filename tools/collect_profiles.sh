@@ -5,7 +5,7 @@ set -euo pipefail
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/final
 TAG=${1:-r03_final}
-for f in bench_chain bench_chain_1stream bench_chain_A bench_chain_B bench_chain_f32 bench_chain_cold bench_infer_B bench_infer_C bench_train bench_train_find_on bench_train_eager bench_extra; do
+for f in bench_chain bench_chain_1stream bench_chain_A bench_chain_B bench_chain_f32 bench_chain_cold bench_infer_B bench_infer_C bench_chain_fused bench_chain_fused_B bench_chain_fused_f32_B bench_train bench_train_find_on bench_train_eager bench_extra; do
   [ -s $SRC/$f.json ] && cp $SRC/$f.json profiles/${TAG}_$f.json
 done
 for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt; do

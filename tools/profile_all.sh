@@ -22,6 +22,9 @@ python $R/bench.py --dtype f32 $Q > $OUT/bench_chain_f32.json 2>/dev/null
 python $R/bench.py --shape $COLD $Q > $OUT/bench_chain_cold.json 2>/dev/null
 python $R/bench.py --workload infer --shape B > $OUT/bench_infer_B.json 2>/dev/null
 python $R/bench.py --workload infer --shape C > $OUT/bench_infer_C.json 2>/dev/null
+python $R/bench.py --workload chain_fused > $OUT/bench_chain_fused.json 2>/dev/null
+python $R/bench.py --workload chain_fused --shape B > $OUT/bench_chain_fused_B.json 2>/dev/null
+python $R/bench.py --workload chain_fused --dtype f32 --shape B > $OUT/bench_chain_fused_f32_B.json 2>/dev/null
 python $R/bench.py --workload train --steps 20 --warmup 3 > $OUT/bench_train.json 2>/dev/null
 python $R/bench.py --workload train --steps 20 --warmup 3 --miopen-find on > $OUT/bench_train_find_on.json 2>/dev/null
 python $R/bench.py --workload train --steps 10 --warmup 3 --graph off > $OUT/bench_train_eager.json 2>/dev/null
@@ -49,6 +52,7 @@ kt chain_B python $R/bench.py --shape B $Q
 kt infer_B python $R/bench.py --workload infer --shape B
 kt infer_C python $R/bench.py --workload infer --shape C
 kt extra python $R/tools/bench_extra.py
+kt chain_fused python $R/bench.py --workload chain_fused
 cp $OUT/kernel_stats_chain.csv $OUT/kernel_stats.csv
 # the training iteration (BASELINE config 3): the timed region only (tools/rocpd_window_stats.py)
 STEPS=10
@@ -75,6 +79,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc $c cold python $R/bench.py --shape $COLD $Q --no-per-kernel --steps 2 --warmup 1
   pmc $c infer_B python $R/bench.py --workload infer --shape B --steps 5 --warmup 2
   pmc $c extra python $R/tools/bench_extra.py
+  pmc $c chain_fused python $R/bench.py --workload chain_fused --steps 3 --warmup 1
   pmc $c calibration $R/tools/membench 96 9 2 pol
   pmc $c calibration_512 $R/tools/membench 512 9 2 pol
   cp $OUT/pmc_${lc}_chain.csv $OUT/pmc_${lc}.csv
