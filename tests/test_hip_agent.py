@@ -452,6 +452,32 @@ def test_training_step_graph_captures_rccl_collectives(gpu_device):
   assert d['config']['capture_drain_verified'] is True, d['config']
 
 
+@pytest.mark.parametrize('workload', ['chain', 'chain_fused', 'infer'])
+def test_bench_workloads_under_the_driver_launch_line(workload, gpu_device):
+  """The driver's multi-GPU launch line (`python -m torch.distributed.run ... bench.py --gpus N ...`) with one rank:
+  the process group is RCCL, the timed region is bracketed by the device-side barrier, the MAX over ranks is an
+  all-reduce -- the code a > 1-GPU run executes, on the one GPU there is -- for the workloads that have no gradient
+  exchange (the train workload: test_training_step_graph_captures_rccl_collectives)."""
+  import json
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+         '127.0.0.1', '--master-port', '29541', os.path.join(root, 'bench.py'), '--gpus', '1', '--workload', workload,
+         '--steps', '5', '--warmup', '2', '--shape', 'B']
+  if workload == 'chain':
+    cmd += ['--no-cpu-baseline', '--cold-shape', 'none']
+  out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-3000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, out.stdout[-2000:]
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 1 and d['steps'] == 5 and d['warmup'] == 2 and d['value'] > 0 and d['unit'] == 'Mpixels/s'
+  assert d['scaling'] == 'weak' and d['data'] == 'synthetic' and 'roofline' in d
+
+
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
 @pytest.mark.parametrize('shape', [(12, 64, 64, 3), (10, 9, 7, 3)])
 def test_masked_dispatch_equals_per_filter_masked_apply(dtype, shape, gpu_device):
