@@ -21,10 +21,12 @@
 // Everything a step needs that does not depend on the pixel is prepared once per block, in front of the chunk loop:
 // the element-wise filters' derived parameters (SGPRs), the curve filters' forward segment tables and backward slope
 // tables (LDS, one per step).  A block walks several 3 KiB chunks per wave, so that set-up and the epilogue are
-// amortised; parameter-gradient partial sums of the element-wise filters (<= 3 per step) stay per lane across the
-// chunks and are reduced once, those of the curve filters (8 / 24 per step) are reduce-scattered over the wave after
-// every chunk (kernel_common.h) and only the lane's slot is carried.  Block records + finish launch as everywhere
-// else (no float atomics, bit-reproducible).
+// amortised; parameter-gradient partial sums of the element-wise filters (<= 3 per step) are carried per lane across
+// the chunks (in an LDS column per thread: the registers are needed elsewhere) and cross the wave once at the end,
+// those of the curve filters (8 / 24 per step) are reduce-scattered over the wave after every half group
+// (kernel_common.h) and only the lane's slot is carried.  Block records + finish launch as everywhere else (no float
+// atomics, bit-reproducible).  Compiled with -fno-slp-vectorize (build.sh): the packed-fp32 pairs the SLP vectoriser
+// forms cost this kernel ~100 VGPRs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -478,8 +478,7 @@ def write_bundle(prefix, tensors):
   with open(_shard_name(prefix, 0, 1), 'wb') as f:
     for name in sorted(tensors, key=lambda s: s.encode('utf-8')):
       a = np.asarray(tensors[name])
-      dt = a.dtype.newbyteorder('<') if a.dtype.byteorder == '>' else a.dtype
-      dt = np.dtype(dt.str.replace('=', '<')) if dt.itemsize > 1 else dt
+      dt = a.dtype.newbyteorder('<') if a.dtype.itemsize > 1 else a.dtype  # the bundle is little-endian
       if dt not in DTYPE_IDS:
         raise BundleError('%s: dtype %s has no TensorFlow counterpart here' % (name, a.dtype))
       raw = np.ascontiguousarray(a.astype(dt, copy=False)).tobytes()
