@@ -106,30 +106,42 @@ class GAN(nn.Module):
     put(self.opt_c, self.cfg.lr_c(it))
 
   def generator_losses(self, fake_input, z, states, progress, is_train=1, dropout_masks=None):
-    """net.py:56-165 (WGAN branch, use_TD, use_penalty)."""
+    """net.py:56-165: reward from the critic (``cfg.gan`` 'w': logit difference; 'ls': 1 - (logit - 1)^2), TD or
+    plain-reward policy gradient (``cfg.use_TD``), over-exposure penalty (``cfg.use_penalty``).  ``cfg.supervised``
+    (a paired-data critic that is not in the reference's ``critics.py``) is not built."""
     cfg = self.cfg
+    if cfg.supervised:
+      raise NotImplementedError('cfg.supervised: the paired-data reward path (net.py:100-102) is not built')
+    assert cfg.gan in ('w', 'ls'), cfg.gan  # net.py:26
     (fake_output, new_states, surrogate, penalty), debug, _ = self.generator(
         (fake_input, z, states), is_train=is_train, progress=progress, dropout_masks=dropout_masks)
     # this step updates theta_g (through g_loss) and theta_v (through v_loss = f(old_value) only): the critic's and the
     # value net's convolution parameters take no part in differentiating fake_logit / new_value
     with frozen_parameters():
       fake_logit = self.critic(fake_output)
-    with torch.no_grad():
-      fake_input_logit = self.critic(fake_input)
+    if cfg.gan != 'ls':
+      with torch.no_grad():
+        fake_input_logit = self.critic(fake_input)
     old_value = self.value(fake_input, states)
     with frozen_parameters():
       new_value = self.value(fake_output, new_states)
     stopped = new_states[:, STATE_STOPPED_DIM:STATE_STOPPED_DIM + 1]
     clear_final = (new_states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1] > cfg.maximum_trajectory_length).float()
     new_value = new_value * (1.0 - clear_final)
-    raw_reward = (cfg.all_reward + (1 - cfg.all_reward) * stopped) * (fake_logit - fake_input_logit) * \
-        cfg.critic_logit_multiplier
+    gate = cfg.all_reward + (1 - cfg.all_reward) * stopped
+    if cfg.gan == 'ls':  # net.py:103-106: the LSGAN discriminator wants 1 for real
+      raw_reward = gate * (1.0 - (fake_logit - 1.0)**2)
+    else:
+      raw_reward = gate * (fake_logit - fake_input_logit) * cfg.critic_logit_multiplier
     reward = raw_reward - penalty if cfg.use_penalty else raw_reward
     q_value = reward + (1.0 - stopped) * cfg.discount_factor * new_value
     advantage = q_value.detach() - old_value
     v_loss = (advantage**2).mean()
-    routine_loss = -q_value * cfg.parameter_lr_mul
-    g_loss = (routine_loss + surrogate * (-advantage).detach()).mean()
+    if cfg.use_TD:  # net.py:135-140, 152-157 (the same in both GAN branches)
+      routine_loss, weight = -q_value * cfg.parameter_lr_mul, -advantage
+    else:
+      routine_loss, weight = -reward, -reward
+    g_loss = (routine_loss + surrogate * weight.detach()).mean()
     return dict(g_loss=g_loss, v_loss=v_loss, fake_output=fake_output, new_states=new_states, reward=reward,
                 q_value=q_value, fake_logit=fake_logit, debug=debug)
 
@@ -251,31 +263,56 @@ class GAN(nn.Module):
     return static_out
 
   def critic_losses(self, real_data, fake_output, alpha=None):
-    """net.py:126-194: c_loss = mean(fake - real) + lambda * mean(max(||grad||-1, 0)^2).
-    ``fake_output`` is FED, as in the reference: the critic update runs on terminated images
+    """net.py:126-199.  ``cfg.gan == 'w'``: c_loss = mean(fake - real) + lambda * mean(max(||grad||-1, 0)^2) (without
+    the penalty term when lambda <= 0: the weights are clipped after the update instead); ``'ls'``:
+    c_loss = mean(fake^2) + mean((real - 1)^2).  ``fake_output`` is FED, as in the reference: the critic update runs on terminated images
     replayed from the memory (``replay_memory.py:168-185`` feeds the ``fake_output`` tensor), the
     generator is not executed."""
     cfg = self.cfg
     fake_output = fake_output.detach().float()
     real_data = real_data.float()
+    n = real_data.shape[0]
+    if cfg.gan == 'ls':
+      fake_output = fake_output.requires_grad_(True)  # for the reported d fake_logit / d fake_output
     # one batched pass for the real and the fake half (the critic is per-sample: no normalisation
     # layers), so their forward and backward are single launches of twice the batch
-    n = real_data.shape[0]
     logits = self.critic(torch.cat([real_data, fake_output], dim=0))
     real_logit, fake_logit = logits[:n], logits[n:]
+    if cfg.gan == 'ls':
+      # net.py:129-147, 195-199: least-squares discriminator, no gradient penalty; the reported norm is that of
+      # d fake_logit / d fake_output (no epsilon), a summary value only
+      c_loss = (fake_logit**2).mean() + ((real_logit - 1.0)**2).mean()
+      with skip_parameter_gradients():
+        fake_gradients, = torch.autograd.grad(fake_logit.sum(), fake_output, retain_graph=True)
+      gradient_norm = torch.sqrt((fake_gradients**2).sum(dim=(1, 2, 3)))
+      zero = torch.zeros((), device=c_loss.device)
+      return dict(c_loss=c_loss, emd=c_loss.detach(), gradient_norm=gradient_norm.mean().detach(),
+                  gradient_penalty=zero, c_average=zero)
     c_loss = (fake_logit - real_logit).mean()
     if alpha is None:
       alpha = self._draw_alpha(real_data.shape[0])
     interpolated = (real_data + alpha * (fake_output - real_data)).requires_grad_(True)
+    use_gp = cfg.gradient_penalty_lambda > 0
     inte_logit = self.critic(interpolated)
     with skip_parameter_gradients():  # only d D / d x^ is wanted here; theta_c is reached by the OUTER backward
-      gradients, = torch.autograd.grad(inte_logit.sum(), interpolated, create_graph=True)
+      gradients, = torch.autograd.grad(inte_logit.sum(), interpolated, create_graph=use_gp)
     gradient_norm = torch.sqrt(1e-6 + (gradients**2).sum(dim=(1, 2, 3)))
     gradient_penalty = cfg.gradient_penalty_lambda * (torch.clamp_min(gradient_norm - 1.0, 0.0)**2).mean()
-    total = c_loss + gradient_penalty if cfg.gradient_penalty_lambda > 0 else c_loss
+    # net.py:188-199: without the penalty (lambda <= 0) the norm is still reported and theta_c is clipped after the
+    # update instead (clip_critic_weights)
+    total = c_loss + gradient_penalty if use_gp else c_loss
     c_average = ((fake_logit + real_logit).mean() * 0.5).detach()
     return dict(c_loss=total, emd=-c_loss.detach(), gradient_norm=gradient_norm.mean().detach(),
                 gradient_penalty=gradient_penalty.detach(), c_average=c_average)
+
+  def clip_critic_weights(self):
+    """net.py:252-262: WGAN without the gradient penalty clamps every critic variable (biases too) to
+    +-cfg.clamp_critic after each critic update."""
+    cfg = self.cfg
+    if cfg.gan == 'w' and cfg.gradient_penalty_lambda <= 0:
+      params = [p.data for p in self.critic.parameters()]
+      torch._foreach_clamp_min_(params, -float(cfg.clamp_critic))
+      torch._foreach_clamp_max_(params, float(cfg.clamp_critic))
 
   def _critic_body(self, real_data, fake_output, alpha):
     out = self.critic_losses(real_data, fake_output, alpha)
@@ -286,6 +323,7 @@ class GAN(nn.Module):
       out['c_average'] = ca
     self._finish_collectives()
     self.opt_c.step()
+    self.clip_critic_weights()
     return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
   def critic_step(self, real_data, fake_output, it=1, alpha=None):

@@ -80,7 +80,11 @@ class ReplayMemory:
     self.features = self.features[:self.target_pool_size]
 
   def get_noise(self, batch_size):
-    """replay_memory.py:187-196 (uniform)."""
+    """replay_memory.py:177-185: cfg.z_type 'uniform' (U(0, 1), both shipped configs) or 'normal' (N(0, 1))."""
+    z_type = getattr(self.cfg, 'z_type', 'uniform')
+    if z_type == 'normal':
+      return torch.randn((batch_size, self.cfg.z_dim), generator=self.rng).to(self.device)
+    assert z_type == 'uniform', 'Unknown noise type: %s' % z_type
     return torch.rand((batch_size, self.cfg.z_dim), generator=self.rng).to(self.device)
 
   # -- replay_memory.py:235-252: pop NON-terminated records from the shuffled pool

@@ -357,7 +357,8 @@ def critic_input_grad(cache, weights, dout=None):
 
 # --------------------------------------------------------------------------------- loss graph
 def generator_losses(fake_input, z, states, progress, cfg, weights, dropout_masks, is_train=1):
-  """net.py:56-165, WGAN branch with use_TD and use_penalty (the shipped configuration)."""
+  """net.py:56-165: both GAN branches (cfg['gan'] 'w' / 'ls'), TD or plain-reward policy gradient (cfg['use_TD']),
+  use_penalty.  Defaults = the shipped configuration (WGAN, TD)."""
   (fake_output, new_states, surrogate, penalty), debug = agent_generator((fake_input, z, states), is_train, progress,
                                                                          cfg, weights, dropout_masks)
   fake_logit = critic(fake_output, cfg, weights, 'critic/')
@@ -368,14 +369,20 @@ def generator_losses(fake_input, z, states, progress, cfg, weights, dropout_mask
   clear_final = (new_states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1] > cfg['maximum_trajectory_length']).astype(
       fake_input.dtype)
   new_value = new_value * (1.0 - clear_final)
-  raw_reward = (cfg['all_reward'] + (1 - cfg['all_reward']) * stopped) * (fake_logit - fake_input_logit) * \
-      cfg['critic_logit_multiplier']
+  gate = cfg['all_reward'] + (1 - cfg['all_reward']) * stopped
+  if cfg.get('gan', 'w') == 'ls':  # net.py:103-106
+    raw_reward = gate * (1 - (fake_logit - 1)**2)
+  else:  # net.py:107-110
+    raw_reward = gate * (fake_logit - fake_input_logit) * cfg['critic_logit_multiplier']
   reward = raw_reward - penalty if cfg['use_penalty'] else raw_reward
   q_value = reward + (1.0 - stopped) * cfg['discount_factor'] * new_value
   advantage = q_value - old_value  # tf.stop_gradient(q_value) - old_value: same VALUE
   v_loss = np.mean(advantage**2)
-  routine_loss = -q_value * cfg['parameter_lr_mul']
-  g_loss = np.mean(routine_loss + surrogate * (-advantage))
+  if cfg.get('use_TD', True):  # net.py:135-140 / 152-157
+    routine_loss, weight = -q_value * cfg['parameter_lr_mul'], -advantage
+  else:
+    routine_loss, weight = -reward, -reward
+  g_loss = np.mean(routine_loss + surrogate * weight)
   return dict(g_loss=g_loss, v_loss=v_loss, fake_output=fake_output, new_states=new_states, reward=reward,
               q_value=q_value, advantage=advantage, fake_logit=fake_logit, penalty=penalty, surrogate=surrogate,
               old_value=old_value, new_value=new_value, debug=debug)
@@ -385,6 +392,12 @@ def critic_losses(real_data, fake_output, alpha, cfg, weights):
   """net.py:126-194: c_loss = mean(fake - real) + lambda mean(max(||grad|| - 1, 0)^2),
   ||grad|| = sqrt(1e-6 + sum grad^2) at interpolated = real + alpha (fake - real)."""
   real_logit = critic(real_data, cfg, weights, 'critic/')
+  if cfg.get('gan', 'w') == 'ls':  # net.py:129-147, 195-199
+    fake_logit, cache = critic_forward(fake_output, cfg, weights, 'critic/')
+    c_loss = np.mean(fake_logit**2) + np.mean((real_logit - 1)**2)
+    fake_gradients = critic_input_grad(cache, weights)
+    gradient_norm = np.sqrt(np.sum(fake_gradients**2, axis=(1, 2, 3)))
+    return dict(c_loss=c_loss, emd=c_loss, gradient_norm=np.mean(gradient_norm), gradient_penalty=0.0, c_average=0.0)
   fake_logit = critic(fake_output, cfg, weights, 'critic/')
   c_loss = np.mean(fake_logit - real_logit)
   interpolated = real_data + alpha * (fake_output - real_data)

@@ -26,6 +26,29 @@ def test_torch_nets_and_losses_match_oracle_gpu(gpu_device, seed):
   assert res['gradient_norm'] > 1.0
 
 
+@pytest.mark.parametrize('gan_kind,use_td,gp_lambda', [('ls', False, 10), ('w', True, 0)])
+def test_loss_branches_match_oracle_gpu(gpu_device, gan_kind, use_td, gp_lambda):
+  """net.py:100-199's other branches on the device: LSGAN with the plain-reward policy gradient; WGAN without the
+  penalty term (a training step of the latter also clips theta_c, net.py:252-262)."""
+  torch.manual_seed(5)
+  cfg = make_cfg()
+  cfg.gan, cfg.use_TD, cfg.gradient_penalty_lambda = gan_kind, use_td, gp_lambda
+  gan = GAN(cfg, device=gpu_device)
+  with torch.no_grad():
+    for p in gan.parameters():
+      if p.dim() == 1:
+        p.normal_(0.0, 0.05)
+    gan.critic.fc2.weight.mul_(40.0)
+  compare_gan_with_oracle(gan, gpu_device, n=8, seed=13)
+  from tests.test_oracle_nets import make_batch
+  fake_input, real, _s, _z, _m, alpha = make_batch(8, 14)
+  t = lambda a: torch.from_numpy(a).to(gpu_device)
+  out = gan.critic_step(t(real), t(fake_input), it=1, alpha=t(alpha))
+  assert torch.isfinite(out['c_loss'])
+  worst = max(float(p.detach().abs().max()) for p in gan.critic.parameters())
+  assert (worst <= cfg.clamp_critic + 1e-12) == (gan_kind == 'w' and gp_lambda == 0)
+
+
 def test_losses_match_oracle_with_f16_image_pool(gpu_device):
   """Same comparison with fp16 image storage feeding the nets (the filter kernels' default dtype)."""
   torch.manual_seed(3)
