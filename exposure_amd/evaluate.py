@@ -7,9 +7,11 @@ full-resolution tensor (``filters.py:88-96``; ``agent.py:124-129``), feeding bot
 (``net.py:796-821``).  ``is_train = 0`` -> the action is ``argmax(pdf)`` (``agent.py:114-116``);
 dropout stays on, as in the reference (``agent.py:36``), unless masks are passed.
 
-Image decoding (16-bit TIFF / ProPhoto linearisation, ``util.py:311-323, 495-501``) and the PNG /
-pickle outputs of ``net.py:825-877`` are file I/O, out of scope: this function works on tensors.
+Image decoding (16-bit TIFF / ProPhoto linearisation, ``util.py:311-323, 495-501``) sits in ``load_image``; of the
+outputs of ``net.py:825-877`` the CLI writes the linear result (.npy) and, with ``--png``, the reference's 8-bit
+``retouched`` / ``input_tone_mapped`` pictures; the debug pickle and the cv2-drawn ``steps`` panel are out of scope.
 """
+import numpy as np
 import torch
 
 from .util import STATE_STOPPED_DIM
@@ -123,6 +125,21 @@ def load_agent_weights(agent, state):
   return agent
 
 
+def save_png(path, img):
+  """``show_and_save`` of ``net.py:769-772``: ``cv2.imwrite(path, img[:, :, ::-1] * 255.0)`` -- 8 bits per channel,
+  rounded to nearest (half to even, as ``cvRound``) and saturated; the file holds RGB."""
+  from PIL import Image
+  a = np.asarray(img, dtype=np.float32)
+  Image.fromarray(np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8), 'RGB').save(path)
+  return path
+
+
+def tone_mapped_input(linear):
+  """``net.py:822-823``: max to white, then gamma 1/2.4 -- the ``input_tone_mapped`` picture of ``GAN.eval``."""
+  a = np.asarray(linear, dtype=np.float32)
+  return (a / a.max())**(1 / 2.4)
+
+
 def output_path(out, image_path, many):
   """--out: a directory (existing, or ending in a path separator) receives <name>.retouched.npy per
   image; with one image it may also be the file itself; with several images and a plain name the
@@ -164,6 +181,10 @@ def main(argv=None):
                   "MODEL_DIR/model.ckpt-<--ckpt> like evaluate.py:27-28 (no TensorFlow needed)")
   ap.add_argument('--ckpt', default='20000', help='checkpoint iteration for --tf-checkpoint (evaluate.py:28: 20000)')
   ap.add_argument('--out', default=None, help='output file (one image) or directory; default <image>.retouched.npy')
+  ap.add_argument('--png', action='store_true',
+                  help="also write <output>.png (8-bit, the reference's `<name>.retouched.png`, net.py:769-772, 832) "
+                  'and, with --show-input, <output>.input_tone_mapped.png (net.py:822-829)')
+  ap.add_argument('--show-input', action='store_true')
   ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
   ap.add_argument('--filters', default=None,
                   help="cfg.filters as comma-separated short names, e.g. 'E,G' (BASELINE config 1); default: all 8")
@@ -195,8 +216,15 @@ def main(argv=None):
     names = [agent.filters[int(j)].get_short_name() for j in trace[0]]
     print('%s: %dx%d  filters: %s' % (path, hi.shape[2], hi.shape[1], ' '.join(names)))
     dst = output_path(args.out, path, len(args.images) > 1)
-    np.save(dst, out[0].float().cpu().numpy())
-    records.append(dict(image=path, output=dst, filters=names, states=states[0].cpu().tolist(),
+    result = out[0].float().cpu().numpy()
+    np.save(dst, result)
+    pngs = {}
+    if args.png:
+      stem = dst[:-4] if dst.endswith('.npy') else dst
+      pngs['retouched'] = save_png(stem + '.png', result)
+      if args.show_input:
+        pngs['input_tone_mapped'] = save_png(stem + '.input_tone_mapped.png', tone_mapped_input(hi[0].float().cpu().numpy()))
+    records.append(dict(image=path, output=dst, png=pngs, filters=names, states=states[0].cpu().tolist(),
                         abi_filter_ids=ops['abi_filter_ids'][0].cpu().tolist(),
                         params24=ops['params24'][0].cpu().numpy()))
   return records

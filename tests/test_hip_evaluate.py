@@ -71,6 +71,23 @@ def test_evaluate_cli_non_tif_branch_and_two_images(gpu_device, tmp_path):
     assert_image_close(got, ref, np.float16, 'evaluate.main non-tif')
 
 
+def test_png_outputs_of_the_cli(gpu_device, tmp_path):
+  """--png / --show-input: the reference's `<name>.retouched.png` and `.input_tone_mapped.png` (net.py:769-772,
+  822-832) next to the linear .npy."""
+  from PIL import Image
+  raw = (np.random.default_rng(9).random((64, 64, 3)) * 40000).astype(np.uint16)
+  tif = str(tmp_path / 'p.tif')
+  write_tiff(tif, raw)
+  rec = evaluate.main(['--filters', 'E,G', '--seed', '2', '--png', '--show-input', '--out', str(tmp_path / 'p.npy'), tif])[0]
+  lin = np.load(rec['output'])
+  png = np.asarray(Image.open(rec['png']['retouched']).convert('RGB'))
+  assert np.array_equal(png, np.clip(np.rint(lin * 255.0), 0, 255).astype(np.uint8))
+  src = evaluate.load_image(tif).astype(np.float16).astype(np.float32)  # the CLI's default storage dtype
+  tone = np.asarray(Image.open(rec['png']['input_tone_mapped']).convert('RGB')).astype(np.int32)
+  want = np.clip(np.rint(evaluate.tone_mapped_input(src) * 255.0), 0, 255).astype(np.int32)
+  assert np.abs(tone - want).max() <= 1
+
+
 def test_stepwise_schedule_matches_fused(gpu_device, tmp_path):
   """--stepwise = the reference's schedule (the high-res tensor filtered at every step, net.py:796-821):
   same operations, one fp16 rounding per step instead of one at the end."""

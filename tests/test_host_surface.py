@@ -40,6 +40,20 @@ def test_output_paths_do_not_collide(tmp_path):
   assert evaluate.output_path(None, '/x/a.tif', True) == '/x/a.tif.retouched.npy'
 
 
+def test_png_output_follows_cv2_imwrite(tmp_path):
+  """net.py:769-772, 822-823: img * 255 rounded to nearest (half to even) and saturated; tone mapping = max to white,
+  gamma 1 / 2.4."""
+  from PIL import Image
+  img = np.array([[[0.0, 0.5 / 255, 1.5 / 255], [2.5 / 255, 1.0, 1.7]], [[-0.2, 0.25, 254.5 / 255], [0.999, 0.001, 0.5]]],
+                 dtype=np.float32)
+  path = evaluate.save_png(str(tmp_path / 'a.png'), img)
+  back = np.asarray(Image.open(path).convert('RGB'))
+  want = np.array([[[0, 0, 2], [2, 255, 255]], [[0, 64, 254], [255, 0, 128]]], dtype=np.uint8)
+  assert np.array_equal(back, want)
+  lin = np.array([[[0.1, 0.2, 0.4]]], dtype=np.float32)
+  np.testing.assert_allclose(evaluate.tone_mapped_input(lin), (lin / 0.4)**(1 / 2.4), rtol=1e-6)
+
+
 def test_load_image_non_tif_branch(tmp_path):
   """net.py:739-747: /255, **2.2, / (2 max)."""
   from PIL import Image
