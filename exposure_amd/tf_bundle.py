@@ -464,8 +464,11 @@ def read_bundle(prefix, names=None, verify=True):
     if e['offset'] + e['size'] > data.size:
       raise BundleError('%s: [%d, %d) runs past the end of its data shard' % (name, e['offset'], e['offset'] + e['size']))
     raw = np.array(data[e['offset']:e['offset'] + e['size']])
-    if verify and e['crc'] is not None and unmask_crc(e['crc']) != crc32c(raw):
-      raise BundleError('%s: tensor checksum mismatch' % name)
+    if verify and e['crc'] is not None:
+      actual = crc32c(raw)
+      # BundleWriter stores the MASKED checksum (crc32c::Mask, as the table blocks do); a plain one is accepted too
+      if unmask_crc(e['crc']) != actual and e['crc'] != actual:
+        raise BundleError('%s: tensor checksum mismatch' % name)
     out[name] = raw.view(dt).reshape(e['shape'])
   return out
 
