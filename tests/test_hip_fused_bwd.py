@@ -105,6 +105,28 @@ def test_fused_backward_matches_oracle_at_its_checkpoints(dtype, shape, steps, g
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('fid', [7, 4, 8, 2])
+def test_eight_steps_of_one_filter(dtype, fid, gpu_device):
+  """Every step the same filter -- eight Color steps are the most per-step state the kernel can be asked to hold
+  (8 x 24 parameter sums, 8 slope and 8 segment tables); Tone, Level (2 sums) and white balance (3) cover the other
+  accumulator counts of the reduce-scatter / per-lane paths."""
+  rng = np.random.default_rng(40 + fid)
+  shape = (3, 64, 72, 3)
+  x = synthetic.make_images(rng, shape, NP_DT[dtype])
+  dy = rng.standard_normal(shape).astype(NP_DT[dtype])
+  ids = np.full((3, 8), fid, dtype=np.int32)
+  p = np.zeros((3, 8, 24), dtype=np.float32)
+  for i in range(3):
+    for st in range(8):
+      p[i, st, :fnp.NUM_PARAMS[fid]] = synthetic.make_params(rng, fid, 1)[0]
+  cks = checkpoints(ids, p, x, gpu_device)
+  dx, dp = fused_bwd(ids, p, x, dy, gpu_device)
+  rdx, rdp, scale = oracle_at_checkpoints(ids, p, cks, dy)
+  assert_image_close(dx, rdx, NP_DT[dtype], 'dx, 8 x filter %d' % fid)
+  assert_param_grad_close(dp, rdp, scale, 'dparams, 8 x filter %d' % fid)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
 def test_nothing_selected_stops_the_gradient(dtype, gpu_device):
   """id -1 (the all-zero one-hot, agent.py:119-125): the image is 0 from that step on, so no gradient reaches the
   input or the earlier steps; later steps still see their (zero) input (the oracle comparison covers their gradients:
