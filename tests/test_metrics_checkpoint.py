@@ -36,6 +36,31 @@ def test_histogram_intersection_properties():
   np.testing.assert_allclose(metrics.calc_hist(torch.from_numpy(st[:, 0])).numpy(), h_np / 200.0, atol=1e-7)
 
 
+def test_metric_cli_reads_folders_like_the_script(tmp_path, capsys):
+  """histogram_intersection.py:36-76: 16 patches of 64x64 per file (4 square crops -> 80x80 -> 4 patches each); a
+  folder against itself with the same sampling scores 100 %, a brighter copy less."""
+  import random
+  from PIL import Image
+  rng = np.random.default_rng(0)
+  a, b = tmp_path / 'out', tmp_path / 'target'
+  a.mkdir(), b.mkdir()
+  for i in range(6):
+    img = (rng.random((120 + 8 * i, 160, 3))**2.0 * 255).astype(np.uint8)
+    Image.fromarray(img).save(str(a / ('%d.png' % i)))
+    Image.fromarray((255 * (img / 255.0)**0.5).astype(np.uint8)).save(str(b / ('%d.png' % i)))
+  pa = metrics.read_images(str(a), rng=random.Random(1))
+  assert pa.shape == (6 * 16, 64, 64, 3) and pa.dtype == torch.float32 and 0.0 <= float(pa.min()) and float(pa.max()) <= 1.0
+  same, avg_same = metrics.histogram_intersection(pa, metrics.read_images(str(a), rng=random.Random(1)))
+  assert abs(avg_same - 1.0) < 1e-6
+  ints, avg = metrics.main([str(a), str(b)])
+  assert 0.0 <= avg < 0.9
+  out = capsys.readouterr().out
+  assert 'Hist. Inter.:' in out and 'Avg:' in out
+  assert metrics.read_images(str(a), tag='3.').shape[0] == 16
+  with pytest.raises(SystemExit):
+    metrics.main([str(a)])
+
+
 def test_tf_layout_roundtrip_and_conv_equivalence():
   torch.manual_seed(0)
   gan = GAN(make_cfg())
