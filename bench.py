@@ -942,16 +942,24 @@ def main():
     return run_dry(args, world, rank)
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
-  if local_rank >= torch.cuda.device_count():
+  # EXPO_BENCH_SHARE_GPU=1 (tests only): the ranks share the visible GPU(s) and talk over gloo -- RCCL refuses two ranks
+  # on one device.  Exercises the launcher, the sharding and the timing bracket of a > 1-rank run on a 1-GPU box; its
+  # numbers mean nothing (the line says so: config.transport).
+  share = os.environ.get('EXPO_BENCH_SHARE_GPU') == '1'
+  if local_rank >= torch.cuda.device_count() and not share:
     raise SystemExit('rank %d: only %d GPU(s) visible' % (local_rank, torch.cuda.device_count()))
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
+  device_index = local_rank % torch.cuda.device_count()
+  torch.cuda.set_device(device_index)
+  dev = torch.device('cuda', device_index)
   dist = None
   if world > 1 or 'LOCAL_RANK' in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
     import torch.distributed as dist
-    # the NCCL flight recorder lets exposure_amd.dist verify the watchdog drain in front of a hipGraph capture
-    os.environ.setdefault('TORCH_FR_BUFFER_SIZE', '2000')  # (TORCH_NCCL_TRACE_BUFFER_SIZE before torch 2.8)
-    dist.init_process_group('nccl', device_id=dev)
+    if share:
+      dist.init_process_group('gloo')
+    else:
+      # the NCCL flight recorder lets exposure_amd.dist verify the watchdog drain in front of a hipGraph capture
+      os.environ.setdefault('TORCH_FR_BUFFER_SIZE', '2000')  # (TORCH_NCCL_TRACE_BUFFER_SIZE before torch 2.8)
+      dist.init_process_group('nccl', device_id=dev)
   if args.gpus != world and rank == 0:
     print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
   if args.workload == 'train':
@@ -1029,6 +1037,9 @@ def main():
           'parallelism': 'image-sharded replicas x%d (no data-path collective), %s scaling' % (world, args.scaling),
           'launch': ('hipGraph replay, %d steps (%d captured launches) per replay' % (chain.unroll, launches * chain.unroll)) if chain.graph is not None else 'eager (one C-ABI call per direction)',
           'chain_streams': chain.streams,
+          'transport': ('none (one process)' if dist is None else
+                        'gloo, ranks SHARING the GPU (EXPO_BENCH_SHARE_GPU test mode: the value means nothing)'
+                        if os.environ.get('EXPO_BENCH_SHARE_GPU') == '1' else 'rccl'),
           'chain_algorithmic_GBps': 8 * 5 * 3 * esz * px / (elapsed / args.steps) / 1e9 * 1.0,
       },
   }
