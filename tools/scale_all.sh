@@ -10,6 +10,9 @@ OUT=${1:-$R/gpurun_out/scale}
 mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0 TORCH_FR_BUFFER_SIZE=${TORCH_FR_BUFFER_SIZE:-2000}
 NG=$(python -c "import torch; print(torch.cuda.device_count())")
+# rehearsal on a 1-GPU box: EXPO_BENCH_SHARE_GPU=1 lets the ranks share the GPU over gloo (bench.py); the table then
+# shows the plumbing works, its numbers mean nothing
+[ "${EXPO_BENCH_SHARE_GPU:-0}" = 1 ] && NG=${EXPO_SCALE_MAX_RANKS:-2}
 Q="--no-cpu-baseline --no-per-kernel --cold-shape none"
 for n in 1 2 4 8; do
   [ $n -gt $NG ] && break
