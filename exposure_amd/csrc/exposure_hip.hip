@@ -269,7 +269,7 @@ __device__ __forceinline__ void zero_image(T* __restrict__ yi, int hw, int group
 
 // ------------------------------------------------ Filter.apply with a spatial mask (masking on)
 // out = (1 - mask) x + mask process(x), mask per pixel from MaskPrm (filters.py:86-88, 110-148).
-template <class F, typename T, bool VEC>
+template <class F, typename T, bool VEC, class IO = IoCached>
 __device__ __forceinline__ void apply_fwd_body(const T* __restrict__ xi, T* __restrict__ yi, const float* __restrict__ prm,
                                                const float* __restrict__ mprm, float sharp, float min_strength, int h,
                                                int w, int groups) {
@@ -298,8 +298,8 @@ __device__ __forceinline__ void apply_fwd_body(const T* __restrict__ xi, T* __re
   };
   if constexpr (VEC) {
     const T* const ins[1] = {xi};
-    stream_groups<T, 1, true, true, IoCached>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                                           [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
+    stream_groups<T, 1, true, true, IO>(ins, yi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                        [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3];
@@ -310,14 +310,14 @@ __device__ __forceinline__ void apply_fwd_body(const T* __restrict__ xi, T* __re
   }
 }
 
-template <class F, typename T, bool VEC>
+template <class F, typename T, bool VEC, class IO = IoCached>
 __global__ __launch_bounds__(kThreads) void apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                              const float* __restrict__ params,
                                                              const float* __restrict__ mask_params, float sharp,
                                                              float min_strength, int h, int w, int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * h * w * 3;
-  apply_fwd_body<F, T, VEC>(x + off, y + off, params + n * F::NP, mask_params + n * 6, sharp, min_strength, h, w, groups);
+  apply_fwd_body<F, T, VEC, IO>(x + off, y + off, params + n * F::NP, mask_params + n * 6, sharp, min_strength, h, w, groups);
 }
 
 // Masked apply with a per-image filter choice: the agent's step with cfg.masking = True.  The reference applies EVERY
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kThreads) void apply_dispatch_fwd_kernel(const int3
 #undef EXPO_CASE
 }
 
-template <class F, typename T, bool VEC, bool HAS_DX, int MODE>
+template <class F, typename T, bool VEC, bool HAS_DX, int MODE, class IO = IoCached>
 __device__ __forceinline__ void apply_bwd_body(const T* __restrict__ xi, const T* __restrict__ dyi, T* __restrict__ dxi,
                                                const float* __restrict__ prm, const float* __restrict__ mprm,
                                                float* __restrict__ rec, float sharp, float min_strength, int h, int w,
@@ -407,8 +407,8 @@ __device__ __forceinline__ void apply_bwd_body(const T* __restrict__ xi, const T
   };
   if constexpr (VEC) {
     const T* const ins[2] = {xi, dyi};
-    stream_groups<T, 2, HAS_DX, true, IoCached>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                      [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
+    stream_groups<T, 2, HAS_DX, true, IO>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                          [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3], d[PPL * 3];
@@ -422,7 +422,7 @@ __device__ __forceinline__ void apply_bwd_body(const T* __restrict__ xi, const T
   block_reduce_record<F::NACC + 6>(acc, rec);
 }
 
-template <class F, typename T, bool VEC, bool HAS_DX, int MODE>
+template <class F, typename T, bool VEC, bool HAS_DX, int MODE, class IO = IoCached>
 __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                              T* __restrict__ dx, const float* __restrict__ params,
                                                              const float* __restrict__ mask_params,
@@ -430,9 +430,9 @@ __global__ __launch_bounds__(kThreads) void apply_bwd_kernel(const T* __restrict
                                                              float min_strength, int h, int w, int groups) {
   const int n = blockIdx.y;
   const size_t off = size_t(n) * h * w * 3;
-  apply_bwd_body<F, T, VEC, HAS_DX, MODE>(x + off, dy + off, HAS_DX ? dx + off : nullptr, params + n * F::NP,
-                                          mask_params + n * 6, records + size_t(n) * gridDim.x * kWsSlots, sharp,
-                                          min_strength, h, w, groups);
+  apply_bwd_body<F, T, VEC, HAS_DX, MODE, IO>(x + off, dy + off, HAS_DX ? dx + off : nullptr, params + n * F::NP,
+                                              mask_params + n * 6, records + size_t(n) * gridDim.x * kWsSlots, sharp,
+                                              min_strength, h, w, groups);
 }
 
 // Backward of apply_dispatch_fwd_kernel: the selected filter's masked-apply backward per image.  One launch for all
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kThreads) void apply_dispatch_bwd_kernel(const int3
 }
 
 // ------------------------------------------------------------ VignetFilter.apply (filters.py:341-396)
-template <typename T, bool VEC>
+template <typename T, bool VEC, class IO = IoCached>
 __global__ __launch_bounds__(kThreads) void vignet_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                               const float* __restrict__ mask_params, float sharp,
                                                               int masking, int h, int w, int groups) {
@@ -494,8 +494,8 @@ __global__ __launch_bounds__(kThreads) void vignet_fwd_kernel(const T* __restric
   };
   if constexpr (VEC) {
     const T* const ins[1] = {x + off};
-    stream_groups<T, 1, true, true, IoCached>(ins, y + off, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                              [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
+    stream_groups<T, 1, true, true, IO>(ins, y + off, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                        [&](float (&v)[1][PPL * 3], int g) { compute(v[0], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3];
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kThreads) void vignet_fwd_kernel(const T* __restric
   }
 }
 
-template <typename T, bool VEC, bool HAS_DX>
+template <typename T, bool VEC, bool HAS_DX, class IO = IoCached>
 __global__ __launch_bounds__(kThreads) void vignet_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                               T* __restrict__ dx, const float* __restrict__ mask_params,
                                                               float* __restrict__ records, float sharp, int masking,
@@ -536,9 +536,9 @@ __global__ __launch_bounds__(kThreads) void vignet_bwd_kernel(const T* __restric
   };
   if constexpr (VEC) {
     const T* const ins[2] = {x + off, dy + off};
-    stream_groups<T, 2, HAS_DX, true, IoCached>(ins, HAS_DX ? dx + off : nullptr, hw,
-                                                blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                                [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
+    stream_groups<T, 2, HAS_DX, true, IO>(ins, HAS_DX ? dx + off : nullptr, hw,
+                                          blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                          [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); });
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3], d[PPL * 3];
@@ -1182,7 +1182,12 @@ static int launch_apply_fwd(const void* x, void* y, const float* params, const f
                             int n, int h, int w, hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  if (g.vec)
+  // cache policy as for the plain kernels: tensors far beyond L2 stream (nt loads, write-through stores) -- 64x512x512
+  // fp16, gpurun r03p40: E 36.6 -> 32.4 us, Ct 42.5 -> 38.9; the curve filters are bound by their arithmetic and lose
+  // a microsecond (C 51.8 -> 52.9), so they keep the default policy
+  if (g.stream && F::kLutFloats == 0)
+    hipLaunchKernelGGL((apply_fwd_kernel<F, T, true, IoStream>), grid, block, 0, s, (const T*)x, (T*)y, params, mp, sharp, ms, h, w, g.groups);
+  else if (g.vec)
     hipLaunchKernelGGL((apply_fwd_kernel<F, T, true>), grid, block, 0, s, (const T*)x, (T*)y, params, mp, sharp, ms, h, w, g.groups);
   else
     hipLaunchKernelGGL((apply_fwd_kernel<F, T, false>), grid, block, 0, s, (const T*)x, (T*)y, params, mp, sharp, ms, h, w, g.groups);
@@ -1195,12 +1200,17 @@ static int launch_apply_bwd(const void* x, const void* dy, void* dx, const float
                             float* records, float sharp, float ms, int n, int h, int w, int mode, hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {x, dy, dx}, kGeomApply);
   const dim3 grid(g.blocks_x, n), block(kThreads);
-#define EXPO_L(VEC, HAS_DX, MODE)                                                                          \
-  hipLaunchKernelGGL((apply_bwd_kernel<F, T, VEC, HAS_DX, MODE>), grid, block, 0, s, (const T*)x,          \
+#define EXPO_LIO(VEC, HAS_DX, MODE, IO)                                                                    \
+  hipLaunchKernelGGL((apply_bwd_kernel<F, T, VEC, HAS_DX, MODE, IO>), grid, block, 0, s, (const T*)x,      \
                      (const T*)dy, (T*)dx, params, mp, records, sharp, ms, h, w, g.groups)
+#define EXPO_L(VEC, HAS_DX, MODE) EXPO_LIO(VEC, HAS_DX, MODE, IoCached)
   const bool m1 = std::is_same<F, SatPlusF>::value && mode == 1;
-  const int key = (g.vec ? 4 : 0) | (dx ? 2 : 0) | (m1 ? 1 : 0);
+  // the streaming policy is instantiated for the full backward (dx wanted) only; it buys 1-2 % here (the masked backward
+  // is bound by its arithmetic: E 60.1 -> 59.0 us, C 109 -> 107.3 at 64x512x512 fp16, gpurun r03p40)
+  const int key = (g.stream && dx ? 8 : 0) | (g.vec ? 4 : 0) | (dx ? 2 : 0) | (m1 ? 1 : 0);
   switch (key) {
+    case 15: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_LIO(true, true, 1, IoStream); break;
+    case 14: EXPO_LIO(true, true, 0, IoStream); break;
     case 7: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(true, true, 1); break;
     case 6: EXPO_L(true, true, 0); break;
     case 5: if constexpr (std::is_same<F, SatPlusF>::value) EXPO_L(true, false, 1); break;
@@ -1211,6 +1221,7 @@ static int launch_apply_bwd(const void* x, const void* dy, void* dx, const float
     default: EXPO_L(false, false, 0); break;
   }
 #undef EXPO_L
+#undef EXPO_LIO
   HIP_TRY(hipGetLastError(), "apply_bwd launch");
   return EXPO_OK;
 }
@@ -1407,7 +1418,8 @@ static int vignet_fwd_t(const void* x, void* y, const float* mp, float sharp, in
                         hipStream_t s) {
   const Geom g = make_geom<T>(n, h, w, {x, y}, kGeomMap);
   const dim3 grid(g.blocks_x, n), block(kThreads);
-  if (g.vec) hipLaunchKernelGGL((vignet_fwd_kernel<T, true>), grid, block, 0, s, (const T*)x, (T*)y, mp, sharp, masking, h, w, g.groups);
+  if (g.stream) hipLaunchKernelGGL((vignet_fwd_kernel<T, true, IoStream>), grid, block, 0, s, (const T*)x, (T*)y, mp, sharp, masking, h, w, g.groups);
+  else if (g.vec) hipLaunchKernelGGL((vignet_fwd_kernel<T, true>), grid, block, 0, s, (const T*)x, (T*)y, mp, sharp, masking, h, w, g.groups);
   else hipLaunchKernelGGL((vignet_fwd_kernel<T, false>), grid, block, 0, s, (const T*)x, (T*)y, mp, sharp, masking, h, w, g.groups);
   HIP_TRY(hipGetLastError(), "vignet_fwd launch");
   return EXPO_OK;
@@ -1420,10 +1432,11 @@ static int vignet_bwd_t(const void* x, const void* dy, void* dx, const float* mp
   const dim3 grid(g.blocks_x, n), block(kThreads);
   float* records;
   if (int rc = ws_check(workspace, workspace_bytes, n, g.blocks_x, 1, &records)) return rc;
-#define EXPO_L(VEC, HAS_DX) \
-  hipLaunchKernelGGL((vignet_bwd_kernel<T, VEC, HAS_DX>), grid, block, 0, s, (const T*)x, (const T*)dy, (T*)dx, mp, records, sharp, masking, h, w, g.groups)
-  if (g.vec) { if (dx) EXPO_L(true, true); else EXPO_L(true, false); }
-  else { if (dx) EXPO_L(false, true); else EXPO_L(false, false); }
+#define EXPO_L(VEC, HAS_DX, IO) \
+  hipLaunchKernelGGL((vignet_bwd_kernel<T, VEC, HAS_DX, IO>), grid, block, 0, s, (const T*)x, (const T*)dy, (T*)dx, mp, records, sharp, masking, h, w, g.groups)
+  // (the streaming policy pays in the forward, 36.3 -> 33.3 us, not here: 53.2 -> 55.5 us, gpurun r03p40)
+  if (g.vec) { if (dx) EXPO_L(true, true, IoCached); else EXPO_L(true, false, IoCached); }
+  else { if (dx) EXPO_L(false, true, IoCached); else EXPO_L(false, false, IoCached); }
 #undef EXPO_L
   HIP_TRY(hipGetLastError(), "vignet_bwd launch");
   FinishArgs fa{};
