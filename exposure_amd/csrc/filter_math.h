@@ -602,12 +602,54 @@ struct LevelF {
 // gx, gy: the constant grid (row + (se-H)/2)/se - .5, (col + (se-W)/2)/se - .5, se = min(H, W).
 // Backward accumulators (6): d/d mp0..mp5.
 // ---------------------------------------------------------------------------------
+// Row and column of the pixels a lane visits inside one group, without a division (or two quarter-rate integer
+// multiplies) per pixel: the first pixel's (row, column) comes from one multiply by 1/w with a +-1 correction, the
+// others follow by constant index steps -- inside a 48-byte group the linear pixel index advances by one of two
+// compile-time steps (pixel_io.h: pixel_step_a / pixel_step_b) whose row / column parts (step / w, step % w) are
+// block-uniform.  Exact integer arithmetic: the same (row, column) as px / w, px % w.
+struct PixelWalk {
+  int w, qa, ra, qb, rb;
+  float inv_w;
+  bool small;
+  __device__ static PixelWalk make(int h, int w, int step_a, int step_b) {
+    PixelWalk p;
+    p.w = w;
+    p.inv_w = 1.0f / float(w);
+    p.small = long(h) * long(w) < (1L << 22);  // float(px) is exact and one correction step suffices
+    p.qa = step_a / w; p.ra = step_a % w;
+    p.qb = step_b / w; p.rb = step_b % w;
+    return p;
+  }
+  __device__ void start(int px, int& row, int& col) const {
+    if (small) {
+      row = int(float(px) * inv_w);
+      const int r = px - row * w;
+      row += (r >= w) ? 1 : 0;
+      row -= (r < 0) ? 1 : 0;
+    } else {
+      row = px / w;
+    }
+    col = px - row * w;
+  }
+  // Keeps the walk in step with the pixel loop: the chain of updates is cheap, and left alone the scheduler runs it
+  // ahead of the pixel arithmetic and holds all the (row, column) pairs of a group in registers (+10 ... +56 VGPRs,
+  // an occupancy step for most of the mask kernels: gpurun r03p42).  `anchor`: a value the previous pixel produced.
+  __device__ static void after(int& row, int& col, float anchor) { asm volatile("" : "+v"(row), "+v"(col) : "v"(anchor)); }
+  __device__ void step(bool b, int& row, int& col) const {
+    col += b ? rb : ra;
+    row += b ? qb : qa;
+    const bool wrap = col >= w;
+    col -= wrap ? w : 0;
+    row += wrap ? 1 : 0;
+  }
+};
+
 struct MaskPrm {
   float a, b, c, d2, k, S, ms, k_over_mp4, dS;  // k = sharp mp4/5; S = strength factor; dS = dS/dmp5
-  float inv_se, oi, oj, inv_w;
-  int w;
-  bool small;
-  __device__ static MaskPrm load(const float* __restrict__ mp, float sharp, float min_strength, int h, int w) {
+  float inv_se, oi, oj;
+  PixelWalk pw;
+  __device__ static MaskPrm load(const float* __restrict__ mp, float sharp, float min_strength, int h, int w,
+                                 int step_a = 1, int step_b = 1) {
     MaskPrm m;
     m.a = mp[0]; m.b = mp[1]; m.c = mp[2]; m.d2 = 2.0f * mp[3];
     m.k_over_mp4 = sharp / 5.0f;
@@ -619,26 +661,17 @@ struct MaskPrm {
     m.inv_se = 1.0f / float(se);
     m.oi = float(se - h) * 0.5f;
     m.oj = float(se - w) * 0.5f;
-    m.w = w;
-    m.inv_w = 1.0f / float(w);
-    m.small = long(h) * long(w) < (1L << 22);
+    m.pw = PixelWalk::make(h, w, step_a, step_b);
     return m;
   }
   struct Eval { float m, sg, inp_raw, gx, gy, lumc; };
   __device__ Eval eval(int px, const float x[3]) const {
+    int row, col;
+    pw.start(px, row, col);
+    return eval_rc(row, col, x);
+  }
+  __device__ Eval eval_rc(int row, int col, const float x[3]) const {
     Eval e;
-    // row / column of a linear pixel index.  Images below 2^22 pixels (every shape the agent uses) take
-    // one multiply by 1/w and a +-1 correction instead of a ~25-instruction integer division per pixel
-    int row;
-    if (small) {
-      row = int(float(px) * inv_w);
-      const int r = px - row * w;
-      row += (r >= w) ? 1 : 0;
-      row -= (r < 0) ? 1 : 0;
-    } else {
-      row = px / w;
-    }
-    const int col = px - row * w;
     e.gx = (float(row) + oi) * inv_se - 0.5f;
     e.gy = (float(col) + oj) * inv_se - 0.5f;
     e.lumc = lum3(x) - 0.5f;
@@ -660,10 +693,11 @@ struct MaskPrm {
 // ---------------------------------------------------------------------------------
 struct VignetPrm {
   float a, b, c5, k, S;  // c5 = mp2 - 5; k = sharp mp3 / 5; S = mp4/5 * .5 + .5
-  float inv_se, oi, oj, inv_w;
-  int w;
-  bool small, masking;
-  __device__ static VignetPrm load(const float* __restrict__ mp, float sharp, int masking, int h, int w) {
+  float inv_se, oi, oj;
+  PixelWalk pw;
+  bool masking;
+  __device__ static VignetPrm load(const float* __restrict__ mp, float sharp, int masking, int h, int w,
+                                   int step_a = 1, int step_b = 1) {
     VignetPrm m;
     m.a = mp[0]; m.b = mp[1]; m.c5 = mp[2] - 5.0f;
     m.k = sharp * mp[3] / 5.0f;
@@ -672,25 +706,18 @@ struct VignetPrm {
     m.inv_se = 1.0f / float(se);
     m.oi = float(se - h) * 0.5f;
     m.oj = float(se - w) * 0.5f;
-    m.w = w;
-    m.inv_w = 1.0f / float(w);
-    m.small = long(h) * long(w) < (1L << 22);
+    m.pw = PixelWalk::make(h, w, step_a, step_b);
     m.masking = masking != 0;
     return m;
   }
   struct Eval { float m, sg, u, gx2, gy2; };
   __device__ Eval eval(int px) const {
+    int row, col;
+    pw.start(px, row, col);
+    return eval_rc(row, col);
+  }
+  __device__ Eval eval_rc(int row, int col) const {
     Eval e;
-    int row;
-    if (small) {  // one multiply by 1/w and a +-1 correction instead of an integer division (see MaskPrm::eval)
-      row = int(float(px) * inv_w);
-      const int r = px - row * w;
-      row += (r >= w) ? 1 : 0;
-      row -= (r < 0) ? 1 : 0;
-    } else {
-      row = px / w;
-    }
-    const int col = px - row * w;
     const float gx = (float(row) + oi) * inv_se - 0.5f, gy = (float(col) + oj) * inv_se - 0.5f;
     e.gx2 = gx * gx;
     e.gy2 = gy * gy;

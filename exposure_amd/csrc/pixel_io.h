@@ -231,6 +231,15 @@ __device__ __forceinline__ int pixel_index(int g, int k, int lane) {
   return g * PPL + k;
 }
 
+// Inside a group the linear pixel index of slot k follows slot k - 1 by one of two steps (PixelWalk, filter_math.h):
+// step a = 1 (the second pixel of a 12-byte vector; every slot of the element-wise path), step b = the jump to the next
+// 768-byte row of the chunk.
+template <typename T, bool VEC> constexpr int pixel_step_a() { return 1; }
+template <typename T, bool VEC> constexpr int pixel_step_b() {
+  return VEC ? 64 * VecTraits<T>::PPV - (VecTraits<T>::PPV - 1) : 1;
+}
+template <typename T, bool VEC> constexpr bool pixel_step_is_b(int k) { return VEC && (k % VecTraits<T>::PPV) == 0; }
+
 // element-wise (ragged / unaligned) path: group g covers pixels [g*PPL, g*PPL+PPL) ∩ [0,hw)
 template <typename T>
 __device__ __forceinline__ void load_slow(const T* img, int g, int hw, float* out) {

@@ -50,7 +50,8 @@ def test_vignet_apply_matches_oracle(dtype, shape, masking, gpu_device):
     assert float(dmp.abs().max()) == 0.0
   dmp2 = torch.empty_like(dmp)
   _cabi.vignet_apply_bwd(tx, tdy, None, tmp, dmp2, 1.0, masking)  # parameter gradients only
-  assert torch.equal(dmp, dmp2)
+  # (two template instantiations of the kernel: the same sums in the same order, possibly contracted differently)
+  assert torch.allclose(dmp, dmp2, rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize('masking', [True, False])
