@@ -134,19 +134,6 @@ __device__ __forceinline__ int nacc_of(int id) {
   }
 }
 
-// wave_reduce_scatter's slot map for a run-time accumulator count (kernel_common.h: the same halvings)
-__device__ __forceinline__ int reduce_scatter_index(int N, int lane) {
-  const int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
-  int l = 0;
-  bool ok = true;
-  if (n4 > 1) { l += (lane & 2) ? n5 : 0; ok = ok && l < n4; }
-  if (n3 > 1) { l += (lane & 4) ? n4 : 0; ok = ok && l < n3; }
-  if (n2 > 1) { l += (lane & 8) ? n3 : 0; ok = ok && l < n2; }
-  if (n1 > 1) { l += (lane & 16) ? n2 : 0; ok = ok && l < n1; }
-  if (N > 1) { l += (lane & 32) ? n1 : 0; ok = ok && l < N; }
-  return ok ? l : -1;
-}
-
 // derived parameters of an element-wise filter (<= 3 floats), wave-uniform -> SGPRs
 struct StepPrm { float f[3]; };
 template <class F>

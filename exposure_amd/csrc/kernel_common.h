@@ -29,6 +29,39 @@ __device__ __forceinline__ void reduce_scatter_step(float* acc, int lane) {
     acc[j] = keep + __shfl_xor(send, M, 64);
   }
 }
+// Which accumulator does a lane's surviving slot 0 hold after the butterfly over N accumulators?  Walk the halvings
+// backwards; a slot that was padding at any level (odd split) is invalid (-1).  A plain function of (N, lane) for a
+// kernel that only knows N at run time (chain_fused_bwd.hip: the filter of a step); wave_reduce_scatter<N> below
+// returns the same map.
+__host__ __device__ constexpr int reduce_scatter_index(int N, int lane) {
+  const int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
+  int l = 0;
+  bool ok = true;
+  if (n4 > 1) { l += (lane & 2) ? n5 : 0; ok = ok && l < n4; }
+  if (n3 > 1) { l += (lane & 4) ? n4 : 0; ok = ok && l < n3; }
+  if (n2 > 1) { l += (lane & 8) ? n3 : 0; ok = ok && l < n2; }
+  if (n1 > 1) { l += (lane & 16) ? n2 : 0; ok = ok && l < n1; }
+  if (N > 1) { l += (lane & 32) ? n1 : 0; ok = ok && l < N; }
+  return ok ? l : -1;
+}
+// every accumulator of every count the kernels use ends in at least one EVEN lane (the lanes that write the records),
+// and no lane claims an index outside [0, N)
+constexpr bool reduce_scatter_map_is_complete(int N) {
+  for (int a = 0; a < N; ++a) {
+    bool held = false;
+    for (int lane = 0; lane < 64; lane += 2) held = held || reduce_scatter_index(N, lane) == a;
+    if (!held) return false;
+  }
+  for (int lane = 0; lane < 64; ++lane)
+    if (reduce_scatter_index(N, lane) >= N) return false;
+  return true;
+}
+static_assert(reduce_scatter_map_is_complete(1) && reduce_scatter_map_is_complete(2) && reduce_scatter_map_is_complete(3) &&
+              reduce_scatter_map_is_complete(5) && reduce_scatter_map_is_complete(6) && reduce_scatter_map_is_complete(7) &&
+              reduce_scatter_map_is_complete(8) && reduce_scatter_map_is_complete(9) && reduce_scatter_map_is_complete(14) &&
+              reduce_scatter_map_is_complete(24) && reduce_scatter_map_is_complete(30) && reduce_scatter_map_is_complete(32),
+              "wave_reduce_scatter: slot map");
+
 template <int N>
 __device__ __forceinline__ int wave_reduce_scatter(float* acc, int lane) {
   constexpr int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
@@ -40,7 +73,9 @@ __device__ __forceinline__ int wave_reduce_scatter(float* acc, int lane) {
   if constexpr (n4 > 1) reduce_scatter_step<n4, 2>(acc, lane); else acc[0] += __shfl_xor(acc[0], 2, 64);
   acc[0] += __shfl_xor(acc[0], 1, 64);
   // Which accumulator does this lane's surviving slot 0 hold?  Walk the halvings backwards; a slot
-  // that was padding at any level (odd split) is invalid (-1).
+  // that was padding at any level (odd split) is invalid (-1).  (= reduce_scatter_index(N, lane); spelled out with
+  // the compile-time counts because this is the epilogue of every reducing kernel of the chain and its code is left
+  // exactly as measured; the one-pass backward's eight-steps-of-one-filter tests hold the two to the same map.)
   int l = 0;
   bool ok = true;
   if constexpr (n4 > 1) { l += (lane & 2) ? n5 : 0; ok = ok && l < n4; }
