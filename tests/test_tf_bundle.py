@@ -199,3 +199,31 @@ def test_restore_mirrors_the_reference_call(tmp_path):
   tf_bundle.write_bundle(checkpoint.checkpoint_prefix(model_dir, 501), d)
   with pytest.raises(ValueError, match='generator/Conv/biases: shape'):
     checkpoint.restore(agent, model_dir, 501)
+
+
+def test_table_round_trip_property(tmp_path):
+  """Random key sets (shared prefixes, empty values, keys longer than a block) through write_table / read_table, and
+  random varints through the wire helpers."""
+  from hypothesis import given, settings, strategies as st
+  import itertools
+  counter = itertools.count()
+
+  @settings(max_examples=60, deadline=None)
+  @given(st.dictionaries(st.binary(min_size=0, max_size=40), st.binary(min_size=0, max_size=300), min_size=1, max_size=80),
+         st.sampled_from([64, 512, 4096]))
+  def table(items, block_size):
+    path = str(tmp_path / ('t%d.index' % next(counter)))
+    ordered = sorted(items.items())
+    tf_bundle.write_table(path, ordered, block_size=block_size)
+    assert tf_bundle.read_table(path) == ordered
+
+  @settings(max_examples=200, deadline=None)
+  @given(st.integers(min_value=0, max_value=(1 << 64) - 1))
+  def varint(v):
+    out = bytearray()
+    tf_bundle._put_varint(out, v)
+    got, pos = tf_bundle._get_varint(bytes(out), 0)
+    assert got == v and pos == len(out) <= 10
+
+  table()
+  varint()
