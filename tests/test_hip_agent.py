@@ -465,7 +465,8 @@ def test_bench_workloads_under_the_driver_launch_line(workload, gpu_device):
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
-         '127.0.0.1', '--master-port', '29541', os.path.join(root, 'bench.py'), '--gpus', '1', '--workload', workload,
+         '127.0.0.1', '--master-port', str(29541 + ['chain', 'chain_fused', 'infer'].index(workload)),
+         os.path.join(root, 'bench.py'), '--gpus', '1', '--workload', workload,
          '--steps', '5', '--warmup', '2', '--shape', 'B']
   if workload == 'chain':
     cmd += ['--no-cpu-baseline', '--cold-shape', 'none']
