@@ -95,3 +95,17 @@ def test_no_oracle_import_in_product():
       if fn.endswith(('.py', '.hip', '.h')):
         src = open(os.path.join(dirpath, fn)).read()
         assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), fn
+
+
+def test_integration_document_covers_every_entry_point():
+  """INTEGRATION.md's table must name every function the header declares (as `expo_x`, or folded as
+  `expo_x_fwd/bwd` / `expo_x_fwd/_bwd`), so a maintainer binding the library finds what each one replaces."""
+  import re
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  header = open(os.path.join(root, 'include', 'exposure_hip.h')).read()
+  doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+  names = sorted(set(re.findall(r'\b(expo_[a-z0-9_]+)\s*\(', header)))
+  assert len(names) >= 30
+  for n in names:
+    folded = n.endswith('_bwd') and (n[:-4] + '_fwd/bwd' in doc or n[:-4] + '_fwd/_bwd' in doc or n[:-4] + '_fwd / _bwd' in doc)
+    assert n in doc or folded, n
