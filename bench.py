@@ -423,13 +423,23 @@ def parity_sample(dev):
   _cabi.chain_fwd(list(range(8)), acts, prm)
   _cabi.chain_bwd(list(range(8)), acts, grads, prm, dprm)
   torch.cuda.synchronize()
-  worst, worst_lt2, count, ok = 0.0, 0.0, 0, True
+  worst, worst_lt2, count, ok, dp_ok, dp_worst = 0.0, 0.0, 0, True, True, {}
   for i in range(8):
     xin = acts[i].cpu().numpy().astype(np.float64)
     gin = grads[i + 1].cpu().numpy().astype(np.float64)
     p64 = params[i].astype(np.float64)
     ry = orc.process_packed(i, xin, p64)
-    rdx, _ = orc.backward_packed(i, xin, p64, gin)
+    if which.startswith('oracle/filters_c'):
+      rdx, rdp, adp = orc.backward_packed(i, xin, p64, gin, with_abs=True)
+    else:
+      rdx, rdp = orc.backward_packed(i, xin, p64, gin)
+      adp = orc.param_grad_abs(i, xin, p64, gin)
+    # parameter gradients (sums over H*W*3): error relative to A, the sum of the absolute terms; bound 1e-4 |ref| + 2e-6 A
+    dp_err = np.abs(dprm[i].cpu().numpy().astype(np.float64) - rdp)
+    dp_ok = dp_ok and bool((dp_err <= 1e-4 * np.abs(rdp) + 2e-6 * adp).all())
+    dp_worst[FILTER_NAMES[i]] = {'err_over_A': float((dp_err / adp).max()),
+                                 'err_over_ref': float((dp_err / np.maximum(np.abs(rdp), 1e-300)).max()),
+                                 'min_ref_over_A': float((np.abs(rdp) / adp).min())}
     for got, ref in ((acts[i + 1], ry), (grads[i], rdx)):
       ref = np.clip(ref, -65504.0, 65504.0)
       err = np.abs(got.float().cpu().numpy().astype(np.float64) - ref)
@@ -446,7 +456,10 @@ def parity_sample(dev):
       'bound_below_2': 1e-3,
       'max_abs_err_all_values': worst,
       'bound_all_values': '1e-3 + |ref| * 2^-11 (half an fp16 ulp of the stored value)',
-      'within_bounds': ok and worst_lt2 <= 1e-3,
+      'dparams': dp_worst,
+      'dparams_bound': '|err| <= 1e-4 |ref| + 2e-6 A, A = sum of the absolute per-element terms of each parameter gradient',
+      'dparams_values_checked': int(sum(p.size for p in params)),
+      'within_bounds': ok and worst_lt2 <= 1e-3 and dp_ok,
   }
 
 

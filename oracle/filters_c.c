@@ -26,7 +26,9 @@
  *
  * Compiled twice by oracle/build_c.sh: REAL=double (the checker) and REAL=float with OpenMP (the CPU baseline:
  * the reference's own dtype, one fused pass per step and direction, all host cores).  Parameter gradients are
- * accumulated in double in both.
+ * accumulated in double in both.  The checker build (-DORACLE_ABS_TERMS) also accumulates, per parameter, the sum
+ * of the ABSOLUTE per-element terms |dy_e * dy_e/dp_k| (slots 24..47 of every accumulator): the scale A that
+ * tests/_tol.py judges an fp32 accumulation against (tolerance 1e-4 |ref| + 2e-6 A).
  */
 #include <math.h>
 #include <stddef.h>
@@ -42,6 +44,19 @@
 typedef REAL real;
 
 #define L 8
+#define NACC 48 /* 24 sums + 24 sums of absolute terms */
+#ifdef ORACLE_ABS_TERMS
+#define ABS_TERM(dp, k, v) ((dp)[24 + (k)] += fabs((double)(v)))
+#else
+#define ABS_TERM(dp, k, v) ((void)0)
+#endif
+int oracle_c_has_abs_terms(void) {
+#ifdef ORACLE_ABS_TERMS
+  return 1;
+#else
+  return 0;
+#endif
+}
 #define LUM_R ((real)0.27)
 #define LUM_G ((real)0.67)
 #define LUM_B ((real)0.06)
@@ -174,7 +189,11 @@ static void curve_bwd(const real* k, real x, real dy, real* dx, double* dp) {
   const real Se = S + (real)1e-30;
   *dx = dy * slope * L / Se;
   /* y = t L / Se:  dy/dk_i = L cl_i / Se - t L / Se^2 */
-  for (int i = 0; i < L; ++i) dp[i] += (double)(dy * (L * cl[i] / Se - t * L / (Se * Se)));
+  for (int i = 0; i < L; ++i) {
+    const real term = dy * (L * cl[i] / Se - t * L / (Se * Se));
+    dp[i] += (double)term;
+    ABS_TERM(dp, i, term);
+  }
 }
 static void pixel_bwd(int fid, const real* p, const real* x, const real* dy, real* dx, double* dp) {
   switch (fid) {
@@ -183,6 +202,7 @@ static void pixel_bwd(int fid, const real* p, const real* x, const real* dy, rea
       for (int c = 0; c < 3; ++c) {
         dx[c] = dy[c] * s;
         dp[0] += (double)(R_LN2 * dy[c] * (x[c] * s));
+        ABS_TERM(dp, 0, R_LN2 * dy[c] * (x[c] * s));
       }
     } break;
     case 1:
@@ -191,12 +211,14 @@ static void pixel_bwd(int fid, const real* p, const real* x, const real* dy, rea
         const real y = r_pow(xm, p[0]);
         dx[c] = (x[c] >= (real)0.001) ? dy[c] * p[0] * y / xm : 0; /* tf.maximum passes on x >= 0.001 */
         dp[0] += (double)(dy[c] * y * r_log(xm));
+        ABS_TERM(dp, 0, dy[c] * y * r_log(xm));
       }
       break;
     case 2:
       for (int c = 0; c < 3; ++c) {
         dx[c] = dy[c] * p[c];
         dp[c] += (double)dy[c] * (double)x[c];
+        ABS_TERM(dp, c, (double)dy[c] * (double)x[c]);
       }
       break;
     case 3: {
@@ -205,6 +227,7 @@ static void pixel_bwd(int fid, const real* p, const real* x, const real* dy, rea
       satplus_full(xc, full);
       for (int c = 0; c < 3; ++c) {
         dp[0] += (double)dy[c] * (double)(full[c] - xc[c]);
+        ABS_TERM(dp, 0, (double)dy[c] * (double)(full[c] - xc[c]));
         g[c] = dy[c] * (1 - p[0]);
       }
       /* TF 1.x: no gradient through rgb_to_hsv / hsv_to_rgb (the build's optional analytic mode is an extension
@@ -232,6 +255,7 @@ static void pixel_bwd(int fid, const real* p, const real* x, const real* dy, rea
       dx[1] = dy[1] * f + LUM_G * common;
       dx[2] = dy[2] * f + LUM_B * common;
       dp[0] += (double)(dot * (ratio - 1));
+      for (int c = 0; c < 3; ++c) ABS_TERM(dp, 0, dy[c] * x[c] * (ratio - 1)); /* per output ELEMENT: dy_c (ci_c - x_c) */
     } break;
     case 6: {
       const real l = lum(x);
@@ -244,6 +268,7 @@ static void pixel_bwd(int fid, const real* p, const real* x, const real* dy, rea
       dx[1] = (1 - p[0]) * dy[1] + p[0] * sdy * LUM_G;
       dx[2] = (1 - p[0]) * dy[2] + p[0] * sdy * LUM_B;
       dp[0] += (double)(l * sdy - dot);
+      for (int c = 0; c < 3; ++c) ABS_TERM(dp, 0, dy[c] * (l - x[c]));
     } break;
     case 7:
       for (int c = 0; c < 3; ++c) curve_bwd(p + c * L, x[c], dy[c], &dx[c], dp + c * L);
@@ -263,29 +288,38 @@ void oracle_c_process(int fid, const real* x, const real* p, real* y, long n, lo
 }
 
 #define ROW_BLOCK 4096
-void oracle_c_backward(int fid, const real* x, const real* p, const real* dy, real* dx, real* dp, long n, long hw) {
+/* adp (n, P), may be NULL: the sums of absolute terms (checker build only; zeros otherwise) */
+void oracle_c_backward_abs(int fid, const real* x, const real* p, const real* dy, real* dx, real* dp, double* adp,
+                           long n, long hw) {
   const int P = oracle_c_num_params(fid);
   const long nb = (hw + ROW_BLOCK - 1) / ROW_BLOCK;
-  double* part = (double*)calloc((size_t)(n * nb) * 24, sizeof(double));
+  double* part = (double*)calloc((size_t)(n * nb) * NACC, sizeof(double));
 #pragma omp parallel for collapse(2) schedule(static)
   for (long i = 0; i < n; ++i)
     for (long b = 0; b < nb; ++b) {
-      double acc[24];
+      double acc[NACC];
       memset(acc, 0, sizeof(acc));
       const long j1 = (b + 1) * ROW_BLOCK < hw ? (b + 1) * ROW_BLOCK : hw;
       for (long j = b * ROW_BLOCK; j < j1; ++j) {
         const long o = (i * hw + j) * 3;
         pixel_bwd(fid, p + i * P, x + o, dy + o, dx + o, acc);
       }
-      memcpy(part + (i * nb + b) * 24, acc, sizeof(acc));
+      memcpy(part + (i * nb + b) * NACC, acc, sizeof(acc));
     }
   for (long i = 0; i < n; ++i) /* fixed order: reproducible whatever the thread count */
     for (int k = 0; k < P; ++k) {
-      double s = 0;
-      for (long b = 0; b < nb; ++b) s += part[(i * nb + b) * 24 + k];
+      double s = 0, a = 0;
+      for (long b = 0; b < nb; ++b) {
+        s += part[(i * nb + b) * NACC + k];
+        a += part[(i * nb + b) * NACC + 24 + k];
+      }
       dp[i * P + k] = (real)s;
+      if (adp) adp[i * P + k] = a;
     }
   free(part);
+}
+void oracle_c_backward(int fid, const real* x, const real* p, const real* dy, real* dx, real* dp, long n, long hw) {
+  oracle_c_backward_abs(fid, x, p, dy, dx, dp, NULL, n, hw);
 }
 
 /* The benchmark chain of BASELINE.json: `steps` filters applied in sequence (acts[s+1] = f_s(acts[s])), then the

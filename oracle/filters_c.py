@@ -39,6 +39,10 @@ def load(dtype=np.float64):
     lib.oracle_c_backward.argtypes = [ctypes.c_int, real_p, real_p, real_p, real_p, real_p, ctypes.c_long,
                                       ctypes.c_long]
     lib.oracle_c_backward.restype = None
+    lib.oracle_c_backward_abs.argtypes = [ctypes.c_int, real_p, real_p, real_p, real_p, real_p,
+                                          ctypes.POINTER(ctypes.c_double), ctypes.c_long, ctypes.c_long]
+    lib.oracle_c_backward_abs.restype = None
+    lib.oracle_c_has_abs_terms.restype = ctypes.c_int
     pp = ctypes.POINTER(real_p)
     lib.oracle_c_chain.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, pp, pp, real_p, real_p, real_p, pp,
                                    ctypes.c_long, ctypes.c_long]
@@ -64,17 +68,27 @@ def process_packed(fid, img, packed, dtype=np.float64):
   return y
 
 
-def backward_packed(fid, img, packed, dy, dtype=np.float64):
-  """(dx, dpacked) -- the TF-1-faithful gradient (no gradient through the HSV round trip)."""
+def backward_packed(fid, img, packed, dy, dtype=np.float64, with_abs=False):
+  """(dx, dpacked) -- the TF-1-faithful gradient (no gradient through the HSV round trip).  ``with_abs`` (float64
+  checker build only) adds ``A[n, k] = sum_e |dy_e dy_e/dp_k|``, the sum of the absolute per-element terms of each
+  parameter gradient: (dx, dpacked, A)."""
   lib, real_p = load(dtype)
   x, g = _prep(img, dtype), _prep(dy, dtype)
   p = _prep(packed, dtype).reshape(x.shape[0], NUM_PARAMS[fid])
   dx = np.empty_like(x)
   dp = np.empty_like(p)
   n, hw = x.shape[0], x.shape[1] * x.shape[2]
-  lib.oracle_c_backward(fid, x.ctypes.data_as(real_p), p.ctypes.data_as(real_p), g.ctypes.data_as(real_p),
-                        dx.ctypes.data_as(real_p), dp.ctypes.data_as(real_p), n, hw)
-  return dx, dp
+  if not with_abs:
+    lib.oracle_c_backward(fid, x.ctypes.data_as(real_p), p.ctypes.data_as(real_p), g.ctypes.data_as(real_p),
+                          dx.ctypes.data_as(real_p), dp.ctypes.data_as(real_p), n, hw)
+    return dx, dp
+  if not lib.oracle_c_has_abs_terms():
+    raise ValueError('this build of the C oracle does not accumulate absolute terms (float64 checker only)')
+  adp = np.zeros(p.shape, dtype=np.float64)
+  lib.oracle_c_backward_abs(fid, x.ctypes.data_as(real_p), p.ctypes.data_as(real_p), g.ctypes.data_as(real_p),
+                            dx.ctypes.data_as(real_p), dp.ctypes.data_as(real_p),
+                            adp.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n, hw)
+  return dx, dp, adp
 
 
 def set_threads(n, dtype=np.float32):

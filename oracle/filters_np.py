@@ -532,6 +532,125 @@ def backward_packed(fid, img, packed, dy, hsv_grad_mode=0):
 
 
 # ---------------------------------------------------------------------------
+# per-element TERMS of the parameter gradients: dparams = sum(terms), A = sum(|terms|)
+# ---------------------------------------------------------------------------
+def param_grad_terms(fid, img, packed, dy):
+  """The per-output-element terms ``dy_e * d y_e / d p_k`` whose sum over (H, W, 3) is the parameter gradient
+  ``backward_packed`` returns: shape (N, H, W, 3, P).  Written separately from the ``*_backward`` functions
+  above (the tests require ``terms.sum == dparams``); small sizes only (Color: 24 values per element)."""
+  img = np.asarray(img)
+  p = np.asarray(packed, dtype=img.dtype)
+  dy = np.asarray(dy, dtype=img.dtype)
+  name = FILTER_NAMES[fid]
+  L = CURVE_STEPS
+  if name == 'E':  # y = x 2^p: dy/dp = ln2 y
+    return (np.log(2) * dy * exposure_process(img, p))[..., None]
+  if name == 'G':  # y = xm^g: dy/dg = y ln xm
+    return (dy * gamma_process(img, p) * np.log(np.maximum(img, 0.001)))[..., None]
+  if name == 'W':  # y_c = x_c s_c: only channel c's elements see s_c
+    return (dy * img)[..., None] * np.eye(3, dtype=img.dtype)
+  if name == 'S+':  # y = xc (1-p) + full p
+    xc, full = satplus_full_color(img)
+    return (dy * (full - xc))[..., None]
+  if name in ('T', 'C'):
+    cc = 1 if name == 'T' else 3
+    k = p.reshape(-1, 1, 1, cc, L)
+    S = k.sum(axis=4) + 1e-30
+    clips = np.stack([np.clip(img - 1.0 * i / L, 0, 1.0 / L) for i in range(L)], axis=-1)  # (N,H,W,3,L)
+    y = (clips * k).sum(axis=-1) * (L / S)
+    per_knot = dy[..., None] * ((L / S)[..., None] * clips - (y / S)[..., None])  # (N,H,W,3,L)
+    if name == 'T':
+      return per_knot
+    out = np.zeros(img.shape + (3 * L,), dtype=img.dtype)
+    for c in range(3):
+      out[..., c, c * L:(c + 1) * L] = per_knot[..., c, :]
+    return out
+  if name == 'Ct':  # y = lerp(x, ci, p)
+    l = np.minimum(np.maximum(rgb2lum(img), 0.0), 1.0)
+    ci = img / (l + 1e-6) * (-np.cos(math.pi * l) * 0.5 + 0.5)
+    return (dy * (ci - img))[..., None]
+  if name == 'BW':  # y = lerp(x, lum, p)
+    return (dy * (rgb2lum(img) - img))[..., None]
+  if name == 'Le':
+    lower = p[:, 0][:, None, None, None]
+    upper = (p[:, 1] + 1)[:, None, None, None]
+    r = 1.0 / (upper - lower + 1e-6)
+    t = (img - lower) * r
+    inside = ((t >= 0.0) & (t <= 1.0)).astype(img.dtype)
+    return np.stack([dy * inside * r * (t - 1.0), -dy * inside * t * r], axis=-1)
+  raise ValueError(fid)
+
+
+def param_grad_abs(fid, img, packed, dy):
+  """``A[n, k] = sum_e |dy_e * d y_e / d p_k|``: the sum of the ABSOLUTE terms of each parameter gradient -- the
+  scale against which the rounding of an fp32 accumulation is judged (tests/_tol.py).  (N, P)."""
+  t = param_grad_terms(fid, img, packed, dy)
+  return np.abs(t).sum(axis=(1, 2, 3))
+
+
+def curve_grad_abs_pieces(fid, img, packed, dy):
+  """Tone / Color only: the scale of a parameter gradient evaluated as TWO sums,
+  ``dk_i = (L/S) sum dy clip_i  -  (1/S) sum dy y``  (what any implementation that accumulates the clipped values and
+  ``sum dy y`` separately computes -- the HIP kernels keep Q_i = sum dy min(x^, i/L) and combine them per image):
+  ``A3[n, k] = sum_e |dy_e| ((L/S) clip_i + |y_e| / S) >= A``.  On a SATURATED image (every x >= 1) the two sums
+  cancel exactly term by term, A is 0 and only A3 describes the rounding of such an evaluation; the tests use A3 there
+  (constant images at the clamp edge, steps of a sequence that follow a strong exposure) and the strict A elsewhere."""
+  img = np.asarray(img)
+  p = np.asarray(packed, dtype=img.dtype)
+  dy = np.abs(np.asarray(dy, dtype=img.dtype))
+  name = FILTER_NAMES[fid]
+  assert name in ('T', 'C'), name
+  L = CURVE_STEPS
+  cc = 1 if name == 'T' else 3
+  k = p.reshape(-1, 1, 1, cc, L)
+  S = k.sum(axis=4) + 1e-30
+  clips = np.stack([np.clip(img - 1.0 * i / L, 0, 1.0 / L) for i in range(L)], axis=-1)
+  y = (clips * k).sum(axis=-1) * (L / S)
+  pieces = dy[..., None] * (np.abs(L / S)[..., None] * clips + np.abs(y / S)[..., None])  # (N,H,W,3,L)
+  if name == 'T':
+    return pieces.sum(axis=(1, 2, 3))
+  return pieces.sum(axis=(1, 2)).reshape(img.shape[0], 3 * L)
+
+
+def masked_raw_grad_abs(fid, img, packed, mask_parameters, dy, maximum_sharpness=1, minimum_strength=0.3, h=1e-6):
+  """Scale of the RAW mask-parameter gradients of the masked apply ``out = lerp(img, process(img), mask)``
+  (filters.py:86-88): the terms are ``dy_e (process_e - img_e) d mask_e / d raw_k``, and both the reference (fp32 TF)
+  and the kernels form ``process - img`` from an fp32 ``process(img)``, i.e. to an ulp of the COLOUR, not of the
+  difference.  The scale is therefore the sum over the operands of that subtraction,
+  ``A2[n, k] = sum_e |dy_e| (|process_e| + |img_e|) |d mask_e / d raw_k|  >=  A``  (d mask / d raw by central
+  differences of ``get_mask``)."""
+  img = np.asarray(img, dtype=np.float64)
+  raw = np.asarray(mask_parameters, dtype=np.float64)
+  w = np.abs(np.asarray(dy, dtype=np.float64)) * (np.abs(process_packed(fid, img, packed)) + np.abs(img))
+  out = np.zeros_like(raw)
+  for k in range(raw.shape[1]):
+    e = np.zeros_like(raw)
+    e[:, k] = h
+    dm = (get_mask(img, raw + e, maximum_sharpness, minimum_strength) -
+          get_mask(img, raw - e, maximum_sharpness, minimum_strength)) / (2 * h)
+    out[:, k] = (w * np.abs(dm)).reshape(img.shape[0], -1).sum(axis=1)
+  return out
+
+
+def abs_terms_fd(fn, params, dy, h=1e-6):
+  """The same ``A`` for ANY per-image parameter vector of any restated map ``fn(params) -> y`` (mask parameters,
+  vignet parameters, raw pre-activation parameters ...), from central differences of the float64 restatement:
+  ``A[n, k] = sum_e |dy_e (y_e(p + h e_k) - y_e(p - h e_k)) / 2h|``.  Images are independent, so column k of every
+  image is perturbed at once.  ``A`` is a SCALE (needs percent accuracy, not digits)."""
+  params = np.asarray(params, dtype=np.float64)
+  dy = np.asarray(dy, dtype=np.float64)
+  out = np.zeros(params.shape, dtype=np.float64)
+  flat = params.reshape(params.shape[0], -1)
+  for k in range(flat.shape[1]):
+    e = np.zeros_like(flat)
+    e[:, k] = h
+    d = (np.asarray(fn((flat + e).reshape(params.shape)), dtype=np.float64) -
+         np.asarray(fn((flat - e).reshape(params.shape)), dtype=np.float64)) / (2 * h)
+    out.reshape(flat.shape)[:, k] = np.abs(dy * d).reshape(flat.shape[0], -1).sum(axis=1)
+  return out
+
+
+# ---------------------------------------------------------------------------
 # Filter.apply with specified_parameter (filters.py:62-99, masking off)
 # ---------------------------------------------------------------------------
 def apply_specified(fid, img, packed, high_res=None):

@@ -285,6 +285,19 @@ def stat_features_jvp(cache, v):
   return np.stack([j0, j1, j2], axis=1)
 
 
+def stat_features_jvp_abs(cache, v):
+  """A[n, k] = sum_e |J[n, k, e] v[n, e]|: the sum of the absolute TERMS of ``stat_features_jvp`` (the scale its fp32
+  accumulation is judged against, tests/_tol.py).  The rows of J come from ``stat_features_backward`` with unit
+  upstream gradients -- written independently of ``stat_features_jvp``; the tests require sum(J v) == jvp."""
+  n = v.shape[0]
+  out = np.zeros((n, 3))
+  for k in range(3):
+    e = np.zeros((n, 3))
+    e[:, k] = 1.0
+    out[:, k] = np.abs(stat_features_backward(cache, e) * v).reshape(n, -1).sum(axis=1)
+  return out
+
+
 def stat_features_hvp(cache, dstats, v):
   """d <stat_features_backward(cache, dstats), v> / d images (tie selectors and clip masks locally constant)."""
   n, h, w, _ = v.shape
@@ -356,9 +369,14 @@ def critic_input_grad(cache, weights, dout=None):
 
 
 # --------------------------------------------------------------------------------- loss graph
-def generator_losses(fake_input, z, states, progress, cfg, weights, dropout_masks, is_train=1):
+def generator_losses(fake_input, z, states, progress, cfg, weights, dropout_masks, is_train=1, frozen=None):
   """net.py:56-165: both GAN branches (cfg['gan'] 'w' / 'ls'), TD or plain-reward policy gradient (cfg['use_TD']),
-  use_penalty.  Defaults = the shipped configuration (WGAN, TD)."""
+  use_penalty.  Defaults = the shipped configuration (WGAN, TD).
+
+  ``frozen``: {'q_value', 'weight'} from an earlier call -- the operands the reference wraps in ``tf.stop_gradient``
+  (net.py:130 ``tf.stop_gradient(self.q_value)``, net.py:141/158 ``tf.stop_gradient(advantage)``) held at those
+  VALUES.  With them fixed, finite differences of g_loss / v_loss along a weight direction are the directional
+  derivatives of the gradients TF takes (tests/test_oracle_nets.py::weight_gradient_check)."""
   (fake_output, new_states, surrogate, penalty), debug = agent_generator((fake_input, z, states), is_train, progress,
                                                                          cfg, weights, dropout_masks)
   fake_logit = critic(fake_output, cfg, weights, 'critic/')
@@ -376,16 +394,18 @@ def generator_losses(fake_input, z, states, progress, cfg, weights, dropout_mask
     raw_reward = gate * (fake_logit - fake_input_logit) * cfg['critic_logit_multiplier']
   reward = raw_reward - penalty if cfg['use_penalty'] else raw_reward
   q_value = reward + (1.0 - stopped) * cfg['discount_factor'] * new_value
-  advantage = q_value - old_value  # tf.stop_gradient(q_value) - old_value: same VALUE
+  advantage = (q_value if frozen is None else frozen['q_value']) - old_value  # tf.stop_gradient(q_value) - old_value
   v_loss = np.mean(advantage**2)
   if cfg.get('use_TD', True):  # net.py:135-140 / 152-157
     routine_loss, weight = -q_value * cfg['parameter_lr_mul'], -advantage
   else:
     routine_loss, weight = -reward, -reward
+  if frozen is not None:
+    weight = frozen['weight']  # tf.stop_gradient(advantage)
   g_loss = np.mean(routine_loss + surrogate * weight)
   return dict(g_loss=g_loss, v_loss=v_loss, fake_output=fake_output, new_states=new_states, reward=reward,
               q_value=q_value, advantage=advantage, fake_logit=fake_logit, penalty=penalty, surrogate=surrogate,
-              old_value=old_value, new_value=new_value, debug=debug)
+              old_value=old_value, new_value=new_value, debug=debug, weight=weight)
 
 
 def critic_losses(real_data, fake_output, alpha, cfg, weights):

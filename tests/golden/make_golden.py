@@ -51,6 +51,9 @@ def main():
       out['y_%d' % fid] = y.astype(np.float32)
       out['dx_%d' % fid] = dx.astype(np.float32)
       out['dp_%d' % fid] = dp.astype(np.float32)
+      # round 4: the sum of ABSOLUTE terms of every parameter gradient -- the scale the accumulated rounding of dp is
+      # judged against (tests/_tol.py: |err| <= 1e-4 |dp| + 2e-6 adp)
+      out['adp_%d' % fid] = fnp.param_grad_abs(fid, x64, p64, dy64).astype(np.float32)
     rng = np.random.default_rng(77)
     img = synthetic.make_images(rng, shape, np.float16)
     if name == 'negative':

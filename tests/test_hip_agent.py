@@ -37,6 +37,7 @@ def dispatch_oracle(x, dy, ids, p24, dpen):
   y = np.zeros_like(x64)
   dx = np.zeros_like(x64)
   dp = np.zeros((n, 24))
+  adp = np.zeros((n, 24))  # sums of absolute terms of dp (tests/_tol.py); all-zero rows (id -1) must come out exactly 0
   cnt = x.shape[1] * x.shape[2] * 3
   for i, fid in enumerate(ids):
     if fid < 0:
@@ -47,7 +48,8 @@ def dispatch_oracle(x, dy, ids, p24, dpen):
     gx, gp = fnp.backward_packed(int(fid), x64[i:i + 1], p, g)
     dx[i:i + 1] = gx
     dp[i, :fnp.NUM_PARAMS[fid]] = gp[0]
-  return y, agent_np.overexposure_penalty(y), dx, dp
+    adp[i, :fnp.NUM_PARAMS[fid]] = fnp.param_grad_abs(int(fid), x64[i:i + 1], p, g)[0]
+  return y, agent_np.overexposure_penalty(y), dx, dp, adp
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
@@ -65,11 +67,10 @@ def test_dispatch_matches_oracle(dtype, shape, with_pen, gpu_device):
   dp = torch.full_like(tp, 9.0)
   tdpen = torch.from_numpy(dpen).to(dev) if with_pen else None
   _cabi.dispatch_bwd(tid, tx, tdy, dx, tp, dp, tdpen)
-  ry, rpen, rdx, rdp = dispatch_oracle(x, dy, ids, p24, dpen if with_pen else None)
+  ry, rpen, rdx, rdp, adp = dispatch_oracle(x, dy, ids, p24, dpen if with_pen else None)
   assert_image_close(y.float().cpu().numpy(), ry, NP_DT[dtype], 'dispatch y')
   assert_image_close(dx.float().cpu().numpy(), rdx, NP_DT[dtype], 'dispatch dx')
-  scale = np.abs(dy.astype(np.float64)).reshape(shape[0], -1).sum(axis=1, keepdims=True) * 4 + 50.0
-  assert_param_grad_close(dp.cpu().numpy(), rdp, np.broadcast_to(scale, rdp.shape), 'dispatch dparams')
+  assert_param_grad_close(dp.cpu().numpy(), rdp, adp, 'dispatch dparams')
   if with_pen:
     np.testing.assert_allclose(pen.cpu().numpy(), rpen, rtol=2e-4, atol=1e-7)
   # id -1: y == 0, dx == 0, dparams == 0
@@ -107,15 +108,12 @@ def test_dispatch_penalty_of_curves_that_exceed_one(dtype, shape, gpu_device):
   dx = torch.empty_like(tx)
   dp = torch.empty_like(tp)
   _cabi.dispatch_bwd(tid, tx, tdy, dx, tp, dp, torch.from_numpy(dpen).to(dev))
-  ry, rpen, rdx, rdp = dispatch_oracle(x, dy, ids, p24, dpen)
+  ry, rpen, rdx, rdp, adp = dispatch_oracle(x, dy, ids, p24, dpen)
   assert rpen[0] > 1e-3 and rpen[1] > 1e-3 and rpen[4] > 1e-3, 'the case must exercise the live penalty'
   assert_image_close(y.float().cpu().numpy(), ry, NP_DT[dtype], 'dispatch y')
   assert_image_close(dx.float().cpu().numpy(), rdx, NP_DT[dtype], 'dispatch dx')
   np.testing.assert_allclose(pen.cpu().numpy(), rpen, rtol=2e-4, atol=1e-7)
-  g_eff = np.abs(dy.astype(np.float64)) + 2.0 * np.maximum(ry - 1, 0) * np.abs(dpen)[:, None, None, None] / (
-      shape[1] * shape[2] * 3)
-  scale = g_eff.reshape(shape[0], -1).sum(axis=1, keepdims=True) * 4 + 50.0
-  assert_param_grad_close(dp.cpu().numpy(), rdp, np.broadcast_to(scale, rdp.shape), 'dispatch dparams')
+  assert_param_grad_close(dp.cpu().numpy(), rdp, adp, 'dispatch dparams (live penalty)')
 
 
 def test_dispatch_at_config5_size_every_pixel_against_the_c_oracle(gpu_device):
@@ -150,21 +148,20 @@ def test_dispatch_at_config5_size_every_pixel_against_the_c_oracle(gpu_device):
   _cabi.dispatch_fwd(tid, tx, y, tp, pen)
   _cabi.dispatch_bwd(tid, tx, tdy, dx, tp, dp, torch.from_numpy(dpen).to(dev))
   x64, dy64 = x.astype(np.float64), dy.astype(np.float64)
-  ry, rdx, rdp = np.zeros_like(x64), np.zeros_like(x64), np.zeros((n, 24))
+  ry, rdx, rdp, adp = np.zeros_like(x64), np.zeros_like(x64), np.zeros((n, 24)), np.zeros((n, 24))
   for fid in range(8):
     sel = np.nonzero(ids == fid)[0]
     npar = fnp.NUM_PARAMS[fid]
     pp = p24[sel, :npar].astype(np.float64)
     ry[sel] = fc.process_packed(fid, x64[sel], pp)
     g = dy64[sel] + 2.0 * np.maximum(ry[sel] - 1, 0) * dpen[sel].astype(np.float64)[:, None, None, None] / cnt
-    rdx[sel], rdp[sel, :npar] = fc.backward_packed(fid, x64[sel], pp, g)
+    rdx[sel], rdp[sel, :npar], adp[sel, :npar] = fc.backward_packed(fid, x64[sel], pp, g, with_abs=True)
   rpen = np.mean(np.maximum(ry - 1, 0)**2, axis=(1, 2, 3))
   assert (rpen[ids >= 0] > 1e-4).any(), 'the case must exercise the penalty'
   np.testing.assert_allclose(pen.cpu().numpy(), rpen, rtol=2e-4, atol=1e-7)
   assert_image_close(y.cpu().numpy(), np.clip(ry, -65504.0, 65504.0), np.float16, 'dispatch y')
   assert_image_close(dx.cpu().numpy(), np.clip(rdx, -65504.0, 65504.0), np.float16, 'dispatch dx')
-  scale = np.abs(dy64).reshape(n, -1).sum(axis=1, keepdims=True) * 4 + 50.0
-  assert_param_grad_close(dp.cpu().numpy(), rdp, np.broadcast_to(scale, rdp.shape), 'dispatch dparams')
+  assert_param_grad_close(dp.cpu().numpy(), rdp, adp, 'dispatch dparams (16x512x512)')
 
 
 def test_dispatch_autograd_matches_per_filter(gpu_device):
@@ -175,8 +172,9 @@ def test_dispatch_autograd_matches_per_filter(gpu_device):
   y, pen = filters.dispatch_filters(tx, tp, torch.from_numpy(ids).to(dev))
   w = torch.linspace(-1, 1, 9, device=dev)
   ((y * torch.from_numpy(dy).to(dev)).sum() + (pen * w).sum()).backward()
-  ry, rpen, rdx, rdp = dispatch_oracle(x, dy, ids, p24, w.cpu().numpy())
+  ry, rpen, rdx, rdp, adp = dispatch_oracle(x, dy, ids, p24, w.cpu().numpy())
   assert_image_close(tx.grad.cpu().numpy(), rdx, np.float32)
+  assert_param_grad_close(tp.grad.cpu().numpy(), rdp, adp, 'dispatch autograd dparams')
   np.testing.assert_allclose(pen.detach().cpu().numpy(), rpen, rtol=2e-4, atol=1e-7)
 
 

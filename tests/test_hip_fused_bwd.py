@@ -22,6 +22,14 @@ pytestmark = pytest.mark.gpu
 NP_DT = {torch.float16: np.float16, torch.float32: np.float32}
 
 
+def fused_coeff(np_dt):
+  """Coefficient of A in the parameter-gradient bound (tests/_tol.py).  fp32 storage: the accumulation bound itself.
+  fp16 storage: the one-pass kernel keeps every intermediate image in fp32 registers while the oracle is evaluated at
+  the fp16-ROUNDED checkpoints (the only form in which the intermediate images can leave the device), so every term
+  differs by the 2^-11 relative rounding of its inputs -- not an accumulation error; 10x the bound."""
+  return 2e-6 if np_dt == np.float32 else 2e-5
+
+
 def make_sequence(rng, n, steps, with_level=True):
   ids = rng.integers(0, 9 if with_level else 8, (n, steps)).astype(np.int32)
   p = np.zeros((n, steps, 24), dtype=np.float32)
@@ -72,7 +80,10 @@ def oracle_at_checkpoints(ids, p, cks, dy, mode=0):
                                    d[i:i + 1], hsv_grad_mode=mode)
       nd[i] = gx[0]
       dp[i, k, :npar] = gp[0]
-      scale[i, k, :npar] = np.abs(d[i]).sum() * (4.0 if fid in (0, 1) else 1.0)
+      # A: sum of absolute terms (tests/_tol.py); a curve step inside a sequence may see a saturated image (after a
+      # strong exposure every x >= 1: A = 0 while the two-sum evaluation leaves its rounding): the scale of the pieces
+      a_of = fnp.curve_grad_abs_pieces if fid in (4, 7) else fnp.param_grad_abs
+      scale[i, k, :npar] = a_of(fid, cks[k][i:i + 1].astype(np.float64), p[i:i + 1, k, :npar].astype(np.float64), d[i:i + 1])[0]
     d = nd
   return d, dp, scale
 
@@ -97,7 +108,7 @@ def test_fused_backward_matches_oracle_at_its_checkpoints(dtype, shape, steps, g
   dx, dp = fused_bwd(ids, p, x, dy, gpu_device)
   rdx, rdp, scale = oracle_at_checkpoints(ids, p, cks, dy)
   assert_image_close(dx, rdx, NP_DT[dtype], 'fused dx')
-  assert_param_grad_close(dp, rdp, scale, 'fused dparams')
+  assert_param_grad_close(dp, rdp, scale, 'fused dparams %s' % NP_DT[dtype].__name__, abs_coeff=fused_coeff(NP_DT[dtype]))
   # rows are fully overwritten: the unused tail of every row is 0
   for i in range(n):
     for st in range(steps):
@@ -123,7 +134,7 @@ def test_eight_steps_of_one_filter(dtype, fid, gpu_device):
   dx, dp = fused_bwd(ids, p, x, dy, gpu_device)
   rdx, rdp, scale = oracle_at_checkpoints(ids, p, cks, dy)
   assert_image_close(dx, rdx, NP_DT[dtype], 'dx, 8 x filter %d' % fid)
-  assert_param_grad_close(dp, rdp, scale, 'dparams, 8 x filter %d' % fid)
+  assert_param_grad_close(dp, rdp, scale, 'fused dparams, 8 x filter %d %s' % (fid, NP_DT[dtype].__name__), abs_coeff=fused_coeff(NP_DT[dtype]))
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
@@ -149,7 +160,7 @@ def test_nothing_selected_stops_the_gradient(dtype, gpu_device):
   assert (dp[0, 0] == 0).all() and (dp[1, :4] == 0).all() and (dp[2] == 0).all()
   rdx, rdp, scale = oracle_at_checkpoints(ids, p, cks, dy)
   assert_image_close(dx, rdx, NP_DT[dtype], 'dx with -1')
-  assert_param_grad_close(dp, rdp, scale, 'dparams with -1')
+  assert_param_grad_close(dp, rdp, scale, 'fused dparams with -1 %s' % NP_DT[dtype].__name__, abs_coeff=fused_coeff(NP_DT[dtype]))
 
 
 def test_fused_backward_equals_the_per_step_kernels_in_fp32_storage(gpu_device):
@@ -186,8 +197,10 @@ def test_fused_backward_equals_the_per_step_kernels_in_fp32_storage(gpu_device):
   rdx = d.cpu().numpy().astype(np.float64)
   assert np.abs(dx - rdx).max() <= 1e-5 * max(1.0, np.abs(rdx).max())
   rdp = ref_dp.cpu().numpy().astype(np.float64)
-  scale = np.abs(dy.astype(np.float64)).reshape(n, -1).sum(axis=1)[:, None, None] * np.ones_like(rdp)
-  assert (np.abs(dp - rdp) <= 2e-5 * np.maximum(np.abs(rdp), scale) + 1e-6).all()
+  # two fp32 summation orders of the same terms: each within 1e-4 |ref| + 2e-6 A of the float64 value (tests/_tol.py),
+  # A from the oracle at the per-step kernels' own (fp32, unrounded) activations
+  _, _, a = oracle_at_checkpoints(ids, p, [t.cpu().numpy() for t in acts[:steps]], dy)
+  assert_param_grad_close(dp, rdp, 2 * a, 'fused vs per-step dparams (fp32 storage)')
 
 
 def test_fused_backward_against_float64_autograd_end_to_end(gpu_device):
@@ -209,6 +222,7 @@ def test_fused_backward_against_float64_autograd_end_to_end(gpu_device):
     for st in range(steps):
       p[i, st, :fnp.NUM_PARAMS[ids[i, st]]] = synthetic.make_params(rng, int(ids[i, st]), 1)[0]
   dx, dp = fused_bwd(ids, p, x, dy, dev)
+  cks = checkpoints(ids, p, x, dev)
   for i in range(n):
     xi = torch.from_numpy(x[i:i + 1].astype(np.float64)).requires_grad_(True)
     ps = [torch.from_numpy(p[i:i + 1, st, :fnp.NUM_PARAMS[ids[i, st]]].astype(np.float64)).requires_grad_(True)
@@ -236,12 +250,15 @@ def test_fused_backward_against_float64_autograd_end_to_end(gpu_device):
     err = np.abs(dx[i] - rdx)[keep]
     tol = (2e-4 + 2e-4 * np.abs(rdx))[keep]
     assert (err <= tol).all(), (i, float(err.max()))
-    s = float(np.abs(dy[i].astype(np.float64)).sum())
+    # A at the kernel's own activations (float64 restatement of the fp32 chain); the float64 autograd chain differs from
+    # the kernel's fp32 one by the forward's rounding (1e-7 relative per value, and a different sub-gradient for the few
+    # activations that land within that distance of a knot): 10x the accumulation bound
+    _, _, a_all = oracle_at_checkpoints(ids[i:i + 1], p[i:i + 1], [c[i:i + 1] for c in cks], dy[i:i + 1])
     for st in range(steps):
       npar = fnp.NUM_PARAMS[ids[i, st]]
       ref = grads[1 + st][0].numpy()
-      # the gradient that reaches step st has been scaled by the later steps' Jacobians: bound by its own size too
-      assert (np.abs(dp[i, st, :npar] - ref) <= 2e-3 * np.maximum(np.abs(ref), s) + 1e-5).all(), (i, st)
+      assert_param_grad_close(dp[i, st, :npar], ref, a_all[0, st, :npar] * (1 + 1e-3), 'end-to-end dparams image %d step %d' % (i, st),
+                              abs_coeff=2e-5)
 
 
 @pytest.mark.parametrize('mode', [0, 1])
@@ -261,7 +278,7 @@ def test_hsv_grad_mode_and_aliasing(mode, gpu_device):
   assert np.array_equal(dx, dx2) and np.array_equal(dp, dp2)  # dx may alias dy; results are bit-reproducible
   rdx, rdp, scale = oracle_at_checkpoints(ids, p, cks, dy, mode=mode)
   assert_image_close(dx, rdx, np.float16, 'dx mode %d' % mode)
-  assert_param_grad_close(dp, rdp, scale, 'dparams mode %d' % mode)
+  assert_param_grad_close(dp, rdp, scale, 'fused dparams mode %d float16' % mode, abs_coeff=fused_coeff(np.float16))
 
 
 def test_empty_sequence_and_argument_errors(gpu_device):

@@ -8,7 +8,7 @@ import torch
 
 from exposure_amd.config import make_cfg
 from exposure_amd.gan import GAN
-from tests.test_oracle_nets import compare_gan_with_oracle
+from tests.test_oracle_nets import GRAD_TENSORS_SHORT, compare_gan_with_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -24,6 +24,9 @@ def test_torch_nets_and_losses_match_oracle_gpu(gpu_device, seed):
     gan.critic.fc2.weight.mul_(40.0)  # gradient norm > 1: the one-sided penalty is active
   res = compare_gan_with_oracle(gan, gpu_device, n=8, seed=seed)
   assert res['gradient_norm'] > 1.0
+  # weight gradients of g_loss / v_loss / c_loss against finite differences of the float64 oracle: every filter head
+  # (the HIP kernels' parameter gradients feed them) must have been reached
+  assert not any(k[2] == 'zero' and 'filter_' in k[1] for k in res['grad_report'])
 
 
 @pytest.mark.parametrize('gan_kind,use_td,gp_lambda', [('ls', False, 10), ('w', True, 0)])
@@ -39,7 +42,7 @@ def test_loss_branches_match_oracle_gpu(gpu_device, gan_kind, use_td, gp_lambda)
       if p.dim() == 1:
         p.normal_(0.0, 0.05)
     gan.critic.fc2.weight.mul_(40.0)
-  compare_gan_with_oracle(gan, gpu_device, n=8, seed=13)
+  compare_gan_with_oracle(gan, gpu_device, n=8, seed=13, grad_tensors=GRAD_TENSORS_SHORT)
   from tests.test_oracle_nets import make_batch
   fake_input, real, _s, _z, _m, alpha = make_batch(8, 14)
   t = lambda a: torch.from_numpy(a).to(gpu_device)

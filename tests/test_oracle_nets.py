@@ -4,6 +4,8 @@ finite differences, TF SAME-padding arithmetic against an independent implementa
 cross-correlation with explicit padding), and then the torch modules of exposure_amd -- holding the
 SAME weights -- against the oracle (CPU: the C-ABI binding is mocked by the oracle's filter maths;
 the -m gpu twin of the last part is tests/test_hip_nets.py)."""
+from unittest import mock
+
 import numpy as np
 import pytest
 import torch
@@ -199,7 +201,92 @@ def make_batch(n, seed, dtype=np.float32):
   return fake_input, real, states, z, masks, alpha
 
 
-def compare_gan_with_oracle(gan, dev, n=4, seed=11, rel=1e-4):
+GRAD_TENSORS = {
+    # (loss, TF variable names): generator -- both trunks' first and last convolution, EVERY filter's output head (the
+    # path the HIP kernels' parameter gradients take into theta_g), one hidden FC, the selector heads; value net and critic
+    'g_loss': ['generator/Conv/weights', 'generator/Conv_3/weights', 'generator/filter_0/fc1/weights'] +
+              ['generator/filter_%d/fc2/weights' % j for j in range(8)] + ['generator/filter_7/fc2/biases',
+              'generator/action_selection/Conv_3/weights', 'generator/action_selection/selector_fc1/weights',
+              'generator/action_selection/selector_fc2/weights', 'generator/action_selection/selector_fc2/biases'],
+    'v_loss': ['rl_value/critic/Conv/weights', 'rl_value/critic/fully_connected/weights',
+               'rl_value/critic/fully_connected_1/biases'],
+    'c_loss': None,  # every critic variable (the double backward of the gradient penalty reaches all of them)
+}
+
+
+def weight_gradient_check(gan, dev, cfg, weights, batch, progress, rel, tensors=None):
+  """WEIGHT gradients of g_loss (theta_g), v_loss (theta_v) and c_loss (theta_c) -- what an optimizer step consumes --
+  against the float64 oracle.  The oracle has no backward through the networks; its forward is differentiated
+  numerically instead: for a variable W and a direction D, (L(W + h D) - L(W - h D)) / 2h in float64 (stop_gradient
+  operands frozen at the base point) must equal <dL/dW, D> with dL/dW from the product's autograd.  Two directions per
+  variable: the product's own gradient (first-order sensitive to a wrong scale, sign or missing term) and a seeded
+  random one (first-order sensitive, in expectation, to an error in any direction)."""
+  fake_input, real, states, z, masks, alpha = batch
+  t = lambda a: torch.from_numpy(a).to(dev)
+  d = lambda a: a.astype(np.float64)
+  name_map = {name: (p, kind) for name, p, kind in checkpoint.tf_name_map(gan)}
+  out = gan.generator_losses(t(fake_input), t(z), t(states), progress, 1, [t(m) for m in masks])
+  c = gan.critic_losses(t(real), t(fake_input), t(alpha))
+  base = nn_np.generator_losses(d(fake_input), d(z), d(states), progress, cfg, weights, [d(m) for m in masks], 1)
+  frozen = dict(q_value=base['q_value'], weight=base['weight'])
+
+  def oracle_loss(key, w):
+    if key == 'c_loss':
+      return nn_np.critic_losses(d(real), d(fake_input), d(alpha), cfg, w)['c_loss']
+    return nn_np.generator_losses(d(fake_input), d(z), d(states), progress, cfg, w, [d(m) for m in masks], 1,
+                                  frozen=frozen)[key]
+
+  rng = np.random.default_rng(99)
+  report = {}
+  for key, loss in (('g_loss', out['g_loss']), ('v_loss', out['v_loss']), ('c_loss', c['c_loss'])):
+    if tensors is not None and key not in tensors:
+      continue
+    names = (tensors or GRAD_TENSORS)[key] or [nm for nm in name_map if nm.startswith('critic/')]
+    grads = torch.autograd.grad(loss, [name_map[nm][0] for nm in names], retain_graph=True, allow_unused=True)
+    for nm, g in zip(names, grads):
+      assert g is not None, '%s does not reach %s' % (key, nm)
+      g = checkpoint.to_tf_layout(g, name_map[nm][1]).astype(np.float64)
+      w0 = weights[nm]
+      s = max(float(np.abs(w0).std()), 0.02)  # step in units of the variable's own scale
+      gnorm = float(np.sqrt((g**2).sum()))
+      if gnorm == 0:  # a filter head no image of this batch selected: the oracle's loss must not move either
+        direction = rng.standard_normal(g.shape)
+        h = 1e-4 * s
+        fd = (oracle_loss(key, dict(weights, **{nm: w0 + h * direction})) -
+              oracle_loss(key, dict(weights, **{nm: w0 - h * direction}))) / (2 * h)
+        assert abs(fd) <= 1e-9, '%s: all-zero gradient of %s but the oracle moves (%.3e)' % (nm, key, fd)
+        report[(key, nm, 'zero')] = 0.0
+        continue
+      for tag, direction in (('own', g / gnorm * np.sqrt(g.size)), ('random', rng.standard_normal(g.shape))):
+        got = float((g * direction).sum())
+        typical = gnorm * float(np.sqrt((direction**2).sum())) / np.sqrt(g.size)  # E|<g, random D>|
+        # the losses are piecewise smooth (lrelu, clips, the one-sided penalty): a step that carries some unit across
+        # a kink pollutes the difference quotient at the 1e-3 level -- relatively more along a random direction, whose
+        # derivative is a sum of ~sqrt(#units) random-sign unit contributions -- so the step is shrunk (at most three
+        # times) before a mismatch counts; float64 leaves ~1e-7 of relative noise at the smallest step
+        for h in (1e-6 * s, 2.5e-7 * s, 6e-8 * s, 1.5e-8 * s):
+          lp = oracle_loss(key, dict(weights, **{nm: w0 + h * direction}))
+          lm = oracle_loss(key, dict(weights, **{nm: w0 - h * direction}))
+          fd = (lp - lm) / (2 * h)
+          scale = max(abs(fd), 0.1 * typical)
+          if abs(got - fd) <= rel * scale:
+            break
+        report[(key, nm, tag)] = abs(got - fd) / scale
+        assert abs(got - fd) <= rel * scale, ('%s wrt %s along %s: autograd %.8g vs oracle finite difference %.8g' %
+                                              (key, nm, tag, got, fd))
+  return report
+
+
+# a short list for the other loss branches (the full one runs on the shipped configuration)
+GRAD_TENSORS_SHORT = {
+    'g_loss': ['generator/Conv/weights', 'generator/filter_1/fc2/weights', 'generator/filter_3/fc2/weights',
+               'generator/action_selection/selector_fc2/weights'],
+    'v_loss': ['rl_value/critic/fully_connected/weights'],
+    'c_loss': ['critic/Conv/weights', 'critic/fully_connected/weights'],
+}
+
+
+def compare_gan_with_oracle(gan, dev, n=4, seed=11, rel=1e-4, grad_rel=1e-3, grad_tensors=None):
   """Shared by the CPU (mocked C-ABI) and GPU (HIP library) tests.  The loss branches follow gan.cfg (cfg.gan,
   cfg.use_TD, cfg.gradient_penalty_lambda)."""
   cfg = dict(nn_np.DEFAULT_CFG, gan=gan.cfg.gan, use_TD=gan.cfg.use_TD,
@@ -209,6 +296,14 @@ def compare_gan_with_oracle(gan, dev, n=4, seed=11, rel=1e-4):
   t = lambda a: torch.from_numpy(a).to(dev)
   d = lambda a: a.astype(np.float64)
   progress = 0.3
+  # selection noise placed in the middle of filter (i % 8)'s interval of image i's action pdf (the pdf does not depend on
+  # z): a batch of 8 sends a gradient into every filter head
+  with torch.no_grad():
+    pdf = gan.generator_losses(t(fake_input), t(z), t(states), progress, 1,
+                               [t(m) for m in masks])['debug']['pdf_batch'].double().cpu().numpy()
+  cum = np.concatenate([np.zeros((n, 1)), np.cumsum(pdf / pdf.sum(axis=1, keepdims=True), axis=1)], axis=1)
+  want = np.arange(n) % 8
+  z[:, 0] = (0.5 * (cum[np.arange(n), want] + cum[np.arange(n), want + 1])).astype(np.float32)
   # --- features / logits (rows a-12, a-13)
   ag = gan.generator
   from exposure_amd.util import enrich_image_input
@@ -245,8 +340,42 @@ def compare_gan_with_oracle(gan, dev, n=4, seed=11, rel=1e-4):
   for key in ('c_loss', 'emd', 'gradient_norm', 'gradient_penalty', 'c_average'):
     got = float(c[key].detach())
     assert abs(got - rc[key]) <= rel * max(1.0, abs(rc[key])), (key, got, rc[key])
+  # --- weight gradients of the three losses (what the optimizers consume)
+  grad_report = weight_gradient_check(gan, dev, cfg, weights, (fake_input, real, states, z, masks, alpha), progress,
+                                      grad_rel, grad_tensors)
   return dict(g_loss=float(out['g_loss'].detach()), c_loss=float(c['c_loss'].detach()),
-              gradient_norm=float(c['gradient_norm'].detach()))
+              gradient_norm=float(c['gradient_norm'].detach()), grad_report=grad_report)
+
+
+def test_weight_gradient_check_rejects_wrong_gradients():
+  """The check itself must be able to fail: a generator whose filter step returns parameter gradients scaled by 0.97
+  (a wrong `dparams` from the kernels -- exactly what the loss values cannot see) and a critic loss whose penalty
+  term carries a 3 % wrong weight are both rejected."""
+  from tests import _fake_hip
+  torch.manual_seed(0)
+  gan = GAN(make_cfg())
+  with torch.no_grad():
+    for p in gan.parameters():
+      if p.dim() == 1:
+        p.normal_(0.0, 0.05)
+    gan.critic.fc2.weight.mul_(40.0)
+  cfg = dict(nn_np.DEFAULT_CFG)
+  weights = {k: v.astype(np.float64) for k, v in checkpoint.export_tf_dict(gan).items()}
+  batch = list(make_batch(8, 11))
+  batch[3][:, 0] = ((np.arange(8) % 8) + 0.5) / 8.0
+  honest = _fake_hip._dispatch_bwd
+
+  def scaled_dparams(ids, x, dy, dx, params, dparams, dpenalty=None, hsv_grad_mode=0):
+    honest(ids, x, dy, dx, params, dparams, dpenalty, hsv_grad_mode)
+    dparams.mul_(0.97)
+
+  with mock.patch.object(_fake_hip, '_dispatch_bwd', scaled_dparams), fake_hip():
+    with pytest.raises(AssertionError, match='g_loss wrt generator/'):
+      weight_gradient_check(gan, torch.device('cpu'), cfg, weights, batch, 0.3, 1e-3)
+  # the critic: a penalty weight of 9.7 instead of the oracle's 10 (a 3 % error in the double-backward term)
+  with mock.patch.object(gan.cfg, 'gradient_penalty_lambda', 9.7), fake_hip():
+    with pytest.raises(AssertionError, match='c_loss wrt critic/'):
+      weight_gradient_check(gan, torch.device('cpu'), cfg, weights, batch, 0.3, 1e-3, {'c_loss': None})
 
 
 def test_torch_nets_and_losses_match_oracle_cpu():
@@ -259,7 +388,9 @@ def test_torch_nets_and_losses_match_oracle_cpu():
         p.normal_(0.0, 0.05)
     gan.critic.fc2.weight.mul_(40.0)
   with fake_hip():
-    res = compare_gan_with_oracle(gan, torch.device('cpu'))
+    res = compare_gan_with_oracle(gan, torch.device('cpu'), n=8)
+  assert not any(k[2] == 'zero' and 'filter_' in k[1] for k in res['grad_report']), 'a filter head saw no gradient'
+  assert max(res['grad_report'].values()) <= 1e-3
   assert res['gradient_norm'] > 1e-3
 
 
@@ -278,11 +409,11 @@ def test_loss_branches_match_oracle_cpu(gan_kind, use_td, gp_lambda):
         p.normal_(0.0, 0.05)
     gan.critic.fc2.weight.mul_(40.0)
   with fake_hip():
-    res = compare_gan_with_oracle(gan, torch.device('cpu'))
+    res = compare_gan_with_oracle(gan, torch.device('cpu'), grad_tensors=GRAD_TENSORS_SHORT)
     # the branch really is a different number than the shipped configuration's
     base = GAN(make_cfg())
     base.load_state_dict(gan.state_dict())
-    ref = compare_gan_with_oracle(base, torch.device('cpu'))
+    ref = compare_gan_with_oracle(base, torch.device('cpu'), grad_tensors={})
   if gan_kind == 'ls' or not use_td:
     assert abs(res['g_loss'] - ref['g_loss']) > 1e-6
   if gan_kind == 'ls' or gp_lambda == 0:
