@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 from exposure_amd import _cabi, synthetic  # noqa: E402
 
 FILTER_NAMES = synthetic.FILTER_NAMES
+MFMA_FP32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (v_mfma_f32_*_f32), MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceilings: DESIGN.md 3.1
 
 
@@ -49,6 +50,8 @@ def parse():
                   help='also time the dominant kernel back to back on operands rotating through three buffer sets '
                   '(roofline.avg_launch_ms_rotating_buffers)')
   ap.add_argument('--no-per-kernel', action='store_true')
+  ap.add_argument('--no-legs', action='store_true', help='skip the extra legs of the default line (64x64x64 chain, training '
+                  'iteration, all-reduce): profiling runs that want the chain kernels only')
   ap.add_argument('--seed', type=int, default=1234)
   ap.add_argument('--order', default='0,1,2,3,4,5,6,7', help='filter ids of the chain steps (experiments only; the '
                   'metric is defined on the cfg.filters order 0..7)')
@@ -497,9 +500,66 @@ def trace(msg):
     print('[trace rank %s] %s' % (os.environ.get('RANK', '0'), msg), file=sys.stderr, flush=True)
 
 
-def run_train(args, world, rank, dev, dist):
-  """BASELINE configs 3/4: agent rollout step + policy CNN + WGAN-GP critic, batch 64 per GPU,
-  random-init weights, synthetic FiveK-shaped inputs, gradients all-reduced over RCCL."""
+def bracket(fn, dist, dev):
+  """The timing bracket of the contract: barrier + synchronize on both sides, MAX over ranks (seconds)."""
+  torch.cuda.synchronize()
+  light_barrier(dist, dev)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  fn()
+  torch.cuda.synchronize()
+  light_barrier(dist, dev)
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  return elapsed
+
+
+def conv_stack_macs(c_in, size=64, base=32, out_ch=None):
+  """MACs per image of one forward pass of the reference's conv stack (4x4 / stride 2 until 4x4; agent.py:11-37 ends on
+  output_dim / 16 channels, critics.py:6-38 keeps doubling) + its FC 4096 -> 128: [(macs, has_input_grad)] per layer."""
+  layers, ch, prev, sz = [], base, c_in, size // 2
+  while True:
+    last = sz == 4
+    co = (out_ch if (last and out_ch) else ch)
+    layers.append(sz * sz * co * 16 * prev)
+    prev = co
+    if last:
+      break
+    ch *= 2
+    sz //= 2
+  layers.append(prev * 16 * 128)  # FC on the flattened 4x4 map
+  return layers
+
+
+def train_flops_per_iteration(cfg, n):
+  """Analytic GEMM flops (2 x MACs) of ONE training iteration on n images per GPU (net.py:307-365): one generator /
+  value step + cfg.citers critic steps.  A layer's forward costs its MACs once; a backward costs them once per wanted
+  gradient (data, weight); the gradient penalty's double backward re-runs every critic layer three more times (the
+  forward-mode pass J v through the data-gradient graph, and its two gradients).  First layers have no data gradient
+  except where the gradient reaches the IMAGE (critic / value nets on generated images, the penalty)."""
+  trunk = conv_stack_macs(3 + cfg.num_state_dim, out_ch=cfg.feature_extractor_dims // 16)
+  crit = conv_stack_macs(3 + 3)
+  val = conv_stack_macs(3 + cfg.num_state_dim + 3)
+  heads = sum(128 * (f_np + 6) for f_np in (1, 1, 3, 1, 8, 1, 1, 24)) + 7 * 4096 * 128 + 128 * 8  # 8 fc2 + 7 more fc1 + selector fc2
+  fwd = lambda net: sum(net)
+  wgrad = lambda net: sum(net)
+  dgrad_to_image = lambda net: sum(net)
+  dgrad_inner = lambda net: sum(net[1:])
+  g = 2 * (fwd(trunk) + wgrad(trunk) + dgrad_inner(trunk)) + 3 * heads  # two trunks, all their gradients; FC heads x3
+  g += 2 * fwd(crit) + dgrad_to_image(crit)  # critic(fake_output) with the image gradient, critic(fake_input) forward only
+  g += 2 * fwd(val) + wgrad(val) + dgrad_inner(val) + dgrad_to_image(val)  # old_value (theta_v), new_value (image)
+  c = 3 * fwd(crit) + 2 * (wgrad(crit) + dgrad_inner(crit))  # real + fake + interpolated forward; emd backward on 2n
+  c += dgrad_to_image(crit) + 3 * fwd(crit)  # penalty: d D / d x^, then its double backward (three passes per layer)
+  return 2.0 * n * (g + cfg.citers * c)
+
+
+def measure_train(args, world, rank, dev, dist, steps, warmup):
+  """BASELINE configs 3/4: agent rollout step + policy CNN + WGAN-GP critic, batch 64 per GPU, random-init weights,
+  synthetic FiveK-shaped inputs, gradients all-reduced over RCCL.  Returns the measurement as a dict (every rank)."""
   from exposure_amd.config import make_cfg
   from exposure_amd.gan import GAN
   cfg = make_cfg()
@@ -529,39 +589,111 @@ def run_train(args, world, rank, dev, dist):
       gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
     return out
 
-  def barrier():
-    light_barrier(dist, dev)
-
   trace('pool primed')
-  for i in range(args.warmup):
+  for i in range(warmup):
     iteration(i + 1)
     trace('warm-up iteration %d done' % i)
-  torch.cuda.synchronize()
-  barrier()
-  torch.cuda.synchronize()
+
+  def timed():
+    for i in range(steps):
+      iteration(i + 1)
+
   trace('timed region starts')
-  t0 = time.perf_counter()
-  for i in range(args.steps):
-    iteration(i + 1)
-  torch.cuda.synchronize()
-  barrier()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
+  elapsed = bracket(timed, dist, dev)
   trace('timed region done')
-  if dist is not None:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+  ms = elapsed / steps * 1e3
+  flops = train_flops_per_iteration(cfg, n)
+  achieved = flops / (ms * 1e-3) / 1e12
+  return {
+      'ms_per_iteration': ms,
+      'images_per_s': world * n / (elapsed / steps),
+      'steps': steps,
+      'warmup': warmup,
+      'batch_per_gpu': n,
+      'critic_steps_per_iteration': cfg.citers,
+      'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
+      'miopen_find': bool(torch.backends.cudnn.benchmark),
+      'capture_drain_verified': getattr(gan, 'capture_drain_verified', None),
+      'roofline': {
+          'bound': 'mfma_fp32',
+          'flops_per_iteration': flops,
+          'flops_note': 'analytic GEMM flops of the conv stacks (agent.py:11-37, critics.py:6-38) and FC layers for every '
+                        'forward / data-gradient / weight-gradient pass of the iteration incl. the penalty\'s double '
+                        'backward (bench.py::train_flops_per_iteration); element-wise work not counted',
+          'achieved': achieved,
+          'peak': MFMA_FP32_PEAK_TFLOPS,
+          'unit': 'TFLOP/s',
+          'frac': achieved / MFMA_FP32_PEAK_TFLOPS,
+          'note': 'the nets are fp32 like the reference\'s (MIOpen igemm on v_mfma_f32_*_f32); at batch 64 x 64x64 the '
+                  'iteration is bound by launch count, not by the matrix pipes',
+      },
+  }
+
+
+def train_cpu_baseline(steps=2):
+  """The same iteration (same modules, fp32) on the host cores through torch's CPU kernels, with the filter step
+  through the oracle-backed mock of the C-ABI (tests/_fake_hip.py: the checker standing in for the library -- a CPU
+  baseline, never shipped).  Bounded sample: one warm-up + `steps` iterations at batch 64."""
+  try:
+    from exposure_amd.config import make_cfg
+    from exposure_amd.gan import GAN
+    from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
+    from tests._fake_hip import fake_hip
+  except Exception as e:
+    return {'error': str(e)[:200]}
+  t_start = time.perf_counter()
+  cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  threads = min(cores, 64)
+  torch.set_num_threads(threads)
+  cfg = make_cfg()
+  torch.manual_seed(0)
+  cpu = torch.device('cpu')
+  try:
+    with fake_hip():
+      gan = GAN(cfg, device=cpu, use_graphs=False, seed=0)
+      n = cfg.batch_size
+      memory = ReplayMemory(cfg, SyntheticProvider(cpu, dtype=torch.float32, seed=1),
+                            SyntheticProvider(cpu, gamma=1.0, dtype=torch.float32, seed=2), seed=0)
+      for _ in range(6):
+        feed, feats = memory.get_feed_dict_and_states(n)
+        out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
+        memory.replace_memory(out['fake_output'], out['new_states'], feats)
+
+      def iteration(it):
+        feed, feats = memory.get_feed_dict_and_states(n)
+        out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], progress=0.1, it=it)
+        memory.replace_memory(out['fake_output'], out['new_states'], feats)
+        for _ in range(cfg.citers):
+          rep = memory.get_replay_feed_dict(n)
+          gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
+
+      iteration(1)
+      times = []
+      for i in range(steps):
+        t0 = time.perf_counter()
+        iteration(i + 2)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > 40:
+          break
+  except Exception as e:  # a baseline, not a reason to lose the line
+    return {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+  return {'value': n / min(times), 'unit': 'images/s', 'ms_per_iteration': min(times) * 1e3, 'cores': threads,
+          'kind': 'port', 'sample': '%d iterations at batch %d after one warm-up (best), torch CPU kernels, fp32; filter '
+          'step through the oracle' % (len(times), n), 'seconds': time.perf_counter() - t_start}
+
+
+def run_train(args, world, rank, dev, dist):
+  m = measure_train(args, world, rank, dev, dist, args.steps, args.warmup)
   if rank == 0:
-    ms = elapsed / args.steps * 1e3
-    print(json.dumps({
-        'metric': 'generator-step images/s (1 G/V step + %d critic steps per iteration)' % cfg.citers,
-        'value': world * n / (elapsed / args.steps),
+    n = m['batch_per_gpu']
+    line = {
+        'metric': 'generator-step images/s (1 G/V step + %d critic steps per iteration)' % m['critic_steps_per_iteration'],
+        'value': m['images_per_s'],
         'unit': 'images/s',
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
-        'ms_per_step': ms,
+        'ms_per_step': m['ms_per_iteration'],
         'higher_is_better': True,
         'scaling': args.scaling,
         'vs_baseline': None,
@@ -573,12 +705,16 @@ def run_train(args, world, rank, dev, dist):
             'global_batch': world * n,
             'parallelism': 'dp%d image-sharded; flat gradient buckets (theta_g heads / trunks, theta_v, theta_c) '
                            'all-reduced over RCCL from backward hooks' % world,
-            'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
-            'miopen_find': bool(torch.backends.cudnn.benchmark),
-            'capture_drain_verified': getattr(gan, 'capture_drain_verified', None),
+            'launch': m['launch'],
+            'miopen_find': m['miopen_find'],
+            'capture_drain_verified': m['capture_drain_verified'],
             'reference_note': 'README.md:43: ~0.30 s/iteration on a GTX 1080 Ti (whole run ~100 min / 20000 it)',
         },
-    }), flush=True)
+        'roofline': m['roofline'],
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      line['cpu_baseline'] = train_cpu_baseline()
+    print(json.dumps(line), flush=True)
   trace('line printed')
   if dist is not None:
     dist.barrier()
@@ -587,10 +723,10 @@ def run_train(args, world, rank, dev, dist):
     trace('process group destroyed')
 
 
-def run_allreduce(args, world, rank, dev, dist):
+def measure_allreduce(args, world, rank, dev, dist, steps, warmup):
   """SURVEY.md section 8(e) "all-reduce only": the flat fp32 gradient buckets of one training iteration
   (theta_v 4.9 MB, theta_g heads 18.9 MB + trunks 5.6 MB once, theta_c 4.9 MB x citers) reduced over RCCL, no
-  compute.  With one rank the collective degenerates to nothing and the line reports 0 bytes."""
+  compute.  With one rank the collective degenerates to nothing and the rate is 0."""
   from exposure_amd.config import make_cfg
   from exposure_amd.gan import GAN
   cfg = make_cfg()
@@ -598,6 +734,7 @@ def run_allreduce(args, world, rank, dev, dist):
   gan = GAN(cfg, device=dev, use_graphs=False)
   sizes = {name: b.numel for name, b in gan.buckets.items()}
   bufs = {k: torch.zeros(v, dtype=torch.float32, device=dev) for k, v in sizes.items()}
+  del gan
 
   def iteration():
     if dist is None:
@@ -608,34 +745,41 @@ def run_allreduce(args, world, rank, dev, dist):
     for _ in range(cfg.citers):
       dist.all_reduce(bufs['c'])
 
-  for _ in range(args.warmup):
+  for _ in range(warmup):
     iteration()
-  torch.cuda.synchronize()
-  light_barrier(dist, dev)
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    iteration()
-  torch.cuda.synchronize()
-  light_barrier(dist, dev)
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  if dist is not None:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+
+  def timed():
+    for _ in range(steps):
+      iteration()
+
+  elapsed = bracket(timed, dist, dev)
   sizes['g'] = sizes['g_head'] + sizes['g_trunk']
   nbytes = 4 * (sizes['g'] + sizes['v'] + cfg.citers * sizes['c'])
+  algo = (nbytes / 1e9) / (elapsed / steps) if world > 1 else 0.0
+  return {
+      'ms_per_iteration': elapsed / steps * 1e3,
+      'bytes_per_iteration': nbytes,
+      'collectives_per_iteration': 3 + cfg.citers,
+      'algorithm_GBps': algo,  # bucket bytes / time
+      'bus_GBps': algo * 2.0 * (world - 1) / world,  # ring all-reduce: each rank moves 2 (p-1)/p of the bytes over its links
+      'elements': {'theta_g': sizes['g'], 'theta_v': sizes['v'], 'theta_c': sizes['c'], 'citers': cfg.citers},
+      'steps': steps,
+      'warmup': warmup,
+  }
+
+
+def run_allreduce(args, world, rank, dev, dist):
+  m = measure_allreduce(args, world, rank, dev, dist, args.steps, args.warmup)
   if rank == 0:
-    ms = elapsed / args.steps * 1e3
+    e = m['elements']
     print(json.dumps({
         'metric': 'gradient all-reduce GB/s per training iteration (bucket bytes / time)',
-        'value': (nbytes / 1e9) / (elapsed / args.steps) if world > 1 else 0.0,
+        'value': m['algorithm_GBps'],
         'unit': 'GB/s',
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
-        'ms_per_step': ms,
+        'ms_per_step': m['ms_per_iteration'],
         'higher_is_better': True,
         'scaling': args.scaling,
         'vs_baseline': None,
@@ -643,14 +787,82 @@ def run_allreduce(args, world, rank, dev, dist):
         'data': 'synthetic',
         'config': {
             'workload': 'all-reduce only: theta_g %d (2 buckets) + theta_v %d + %d x theta_c %d fp32 elements per iteration'
-                        % (sizes['g'], sizes['v'], cfg.citers, sizes['c']),
-            'bytes_per_iteration': nbytes,
+                        % (e['theta_g'], e['theta_v'], e['citers'], e['theta_c']),
+            'bytes_per_iteration': m['bytes_per_iteration'],
+            'bus_GBps': m['bus_GBps'],
             'parallelism': 'dp%d, flat buckets over RCCL' % world,
         },
     }))
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()
+
+
+def measure_shape(name, args, world, rank, dev, dist, steps=200, warmup=20):
+  """The 8-step chain fwd+bwd on another of north_star's shapes (64x64x64x3: BASELINE config 2), hipGraph replay,
+  same bracket: every rank runs its own batch, value = units of all ranks / slowest rank's time."""
+  shape = synthetic.SHAPES[name]
+  dtype = torch.float16 if args.dtype == 'f16' else torch.float32
+  chain = Chain(shape, dtype, dev, args.seed + 1000 + rank, [int(v) for v in args.order.split(',')])
+  if args.graph != 'off':
+    chain.capture(10)
+  chain.run(warmup)
+  elapsed = bracket(lambda: chain.run(steps), dist, dev)
+  px = shape[0] * shape[1] * shape[2]
+  esz = 2 if args.dtype == 'f16' else 4
+  return {
+      'ms_per_step': elapsed / steps * 1e3,
+      'Mpixels_per_s': world * px / (elapsed / steps) / 1e6,
+      'steps': steps,
+      'chain_algorithmic_GBps_per_gpu': 8 * 5 * 3 * esz * px / (elapsed / steps) / 1e9,
+      'note': 'launch-latency bound at this size (17 launches on 1.5 MB tensors): Mpixels/s only, no roofline claim'
+              if px * 3 * esz < (8 << 20) else 'tensors inside the 256 MiB Infinity Cache',
+  }
+
+
+def run_legs(result, args, world, rank, dev, dist):
+  """Outside the timed region, after the headline measurement: the other numbers north_star names, from the SAME
+  driver-run command -- the 64x64x64x3 chain (config 2), one training iteration (configs 3 / 4: ms, images/s, whether the
+  hipGraph capture of the collectives was verified) and, for N > 1, the gradient buckets' all-reduce alone (bus GB/s).
+  A watchdog thread prints the line as it stands and exits if a leg hangs (a collective on hardware this code has not
+  met must not cost the headline); a leg that raises is recorded as {'error': ...}."""
+  import threading
+  legs = {}
+  result['legs'] = legs
+  state = {'leg': None}
+  deadline = float(os.environ.get('EXPO_BENCH_LEGS_TIMEOUT_S', '300'))
+
+  def fire():
+    if rank == 0:
+      legs['error'] = 'watchdog: leg %r still running after %.0f s; line printed without it' % (state['leg'], deadline)
+      print(json.dumps(result), flush=True)
+    os._exit(0)
+
+  timer = threading.Timer(deadline, fire)
+  timer.daemon = True
+  timer.start()
+
+  def leg(name, fn):
+    state['leg'] = name
+    t0 = time.perf_counter()
+    try:
+      legs[name] = fn()
+      legs[name]['leg_seconds'] = time.perf_counter() - t0
+    except Exception as e:
+      legs[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    torch.cuda.empty_cache()
+
+  try:
+    leg('chain_64x64x64x3', lambda: measure_shape('A', args, world, rank, dev, dist))
+    leg('train', lambda: measure_train(args, world, rank, dev, dist, steps=10, warmup=3))
+    if world > 1:
+      leg('allreduce', lambda: measure_allreduce(args, world, rank, dev, dist, steps=20, warmup=5))
+  finally:
+    timer.cancel()
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and 'error' not in legs.get('train', {'error': 1}):
+    legs['train']['cpu_baseline'] = train_cpu_baseline()
+  legs['note'] = ('measured after the timed region with the same barrier + synchronize bracket and MAX over ranks; '
+                  'whole-job aggregates (images/s, Mpixels/s over all ranks)')
 
 
 def run_infer(args, world, rank, dev, dist):
@@ -1120,6 +1332,13 @@ def main():
       if cold is not None:
         result['roofline']['hbm_cold'] = cold
   barrier()
+  if not args.no_legs and os.environ.get('EXPO_BENCH_LEGS', '1') != '0':
+    try:
+      del chain  # (rank 0 may already have dropped it in front of the cold leg)
+    except NameError:
+      pass
+    torch.cuda.empty_cache()
+    run_legs(result, args, world, rank, dev, dist)
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     result['cpu_baseline'] = cpu_baseline()
     try:

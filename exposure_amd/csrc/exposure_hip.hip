@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <mutex>
+#include <vector>
 #include <string>
 #include <type_traits>
 
@@ -1603,6 +1604,50 @@ static bool chain_snake(int n, int h, int w, int dtype) {
   return bytes >= (256L << 20);
 }
 
+// Image tiles inside a chain when one tensor is larger than the Infinity Cache (round 4).  Images are independent, so
+// a chain over n images may run TILE-MAJOR: all steps on the first tile, then all steps on the next.  A tile whose
+// tensors fit the 256 MiB cache beside their neighbours (default 96 MiB per tensor = 64 images of 512x512 fp16) is
+// written by step i and read by step i+1 while it is still cached -- the regime the 64-image metric shape runs in --
+// instead of every launch streaming a 384 MiB tensor that its consumer finds evicted (the alternating image walk above
+// saved the cached tail only).  Within the plan a tile is split over the two streams like a whole batch of its size.
+// EXPO_CHAIN_TILE_MIB=<MiB per tensor and tile> (0: off, the alternating walk is used instead).
+struct ChainChunk { int nb, np, lane; };  // images [nb, nb + np) on the caller's stream (lane 0) or the helper (lane 1)
+struct ChainPlan {
+  std::vector<ChainChunk> chunks;  // in launch order per lane
+  bool two_lanes = false, snake = false;
+};
+static ChainPlan chain_plan(int n, int h, int w, int dtype) {
+  static const int tile_mib = getenv("EXPO_CHAIN_TILE_MIB") ? atoi(getenv("EXPO_CHAIN_TILE_MIB")) : 96;
+  ChainPlan plan;
+  const long image_bytes = long(h) * w * 3L * (dtype == EXPO_F16 ? 2L : 4L);
+  const long bytes = long(n) * image_bytes;
+  int tiles = 1;
+  if (tile_mib > 0 && bytes >= (256L << 20) && n > 1) {
+    long tile_n = (long(tile_mib) << 20) / image_bytes;
+    if (tile_n < 1) tile_n = 1;
+    tiles = int((n + tile_n - 1) / tile_n);
+  }
+  if (tiles == 1) {
+    plan.snake = chain_snake(n, h, w, dtype);
+    plan.two_lanes = chain_split(n, h, w, dtype);
+    const int n0 = plan.two_lanes ? n / 2 : n;
+    plan.chunks.push_back({0, n0, 0});
+    if (plan.two_lanes) plan.chunks.push_back({n0, n - n0, 1});
+    return plan;
+  }
+  const int base = n / tiles, rem = n % tiles;  // balanced tiles
+  plan.two_lanes = chain_split(base, h, w, dtype);
+  int at = 0;
+  for (int t = 0; t < tiles; ++t) {
+    const int tn = base + (t < rem ? 1 : 0);
+    const int n0 = (plan.two_lanes && tn >= 2) ? tn / 2 : tn;
+    plan.chunks.push_back({at, n0, 0});
+    if (n0 < tn) plan.chunks.push_back({at + n0, tn - n0, 1});
+    at += tn;
+  }
+  return plan;
+}
+
 extern "C" {
 
 int expo_version(void) { return EXPO_ABI_VERSION; }
@@ -1764,7 +1809,7 @@ int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const voi
 
 int expo_chain_streams(int n, int h, int w, int dtype) {
   if (check_common(n, h, w, dtype) != EXPO_OK) return 0;
-  return chain_split(n, h, w, dtype) ? 2 : 1;
+  return chain_plan(n, h, w, dtype).two_lanes ? 2 : 1;
 }
 
 int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const float* const* params, int n, int h,
@@ -1779,29 +1824,32 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
     if (!acts[i] || !acts[i + 1] || !params[i]) return fail(EXPO_E_BADARG, "null pointer");
   }
   const size_t esz = dtype == EXPO_F16 ? 2 : 4;
-  ForkJoin* fj = chain_split(n, h, w, dtype) ? fork_join_for_device() : nullptr;
-  const int n0 = fj ? n / 2 : n;  // images [0, n0) on the caller's stream, [n0, n) on the helper stream
+  const ChainPlan plan = chain_plan(n, h, w, dtype);
+  ForkJoin* fj = plan.two_lanes ? fork_join_for_device() : nullptr;
+  if (plan.two_lanes && !fj) return fail(EXPO_E_HIP, "helper stream unavailable");
   if (fj) {
     if (int rc = chain_fork(fj, s)) return rc;
   }
-  for (int i = 0; i < steps; ++i) {
-    const int rev = chain_snake(n, h, w, dtype) ? (i & 1) : 0;
-    for (int part = 0; part < (fj ? 2 : 1); ++part) {
-      const int nb = part ? n0 : 0, np = part ? n - n0 : n0;
-      const size_t ioff = size_t(nb) * h * w * 3 * esz;
+  int rc = EXPO_OK;
+  // chunk-major: every chunk (a tile, or half a tile per stream) goes through all the steps before the next one starts
+  for (size_t c = 0; c < plan.chunks.size() && !rc; ++c) {
+    const ChainChunk& ck = plan.chunks[c];
+    hipStream_t sp = ck.lane ? fj->helper : s;
+    const size_t ioff = size_t(ck.nb) * h * w * 3 * esz;
+    for (int i = 0; i < steps && !rc; ++i) {
+      const int rev = plan.snake ? (i & 1) : 0;
       const void* xin = static_cast<const char*>(acts[i]) + ioff;
       void* yout = static_cast<char*>(acts[i + 1]) + ioff;
-      const float* prm = params[i] + size_t(nb) * kNumParams[filter_ids[i]];
-      hipStream_t sp = part ? fj->helper : s;
-      const int rc = dtype == EXPO_F16 ? fwd_by_id<half_t>(filter_ids[i], xin, yout, prm, np, h, w, sp, rev, n)
-                                       : fwd_by_id<float>(filter_ids[i], xin, yout, prm, np, h, w, sp, rev, n);
-      if (rc) return rc;
+      const float* prm = params[i] + size_t(ck.nb) * kNumParams[filter_ids[i]];
+      rc = dtype == EXPO_F16 ? fwd_by_id<half_t>(filter_ids[i], xin, yout, prm, ck.np, h, w, sp, rev, n)
+                             : fwd_by_id<float>(filter_ids[i], xin, yout, prm, ck.np, h, w, sp, rev, n);
     }
   }
-  if (fj) {
-    if (int rc = chain_join(fj, s)) return rc;
+  if (fj) {  // always joined, also on an error path: a forked helper must not stay outside the caller's stream order
+    const int jrc = chain_join(fj, s);
+    if (!rc) rc = jrc;
   }
-  return EXPO_OK;
+  return rc;
 }
 
 int expo_filter_bwd_records(int filter_id, const void* x, const void* dy, void* dx, const float* params, int n,
@@ -1869,33 +1917,36 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
   if (int rc = ws_check(workspace, workspace_bytes, n, bx_max, steps, &records)) return rc;
   const size_t step_floats = ws_step_bytes(n, bx_max) / sizeof(float);
   const size_t esz = dtype == EXPO_F16 ? 2 : 4;
-  ForkJoin* fj = chain_split(n, h, w, dtype) ? fork_join_for_device() : nullptr;
-  const int n0 = fj ? n / 2 : n;
+  const ChainPlan plan = chain_plan(n, h, w, dtype);
+  ForkJoin* fj = plan.two_lanes ? fork_join_for_device() : nullptr;
+  if (plan.two_lanes && !fj) return fail(EXPO_E_HIP, "helper stream unavailable");
   if (fj) {
     if (int rc = chain_fork(fj, s)) return rc;
   }
-  for (int i = steps - 1; i >= 0; --i) {
-    // the forward chain ended descending (or ascending) on step steps-1; the backward starts where it ended
-    const int rev = chain_snake(n, h, w, dtype) ? ((steps - i) & 1) : 0;
-    const int bx = geom_bx(bwd_geom_kind(filter_ids[i]), n, h, w, dtype);  // records per image of this step's kernel
-    for (int part = 0; part < (fj ? 2 : 1); ++part) {
-      const int nb = part ? n0 : 0, np = part ? n - n0 : n0;
-      const size_t ioff = size_t(nb) * h * w * 3 * esz;
-      float* rec = records + size_t(i) * step_floats + size_t(nb) * bx * kWsSlots;
+  int rc = EXPO_OK;
+  for (size_t c = 0; c < plan.chunks.size() && !rc; ++c) {
+    const ChainChunk& ck = plan.chunks[c];
+    hipStream_t sp = ck.lane ? fj->helper : s;
+    const size_t ioff = size_t(ck.nb) * h * w * 3 * esz;
+    for (int i = steps - 1; i >= 0 && !rc; --i) {
+      // the forward chain ended descending (or ascending) on step steps-1; the backward starts where it ended
+      const int rev = plan.snake ? ((steps - i) & 1) : 0;
+      const int bx = geom_bx(bwd_geom_kind(filter_ids[i]), n, h, w, dtype);  // records per image of this step's kernel
+      float* rec = records + size_t(i) * step_floats + size_t(ck.nb) * bx * kWsSlots;
       const void* xin = static_cast<const char*>(acts[i]) + ioff;
       const void* gin = static_cast<const char*>(grads[i + 1]) + ioff;
       void* gout = grads[i] ? static_cast<char*>(grads[i]) + ioff : nullptr;
-      const float* prm = params[i] + size_t(nb) * kNumParams[filter_ids[i]];
-      hipStream_t sp = part ? fj->helper : s;
-      const int rc = dtype == EXPO_F16
-                         ? bwd_by_id<half_t>(filter_ids[i], xin, gin, gout, prm, rec, np, h, w, hsv_grad_mode, sp, rev, n)
-                         : bwd_by_id<float>(filter_ids[i], xin, gin, gout, prm, rec, np, h, w, hsv_grad_mode, sp, rev, n);
-      if (rc) return rc;
+      const float* prm = params[i] + size_t(ck.nb) * kNumParams[filter_ids[i]];
+      rc = dtype == EXPO_F16
+               ? bwd_by_id<half_t>(filter_ids[i], xin, gin, gout, prm, rec, ck.np, h, w, hsv_grad_mode, sp, rev, n)
+               : bwd_by_id<float>(filter_ids[i], xin, gin, gout, prm, rec, ck.np, h, w, hsv_grad_mode, sp, rev, n);
     }
   }
   if (fj) {
-    if (int rc = chain_join(fj, s)) return rc;
+    const int jrc = chain_join(fj, s);
+    if (!rc) rc = jrc;
   }
+  if (rc) return rc;
   return expo_finish_bwd(filter_ids, steps, params, dparams, n, h, w, dtype, workspace, workspace_bytes, stream);
 }
 

@@ -213,6 +213,14 @@ class GradBucket:
     self._armed = True
     self.launched = False
 
+  def release(self):
+    """Single-rank use: drop the views (``p.grad = None``) so that the next backward pass STORES each gradient
+    instead of accumulating it into the flat buffer; ``zero()`` re-attaches whenever a collective is wanted again."""
+    for p in self.params:
+      p.grad = None
+    self._armed = False
+    self.launched = False
+
   def disarm(self):
     """End of the backward pass this bucket was zero()ed for: gradient hooks fired by any OTHER backward (user
     code, a pre-training loop, a test) must not count towards -- or trigger -- this bucket's all-reduce: a

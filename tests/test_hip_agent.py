@@ -475,6 +475,9 @@ def test_bench_workloads_under_the_driver_launch_line(workload, gpu_device):
   d = json.loads(lines[0])
   assert d['n_gpus'] == 1 and d['steps'] == 5 and d['warmup'] == 2 and d['value'] > 0 and d['unit'] == 'Mpixels/s'
   assert d['scaling'] == 'weak' and d['data'] == 'synthetic' and 'roofline' in d
+  if workload == 'chain':  # the default line's extra legs under a (1-rank) RCCL process group
+    assert 'error' not in d['legs'] and 'error' not in d['legs']['train'] and 'allreduce' not in d['legs'], d['legs']
+    assert d['legs']['train']['roofline']['flops_per_iteration'] > 1e11
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])

@@ -120,7 +120,7 @@ def test_bench_launches_two_ranks_that_share_the_gpu(gpu_device):
   env = dict(os.environ, EXPO_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
   for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
     env.pop(k, None)
-  for extra in (['--scaling', 'weak', '--shape', 'B'], ['--scaling', 'strong', '--shape', 'B']):
+  for extra in (['--scaling', 'weak', '--shape', 'B'], ['--scaling', 'strong', '--shape', 'B', '--no-legs']):
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
                           '--no-cpu-baseline', '--cold-shape', 'none'] + extra, env=env, cwd=ROOT, capture_output=True,
                          text=True, timeout=600)
@@ -132,6 +132,19 @@ def test_bench_launches_two_ranks_that_share_the_gpu(gpu_device):
     per_gpu = 16 if extra[1] == 'weak' else 8
     assert d['config']['batch_per_gpu'] == per_gpu and d['config']['global_batch'] == 2 * per_gpu
     assert 'gloo' in d['config']['transport']
+    if '--no-legs' in extra:
+      assert 'legs' not in d
+      continue
+    # the extra legs of the default line, run by BOTH ranks after the timed region: config 2's shape, one training
+    # iteration with its gradient exchange, the gradient buckets' all-reduce alone
+    legs = d['legs']
+    assert 'error' not in legs, legs
+    for name in ('chain_64x64x64x3', 'train', 'allreduce'):
+      assert name in legs and 'error' not in legs[name], (name, legs.get(name))
+    assert legs['chain_64x64x64x3']['Mpixels_per_s'] > 0
+    assert legs['train']['ms_per_iteration'] > 0 and legs['train']['images_per_s'] > 0
+    assert 0 < legs['train']['roofline']['frac'] < 1 and legs['train']['roofline']['bound'] == 'mfma_fp32'
+    assert legs['allreduce']['bytes_per_iteration'] > 50e6 and legs['allreduce']['bus_GBps'] > 0
 
 
 @pytest.mark.parametrize('workload', ['train', 'allreduce', 'infer'])

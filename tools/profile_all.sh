@@ -11,7 +11,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 db() { find "$1" -name "*.db" | head -1; }
 COLD=256,512,512
-Q="--no-cpu-baseline --cold-shape none"
+Q="--no-cpu-baseline --cold-shape none --no-legs"
 
 python -m pytest $R/tests -x -q -m gpu 2>&1 | tail -2 > $OUT/pytest_gpu.txt
 python $R/bench.py > $OUT/bench_chain.json 2> $OUT/bench_chain.err
