@@ -1141,7 +1141,32 @@ def time_cold(args, dev, dom, ids, ev_over=0.0):
   px = shape[0] * shape[1] * shape[2]
   gbps = lambda k: (2 if k.startswith('fwd') else 3) * 3 * esz * px / (per[k] * 1e-3) / 1e9
   chain_ms = sum(per.values())
-  return {
+  # the chain CALLS at this size (expo_chain_fwd / _bwd run tile-major beyond the Infinity Cache: every tile goes
+  # through all the steps while its tensors are cached): whole steps between one event pair
+  call_ms = None
+  try:
+    chain = Chain(shape, dtype, dev, args.seed + 77, ids)
+    chain.run(2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    chain.run(5)
+    e1.record()
+    torch.cuda.synchronize()
+    call_ms = e0.elapsed_time(e1) / 5
+    del chain
+  except RuntimeError as e:
+    print('warning: cold chain-call measurement skipped (%s)' % e, file=sys.stderr)
+  finally:
+    torch.cuda.empty_cache()
+  call = {} if call_ms is None else {
+      'chain_call_ms_per_step': call_ms,
+      'chain_call_achieved': 8 * 5 * 3 * esz * px / (call_ms * 1e-3) / 1e9,
+      'chain_call_frac': 8 * 5 * 3 * esz * px / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+      'chain_call_note': 'expo_chain_fwd + expo_chain_bwd (16 launches per tile and stream + 1 finish), eager, 5 steps '
+                         'between one event pair: the calls walk the batch tile-major (EXPO_CHAIN_TILE_MIB, default 96 MiB '
+                         'per tensor and tile), so a consumer finds its producer\'s tile in the Infinity Cache',
+  }
+  return dict(call, **{
       'shape': 'x'.join(str(v) for v in shape),
       'tensor_MiB': px * 3 * esz / 2**20,
       'kernel': dom,
@@ -1153,7 +1178,7 @@ def time_cold(args, dev, dom, ids, ev_over=0.0):
       'chain_achieved': 8 * 5 * 3 * esz * px / (chain_ms * 1e-3) / 1e9,
       'note': 'HIP-event pairs around every launch minus the calibrated pair overhead; chain_achieved = 240 B/px over '
               'the sum of the 16 launch times',
-  }
+  })
 
 
 def main():

@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # never a non-HIP implementation.
 LIB_PATH = os.environ.get('EXPO_HIP_LIB') or os.path.join(_HERE, 'libexposure_hip.so')
 
-EXPO_ABI_VERSION = 3
+EXPO_ABI_VERSION = 4
+EXPO_CURVE_MAX_STEPS = 16
 EXPO_F16, EXPO_F32 = 0, 1
 EXPO_MAX_PARAMS = 24
 NUM_PARAMS = (1, 1, 3, 1, 8, 1, 1, 24, 2)  # ids 0..7 = cfg.filters order, 8 = LevelFilter
@@ -60,6 +61,9 @@ SIGNATURES = {
     'expo_vignet_apply_bwd': (_i, [_vp, _vp, _vp, _fp, _fp, _f, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_bias_lrelu_fwd': (_i, [_fp, _fp, _fp, _sz, _i, _f, _vp]),
     'expo_lrelu_bwd': (_i, [_fp, _fp, _fp, _sz, _f, _vp]),
+    'expo_curve_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'expo_curve_fwd': (_i, [_vp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
+    'expo_curve_bwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 _lib = None
@@ -542,6 +546,38 @@ def vignet_apply_bwd(x, dy, dx, mask_params, dmask_params, maximum_sharpness, ma
     _check(lib.expo_vignet_apply_bwd(_ptr(x), _ptr(dy), _ptr(dx), _ptr(mask_params), _ptr(dmask_params),
                                      float(maximum_sharpness), int(bool(masking)), n, h, w, _dtype_code(x), wsp, wsb,
                                      _stream()), 'expo_vignet_apply_bwd')
+
+
+def curve_fwd(x, y, params, curves, steps):
+  """Tone (curves = 1) / Color (curves = 3) with any cfg.curve_steps: params (N, curves * steps)."""
+  lib = load()
+  _img(x, 'x'), _img(y, 'y')
+  n, h, w, _ = x.shape
+  assert y.shape == x.shape and y.dtype == x.dtype
+  _f32(params, 'params', (n, curves * steps))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_curve_fwd(_ptr(x), _ptr(y), _ptr(params), n, h, w, _dtype_code(x), int(curves), int(steps), _stream()),
+           'expo_curve_fwd')
+
+
+def curve_bwd(x, dy, dx, params, dparams, curves, steps, workspace=None):
+  lib = load()
+  _img(x, 'x'), _img(dy, 'dy')
+  n, h, w, _ = x.shape
+  if dx is not None:
+    _img(dx, 'dx')
+  _f32(params, 'params', (n, curves * steps))
+  _f32(dparams, 'dparams', (n, curves * steps))
+  need = int(lib.expo_curve_workspace_bytes(n, h, w, int(curves), int(steps)))
+  with torch.cuda.device(x.device):
+    if workspace is None:
+      workspace = reserve_workspace(x.device, need)
+      _order_shared_workspace(x.device)
+    if not workspace.is_cuda or workspace.numel() * workspace.element_size() < need:
+      raise ExposureHipError('exposure_amd: workspace must be a device tensor of at least %d bytes' % need)
+    _check(lib.expo_curve_bwd(_ptr(x), _ptr(dy), _ptr(dx), _ptr(params), _ptr(dparams), n, h, w, _dtype_code(x),
+                              int(curves), int(steps), ctypes.c_void_p(workspace.data_ptr()),
+                              ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()), 'expo_curve_bwd')
 
 
 def chain_streams(n, h, w, dtype_code):

@@ -197,6 +197,9 @@ class Agent(nn.Module):
     filter_one_hot = (selected_filter_id[:, None] == torch.arange(k, device=net.device)[None, :]).to(pdf.dtype)
     surrogate = (filter_one_hot * torch.log(pdf + 1e-10)).sum(dim=1, keepdim=True)
 
+    if any(f.uses_generic_kernels() for f in self.filters):
+      return self._forward_generic(net, states, params, mask_params, pdf, entropy, selected_filter_id, filter_one_hot,
+                                   surrogate, progress, high_res)
     # one-hot gather of the selected filter's packed parameters -> (N, 24); same gradient
     # routing as the reference's one-hot product over the stacked images
     params24 = net.new_zeros((n, F._cabi.EXPO_MAX_PARAMS), dtype=torch.float32)
@@ -264,6 +267,68 @@ class Agent(nn.Module):
     if high_res is None:
       return (out, new_states, surrogate, penalty), debug_info, None
     return (out, new_states, high_res_output), debug_info, None
+
+
+def _new_states_and_penalty(cfg, states, filter_one_hot, entropy, overexposure, progress, k):
+  """agent.py:207-252: the state update and the penalty that is subtracted from the reward."""
+  is_last_step = (torch.abs(states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1] + 1 - cfg.test_steps) < 1e-4).to(states.dtype)
+  submitted = is_last_step
+  new_states = [None for _ in range(STATE_DROPOUT_BEGIN + 1)]
+  new_states[STATE_REWARD_DIM] = submitted
+  new_states[STATE_STOPPED_DIM] = submitted
+  new_states[STATE_STEP_DIM] = (states[:, STATE_STEP_DIM] + 1)[:, None]
+  filter_usage = states[:, STATE_STEP_DIM + 1:]
+  early_stop_penalty = (1 - is_last_step) * submitted * cfg.early_stop_penalty
+  usage_penalty = (filter_usage * filter_one_hot).sum(dim=1, keepdim=True)
+  new_states[STATE_STEP_DIM + 1] = torch.maximum(filter_usage, filter_one_hot)
+  new_states = torch.cat(new_states, dim=1)
+  entropy_penalty = (1.0 - progress) * cfg.exploration_penalty * (-entropy + math.log(k))
+  penalty = overexposure[:, None] + entropy_penalty + usage_penalty * cfg.filter_usage_penalty + early_stop_penalty
+  return new_states, penalty
+
+
+def _forward_generic(self, net, states, params, mask_params, pdf, entropy, selected_filter_id, filter_one_hot, surrogate,
+                     progress, high_res):
+  """The step for a configuration the per-image dispatch kernels are not instantiated for (a curve filter with
+  cfg.curve_steps != 8; its parameter row would not fit EXPO_MAX_PARAMS either): the reference's own structure --
+  every filter's ``apply`` on the whole batch, stack, reduce with the one-hot (agent.py:58-77, 119-125) -- with every
+  filter still a HIP kernel (the curve filters on expo_curve_*).  Eight launches instead of one; 64x64 proxies."""
+  cfg = self.cfg
+  k = len(self.filters)
+
+  def select(img):
+    out = None
+    for j, (filt, p) in enumerate(zip(self.filters, params)):
+      if cfg.masking:
+        from .util import lerp
+        y = lerp(img.float(), filt.process(img, p).float(), filt.get_mask(img.float(), mask_params[j]))
+      else:
+        y = filt.process(img, p).float()
+      term = y * filter_one_hot[:, j, None, None, None]
+      out = term if out is None else out + term
+    return out.to(img.dtype)
+
+  out = select(net)
+  high_res_output = select(high_res) if high_res is not None else None
+  if cfg.clamp:
+    out = torch.clamp(out, 0.0, 5.0)
+  overexposure = F.overexposure_penalty(out)
+  new_states, penalty = _new_states_and_penalty(cfg, states, filter_one_hot, entropy, overexposure, progress, k)
+  debug_info = {
+      'state': states,
+      'selected_filter_id': selected_filter_id[0],
+      'filter_debug_info': [{'filter_parameters': p[0]} for p in params],
+      'pdf': pdf[0],
+      'selected_filter_ids': selected_filter_id,
+      'pdf_batch': pdf,
+      'packed_params': [f.pack(p) for f, p in zip(self.filters, params)],
+  }
+  if high_res is None:
+    return (out, new_states, surrogate, penalty), debug_info, None
+  return (out, new_states, high_res_output), debug_info, None
+
+
+Agent._forward_generic = _forward_generic
 
 
 def agent_generator(inp, is_train, progress, cfg, high_res=None, alex_in=None, module=None, dropout_masks=None):

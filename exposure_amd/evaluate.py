@@ -63,6 +63,9 @@ def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trac
   cfg = agent.cfg
   if cfg.masking:
     fused = False  # the spatial mask depends on the running image: no parameters-only replay
+  generic = any(f.uses_generic_kernels() for f in agent.filters)
+  if generic:
+    fused = False  # cfg.curve_steps != 8: the one-pass kernel is instantiated for 8-step curves (reference schedule instead)
   steps = steps or cfg.test_steps
   n = high_res.shape[0]
   dev = high_res.device
@@ -79,8 +82,12 @@ def retouch(agent, high_res, steps=None, z=None, dropout_masks=None, return_trac
     else:
       (low, states, hi), dbg, _ = agent((low, z, states), is_train=0, progress=0.0, high_res=hi,
                                         dropout_masks=masks)
-    abi_ids.append(dbg['abi_filter_ids'])
-    params.append(dbg['params24'])
+    if generic:  # no (N, 24) parameter rows exist for this configuration: record the ids only
+      abi_ids.append(agent.abi_filter_ids[dbg['selected_filter_ids'].clamp_min(0).long()])
+      params.append(torch.zeros((n, 24), dtype=torch.float32, device=dev))
+    else:
+      abi_ids.append(dbg['abi_filter_ids'])
+      params.append(dbg['params24'])
     trace.append(dbg['selected_filter_ids'].clone())
     if bool((states[:, STATE_STOPPED_DIM] > 0).all()):
       break

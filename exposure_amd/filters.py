@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import _cabi
-from .util import lrelu, tanh_range
+from .util import lerp, lrelu, tanh_range
 
 FILTER_SHORT_NAMES = ('E', 'G', 'W', 'S+', 'T', 'Ct', 'BW', 'C')
 
@@ -140,6 +140,31 @@ class _MaskedApplyFunction(torch.autograd.Function):
     return dx, dparams, dmask, None, None, None, None
 
 
+class _CurveFunction(torch.autograd.Function):
+  """Tone / Color with a step count the tuned kernels are not built for (cfg.curve_steps != 8):
+  expo_curve_fwd / expo_curve_bwd, one element-wise pass per direction."""
+
+  @staticmethod
+  def forward(ctx, img, packed, curves, steps):
+    img = img.contiguous()
+    packed = packed.contiguous().float()
+    y = torch.empty_like(img)
+    _cabi.curve_fwd(img, y, packed, curves, steps)
+    ctx.save_for_backward(img, packed)
+    ctx.args = (curves, steps)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    img, packed = ctx.saved_tensors
+    curves, steps = ctx.args
+    dy = dy.contiguous().to(img.dtype)
+    dx = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+    dparams = torch.empty_like(packed)
+    _cabi.curve_bwd(img, dy, dx, packed, dparams, curves, steps)
+    return dx, dparams, None, None
+
+
 def pixel_filter(fid, img, packed, hsv_grad_mode=0):
   """Functional entry: filter ``fid`` (0..7, ``cfg.filters`` order) with packed (N,P) params."""
   return _PixelFilterFunction.apply(img, packed, fid, hsv_grad_mode)
@@ -245,7 +270,7 @@ class Filter(nn.Module):
       # lerp(img, process(img, p), ones(1,1,1,1)) == process(img, p): the constant-one mask of the
       # shipped configs (cfg.masking = False) is folded away instead of spending two more passes.
       apply_one = lambda im: self.process(im, filter_parameters)
-      if high_res is not None and not self.no_high_res():
+      if high_res is not None and not self.no_high_res() and not self.uses_generic_kernels():
         # proxy + full-resolution image share the parameters: ONE autograd node, ONE parameter gradient
         hsv_mode = int(self.cfg.get('hsv_grad_mode', 0)) if hasattr(self.cfg, 'get') else 0
         low_res_output, high_res_output = _PixelFilterPairFunction.apply(img, high_res, self.pack(filter_parameters),
@@ -260,6 +285,11 @@ class Filter(nn.Module):
       hsv_mode = int(self.cfg.get('hsv_grad_mode', 0))
       apply_one = lambda im: _MaskedApplyFunction.apply(im, packed, mp, self.filter_id, float(
           self.cfg.maximum_sharpness), float(self.cfg.minimum_strength), hsv_mode)
+      if self.uses_generic_kernels():
+        # a curve filter with cfg.curve_steps != 8: process() on the generic kernel, mask and lerp as tensor ops
+        # (filters.py:86-88 literally)
+        apply_one = lambda im: lerp(im.float(), self.process(im, filter_parameters).float(),
+                                    self.get_mask(im.float(), mask_parameters)).to(im.dtype)
     low_res_output = apply_one(img)
     if high_res is not None:
       if self.no_high_res():
@@ -275,6 +305,11 @@ class Filter(nn.Module):
 
   def use_masking(self):
     return self.cfg.masking
+
+  def uses_generic_kernels(self):
+    """True for a filter whose configuration the tuned per-id kernels are not built for (Tone / Color with
+    cfg.curve_steps != 8): its process() runs on expo_curve_*, and the agent selects by stack-and-reduce."""
+    return False
 
   def get_num_mask_parameters(self):
     return 6
@@ -359,17 +394,30 @@ class ImprovedWhiteBalanceFilter(Filter):
     return color_scaling
 
 
+# the curve step count the streaming / dispatch / fused kernels are instantiated for (config_example.py:27, config_sintel.py:28);
+# any other cfg.curve_steps runs the generic element-wise kernels (expo_curve_*) and the agent's stack-and-select path
+CURVE_STEPS_TUNED = 8
+
+
 class ColorFilter(Filter):
   """filters.py:247-273 (north_star calls it ColorCurveFilter)."""
   filter_id = 7
 
   def __init__(self, net, cfg):
     Filter.__init__(self, net, cfg)
-    self.curve_steps = cfg.curve_steps
-    assert cfg.curve_steps == 8, 'the HIP curve kernels are built for cfg.curve_steps == 8'
+    self.curve_steps = int(cfg.curve_steps)
+    assert 1 <= self.curve_steps <= _cabi.EXPO_CURVE_MAX_STEPS, 'cfg.curve_steps must be in [1, 16]'
     self.short_name = 'C'
     self.num_filter_parameters = self.channels * cfg.curve_steps
     self._build_regressor()
+
+  def uses_generic_kernels(self):
+    return self.curve_steps != CURVE_STEPS_TUNED
+
+  def process(self, img, param):
+    if self.curve_steps == CURVE_STEPS_TUNED:
+      return Filter.process(self, img, param)
+    return _CurveFunction.apply(img, self.pack(param), 3, self.curve_steps)
 
   def filter_param_regressor(self, features):
     color_curve = features.reshape(-1, self.channels, self.cfg.curve_steps)[:, None, None, :]
@@ -385,11 +433,19 @@ class ToneFilter(Filter):
 
   def __init__(self, net, cfg):
     Filter.__init__(self, net, cfg)
-    self.curve_steps = cfg.curve_steps
-    assert cfg.curve_steps == 8, 'the HIP curve kernels are built for cfg.curve_steps == 8'
+    self.curve_steps = int(cfg.curve_steps)
+    assert 1 <= self.curve_steps <= _cabi.EXPO_CURVE_MAX_STEPS, 'cfg.curve_steps must be in [1, 16]'
     self.short_name = 'T'
     self.num_filter_parameters = cfg.curve_steps
     self._build_regressor()
+
+  def uses_generic_kernels(self):
+    return self.curve_steps != CURVE_STEPS_TUNED
+
+  def process(self, img, param):
+    if self.curve_steps == CURVE_STEPS_TUNED:
+      return Filter.process(self, img, param)
+    return _CurveFunction.apply(img, self.pack(param), 1, self.curve_steps)
 
   def filter_param_regressor(self, features):
     tone_curve = features.reshape(-1, 1, self.cfg.curve_steps)[:, None, None, :]

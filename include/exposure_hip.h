@@ -48,8 +48,9 @@
 extern "C" {
 #endif
 
-#define EXPO_ABI_VERSION 3 /* 2: caller-owned reduction workspace (no float atomics, no fills); 3: derivatives of the
-                              critic statistics and of the penalty, VignetFilter, bias + lrelu, masked per-image dispatch */
+#define EXPO_ABI_VERSION 4 /* 2: caller-owned reduction workspace (no float atomics, no fills); 3: derivatives of the
+                              critic statistics and of the penalty, VignetFilter, bias + lrelu, masked per-image dispatch;
+                              4: Tone / Color curves of any cfg.curve_steps (expo_curve_*) */
 
 #define EXPO_OK 0
 #define EXPO_E_BADARG (-1)
@@ -61,6 +62,7 @@ extern "C" {
 
 #define EXPO_NUM_FILTERS 9
 #define EXPO_MAX_PARAMS 24
+#define EXPO_CURVE_MAX_STEPS 16 /* largest cfg.curve_steps of expo_curve_fwd / _bwd */
 
 #define EXPO_FILTER_EXPOSURE 0
 #define EXPO_FILTER_GAMMA 1
@@ -354,6 +356,24 @@ int expo_critic_stats_hvp(const void* x, const float* dstats, const float* jv, c
 int expo_bias_lrelu_fwd(const float* y, const float* bias, float* z, size_t count, int channels, float leak,
                         void* stream);
 int expo_lrelu_bwd(const float* z, const float* dz, float* dy, size_t count, float leak, void* stream);
+
+/*
+ * ToneFilter / ColorFilter with ANY number of curve steps L = cfg.curve_steps (config_example.py:27; the reference
+ * loops `for i in range(self.cfg.curve_steps)`, filters.py:264-273, 312-322):
+ *     y = (L / S) sum_{i<L} clip(x - i/L, 0, 1/L) k_i,   S = sum_i k_i + 1e-30
+ * `curves` = 1 (Tone: one curve for the three channels, params float32 [N][L]) or 3 (Color: one per channel,
+ * params [N][3][L], channel-major like filter 7).  1 <= L <= EXPO_CURVE_MAX_STEPS.  Filters 4 and 7 of the entry
+ * points above ARE these with L = 8, on kernels tuned for that count; other counts run here (one element-wise
+ * pass per direction, O(1) work per element).  Gradient conventions as everywhere (tf.clip_by_value passes on both
+ * inclusive bounds; x exactly on a knot receives both neighbouring slopes).  expo_curve_bwd: dx nullable, may alias
+ * dy; dparams [N][curves * L] is overwritten; `workspace` >= expo_curve_workspace_bytes(n, h, w, curves, steps)
+ * bytes, uninitialised, no atomics, bit-reproducible (block records + a finish launch, like expo_filter_bwd).
+ */
+size_t expo_curve_workspace_bytes(int n, int h, int w, int curves, int steps);
+int expo_curve_fwd(const void* x, void* y, const float* params, int n, int h, int w, int dtype, int curves,
+                   int steps, void* stream);
+int expo_curve_bwd(const void* x, const void* dy, void* dx, const float* params, float* dparams, int n, int h,
+                   int w, int dtype, int curves, int steps, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -221,14 +221,14 @@ def _curve_process(img, param, L):
   return total
 
 
-def color_process(img, param, L=CURVE_STEPS):
-  """filters.py:264-273; param (N,1,1,3,L)."""
-  return _curve_process(img, param, L)
+def color_process(img, param, L=None):
+  """filters.py:264-273; param (N,1,1,3,L), L = cfg.curve_steps (taken from the parameter's last dimension)."""
+  return _curve_process(img, param, param.shape[4] if L is None else L)
 
 
-def tone_process(img, param, L=CURVE_STEPS):
+def tone_process(img, param, L=None):
   """filters.py:312-322; param (N,1,1,1,L)."""
-  return _curve_process(img, param, L)
+  return _curve_process(img, param, param.shape[4] if L is None else L)
 
 
 def contrast_process(img, param):
@@ -343,17 +343,19 @@ def vignet_apply(img, mask_parameters, maximum_sharpness=1, masking=True):
 def unpack_params(fid, packed):
   packed = np.asarray(packed)
   n = packed.shape[0]
-  assert packed.shape == (n, NUM_PARAMS[fid]), (packed.shape, fid)
+  # (the curve filters' step count is cfg.curve_steps: L = P for Tone, P / 3 for Color; 8 in the shipped configs)
   if fid == FILTER_ID['T']:
-    return packed.reshape(n, 1, 1, 1, CURVE_STEPS)
+    return packed.reshape(n, 1, 1, 1, packed.shape[1])
   if fid == FILTER_ID['C']:
-    return packed.reshape(n, 1, 1, 3, CURVE_STEPS)
+    assert packed.shape[1] % 3 == 0
+    return packed.reshape(n, 1, 1, 3, packed.shape[1] // 3)
+  assert packed.shape == (n, NUM_PARAMS[fid]), (packed.shape, fid)
   return packed
 
 
 def pack_params(fid, param):
   param = np.asarray(param)
-  return param.reshape(param.shape[0], NUM_PARAMS[fid])
+  return param.reshape(param.shape[0], -1)
 
 
 def regress_packed(fid, features, cfg=DEFAULT_CFG):
@@ -408,13 +410,15 @@ def _curve_backward(img, k, dy, L):
   return dx, dk
 
 
-def tone_backward(img, p, dy, L=CURVE_STEPS):
+def tone_backward(img, p, dy, L=None):
+  L = p.shape[1] if L is None else L
   k = p.reshape(-1, 1, 1, 1, L)
   dx, dk = _curve_backward(img, k, dy, L)
   return dx, dk.sum(axis=(1, 2, 3))
 
 
-def color_backward(img, p, dy, L=CURVE_STEPS):
+def color_backward(img, p, dy, L=None):
+  L = p.shape[1] // 3 if L is None else L
   k = p.reshape(-1, 1, 1, 3, L)
   dx, dk = _curve_backward(img, k, dy, L)
   return dx, dk.sum(axis=(1, 2)).reshape(-1, 3 * L)
@@ -542,7 +546,7 @@ def param_grad_terms(fid, img, packed, dy):
   p = np.asarray(packed, dtype=img.dtype)
   dy = np.asarray(dy, dtype=img.dtype)
   name = FILTER_NAMES[fid]
-  L = CURVE_STEPS
+  L = p.shape[1] // (3 if name == 'C' else 1) if name in ('T', 'C') else CURVE_STEPS  # cfg.curve_steps
   if name == 'E':  # y = x 2^p: dy/dp = ln2 y
     return (np.log(2) * dy * exposure_process(img, p))[..., None]
   if name == 'G':  # y = xm^g: dy/dg = y ln xm
@@ -600,8 +604,8 @@ def curve_grad_abs_pieces(fid, img, packed, dy):
   dy = np.abs(np.asarray(dy, dtype=img.dtype))
   name = FILTER_NAMES[fid]
   assert name in ('T', 'C'), name
-  L = CURVE_STEPS
   cc = 1 if name == 'T' else 3
+  L = p.shape[1] // cc
   k = p.reshape(-1, 1, 1, cc, L)
   S = k.sum(axis=4) + 1e-30
   clips = np.stack([np.clip(img - 1.0 * i / L, 0, 1.0 / L) for i in range(L)], axis=-1)

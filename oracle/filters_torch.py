@@ -94,7 +94,8 @@ def wb_process(img, param):
   return img * param[:, None, None, :]
 
 
-def _curve_process(img, param, L):
+def _curve_process(img, param, L=None):
+  L = param.shape[4] if L is None else L  # cfg.curve_steps
   curve_sum = torch.sum(param, dim=4) + 1e-30
   total = img * 0
   for i in range(L):
@@ -103,12 +104,12 @@ def _curve_process(img, param, L):
   return total
 
 
-def color_process(img, param, L=CURVE_STEPS):
+def color_process(img, param, L=None):
   """filters.py:264-273."""
   return _curve_process(img, param, L)
 
 
-def tone_process(img, param, L=CURVE_STEPS):
+def tone_process(img, param, L=None):
   """filters.py:312-322."""
   return _curve_process(img, param, L)
 
@@ -208,9 +209,9 @@ def apply_masked_backward(fid, img, packed, mask_parameters, dy, maximum_sharpne
 def unpack_params(fid, packed):
   n = packed.shape[0]
   if FILTER_NAMES[fid] == 'T':
-    return packed.reshape(n, 1, 1, 1, CURVE_STEPS)
+    return packed.reshape(n, 1, 1, 1, packed.shape[1])
   if FILTER_NAMES[fid] == 'C':
-    return packed.reshape(n, 1, 1, 3, CURVE_STEPS)
+    return packed.reshape(n, 1, 1, 3, packed.shape[1] // 3)
   return packed
 
 

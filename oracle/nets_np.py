@@ -180,7 +180,9 @@ def agent_generator(inp, is_train, progress, cfg, weights, dropout_masks, filter
                                       weights, 'generator/', dropout_masks[0])
   filtered_images, packed_params = [], []
   for j, fid in enumerate(filter_ids):
-    f, _mask_parameters = extract_parameters(filter_features, weights, 'generator/filter_%d/' % j, fnp.NUM_PARAMS[fid])
+    # (the curve filters' parameter count follows cfg.curve_steps: filters.py:254, 304)
+    n_par = {4: cfg['curve_steps'], 7: 3 * cfg['curve_steps']}.get(fid, fnp.NUM_PARAMS[fid])
+    f, _mask_parameters = extract_parameters(filter_features, weights, 'generator/filter_%d/' % j, n_par)
     packed = fnp.regress_packed(fid, f, cfg)
     packed_params.append(packed)
     # Filter.apply with masking off: lerp(img, process(img), ones) (filters.py:86-88, 111-113)

@@ -209,6 +209,20 @@ def _lrelu_bwd(z, dz, dy, leak=0.2):
   dy.copy_(dz * torch.where(z > 0, torch.ones_like(z), torch.where(z < 0, torch.full_like(z, leak), torch.full_like(z, f1))))
 
 
+def _curve_fwd(x, y, params, curves, steps):
+  fid = 4 if curves == 1 else 7
+  y.copy_(ft.process_packed(fid, x.double(), params.double()).to(y.dtype))
+
+
+def _curve_bwd(x, dy, dx, params, dparams, curves, steps, workspace=None):
+  fid = 4 if curves == 1 else 7
+  with torch.enable_grad():
+    gx, gp = ft.backward_packed(fid, x.double(), params.double(), dy.double(), 0)
+  if dx is not None:
+    dx.copy_(gx.to(dx.dtype))
+  dparams.copy_(gp.float())
+
+
 def _penalty(y, pen):
   pen.copy_(torch.from_numpy(agent_np.overexposure_penalty(y.double().numpy())).float())
 
@@ -221,5 +235,6 @@ def fake_hip():
                            overexposure_penalty_bwd=_penalty_bwd, bias_lrelu_fwd=_bias_lrelu_fwd, lrelu_bwd=_lrelu_bwd,
                            vignet_apply_fwd=_vignet_fwd, vignet_apply_bwd=_vignet_bwd,
                            apply_dispatch_fwd=_apply_dispatch_fwd, apply_dispatch_bwd=_apply_dispatch_bwd,
-                           chain_fused_fwd=_chain_fused_fwd, chain_fused_bwd=_chain_fused_bwd, apply_fwd=_apply_fwd, apply_bwd=_apply_bwd):
+                           chain_fused_fwd=_chain_fused_fwd, chain_fused_bwd=_chain_fused_bwd, apply_fwd=_apply_fwd, apply_bwd=_apply_bwd,
+                           curve_fwd=_curve_fwd, curve_bwd=_curve_bwd):
     yield

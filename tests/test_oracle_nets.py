@@ -201,6 +201,20 @@ def make_batch(n, seed, dtype=np.float32):
   return fake_input, real, states, z, masks, alpha
 
 
+def spread_selection_noise(gan, dev, fake_input, z, states, masks, progress=0.3):
+  """Selection noise placed in the middle of filter (i % 8)'s interval of image i's action pdf (the pdf does not depend
+  on z): a batch of 8 then selects every filter once -- every head receives a gradient, both curve filters run."""
+  t = lambda a: torch.from_numpy(a).to(dev)
+  n = fake_input.shape[0]
+  with torch.no_grad():
+    pdf = gan.generator_losses(t(fake_input), t(z), t(states), progress, 1,
+                               [t(m) for m in masks])['debug']['pdf_batch'].double().cpu().numpy()
+  cum = np.concatenate([np.zeros((n, 1)), np.cumsum(pdf / pdf.sum(axis=1, keepdims=True), axis=1)], axis=1)
+  want = np.arange(n) % 8
+  z[:, 0] = (0.5 * (cum[np.arange(n), want] + cum[np.arange(n), want + 1])).astype(np.float32)
+  return z
+
+
 GRAD_TENSORS = {
     # (loss, TF variable names): generator -- both trunks' first and last convolution, EVERY filter's output head (the
     # path the HIP kernels' parameter gradients take into theta_g), one hidden FC, the selector heads; value net and critic
@@ -304,14 +318,7 @@ def compare_gan_with_oracle(gan, dev, n=4, seed=11, rel=1e-4, grad_rel=1e-3, gra
   t = lambda a: torch.from_numpy(a).to(dev)
   d = lambda a: a.astype(np.float64)
   progress = 0.3
-  # selection noise placed in the middle of filter (i % 8)'s interval of image i's action pdf (the pdf does not depend on
-  # z): a batch of 8 sends a gradient into every filter head
-  with torch.no_grad():
-    pdf = gan.generator_losses(t(fake_input), t(z), t(states), progress, 1,
-                               [t(m) for m in masks])['debug']['pdf_batch'].double().cpu().numpy()
-  cum = np.concatenate([np.zeros((n, 1)), np.cumsum(pdf / pdf.sum(axis=1, keepdims=True), axis=1)], axis=1)
-  want = np.arange(n) % 8
-  z[:, 0] = (0.5 * (cum[np.arange(n), want] + cum[np.arange(n), want + 1])).astype(np.float32)
+  z = spread_selection_noise(gan, dev, fake_input, z, states, masks, progress)
   # --- features / logits (rows a-12, a-13)
   ag = gan.generator
   from exposure_amd.util import enrich_image_input
