@@ -131,8 +131,17 @@ def test_generic_curve_kernels_match_oracle(steps, curves, dtype, shape, gpu_dev
   ry = fnp.process_packed(fid, x64, p64)
   rdx, rdp = fnp.backward_packed(fid, x64, p64, dy64)
   assert_image_close(y, ry, NP_DT[dtype], 'generic curve y (L = %d)' % steps)
-  assert_image_close(dx, rdx, NP_DT[dtype], 'generic curve dx (L = %d)' % steps)
-  assert_param_grad_close(dp, rdp, fnp.param_grad_abs(fid, x64, p64, dy64),
+  # For step counts that are not powers of two the knots i/L are not representable: whether an input within rounding of
+  # a knot (0.25 = 3/12 ...) counts as ON it -- both neighbouring slopes, TF's inclusive clip gradient -- is decided by
+  # the rounding of `x - i/L` in whatever dtype evaluates it (float64 here, fp32 in TF, exact u = L x in the kernel).
+  # Those elements have two equally valid sub-gradients and are left out of the dx comparison.
+  on_knot = np.abs(x64 * steps - np.round(x64 * steps)) < 1e-6 if steps & (steps - 1) else np.zeros(x64.shape, bool)
+  assert on_knot.mean() < 0.01
+  assert_image_close(np.where(on_knot, 0, dx), np.where(on_knot, 0, rdx), NP_DT[dtype], 'generic curve dx (L = %d)' % steps)
+  # (one step: y = clip(x, 0, 1) whatever k is -- every term of dk is exactly 0, A = 0; the kernels' two-sum evaluation is
+  # judged against the scale of its pieces there, oracle/filters_np.py::curve_grad_abs_pieces)
+  a_of = fnp.curve_grad_abs_pieces if steps == 1 else fnp.param_grad_abs
+  assert_param_grad_close(dp, rdp, a_of(fid, x64, p64, dy64),
                           'generic curve dparams L=%d curves=%d %s' % (steps, curves, NP_DT[dtype].__name__))
   # dx optional; bit-reproducible
   _, none_dx, dp2 = run_curve(x, dy, p, curves, steps, dtype, gpu_device, need_dx=False)
