@@ -116,9 +116,13 @@ def restore(gan, model_dir, ckpt=20000, strict=True):
 
 def save(gan, model_dir, iteration):
   """The ``saver.save(sess, <dir>/model.ckpt, global_step=iter)`` of ``net.py:380-384``: writes
-  ``model.ckpt-<iteration>.index / .data-00000-of-00001`` and the ``checkpoint`` state file TF keeps next to them,
-  readable by ``tf.train.Saver.restore`` of a graph that declares these variables (optimizer slots are not
-  written: a restoring graph that wants them must initialise them itself)."""
+  ``model.ckpt-<iteration>.index / .data-00000-of-00001`` and the ``checkpoint`` state file TF keeps next to them.
+  Only the TRAINABLE variables are written.  The reference's own ``GAN.restore`` builds ``tf.train.Saver(max_to_keep=1)``
+  over ALL global variables (Adam slots, beta powers, the counter_g / v / c step variables, the EMA shadow of
+  c_average): restoring this bundle with that saver fails with NotFoundError.  A consumer restores it with
+  ``tf.train.Saver(var_list=tf.trainable_variables())`` (what ``evaluate.py`` needs) and initialises the rest itself.
+  The reference names its files with ``global_step=iter + 1`` (net.py:380-384); pass that as ``iteration`` for
+  byte-compatible file names."""
   import os
   from . import tf_bundle
   prefix = checkpoint_prefix(model_dir, iteration)

@@ -50,19 +50,33 @@ class GlobalBatchRng:
   (tests/test_dist_gloo.py: two ranks == one process with nothing but the seed in common).  The redundant draw is
   world_size x (N x 4096) uniform numbers per step: negligible next to one convolution."""
 
-  def __init__(self, seed, device):
+  def __init__(self, seed, device=None):
+    self.seed = int(seed)
+    self.device = self.gen = None
+    if device is not None:
+      self._bind(device)
+
+  def _bind(self, device):
     self.device = torch.device(device)
     self.gen = torch.Generator(device=self.device)
-    self.gen.manual_seed(int(seed))
+    self.gen.manual_seed(self.seed)
 
-  def uniform(self, n_local, tail, group=None):
-    """(n_local, *tail) uniform [0, 1) numbers: this rank's rows of the (n_local * world, *tail) global draw."""
+  def uniform(self, n_local, tail, group=None, device=None):
+    """(n_local, *tail) uniform [0, 1) numbers: this rank's rows of the (n_local * world, *tail) global draw.
+    ``device``: where the consumer lives.  The generator is created on first use on that device and FOLLOWS the
+    module when it moves (``GAN(cfg).cuda()``: drawing on the CPU for inputs on the GPU was a device mismatch); a
+    move restarts the stream from the seed, which happens before training, not inside it."""
+    if device is not None and (self.device is None or torch.device(device).type != self.device.type or
+                               (torch.device(device).index is not None and torch.device(device) != self.device)):
+      self._bind(device)
+    elif self.gen is None:
+      self._bind('cpu')
     p, r = world_size(group), rank(group)
     full = torch.rand((n_local * p,) + tuple(tail), generator=self.gen, device=self.device)
     return full[r * n_local:(r + 1) * n_local]
 
 
-def nccl_works_retired(timeout_s=5.0, poll_s=0.01):
+def nccl_works_retired(timeout_s=5.0, poll_s=0.01, skip_ids=None):
   """Block until ProcessGroupNCCL's watchdog has RETIRED every collective issued so far (removed it from its work
   list), i.e. until it holds no work whose end event it would still poll.  Needed before a hipGraph capture that
   pulls RCCL's stream in: a watchdog poll (hipEventQuery) of an earlier eager work's event while that stream is
@@ -89,7 +103,12 @@ def nccl_works_retired(timeout_s=5.0, poll_s=0.01):
     seen_any = seen_any or bool(entries)
     if not entries:
       return False  # nothing recorded although collectives were issued: the recorder is off
-    if all(e.get('retired', False) for e in entries):
+    # collectives issued DURING an earlier hipGraph capture are never handed to the watchdog; a torch build whose
+    # flight recorder logs them anyway would show them un-retired for ever: the caller passes the record ids it saw
+    # while capturing (skip_ids) and they are not waited for
+    pending = [e for e in entries if not e.get('retired', False) and
+               (skip_ids is None or e.get('record_id', e.get('collective_seq_id')) not in skip_ids)]
+    if not pending:
       return True
     if time.monotonic() > deadline:
       return False

@@ -57,7 +57,7 @@ class GAN(nn.Module):
     self.world_size = xdist.world_size(process_group)
     # dropout masks and the gradient penalty's alpha: drawn for the GLOBAL batch from a generator every rank seeds
     # identically, each rank keeping its image shard's rows -- results do not depend on the partition
-    self.rng = xdist.GlobalBatchRng(seed, device if device is not None else 'cpu')
+    self.rng = xdist.GlobalBatchRng(seed, device)  # device None: bound to the parameters' device at the first draw
     # EXPO_FORCE_COLLECTIVES=1: issue the gradient all-reduces even in a one-rank group, so the RCCL
     # path (and its hipGraph capture) can be exercised on a single GPU
     self.force_collectives = os.environ.get('EXPO_FORCE_COLLECTIVES', '0') == '1'
@@ -200,12 +200,13 @@ class GAN(nn.Module):
   def _draw_masks(self, n, device=None):
     """The two always-on dropout masks of feature_extractor (agent.py:36), partition-invariant (self.rng)."""
     keep = self.cfg.dropout_keep_prob
-    return [(self.rng.uniform(n, (self.cfg.feature_extractor_dims,), self.process_group) < keep).float()
+    dev = device if device is not None else next(self.parameters()).device
+    return [(self.rng.uniform(n, (self.cfg.feature_extractor_dims,), self.process_group, device=dev) < keep).float()
             for _ in range(2)]
 
   def _draw_alpha(self, n):
     """net.py:170-172: alpha ~ U(0, 1) per image for the interpolation of the gradient penalty."""
-    return self.rng.uniform(n, (1, 1, 1), self.process_group)
+    return self.rng.uniform(n, (1, 1, 1), self.process_group, device=next(self.parameters()).device)
 
   def generator_step(self, fake_input, z, states, progress, it=1, dropout_masks=None):
     """opt_g on g_loss w.r.t. theta_g and opt_v on v_loss w.r.t. theta_v (net.py:222-241)."""

@@ -18,8 +18,9 @@ frozen since 2016) -- the layout is restated from the published format: block = 
 ``varint shared | varint non_shared | varint value_len | key suffix | value`` followed by the restart
 array and its length; every block is followed by a 5-byte trailer (compression type, masked CRC-32C of
 contents + type); the 48-byte footer holds the metaindex and index block handles and the magic
-``0xdb4775248b80fb57``.  The writer exists so that weights trained here can be handed back to the
-reference's ``saver.restore`` and so that the reader has files to be tested on (no TF-written bundle
+``0xdb4775248b80fb57``.  The writer exists so that weights trained here can be handed back to a TF graph through
+``tf.train.Saver(var_list=<trainable variables>).restore`` (the reference's default saver also expects Adam slots,
+step counters and the EMA shadow, which are not written: exposure_amd/checkpoint.py::save) and so that the reader has files to be tested on (no TF-written bundle
 is available in this image: the reader's parity against TensorFlow itself is unpinned, its parity
 against the published format constants is tested in ``tests/test_tf_bundle.py``).
 

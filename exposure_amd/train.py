@@ -38,7 +38,7 @@ def main(argv=None):
   torch.manual_seed(args.seed)
   cfg = make_cfg()
   cfg.clamp = bool(args.clamp)
-  gan = GAN(cfg, device=dev, use_graphs=not args.no_graphs)
+  gan = GAN(cfg, device=dev, use_graphs=not args.no_graphs, seed=args.seed)  # (--seed also drives dropout / alpha)
   dt = torch.float32 if args.dtype == 'f32' else torch.float16
   # toy task with the statistics of the real one: dark linear-RAW-like inputs, brighter targets
   memory = ReplayMemory(cfg, SyntheticProvider(dev, gamma=2.2, scale=0.35, dtype=dt, seed=args.seed + 1),

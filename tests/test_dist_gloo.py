@@ -161,3 +161,16 @@ def test_drain_before_capture_without_a_process_group():
     assert 0.04 <= time.perf_counter() - t0 < 2.0
   finally:
     del os.environ['EXPO_CAPTURE_GRACE_S']
+
+
+def test_rng_follows_the_module_and_the_seed():
+  """GlobalBatchRng was pinned to the constructor's device ('cpu' by default), so GAN(cfg).to(device)
+  drew masks on the CPU for inputs elsewhere; and train.py --seed did not reach it.  The generator is now bound to
+  the parameters' device at the first draw, and two seeds give two streams."""
+  from exposure_amd.config import make_cfg
+  from exposure_amd.gan import GAN
+  a, b, c = GAN(make_cfg(), seed=1), GAN(make_cfg(), seed=1), GAN(make_cfg(), seed=2)
+  assert a.rng.gen is None  # nothing bound before the first draw
+  ma, mb, mc = a._draw_masks(4), b._draw_masks(4), c._draw_masks(4)
+  assert ma[0].device.type == 'cpu' and torch.equal(ma[0], mb[0]) and not torch.equal(ma[0], mc[0])
+  assert a._draw_alpha(4).shape == (4, 1, 1, 1)
