@@ -1622,7 +1622,8 @@ static ChainPlan chain_plan(int n, int h, int w, int dtype) {
   const long image_bytes = long(h) * w * 3L * (dtype == EXPO_F16 ? 2L : 4L);
   const long bytes = long(n) * image_bytes;
   int tiles = 1;
-  if (tile_mib > 0 && bytes >= (256L << 20) && n > 1) {
+  static const long tile_min = long(getenv("EXPO_CHAIN_TILE_MIN_MIB") ? atoi(getenv("EXPO_CHAIN_TILE_MIN_MIB")) : 256) << 20;
+  if (tile_mib > 0 && bytes >= tile_min && n > 1) {
     long tile_n = (long(tile_mib) << 20) / image_bytes;
     if (tile_n < 1) tile_n = 1;
     tiles = int((n + tile_n - 1) / tile_n);

@@ -57,8 +57,9 @@ def assert_param_grad_close(got, ref, abs_terms, what='', abs_coeff=PARAM_GRAD_A
   err = np.abs(got - ref)
   if _RECORD:
     with np.errstate(divide='ignore', invalid='ignore'):
-      ra = np.where(a > 0, err / a, 0.0)
-      rr = np.where(np.abs(ref) > 0, err / np.abs(ref), 0.0)
+      live = a > 1e-8 * (a.max() if a.size else 0.0)  # entries whose scale is float64-oracle noise: not a measurement
+      ra = np.where(live, err / np.where(live, a, 1.0), 0.0)
+      rr = np.where(live & (np.abs(ref) > 0), err / np.where(ref != 0, np.abs(ref), 1.0), 0.0)
     with open(_RECORD, 'a') as f:
       f.write(json.dumps({'what': what, 'err_over_A': float(ra.max()), 'err_over_ref': float(rr.max()),
                           'ref_over_A': float((np.abs(ref) / np.where(a > 0, a, 1)).min())}) + '\n')

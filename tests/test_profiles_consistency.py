@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, 'profiles')
-TAG = 'r03_final'
+TAG = 'r04_final'
 PX = {'64x512x512x3:f16': 64 * 512 * 512, '256x512x512x3:f16': 256 * 512 * 512}
 FILES = ['pmc_fetch_size', 'pmc_write_size', 'pmc_fetch_size_calibration', 'pmc_write_size_calibration',
          'pmc_fetch_size_cold', 'pmc_write_size_cold', 'pmc_fetch_size_calibration_512', 'pmc_write_size_calibration_512']

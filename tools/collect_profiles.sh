@@ -4,8 +4,8 @@
 set -euo pipefail
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/final
-TAG=${1:-r03_final}
-for f in bench_chain bench_chain_1stream bench_chain_A bench_chain_B bench_chain_f32 bench_chain_cold bench_infer_B bench_infer_C bench_chain_fused bench_chain_fused_B bench_chain_fused_f32_B bench_train bench_train_find_on bench_train_eager bench_extra; do
+TAG=${1:-r04_final}
+for f in bench_chain bench_chain_1stream bench_chain_A bench_chain_B bench_chain_f32 bench_chain_cold bench_chain_cold_untiled bench_infer_B bench_infer_C bench_chain_fused bench_chain_fused_B bench_chain_fused_f32_B bench_train bench_train_find_on bench_train_eager bench_extra; do
   [ -s $SRC/$f.json ] && cp $SRC/$f.json profiles/${TAG}_$f.json
 done
 for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt; do
@@ -29,6 +29,7 @@ for name in ('bench_chain', 'bench_chain_1stream'):
     r['rocprof_avg_us'] = bench.rocprof_avg_us(r['kernel'], prefix=tag.split('_')[0])
     json.dump(d, open(path, 'w'))
 PY
+[ -s $SRC/param_grad_errors.jsonl ] && python tools/r04/param_err_table.py $SRC/param_grad_errors.jsonl > profiles/${TAG}_param_grad_errors.md
 python tools/make_traffic.py $SRC profiles/traffic.json 64x512x512x3:f16 > /dev/null
 python tools/make_traffic.py $SRC profiles/traffic.json 256x512x512x3:f16 cold > /dev/null
 python tools/kernel_table.py $SRC > profiles/${TAG}_kernel_table.md

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every measured artefact under profiles/ in ONE gpurun call:
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/profile_all.sh'
-# then, back in the container:  tools/collect_profiles.sh r03_final
+# then, back in the container:  tools/collect_profiles.sh r04_final
 # (an 8-GPU lease additionally runs tools/scale_all.sh: the section 8(e) scaling table)
 # rocprofv3 passes: --kernel-trace alone (durations) and one --pmc counter per pass (never combined
 # with sys/runtime tracing); the rocpd databases stay on the GPU box, only CSV summaries come back.
@@ -13,13 +13,15 @@ db() { find "$1" -name "*.db" | head -1; }
 COLD=256,512,512
 Q="--no-cpu-baseline --cold-shape none --no-legs"
 
-python -m pytest $R/tests -x -q -m gpu 2>&1 | tail -2 > $OUT/pytest_gpu.txt
+# the gpu suite, recording the worst |err| / A of every reduced-quantity comparison (tests/_tol.py)
+EXPO_RECORD_PARAM_ERR=$OUT/param_grad_errors.jsonl python -m pytest $R/tests -x -q -m gpu 2>&1 | tail -2 > $OUT/pytest_gpu.txt
 python $R/bench.py > $OUT/bench_chain.json 2> $OUT/bench_chain.err
 EXPO_CHAIN_STREAMS=1 python $R/bench.py $Q > $OUT/bench_chain_1stream.json 2>/dev/null
 python $R/bench.py --shape A $Q > $OUT/bench_chain_A.json 2>/dev/null
 python $R/bench.py --shape B $Q > $OUT/bench_chain_B.json 2>/dev/null
 python $R/bench.py --dtype f32 $Q > $OUT/bench_chain_f32.json 2>/dev/null
-python $R/bench.py --shape $COLD $Q > $OUT/bench_chain_cold.json 2>/dev/null
+python $R/bench.py --shape $COLD $Q > $OUT/bench_chain_cold.json 2>/dev/null  # chain calls run tile-major (round 4)
+EXPO_CHAIN_TILE_MIB=0 python $R/bench.py --shape $COLD $Q > $OUT/bench_chain_cold_untiled.json 2>/dev/null  # round 3's alternating walk
 python $R/bench.py --workload infer --shape B > $OUT/bench_infer_B.json 2>/dev/null
 python $R/bench.py --workload infer --shape C > $OUT/bench_infer_C.json 2>/dev/null
 python $R/bench.py --workload chain_fused > $OUT/bench_chain_fused.json 2>/dev/null
@@ -47,7 +49,9 @@ kt() {  # name, command...
 kt chain_all python $R/bench.py $Q
 python $R/tools/rocpd_stats.py "$(db /tmp/kt_chain_all)" grid_y=64,8 > $OUT/kernel_stats_chain.csv  # (8: the finish launch, grid (images, steps))
 python $R/tools/rocpd_stats.py "$(db /tmp/kt_chain_all)" grid_y=32 > $OUT/kernel_stats_chain_halves.csv
-kt cold python $R/bench.py --shape $COLD $Q
+kt cold_all python $R/bench.py --shape $COLD $Q
+python $R/tools/rocpd_stats.py "$(db /tmp/kt_cold_all)" grid_y=256,8 > $OUT/kernel_stats_cold.csv  # whole-batch launches of the per-kernel leg
+python $R/tools/rocpd_stats.py "$(db /tmp/kt_cold_all)" grid_y=32 > $OUT/kernel_stats_cold_tiles.csv  # the chain calls: half-tile launches
 kt chain_B python $R/bench.py --shape B $Q
 kt infer_B python $R/bench.py --workload infer --shape B
 kt infer_C python $R/bench.py --workload infer --shape C
@@ -76,7 +80,7 @@ export EXPO_CHAIN_STREAMS=1  # whole-batch launches: bytes per launch are quoted
 for c in FETCH_SIZE WRITE_SIZE; do
   lc=$(echo $c | tr 'A-Z' 'a-z')
   pmc $c chain python $R/bench.py $Q --no-per-kernel --steps 3 --warmup 1
-  pmc $c cold python $R/bench.py --shape $COLD $Q --no-per-kernel --steps 2 --warmup 1
+  EXPO_CHAIN_TILE_MIB=0 pmc $c cold python $R/bench.py --shape $COLD $Q --no-per-kernel --steps 2 --warmup 1  # whole-batch launches
   pmc $c infer_B python $R/bench.py --workload infer --shape B --steps 5 --warmup 2
   pmc $c extra python $R/tools/bench_extra.py
   pmc $c chain_fused python $R/bench.py --workload chain_fused --steps 3 --warmup 1

@@ -1,0 +1,70 @@
+"""Which Python lines of a training step issue which aten ops (TorchDispatchMode on the real GPU path, eager).
+usage (GPU box): python tools/r04/op_audit.py > out.txt"""
+import collections
+import os
+import sys
+import traceback
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from exposure_amd.config import make_cfg  # noqa: E402
+from exposure_amd.gan import GAN  # noqa: E402
+from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider  # noqa: E402
+
+VIEW_OPS = ('view', 'permute', 'select', 'slice', 'detach', 't.default', 'unsqueeze', 'squeeze', 'expand', 'alias', 'reshape',
+            'as_strided', '_unsafe_view', 'transpose', 'empty', 'lift_fresh', '_local_scalar', 'is_', 'size', 'stride')
+
+
+class Counter(TorchDispatchMode):
+
+  def __init__(self):
+    super().__init__()
+    self.where = collections.Counter()
+    self.ops = collections.Counter()
+
+  def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+    name = str(func).replace('aten.', '')
+    if not any(v in name for v in VIEW_OPS):
+      st = traceback.extract_stack(limit=16)
+      frames = [f for f in st if 'exposure_amd' in f.filename]
+      site = ' < '.join('%s:%d' % (os.path.basename(f.filename), f.lineno) for f in reversed(frames[-3:])) or 'autograd engine'
+      self.where[(site, name)] += 1
+      self.ops[name] += 1
+    return func(*args, **(kwargs or {}))
+
+
+def main():
+  dev = torch.device('cuda:0')
+  cfg = make_cfg()
+  torch.manual_seed(0)
+  gan = GAN(cfg, device=dev, use_graphs=False, seed=0)
+  n = cfg.batch_size
+  memory = ReplayMemory(cfg, SyntheticProvider(dev, dtype=torch.float16, seed=1),
+                        SyntheticProvider(dev, gamma=1.0, dtype=torch.float16, seed=2), seed=0)
+  for _ in range(8):
+    feed, feats = memory.get_feed_dict_and_states(n)
+    o = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
+    memory.replace_memory(o['fake_output'], o['new_states'], feats)
+  rep = memory.get_replay_feed_dict(n)
+  gan.critic_step(rep['real_data'], rep['fake_output'], it=1)
+  for which in ('generator_step', 'critic_step', 'memory'):
+    feed, feats = memory.get_feed_dict_and_states(n)
+    rep = memory.get_replay_feed_dict(n)
+    with Counter() as cnt:
+      if which == 'generator_step':
+        o = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.1, it=1)
+      elif which == 'critic_step':
+        gan.critic_step(rep['real_data'], rep['fake_output'], it=1)
+      else:
+        feed, feats = memory.get_feed_dict_and_states(n)
+        memory.replace_memory(o['fake_output'], o['new_states'], feats)
+        memory.get_replay_feed_dict(n)
+    print('=====', which, sum(cnt.ops.values()), 'non-view ops')
+    for (site, name), c in cnt.where.most_common(90):
+      print('%5d  %-34s %s' % (c, name[:34], site))
+
+
+if __name__ == '__main__':
+  main()
