@@ -1544,24 +1544,26 @@ struct ForkJoin {
   hipStream_t helper = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
 };
-static ForkJoin* fork_join_for_device() {
-  static ForkJoin table[64];
+// One helper stream + event pair PER (device, caller stream): two host threads that drive two user streams -- one of
+// them possibly inside a hipGraph capture, which the helper then joins -- no longer meet on one helper and one event
+// pair (advisor, round 3).  Entries are created on first use and live for the process (a handful of streams).
+static ForkJoin* fork_join_for_device(hipStream_t caller = nullptr) {
+  struct Entry { int dev; hipStream_t caller; ForkJoin fj; };
+  static std::vector<Entry*> table;
   static std::mutex mu;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  ForkJoin& f = table[dev];
-  if (!f.helper) {
-    hipStream_t st;
-    hipEvent_t e0, e1;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return nullptr;
-    f.helper = st;
-    f.fork = e0;
-    f.join = e1;
-  }
-  return &f;
+  for (Entry* e : table)
+    if (e->dev == dev && e->caller == caller) return &e->fj;
+  hipStream_t st;
+  hipEvent_t e0, e1;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return nullptr;
+  Entry* e = new Entry{dev, caller, ForkJoin{st, e0, e1}};
+  table.push_back(e);
+  return &e->fj;
 }
 // fork: helper waits for everything `s` holds; join: `s` waits for everything the helper holds.  The event is shared by
 // all callers of a device, so record + wait must not interleave with another host thread's pair (its record would
@@ -1826,7 +1828,7 @@ int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const fl
   }
   const size_t esz = dtype == EXPO_F16 ? 2 : 4;
   const ChainPlan plan = chain_plan(n, h, w, dtype);
-  ForkJoin* fj = plan.two_lanes ? fork_join_for_device() : nullptr;
+  ForkJoin* fj = plan.two_lanes ? fork_join_for_device(s) : nullptr;
   if (plan.two_lanes && !fj) return fail(EXPO_E_HIP, "helper stream unavailable");
   if (fj) {
     if (int rc = chain_fork(fj, s)) return rc;
@@ -1919,7 +1921,7 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
   const size_t step_floats = ws_step_bytes(n, bx_max) / sizeof(float);
   const size_t esz = dtype == EXPO_F16 ? 2 : 4;
   const ChainPlan plan = chain_plan(n, h, w, dtype);
-  ForkJoin* fj = plan.two_lanes ? fork_join_for_device() : nullptr;
+  ForkJoin* fj = plan.two_lanes ? fork_join_for_device(s) : nullptr;
   if (plan.two_lanes && !fj) return fail(EXPO_E_HIP, "helper stream unavailable");
   if (fj) {
     if (int rc = chain_fork(fj, s)) return rc;
