@@ -61,6 +61,8 @@ SIGNATURES = {
     'expo_vignet_apply_bwd': (_i, [_vp, _vp, _vp, _fp, _fp, _f, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_bias_lrelu_fwd': (_i, [_fp, _fp, _fp, _sz, _i, _f, _vp]),
     'expo_lrelu_bwd': (_i, [_fp, _fp, _fp, _sz, _f, _vp]),
+    'expo_lrelu_bwd_bias_workspace_bytes': (_sz, [_i]),
+    'expo_lrelu_bwd_bias': (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _vp, _sz, _vp]),
     'expo_curve_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'expo_curve_fwd': (_i, [_vp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     'expo_curve_bwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -546,6 +548,33 @@ def vignet_apply_bwd(x, dy, dx, mask_params, dmask_params, maximum_sharpness, ma
     _check(lib.expo_vignet_apply_bwd(_ptr(x), _ptr(dy), _ptr(dx), _ptr(mask_params), _ptr(dmask_params),
                                      float(maximum_sharpness), int(bool(masking)), n, h, w, _dtype_code(x), wsp, wsb,
                                      _stream()), 'expo_vignet_apply_bwd')
+
+
+def lrelu_bwd_bias(z, dz, dy, dbias, leak=0.2, workspace=None):
+  """dy = dz * lrelu'(.) AND dbias = column sums of dy in one pass (channel = last dimension of z)."""
+  lib = load()
+  channels = z.shape[-1]
+  for t in (z, dz, dy):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == z.shape):
+      raise ExposureHipError('exposure_amd: lrelu_bwd_bias wants contiguous float32 device tensors of one shape')
+  _f32(dbias, 'dbias', (channels,))
+  need = int(lib.expo_lrelu_bwd_bias_workspace_bytes(int(channels)))
+  with torch.cuda.device(z.device):
+    if workspace is None:
+      workspace = reserve_workspace(z.device, need)
+      _order_shared_workspace(z.device)
+    _check(lib.expo_lrelu_bwd_bias(_ptr(z), _ptr(dz), _ptr(dy), _ptr(dbias), z.numel(), int(channels), float(leak),
+                                   ctypes.c_void_p(workspace.data_ptr()),
+                                   ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()),
+           'expo_lrelu_bwd_bias')
+
+
+def lrelu_bwd_bias_supported(z, dz):
+  c = z.shape[-1]
+  if os.environ.get('EXPO_FUSED_BIAS_GRAD', '1') == '0':  # A/B switch: the separate column reduction of round 3
+    return False
+  return z.is_cuda and 4 <= c <= 256 and (c & (c - 1)) == 0 and z.numel() > 0 and z.data_ptr() % 16 == 0 and \
+      dz.data_ptr() % 16 == 0 and z.dtype == torch.float32 and dz.dtype == torch.float32 and z.is_contiguous()
 
 
 def curve_fwd(x, y, params, curves, steps):

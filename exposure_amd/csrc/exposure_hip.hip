@@ -42,6 +42,9 @@
 #ifndef EXPO_BWD_MIN_WAVES
 #define EXPO_BWD_MIN_WAVES  // e.g. -DEXPO_BWD_MIN_WAVES=,5 : a register budget for 5 waves per SIMD (probe builds)
 #endif
+#ifndef EXPO_CURVE_BWD_PREFETCH
+#define EXPO_CURVE_BWD_PREFETCH 1  // (probe builds: the curve backward without its one-deep software prefetch)
+#endif
 constexpr bool kFwdPrefetch = false;
 constexpr bool kBwdPrefetch = true;
 constexpr int kAccParts = 4;  // partial sums per thread in the element-wise backward (1 / 2 / 4 measured, r02p27)
@@ -217,9 +220,9 @@ __device__ __forceinline__ void bwd_body(const T* __restrict__ xi, const T* __re
   };
   if constexpr (VEC) {
     const T* const ins[2] = {xi, dyi};
-    stream_groups<T, 2, HAS_DX, kBwdPrefetch, IO>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
-                                                  [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); },
-                                                  stage_lut);
+    constexpr bool kPf = (F::kLutFloats > 0 && !PEN) ? bool(EXPO_CURVE_BWD_PREFETCH) : kBwdPrefetch;
+    stream_groups<T, 2, HAS_DX, kPf, IO>(ins, dxi, hw, blockIdx.x * kThreads + (threadIdx.x & ~63), stride,
+                                         [&](float (&v)[2][PPL * 3], int g) { compute(v[0], v[1], g); }, stage_lut);
   } else {
     for (int g = blockIdx.x * kThreads + threadIdx.x; g < groups; g += stride) {
       float v[PPL * 3], d[PPL * 3];

@@ -68,6 +68,66 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict_
   }
 }
 
+// dy = dz * slope(z) AND the bias gradient db[c] = sum_rows dy[row][c] in the same pass (round 4: the separate column
+// reduction re-read dy -- 8 MB for the first layer at batch 64 -- and was one more launch per layer and backward).
+// 256 threads, one float4 (4 consecutive channels) per thread and trip; gridDim.x * 256 is a multiple of C / 4 (C / 4 is a
+// power of two <= 64), so a thread keeps its channel group and accumulates it in registers; per block the threads of one
+// channel group are added in a fixed order into partial[block][C]; bias_grad_finish_kernel adds the blocks in order.
+// No atomics, no zero fill, bit-reproducible.
+constexpr int kBgMaxBlocks = 2048;  // enough waves to stream at full bandwidth; partial sums: 2048 x C floats
+__global__ __launch_bounds__(256) void lrelu_bwd_bias_kernel(const float* __restrict__ z, const float* __restrict__ dz,
+                                                             float* __restrict__ dy, float* __restrict__ partial,
+                                                             size_t count, int channels, float leak) {
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  const size_t n4 = count / 4;
+  float4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(z)[i];
+    float4 g = reinterpret_cast<const float4*>(dz)[i];
+    g.x *= lrelu_slope(a.x, leak); g.y *= lrelu_slope(a.y, leak);
+    g.z *= lrelu_slope(a.z, leak); g.w *= lrelu_slope(a.w, leak);
+    reinterpret_cast<float4*>(dy)[i] = g;
+    acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+  }
+  __shared__ float4 part[256];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  const int groups = channels / 4;  // threads t, t + groups, t + 2 groups, ... share channel group t
+  if (threadIdx.x < unsigned(groups)) {
+    float4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int k = threadIdx.x; k < 256; k += groups) {
+      const float4 p = part[k];
+      t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+    }
+    reinterpret_cast<float4*>(partial + size_t(blockIdx.x) * channels)[threadIdx.x] = t;
+  }
+}
+// One block per 4 channels: thread (g, c) -- c = 0..3, g = 0..63 -- adds the blocks b = g, g + 64, ... of its channel
+// (independent loads), then the 64 partial sums of a channel are added in order: fixed order, blocks / 64 loads deep.
+__global__ __launch_bounds__(256) void bias_grad_finish_kernel(const float* __restrict__ partial, float* __restrict__ db,
+                                                               int blocks, int channels) {
+  __shared__ float part[256];
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3), g = threadIdx.x >> 2;
+  float t = 0.f;
+  int b = g;
+  for (; b + 3 * 64 < blocks; b += 4 * 64) {
+    const float a0 = partial[size_t(b) * channels + c], a1 = partial[size_t(b + 64) * channels + c];
+    const float a2 = partial[size_t(b + 128) * channels + c], a3 = partial[size_t(b + 192) * channels + c];
+    t += a0;
+    t += a1;
+    t += a2;
+    t += a3;
+  }
+  for (; b < blocks; b += 64) t += partial[size_t(b) * channels + c];
+  part[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float s = 0.f;
+    for (int k = 0; k < 64; ++k) s += part[k * 4 + threadIdx.x];
+    db[blockIdx.x * 4 + threadIdx.x] = s;
+  }
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int grid_for(size_t items) {
   const size_t blocks = (items + 255) / 256;
@@ -107,6 +167,31 @@ int expo_lrelu_bwd(const float* z, const float* dz, float* dy, size_t count, flo
   if (vec) hipLaunchKernelGGL((lrelu_bwd_kernel<true>), dim3(grid), dim3(256), 0, s, z, dz, dy, count, leak);
   else hipLaunchKernelGGL((lrelu_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, z, dz, dy, count, leak);
   HIP_TRY(hipGetLastError(), "lrelu_bwd launch");
+  return EXPO_OK;
+}
+
+size_t expo_lrelu_bwd_bias_workspace_bytes(int channels) {
+  return channels > 0 ? size_t(kBgMaxBlocks) * size_t(channels) * sizeof(float) : 0;
+}
+
+int expo_lrelu_bwd_bias(const float* z, const float* dz, float* dy, float* dbias, size_t count, int channels, float leak,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!z || !dz || !dy || !dbias) return fail(EXPO_E_BADARG, "null pointer");
+  if (channels < 4 || channels > 256 || (channels & (channels - 1)) != 0)
+    return fail(EXPO_E_BADARG, "channels must be a power of two in [4, 256]");
+  if (count == 0 || count % size_t(channels) != 0) return fail(EXPO_E_BADARG, "count must be a positive multiple of channels");
+  if (!aligned16(z) || !aligned16(dz) || !aligned16(dy)) return fail(EXPO_E_BADARG, "pointers must be 16-byte aligned");
+  if (!workspace || workspace_bytes < expo_lrelu_bwd_bias_workspace_bytes(channels) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+    return fail(EXPO_E_BADARG, "workspace missing, misaligned or too small (expo_lrelu_bwd_bias_workspace_bytes)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  size_t blocks = (count / 4 + 255) / 256;
+  if (blocks > size_t(kBgMaxBlocks)) blocks = kBgMaxBlocks;
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(lrelu_bwd_bias_kernel, dim3(unsigned(blocks)), dim3(256), 0, s, z, dz, dy, partial, count, channels, leak);
+  HIP_TRY(hipGetLastError(), "lrelu_bwd_bias launch");
+  hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(channels / 4), dim3(256), 0, s, partial, dbias, int(blocks), channels);
+  HIP_TRY(hipGetLastError(), "bias_grad_finish launch");
   return EXPO_OK;
 }
 

@@ -153,6 +153,30 @@ class _LreluGrad(torch.autograd.Function):
     return None, _LreluGrad.apply(z, v, ctx.leak), None
 
 
+class _LreluGradBias(torch.autograd.Function):
+  """(dy, dbias) = (dz * slope(z), column sums of dy) in ONE pass (``expo_lrelu_bwd_bias``, round 4): the layer's bias
+  gradient no longer costs a second reduction launch that re-reads dy.  Linear in dz; its own backward is the plain
+  ``_LreluGrad`` of the two incoming gradients combined."""
+
+  @staticmethod
+  def forward(ctx, z, dz, leak):
+    dz = dz.contiguous()
+    dy = torch.empty_like(dz)
+    db = torch.empty((z.shape[-1],), dtype=torch.float32, device=z.device)
+    _cabi.lrelu_bwd_bias(z, dz, dy, db, leak)
+    ctx.save_for_backward(z)
+    ctx.leak = leak
+    return dy, db
+
+  @staticmethod
+  def backward(ctx, v_dy, v_db):
+    z, = ctx.saved_tensors
+    if v_dy is None and v_db is None:
+      return None, None, None
+    v = v_dy if v_db is None else (v_db.expand_as(z) if v_dy is None else v_dy + v_db)
+    return None, _LreluGrad.apply(z, v, ctx.leak), None
+
+
 class _BiasLrelu(torch.autograd.Function):
 
   @staticmethod
@@ -168,10 +192,14 @@ class _BiasLrelu(torch.autograd.Function):
   @staticmethod
   def backward(ctx, gz):
     z, = ctx.saved_tensors
+    want_gb = ctx.has_bias and ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS
+    if want_gb:
+      gz = gz.contiguous()
+      if _cabi.lrelu_bwd_bias_supported(z, gz):
+        gy, gb = _LreluGradBias.apply(z, gz, ctx.leak)
+        return gy, gb, None
     gy = _LreluGrad.apply(z, gz, ctx.leak)
-    gb = None
-    if ctx.has_bias and ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS:
-      gb = gy.reshape(-1, gy.shape[-1]).sum(dim=0)
+    gb = gy.reshape(-1, gy.shape[-1]).sum(dim=0) if want_gb else None
     return gy, gb, None
 
 

@@ -356,6 +356,14 @@ int expo_critic_stats_hvp(const void* x, const float* dstats, const float* jv, c
 int expo_bias_lrelu_fwd(const float* y, const float* bias, float* z, size_t count, int channels, float leak,
                         void* stream);
 int expo_lrelu_bwd(const float* z, const float* dz, float* dy, size_t count, float leak, void* stream);
+/* (ABI 4) The same backward WITH the layer's bias gradient: dy as above and dbias[c] = sum over rows of dy[row][c]
+ * (what tf.gradients returns for the biases of ly.conv2d / ly.fully_connected: agent.py:21-32, critics.py:13-35) in one
+ * pass over dz instead of a second reduction pass over dy.  channels: a power of two in [4, 256]; count a multiple of
+ * channels; 16-byte aligned pointers; dbias [channels] is overwritten; workspace >= expo_lrelu_bwd_bias_workspace_bytes(
+ * channels) bytes, 16-byte aligned, uninitialised.  No atomics; bit-reproducible. */
+size_t expo_lrelu_bwd_bias_workspace_bytes(int channels);
+int expo_lrelu_bwd_bias(const float* z, const float* dz, float* dy, float* dbias, size_t count, int channels,
+                        float leak, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * ToneFilter / ColorFilter with ANY number of curve steps L = cfg.curve_steps (config_example.py:27; the reference

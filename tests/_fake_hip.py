@@ -223,6 +223,11 @@ def _curve_bwd(x, dy, dx, params, dparams, curves, steps, workspace=None):
   dparams.copy_(gp.float())
 
 
+def _lrelu_bwd_bias(z, dz, dy, dbias, leak=0.2, workspace=None):
+  _lrelu_bwd(z, dz, dy, leak)
+  dbias.copy_(dy.reshape(-1, dy.shape[-1]).sum(dim=0))
+
+
 def _penalty(y, pen):
   pen.copy_(torch.from_numpy(agent_np.overexposure_penalty(y.double().numpy())).float())
 
@@ -236,5 +241,6 @@ def fake_hip():
                            vignet_apply_fwd=_vignet_fwd, vignet_apply_bwd=_vignet_bwd,
                            apply_dispatch_fwd=_apply_dispatch_fwd, apply_dispatch_bwd=_apply_dispatch_bwd,
                            chain_fused_fwd=_chain_fused_fwd, chain_fused_bwd=_chain_fused_bwd, apply_fwd=_apply_fwd, apply_bwd=_apply_bwd,
-                           curve_fwd=_curve_fwd, curve_bwd=_curve_bwd):
+                           curve_fwd=_curve_fwd, curve_bwd=_curve_bwd, lrelu_bwd_bias=_lrelu_bwd_bias,
+                           lrelu_bwd_bias_supported=lambda z, dz: z.shape[-1] % 4 == 0):
     yield
