@@ -17,7 +17,7 @@ CSRC = os.path.join(ROOT, 'exposure_amd', 'csrc')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # (source, extra flags) exactly as exposure_amd/csrc/build.sh compiles them
 UNITS = [('exposure_hip.hip', []), ('chain_fused.hip', ['-fno-slp-vectorize', '-fno-honor-nans']), ('nn_ops.hip', []),
-         ('chain_fused_bwd.hip', ['-fno-slp-vectorize'])]
+         ('chain_fused_bwd.hip', ['-fno-slp-vectorize']), ('curve_generic.hip', [])]
 
 
 def _listing(unit, tmp):
