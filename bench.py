@@ -578,12 +578,12 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
   for _ in range(8):
     feed, feats = memory.get_feed_dict_and_states(n)
     out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
-    memory.replace_memory(out['fake_output'], out['new_states'], feats)
+    memory.replace_memory(out['fake_output'], out['new_states'], feats, advanced=True)
 
   def iteration(it):
     feed, feats = memory.get_feed_dict_and_states(n)
     out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], progress=it / cfg.max_iter_step, it=it)
-    memory.replace_memory(out['fake_output'], out['new_states'], feats)
+    memory.replace_memory(out['fake_output'], out['new_states'], feats, advanced=True)
     for _ in range(cfg.citers):
       rep = memory.get_replay_feed_dict(n)
       gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
@@ -657,12 +657,12 @@ def train_cpu_baseline(steps=2):
       for _ in range(6):
         feed, feats = memory.get_feed_dict_and_states(n)
         out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
-        memory.replace_memory(out['fake_output'], out['new_states'], feats)
+        memory.replace_memory(out['fake_output'], out['new_states'], feats, advanced=True)
 
       def iteration(it):
         feed, feats = memory.get_feed_dict_and_states(n)
         out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], progress=0.1, it=it)
-        memory.replace_memory(out['fake_output'], out['new_states'], feats)
+        memory.replace_memory(out['fake_output'], out['new_states'], feats, advanced=True)
         for _ in range(cfg.citers):
           rep = memory.get_replay_feed_dict(n)
           gan.critic_step(rep['real_data'], rep['fake_output'], it=it)

@@ -368,7 +368,7 @@ class GAN(nn.Module):
       for _ in range(giters):
         feed, features = memory.get_feed_dict_and_states(cfg.batch_size)
         g_out = self.generator_step(feed['fake_input'], feed['z'], feed['states'], progress, it=it)
-        memory.replace_memory(g_out['fake_output'], g_out['new_states'], features)
+        memory.replace_memory(g_out['fake_output'], g_out['new_states'], features, advanced=True)
       c_out = None
       for _ in range(citers):
         feed = memory.get_replay_feed_dict(cfg.batch_size)

@@ -7,7 +7,26 @@ but the images never leave the GPU: the reference downloads ``fake_output`` and 
 through feed dicts every step (``net.py:325-342``), here the pool is three device tensors and a
 step moves only indices.  Randomness comes from an explicit ``torch.Generator`` (host) so runs are
 reproducible.
+
+Round 4: no host synchronisation in the training loop.  Round 3's pool re-gathered every record at every shuffle and
+asked the DEVICE which records had terminated (``nonzero().cpu()``, boolean-mask indexing): 8+ host syncs and ~150
+eager launches per iteration, 1.8 ms of a 14.2 ms iteration (``tools/r04/memory_cost.py``).  Now
+
+* the records sit in fixed physical SLOTS of three device buffers (capacity = pool size + one batch); the pool's ORDER is
+  a host array of slot ids -- shuffling, popping, cutting and truncating touch no device memory;
+* the two state fields the pool's decisions read (``stopped``, ``step``) are mirrored on the host.  They are known
+  there without asking the device: fresh records start at 0, and an agent step maps ``step -> step + 1`` and
+  ``stopped -> |step + 1 - cfg.test_steps| < 1e-4`` (``agent.py:207-238``) whatever the networks compute.
+  ``replace_memory(..., advanced=True)`` (the training loops) applies that rule to the batch popped last;
+  without it the two columns are read back from the device (one sync: arbitrary caller-made states);
+* index vectors and the selection noise reach the device through a ring of PINNED staging buffers
+  (``non_blocking`` copies: a pageable host-to-device copy would wait for the stream);
+* what remains on the device per call is the gather / scatter of the batch itself (3 launches each).
+
+The sequence of random decisions (shuffles, keep draws, noise) is the one of the round-3 implementation, draw for draw:
+``tests/test_replay_and_loop.py`` runs both side by side and requires identical batches.
 """
+import numpy as np
 import torch
 
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
@@ -33,6 +52,37 @@ class SyntheticProvider:
     return x, feat
 
 
+class _PinnedRing:
+  """Host staging buffers for small host -> device transfers that must not wait for the stream.  A buffer is reused
+  only after the copy that read it has completed (its event; in steady state that was many calls ago)."""
+
+  def __init__(self, device, slots=16):
+    self.device = torch.device(device)
+    self.cuda = self.device.type == 'cuda'
+    self.slots, self.bufs, self.events, self.at = slots, {}, {}, 0
+
+  def put(self, host_tensor):
+    """Device copy of a (small) host tensor; asynchronous on a GPU."""
+    if not self.cuda:
+      return host_tensor.clone()
+    key = (host_tensor.dtype, self.at % self.slots)
+    self.at += 1
+    buf = self.bufs.get(key)
+    if buf is None or buf.numel() < host_tensor.numel():
+      buf = torch.empty(max(host_tensor.numel(), 256), dtype=host_tensor.dtype).pin_memory()
+      self.bufs[key] = buf
+    ev = self.events.get(key)
+    if ev is not None:
+      ev.synchronize()
+    view = buf[:host_tensor.numel()].view(host_tensor.shape)
+    view.copy_(host_tensor)
+    out = view.to(self.device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    self.events[key] = ev
+    return out
+
+
 class ReplayMemory:
 
   def __init__(self, cfg, fake_provider, real_provider, seed=0):
@@ -42,9 +92,14 @@ class ReplayMemory:
     self.device = fake_provider.device
     self.target_pool_size = cfg.replay_memory_size
     self.rng = torch.Generator().manual_seed(seed)  # host generator: shuffles / keep decisions / z
-    self.images = None  # (P, S, S, 3)
-    self.states = None  # (P, num_state_dim)
-    self.features = None  # (P,)
+    self._ring = _PinnedRing(self.device)
+    self._cap = 0
+    self._img = self._st = self._ft = None  # physical slots: (cap, S, S, 3), (cap, D), (cap,)
+    self._order = np.zeros((0,), dtype=np.int64)  # logical pool: slot ids, front = next to pop
+    self._free = []
+    self._h_stopped = np.zeros((0,), dtype=np.float64)  # host mirrors of the two fields the pool reads
+    self._h_step = np.zeros((0,), dtype=np.float64)
+    self._popped = None  # host (step, stopped) of the batch popped last (replace_memory(advanced=True))
     self.fill_pool()
 
   # -- replay_memory.py:54-63
@@ -52,84 +107,154 @@ class ReplayMemory:
     return torch.zeros((batch_size, self.cfg.num_state_dim), dtype=torch.float32, device=self.device)
 
   def __len__(self):
-    return 0 if self.images is None else self.images.shape[0]
+    return int(self._order.size)
 
-  def _append(self, images, states, features):
-    if self.images is None:
-      self.images, self.states, self.features = images, states, features
-    else:
-      self.images = torch.cat([self.images, images], dim=0)
-      self.states = torch.cat([self.states, states], dim=0)
-      self.features = torch.cat([self.features, features], dim=0)
+  # ---- the pool in logical order (tests, debugging; a gather per access)
+  def _idx(self, slots):
+    return self._ring.put(torch.from_numpy(np.ascontiguousarray(slots, dtype=np.int64)))
 
-  def _take(self, idx):
-    idx = idx.to(self.device)
-    return self.images[idx], self.states[idx], self.features[idx]
+  @property
+  def images(self):
+    return self._img.index_select(0, self._idx(self._order))
+
+  @property
+  def states(self):
+    return self._st.index_select(0, self._idx(self._order))
+
+  @property
+  def features(self):
+    return self._ft.index_select(0, self._idx(self._order))
+
+  # ---- slots
+  def _ensure_capacity(self, like_images, like_states, like_features, need):
+    if self._img is not None and self._cap >= need:
+      return
+    cap = max(need, self.target_pool_size + max(int(self.cfg.batch_size), like_images.shape[0]))
+    img = torch.zeros((cap,) + tuple(like_images.shape[1:]), dtype=like_images.dtype, device=self.device)
+    st = torch.zeros((cap,) + tuple(like_states.shape[1:]), dtype=like_states.dtype, device=self.device)
+    ft = torch.zeros((cap,) + tuple(like_features.shape[1:]), dtype=like_features.dtype, device=self.device)
+    if self._img is not None:  # grow (rare: a caller appending more than one batch)
+      img[:self._cap], st[:self._cap], ft[:self._cap] = self._img, self._st, self._ft
+    self._free += list(range(self._cap, cap))
+    self._h_stopped = np.concatenate([self._h_stopped, np.zeros(cap - self._cap)])
+    self._h_step = np.concatenate([self._h_step, np.zeros(cap - self._cap)])
+    self._img, self._st, self._ft, self._cap = img, st, ft, cap
+
+  def _append(self, images, states, features, h_step, h_stopped, rows=None):
+    """Append records (optionally only the rows ``rows`` of the given tensors, a host index array) at the back."""
+    n = images.shape[0] if rows is None else int(len(rows))
+    if n == 0:
+      return
+    self._ensure_capacity(images, states, features, len(self) + n)
+    slots = np.array([self._free.pop() for _ in range(n)], dtype=np.int64)
+    dst = self._idx(slots)
+    if rows is not None and n != images.shape[0]:
+      src = self._idx(rows)
+      images, states, features = images.index_select(0, src), states.index_select(0, src), features.index_select(0, src)
+    self._img.index_copy_(0, dst, images.to(self._img.dtype))
+    self._st.index_copy_(0, dst, states.to(self._st.dtype))
+    self._ft.index_copy_(0, dst, features.to(self._ft.dtype))
+    self._h_step[slots] = h_step
+    self._h_stopped[slots] = h_stopped
+    self._order = np.concatenate([self._order, slots])
+
+  def _drop(self, positions_kept):
+    """Keep the logical positions given (a slice result); the others' slots become free."""
+    keep = self._order[positions_kept]
+    gone = np.setdiff1d(self._order, keep, assume_unique=True)
+    self._free += gone.tolist()
+    self._order = keep
+
+  def _take(self, slots):
+    idx = self._idx(slots)
+    return self._img.index_select(0, idx), self._st.index_select(0, idx), self._ft.index_select(0, idx)
 
   def _shuffle(self):
-    perm = torch.randperm(len(self), generator=self.rng).to(self.device)
-    self.images, self.states, self.features = self.images[perm], self.states[perm], self.features[perm]
+    perm = torch.randperm(len(self), generator=self.rng).numpy()
+    self._order = self._order[perm]
 
   # -- replay_memory.py:65-77
   def fill_pool(self):
     while len(self) < self.target_pool_size:
       batch, features = self.fake_dataset.get_next_batch(self.cfg.batch_size)
-      self._append(batch, self.get_initial_states(batch.shape[0]), features)
-    self.images = self.images[:self.target_pool_size]
-    self.states = self.states[:self.target_pool_size]
-    self.features = self.features[:self.target_pool_size]
+      self._append(batch, self.get_initial_states(batch.shape[0]), features, 0.0, 0.0)
+    if len(self) > self.target_pool_size:
+      self._drop(slice(0, self.target_pool_size))
 
   def get_noise(self, batch_size):
     """replay_memory.py:177-185: cfg.z_type 'uniform' (U(0, 1), both shipped configs) or 'normal' (N(0, 1))."""
     z_type = getattr(self.cfg, 'z_type', 'uniform')
     if z_type == 'normal':
-      return torch.randn((batch_size, self.cfg.z_dim), generator=self.rng).to(self.device)
+      return self._ring.put(torch.randn((batch_size, self.cfg.z_dim), generator=self.rng))
     assert z_type == 'uniform', 'Unknown noise type: %s' % z_type
-    return torch.rand((batch_size, self.cfg.z_dim), generator=self.rng).to(self.device)
+    return self._ring.put(torch.rand((batch_size, self.cfg.z_dim), generator=self.rng))
 
   # -- replay_memory.py:235-252: pop NON-terminated records from the shuffled pool
   def get_next_fake_batch(self, batch_size):
     self._shuffle()
     assert batch_size <= len(self)
-    got_i, got_s, got_f, have = [], [], [], 0
+    got, taken, have = [], [], 0
     while have < batch_size:
       if len(self) == 0:
         self.fill_pool()
-      live = (self.states[:, STATE_STOPPED_DIM] != 1).nonzero().flatten().cpu()
+      live = np.nonzero(self._h_stopped[self._order] != 1)[0]
       need = batch_size - have
-      if live.numel() >= need:
+      if live.size >= need:
         # records in front of (and including) the need-th live one are consumed, like the pops
         cut = int(live[need - 1]) + 1
         take = live[:need]
       else:
         cut = len(self)
         take = live
-      i, s, f = self._take(take)
-      got_i.append(i), got_s.append(s), got_f.append(f)
-      have += take.numel()
-      self.images, self.states, self.features = self.images[cut:], self.states[cut:], self.features[cut:]
-    return torch.cat(got_i), torch.cat(got_s), torch.cat(got_f)
+      slots = self._order[take]
+      got.append(self._take(slots))  # gathered BEFORE the slots are released (a refill may reuse them)
+      taken.append(slots)
+      have += take.size
+      self._drop(slice(cut, None))
+    slots = np.concatenate(taken)
+    self._popped = (self._h_step[slots].copy(), self._h_stopped[slots].copy())
+    if len(got) == 1:
+      return got[0]
+    return tuple(torch.cat([g[k] for g in got]) for k in range(3))
 
   # -- replay_memory.py:254-279: terminated records only (with repetition if there are few)
   def replay_fake_batch(self, batch_size):
     self.fill_pool()
     self._shuffle()
     assert batch_size <= len(self)
-    done = (self.states[:, STATE_STOPPED_DIM] > 0).nonzero().flatten().cpu()
-    assert done.numel() > 0, 'No terminated states discovered'
-    reps = (batch_size + done.numel() - 1) // done.numel()
-    idx = done.repeat(reps)[:batch_size]
-    return self._take(idx)
+    done = self._order[self._h_stopped[self._order] > 0]
+    assert done.size > 0, 'No terminated states discovered'
+    reps = (batch_size + done.size - 1) // done.size
+    return self._take(np.tile(done, reps)[:batch_size])
 
   # -- replay_memory.py:199-209
-  def replace_memory(self, images, states, features):
+  def replace_memory(self, images, states, features, advanced=False):
+    """``advanced=True``: ``states`` are the agent's update (``agent.py:207-238``) of the batch the last
+    ``get_next_fake_batch`` returned, in the same order -- the host then KNOWS the two fields it needs
+    (step + 1; stopped iff step + 1 == cfg.test_steps) and no device read-back happens.  Otherwise they are read from
+    ``states`` (one host sync)."""
     self._shuffle()
-    keep = (states[:, STATE_STEP_DIM].cpu() < self.cfg.maximum_trajectory_length) | \
-        (torch.rand(states.shape[0], generator=self.rng) < self.cfg.over_length_keep_prob)
-    k = keep.to(self.device)
-    self._append(images[k], states[k], features[k])
+    n = states.shape[0]
+    if advanced:
+      assert self._popped is not None and self._popped[0].shape[0] == n, 'advanced=True follows get_next_fake_batch'
+      old_step, _old_stopped = self._popped
+      h_step = old_step + 1.0
+      h_stopped = (np.abs(old_step + 1.0 - float(self.cfg.test_steps)) < 1e-4).astype(np.float64)
+    else:
+      host = states[:, [STATE_STOPPED_DIM, STATE_STEP_DIM]].detach().to('cpu', torch.float64).numpy()
+      h_stopped, h_step = host[:, 0], host[:, 1]
+    keep = torch.from_numpy(h_step < self.cfg.maximum_trajectory_length) | \
+        (torch.rand(n, generator=self.rng) < self.cfg.over_length_keep_prob)
+    rows = np.nonzero(keep.numpy())[0]
+    self._append(images, states, features, h_step[rows], h_stopped[rows], rows=rows)
     self.fill_pool()
     self._shuffle()
+
+  def check_host_mirror(self):
+    """Debug / tests: the host mirrors equal the device states (synchronises)."""
+    st = self.states.detach().to('cpu', torch.float64).numpy()
+    return bool(np.array_equal(st[:, STATE_STOPPED_DIM], self._h_stopped[self._order]) and
+                np.array_equal(st[:, STATE_STEP_DIM], self._h_step[self._order]))
 
   # -- feed-dict builders (replay_memory.py:139-185) as plain dicts of device tensors
   def get_feed_dict_and_states(self, batch_size):
@@ -144,5 +269,5 @@ class ReplayMemory:
     return dict(fake_output=images, fake_output_feature=features, real_data=real, real_data_feature=real_feat)
 
   def debug(self):
-    avg = float(self.states[:, STATE_STEP_DIM].float().mean())
+    avg = float(self._h_step[self._order].mean())
     return '# Replay memory: size %d, avg. traj. %.2f' % (len(self), avg)

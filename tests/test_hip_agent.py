@@ -282,13 +282,17 @@ def test_training_loop_on_gpu(gpu_device):
   for _ in range(6):
     feed, feats = mem.get_feed_dict_and_states(cfg.batch_size)
     out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
-    mem.replace_memory(out['fake_output'], out['new_states'], feats)
+    mem.replace_memory(out['fake_output'], out['new_states'], feats, advanced=True)
+    # the host mirror of (stopped, step) -- derived from the agent's update rule, never read from the device -- equals
+    # what the agent's kernels actually wrote
+    assert mem.check_host_mirror()
   assert mem.images.is_cuda and mem.images.dtype == torch.float16
   assert int((mem.states[:, 1] > 0).sum()) > 0
   for it in range(1, 4):
     feed, feats = mem.get_feed_dict_and_states(cfg.batch_size)
     g = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], it / 3.0, it=it)
-    mem.replace_memory(g['fake_output'], g['new_states'], feats)
+    mem.replace_memory(g['fake_output'], g['new_states'], feats, advanced=(it % 2 == 0))  # both paths
+    assert mem.check_host_mirror()
     for _ in range(cfg.citers):
       rep = mem.get_replay_feed_dict(cfg.batch_size)
       c = gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
@@ -563,3 +567,32 @@ def test_agent_with_masking_on_gpu(gpu_device):
     assert has == (j in chosen), (j, has)
   ref_pen = (np.maximum(out.detach().cpu().numpy().astype(np.float64) - 1, 0)**2).mean(axis=(1, 2, 3))
   assert np.abs(penalty.detach().cpu().numpy()[:, 0] - ref_pen).max() < 2.0  # contains the entropy / usage terms too
+
+
+def test_replay_memory_on_gpu_equals_the_round3_pool(gpu_device):
+  """The slot pool with its pinned staging ring on the device against the round-3 implementation on the same device:
+  identical batches draw for draw (tests/test_replay_and_loop.py runs the same comparison on the CPU)."""
+  from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
+  from tests import _replay_r03 as old
+  dev = gpu_device
+  cfg = make_cfg()
+  cfg.batch_size, cfg.replay_memory_size = 16, 48
+  a = ReplayMemory(cfg, SyntheticProvider(dev, dtype=torch.float16, seed=5), SyntheticProvider(dev, gamma=1.0, seed=6), seed=7)
+  b = old.ReplayMemory(cfg, old.SyntheticProvider(dev, dtype=torch.float16, seed=5), old.SyntheticProvider(dev, gamma=1.0, seed=6),
+                       seed=7)
+  for it in range(25):
+    fa, feat_a = a.get_feed_dict_and_states(16)
+    fb, feat_b = b.get_feed_dict_and_states(16)
+    for k in fa:
+      assert torch.equal(fa[k], fb[k]), (it, k)
+    st = fa['states'].clone()
+    stopped = ((st[:, 2] + 1 - cfg.test_steps).abs() < 1e-4).float()
+    st[:, 0], st[:, 1], st[:, 2] = stopped, stopped, st[:, 2] + 1
+    img = (fa['fake_input'].float() * 1.1).half()
+    a.replace_memory(img, st, feat_a, advanced=True)
+    b.replace_memory(img, st, feat_b)
+    assert torch.equal(a.states, b.states) and torch.equal(a.images, b.images) and a.check_host_mirror()
+    if int((b.states[:, 1] > 0).sum()) > 0:
+      ra, rb = a.get_replay_feed_dict(16), b.get_replay_feed_dict(16)
+      for k in ra:
+        assert torch.equal(ra[k], rb[k]), (it, k)

@@ -44,6 +44,41 @@ def test_pool_semantics():
   assert float(st[:, 1].min()) == 1.0
 
 
+def test_slot_pool_equals_the_round3_pool_draw_for_draw():
+  """Same seeds, same calls -> identical batches, states, features, noise and pool contents as the round-3
+  implementation (tests/_replay_r03.py), through 40 rounds of pop / agent-like update / replace / 3 replays, with the
+  host mirror (advanced=True) and with the read-back path; the mirror equals the device states throughout."""
+  from tests import _replay_r03 as old
+  cfg = make_cfg()
+  cfg.batch_size, cfg.replay_memory_size = 8, 24
+  for advanced in (True, False):
+    dev = torch.device('cpu')
+    a = ReplayMemory(cfg, SyntheticProvider(dev, seed=5), SyntheticProvider(dev, gamma=1.0, seed=6), seed=7)
+    b = old.ReplayMemory(cfg, old.SyntheticProvider(dev, seed=5), old.SyntheticProvider(dev, gamma=1.0, seed=6), seed=7)
+    rng = np.random.default_rng(0)
+    for it in range(40):
+      fa, feat_a = a.get_feed_dict_and_states(8)
+      fb, feat_b = b.get_feed_dict_and_states(8)
+      for k in fa:
+        assert torch.equal(fa[k], fb[k]), (it, k)
+      assert torch.equal(feat_a, feat_b)
+      # the agent's state update (agent.py:207-238) and some image change
+      st = fa['states'].clone()
+      stopped = ((st[:, 2] + 1 - cfg.test_steps).abs() < 1e-4).float()
+      st[:, 0], st[:, 1], st[:, 2] = stopped, stopped, st[:, 2] + 1
+      img = fa['fake_input'] * float(rng.uniform(0.5, 1.5))
+      a.replace_memory(img, st, feat_a, advanced=advanced)
+      b.replace_memory(img, st, feat_b)
+      assert len(a) == len(b) and torch.equal(a.states, b.states) and torch.equal(a.images, b.images)
+      assert torch.equal(a.features, b.features) and a.check_host_mirror()
+      if int((b.states[:, 1] > 0).sum()) > 0:
+        for _ in range(3):
+          ra, rb = a.get_replay_feed_dict(8), b.get_replay_feed_dict(8)
+          for k in ra:
+            assert torch.equal(ra[k], rb[k]), (it, k)
+    assert a.debug() == b.debug()
+
+
 def test_training_loop_runs_and_terminates_trajectories():
   torch.manual_seed(0)
   cfg = make_cfg()

@@ -46,7 +46,7 @@ def main():
   for _ in range(8):
     feed, feats = memory.get_feed_dict_and_states(n)
     o = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
-    memory.replace_memory(o['fake_output'], o['new_states'], feats)
+    memory.replace_memory(o['fake_output'], o['new_states'], feats, advanced=True)
   rep = memory.get_replay_feed_dict(n)
   gan.critic_step(rep['real_data'], rep['fake_output'], it=1)
   for which in ('generator_step', 'critic_step', 'memory'):
@@ -59,7 +59,7 @@ def main():
         gan.critic_step(rep['real_data'], rep['fake_output'], it=1)
       else:
         feed, feats = memory.get_feed_dict_and_states(n)
-        memory.replace_memory(o['fake_output'], o['new_states'], feats)
+        memory.replace_memory(o['fake_output'], o['new_states'], feats, advanced=True)
         memory.get_replay_feed_dict(n)
     print('=====', which, sum(cnt.ops.values()), 'non-view ops')
     for (site, name), c in cnt.where.most_common(90):
