@@ -63,6 +63,9 @@ SIGNATURES = {
     'expo_lrelu_bwd': (_i, [_fp, _fp, _fp, _sz, _f, _vp]),
     'expo_lrelu_bwd_bias_workspace_bytes': (_sz, [_i]),
     'expo_lrelu_bwd_bias': (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _vp, _sz, _vp]),
+    'expo_gp_inputs': (_i, [_vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
+    'expo_grad_penalty_fwd': (_i, [_fp, _fp, _fp, _i, _sz, _vp]),
+    'expo_grad_penalty_bwd': (_i, [_fp, _fp, _fp, _fp, _i, _sz, _vp]),
     'expo_curve_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'expo_curve_fwd': (_i, [_vp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     'expo_curve_bwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -575,6 +578,41 @@ def lrelu_bwd_bias_supported(z, dz):
     return False
   return z.is_cuda and 4 <= c <= 256 and (c & (c - 1)) == 0 and z.numel() > 0 and z.data_ptr() % 16 == 0 and \
       dz.data_ptr() % 16 == 0 and z.dtype == torch.float32 and dz.dtype == torch.float32 and z.is_contiguous()
+
+
+def gp_inputs(real, fake, alpha, cat_out, interp):
+  """cat_out[:n] = real, cat_out[n:] = fake (float32), interp = real + alpha (fake - real): one launch."""
+  lib = load()
+  _img(real, 'real'), _img(fake, 'fake')
+  n = real.shape[0]
+  assert fake.shape == real.shape and fake.dtype == real.dtype
+  m = real[0].numel() if n else 0
+  assert cat_out.dtype == torch.float32 and cat_out.is_contiguous() and tuple(cat_out.shape) == (2 * n,) + tuple(real.shape[1:])
+  assert interp.dtype == torch.float32 and interp.is_contiguous() and interp.shape == real.shape
+  assert alpha.is_cuda and alpha.dtype == torch.float32 and alpha.is_contiguous() and alpha.numel() == n
+  with torch.cuda.device(real.device):
+    _check(lib.expo_gp_inputs(_ptr(real), _ptr(fake), _ptr(alpha), _ptr(cat_out), _ptr(interp), n, m, _dtype_code(real),
+                              _stream()), 'expo_gp_inputs')
+
+
+def grad_penalty_fwd(g, norm, term):
+  lib = load()
+  n = g.shape[0]
+  assert g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()
+  _f32(norm, 'norm', (n,)), _f32(term, 'term', (n,))
+  with torch.cuda.device(g.device):
+    _check(lib.expo_grad_penalty_fwd(_ptr(g), _ptr(norm), _ptr(term), n, g[0].numel() if n else 0, _stream()),
+           'expo_grad_penalty_fwd')
+
+
+def grad_penalty_bwd(g, norm, dterm, dg):
+  lib = load()
+  n = g.shape[0]
+  assert g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and dg.shape == g.shape and dg.is_contiguous()
+  _f32(norm, 'norm', (n,)), _f32(dterm, 'dterm', (n,))
+  with torch.cuda.device(g.device):
+    _check(lib.expo_grad_penalty_bwd(_ptr(g), _ptr(norm), _ptr(dterm), _ptr(dg), n, g[0].numel() if n else 0, _stream()),
+           'expo_grad_penalty_bwd')
 
 
 def curve_fwd(x, y, params, curves, steps):

@@ -128,6 +128,59 @@ __global__ __launch_bounds__(256) void bias_grad_finish_kernel(const float* __re
   }
 }
 
+// ---- the critic step's loss glue (net.py:126-194), three launches instead of ~20 element-wise / reduction launches ----
+// (1) both critic inputs from the replayed batch in ONE pass: cat[0:n] = real, cat[n:2n] = fake (float32), and the
+//     gradient penalty's interpolation x^ = real + alpha (fake - real), alpha per image (net.py:170-172)
+template <typename T>
+__global__ __launch_bounds__(256) void gp_inputs_kernel(const T* __restrict__ real, const T* __restrict__ fake,
+                                                        const float* __restrict__ alpha, float* __restrict__ cat_out,
+                                                        float* __restrict__ interp, int n, size_t m) {
+  const int img = blockIdx.y;
+  const float a = alpha[img];
+  const size_t base = size_t(img) * m;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < m; i += size_t(gridDim.x) * blockDim.x) {
+    const float r = float(real[base + i]), f = float(fake[base + i]);
+    cat_out[base + i] = r;
+    cat_out[size_t(n) * m + base + i] = f;
+    interp[base + i] = r + a * (f - r);
+  }
+}
+// (2) per image: norm = sqrt(1e-6 + sum g^2), term = max(norm - 1, 0)^2 (net.py:185-187: the one-sided penalty);
+//     one block per image, fixed summation order
+__global__ __launch_bounds__(256) void grad_penalty_fwd_kernel(const float* __restrict__ g, float* __restrict__ norm,
+                                                               float* __restrict__ term, size_t m) {
+  const size_t base = size_t(blockIdx.x) * m;
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < m; i += 256) {
+    const float v = g[base + i];
+    s = fmaf(v, v, s);
+  }
+  __shared__ float part[256];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < unsigned(w)) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float nm = sqrtf(1e-6f + part[0]);
+    const float over = fmaxf(nm - 1.0f, 0.0f);
+    norm[blockIdx.x] = nm;
+    term[blockIdx.x] = over * over;
+  }
+}
+// (3) its gradient: d term / d g = 2 max(norm - 1, 0) / norm * g, times the upstream gradient of the image's term
+__global__ __launch_bounds__(256) void grad_penalty_bwd_kernel(const float* __restrict__ g, const float* __restrict__ norm,
+                                                               const float* __restrict__ dterm, float* __restrict__ dg,
+                                                               size_t m) {
+  const int img = blockIdx.y;
+  const float nm = norm[img];
+  const float c = dterm[img] * 2.0f * fmaxf(nm - 1.0f, 0.0f) / nm;
+  const size_t base = size_t(img) * m;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < m; i += size_t(gridDim.x) * blockDim.x)
+    dg[base + i] = g[base + i] * c;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int grid_for(size_t items) {
   const size_t blocks = (items + 255) / 256;
@@ -167,6 +220,51 @@ int expo_lrelu_bwd(const float* z, const float* dz, float* dy, size_t count, flo
   if (vec) hipLaunchKernelGGL((lrelu_bwd_kernel<true>), dim3(grid), dim3(256), 0, s, z, dz, dy, count, leak);
   else hipLaunchKernelGGL((lrelu_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, z, dz, dy, count, leak);
   HIP_TRY(hipGetLastError(), "lrelu_bwd launch");
+  return EXPO_OK;
+}
+
+int expo_gp_inputs(const void* real, const void* fake, const float* alpha, float* cat_out, float* interp, int n,
+                   size_t elems_per_image, int dtype, void* stream) {
+  if (n < 0) return fail(EXPO_E_BADARG, "n >= 0 required");
+  if (n == 0 || elems_per_image == 0) return EXPO_OK;
+  if (!real || !fake || !alpha || !cat_out || !interp) return fail(EXPO_E_BADARG, "null pointer");
+  if (dtype != EXPO_F16 && dtype != EXPO_F32) return fail(EXPO_E_BADDTYPE, "dtype must be EXPO_F16 or EXPO_F32");
+  if (n > 65535) return fail(EXPO_E_BADARG, "n > 65535 not supported (grid.y)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  size_t bx = (elems_per_image + 255) / 256;
+  if (bx > 64) bx = 64;
+  const dim3 grid(unsigned(bx), n), block(256);
+  if (dtype == EXPO_F16)
+    hipLaunchKernelGGL(gp_inputs_kernel<_Float16>, grid, block, 0, s, (const _Float16*)real, (const _Float16*)fake, alpha,
+                       cat_out, interp, n, elems_per_image);
+  else
+    hipLaunchKernelGGL(gp_inputs_kernel<float>, grid, block, 0, s, (const float*)real, (const float*)fake, alpha, cat_out,
+                       interp, n, elems_per_image);
+  HIP_TRY(hipGetLastError(), "gp_inputs launch");
+  return EXPO_OK;
+}
+
+int expo_grad_penalty_fwd(const float* g, float* norm, float* term, int n, size_t elems_per_image, void* stream) {
+  if (n < 0) return fail(EXPO_E_BADARG, "n >= 0 required");
+  if (n == 0) return EXPO_OK;
+  if (!g || !norm || !term) return fail(EXPO_E_BADARG, "null pointer");
+  hipLaunchKernelGGL(grad_penalty_fwd_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), g, norm, term,
+                     elems_per_image);
+  HIP_TRY(hipGetLastError(), "grad_penalty_fwd launch");
+  return EXPO_OK;
+}
+
+int expo_grad_penalty_bwd(const float* g, const float* norm, const float* dterm, float* dg, int n, size_t elems_per_image,
+                          void* stream) {
+  if (n < 0) return fail(EXPO_E_BADARG, "n >= 0 required");
+  if (n == 0 || elems_per_image == 0) return EXPO_OK;
+  if (!g || !norm || !dterm || !dg) return fail(EXPO_E_BADARG, "null pointer");
+  if (n > 65535) return fail(EXPO_E_BADARG, "n > 65535 not supported (grid.y)");
+  size_t bx = (elems_per_image + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(grad_penalty_bwd_kernel, dim3(unsigned(bx), n), dim3(256), 0, static_cast<hipStream_t>(stream), g, norm,
+                     dterm, dg, elems_per_image);
+  HIP_TRY(hipGetLastError(), "grad_penalty_bwd launch");
   return EXPO_OK;
 }
 

@@ -15,7 +15,7 @@ from torch import nn
 from . import dist as xdist
 from .agent import Agent
 from .critics import Critic
-from .nn_ops import frozen_parameters, skip_parameter_gradients
+from .nn_ops import critic_step_inputs, frozen_parameters, grad_penalty_term, skip_parameter_gradients
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
 
 
@@ -281,16 +281,13 @@ class GAN(nn.Module):
     replayed from the memory (``replay_memory.py:168-185`` feeds the ``fake_output`` tensor), the
     generator is not executed."""
     cfg = self.cfg
-    fake_output = fake_output.detach().float()
-    real_data = real_data.float()
     n = real_data.shape[0]
     if cfg.gan == 'ls':
+      fake_output = fake_output.detach().float()
+      real_data = real_data.float()
       fake_output = fake_output.requires_grad_(True)  # for the reported d fake_logit / d fake_output
-    # one batched pass for the real and the fake half (the critic is per-sample: no normalisation
-    # layers), so their forward and backward are single launches of twice the batch
-    logits = self.critic(torch.cat([real_data, fake_output], dim=0))
-    real_logit, fake_logit = logits[:n], logits[n:]
-    if cfg.gan == 'ls':
+      logits = self.critic(torch.cat([real_data, fake_output], dim=0))
+      real_logit, fake_logit = logits[:n], logits[n:]
       # net.py:129-147, 195-199: least-squares discriminator, no gradient penalty; the reported norm is that of
       # d fake_logit / d fake_output (no epsilon), a summary value only
       c_loss = (fake_logit**2).mean() + ((real_logit - 1.0)**2).mean()
@@ -300,20 +297,27 @@ class GAN(nn.Module):
       zero = torch.zeros((), device=c_loss.device)
       return dict(c_loss=c_loss, emd=c_loss.detach(), gradient_norm=gradient_norm.mean().detach(),
                   gradient_penalty=zero, c_average=zero)
-    c_loss = (fake_logit - real_logit).mean()
     if alpha is None:
-      alpha = self._draw_alpha(real_data.shape[0])
-    interpolated = (real_data + alpha * (fake_output - real_data)).requires_grad_(True)
+      alpha = self._draw_alpha(n)
+    # one batched pass for the real and the fake half (the critic is per-sample: no normalisation layers), so their
+    # forward and backward are single launches of twice the batch; both critic inputs come out of ONE kernel
+    # (nn_ops.critic_step_inputs: dtype conversions, concatenation, interpolation)
+    both, interpolated = critic_step_inputs(real_data, fake_output.detach(), alpha)
+    interpolated.requires_grad_(True)
+    logits = self.critic(both)
+    real_logit, fake_logit = logits[:n], logits[n:]
+    c_loss = (fake_logit - real_logit).mean()
     use_gp = cfg.gradient_penalty_lambda > 0
     inte_logit = self.critic(interpolated)
     with skip_parameter_gradients():  # only d D / d x^ is wanted here; theta_c is reached by the OUTER backward
-      gradients, = torch.autograd.grad(inte_logit.sum(), interpolated, create_graph=use_gp)
-    gradient_norm = torch.sqrt(1e-6 + (gradients**2).sum(dim=(1, 2, 3)))
-    gradient_penalty = cfg.gradient_penalty_lambda * (torch.clamp_min(gradient_norm - 1.0, 0.0)**2).mean()
+      gradients, = torch.autograd.grad(inte_logit, interpolated, torch.ones_like(inte_logit), create_graph=use_gp)
+    term, gradient_norm = grad_penalty_term(gradients)  # max(||g|| - 1, 0)^2 and ||g|| = sqrt(1e-6 + sum g^2) per image
+    gradient_penalty = cfg.gradient_penalty_lambda * term.mean()
     # net.py:188-199: without the penalty (lambda <= 0) the norm is still reported and theta_c is clipped after the
     # update instead (clip_critic_weights)
     total = c_loss + gradient_penalty if use_gp else c_loss
-    c_average = ((fake_logit + real_logit).mean() * 0.5).detach()
+    with torch.no_grad():
+      c_average = (fake_logit + real_logit).mean() * 0.5
     return dict(c_loss=total, emd=-c_loss.detach(), gradient_norm=gradient_norm.mean().detach(),
                 gradient_penalty=gradient_penalty.detach(), c_average=c_average)
 

@@ -210,3 +210,50 @@ def bias_lrelu(y, bias=None, leak=0.2):
   if _FROZEN and bias is not None:
     bias = bias.detach()
   return _BiasLrelu.apply(y, bias, leak)
+
+
+class _GradPenaltyTerm(torch.autograd.Function):
+  """Per image: ``term = max(sqrt(1e-6 + sum g^2) - 1, 0)^2`` and the norm itself (net.py:185-187) from the critic's
+  input gradient g -- ``expo_grad_penalty_fwd`` (one block per image) and, for the gradient that flows on into the
+  critic's double backward, ``expo_grad_penalty_bwd``: two launches instead of pow / sum / add / sqrt / sub / clamp /
+  pow and their seven backward launches.  The norm output is not differentiated (a reported value)."""
+
+  @staticmethod
+  def forward(ctx, g):
+    g = g.contiguous()
+    n = g.shape[0]
+    norm = torch.empty((n,), dtype=torch.float32, device=g.device)
+    term = torch.empty((n,), dtype=torch.float32, device=g.device)
+    _cabi.grad_penalty_fwd(g, norm, term)
+    ctx.save_for_backward(g, norm)
+    ctx.mark_non_differentiable(norm)
+    return term, norm
+
+  @staticmethod
+  def backward(ctx, dterm, _dnorm):
+    g, norm = ctx.saved_tensors
+    dg = torch.empty_like(g)
+    _cabi.grad_penalty_bwd(g, norm, dterm.contiguous().float(), dg)
+    return dg
+
+
+def grad_penalty_term(gradients):
+  """(term (N,), norm (N,)) of the one-sided gradient penalty; fused on the device, torch ops elsewhere."""
+  if gradients.is_cuda and gradients.dtype == torch.float32:
+    return _GradPenaltyTerm.apply(gradients)
+  norm = torch.sqrt(1e-6 + (gradients**2).sum(dim=tuple(range(1, gradients.dim()))))
+  return torch.clamp_min(norm - 1.0, 0.0)**2, norm.detach()
+
+
+def critic_step_inputs(real_data, fake_output, alpha):
+  """(cat([real, fake]) as float32, real + alpha (fake - real)) -- ``expo_gp_inputs``: one launch for the two dtype
+  conversions, the concatenation and the three element-wise passes of the interpolation (net.py:170-172)."""
+  if real_data.is_cuda and real_data.dtype in (torch.float16, torch.float32) and real_data.dtype == fake_output.dtype:
+    real_data, fake_output = real_data.contiguous(), fake_output.contiguous()
+    n = real_data.shape[0]
+    cat = torch.empty((2 * n,) + tuple(real_data.shape[1:]), dtype=torch.float32, device=real_data.device)
+    interp = torch.empty(real_data.shape, dtype=torch.float32, device=real_data.device)
+    _cabi.gp_inputs(real_data, fake_output, alpha.contiguous().float(), cat, interp)
+    return cat, interp
+  real_data, fake_output = real_data.float(), fake_output.float()
+  return torch.cat([real_data, fake_output], dim=0), real_data + alpha * (fake_output - real_data)

@@ -366,6 +366,23 @@ int expo_lrelu_bwd_bias(const float* z, const float* dz, float* dy, float* dbias
                         float leak, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * (ABI 4) The critic step's loss glue (net.py:126-194) -- the callers of the critic around the filter path:
+ *   expo_gp_inputs         cat[0:n] = real, cat[n:2n] = fake (float32) and the gradient penalty's interpolation
+ *                          interp = real + alpha[n] (fake - real) (net.py:170-172) in one pass; real / fake of `dtype`,
+ *                          elems_per_image = H*W*3
+ *   expo_grad_penalty_fwd  per image: norm = sqrt(1e-6 + sum g^2), term = max(norm - 1, 0)^2 (net.py:185-187; the
+ *                          penalty is lambda * mean(term)); g float32 [n][elems_per_image]
+ *   expo_grad_penalty_bwd  dg = g * dterm[n] * 2 max(norm - 1, 0) / norm   (the gradient TF takes of that term with
+ *                          respect to `gradients`; it then flows on into the critic's double backward)
+ * No workspace; one block per image for the reduction (fixed order).
+ */
+int expo_gp_inputs(const void* real, const void* fake, const float* alpha, float* cat_out, float* interp, int n,
+                   size_t elems_per_image, int dtype, void* stream);
+int expo_grad_penalty_fwd(const float* g, float* norm, float* term, int n, size_t elems_per_image, void* stream);
+int expo_grad_penalty_bwd(const float* g, const float* norm, const float* dterm, float* dg, int n,
+                          size_t elems_per_image, void* stream);
+
+/*
  * ToneFilter / ColorFilter with ANY number of curve steps L = cfg.curve_steps (config_example.py:27; the reference
  * loops `for i in range(self.cfg.curve_steps)`, filters.py:264-273, 312-322):
  *     y = (L / S) sum_{i<L} clip(x - i/L, 0, 1/L) k_i,   S = sum_i k_i + 1e-30

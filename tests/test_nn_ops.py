@@ -132,3 +132,37 @@ def test_conv_family_matches_torch_on_gpu(cin, cout, size, n, gpu_device):
   for a, b, what in zip(res[0], res[1], ('y', 'dx', 'dW', 'd/dW |dx|^2')):
     scale = float(b.abs().max())
     assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-6, (what, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [(64, 64, 64, 3), (3, 7, 5, 3), (1, 2, 2, 3)])
+def test_critic_step_glue_kernels(dtype, shape, gpu_device):
+  """expo_gp_inputs / expo_grad_penalty_fwd / _bwd (net.py:126-194's loss glue) against the torch formulas in float64."""
+  dev = gpu_device
+  g = torch.Generator(device=dev).manual_seed(3)
+  real = torch.rand(shape, device=dev, generator=g).to(dtype)
+  fake = (torch.rand(shape, device=dev, generator=g) * 1.5).to(dtype)
+  alpha = torch.rand((shape[0], 1, 1, 1), device=dev, generator=g)
+  both, interp = nn_ops.critic_step_inputs(real, fake, alpha)
+  assert both.dtype == torch.float32 and torch.equal(both[:shape[0]], real.float()) and torch.equal(both[shape[0]:], fake.float())
+  ref = real.double() + alpha.double() * (fake.double() - real.double())
+  assert float((interp.double() - ref).abs().max()) <= 2e-7 * 1.5
+  # the penalty term: gradients with norms on both sides of 1 (the one-sided penalty's kink) and exactly small ones
+  grads = torch.randn(shape, device=dev, generator=g) * torch.linspace(0.001, 0.05, shape[0], device=dev)[:, None, None, None]
+  grads.requires_grad_(True)
+  term, norm = nn_ops.grad_penalty_term(grads)
+  gd = grads.detach().double()
+  rnorm = torch.sqrt(1e-6 + (gd**2).sum(dim=(1, 2, 3)))
+  rterm = torch.clamp_min(rnorm - 1.0, 0.0)**2
+  assert float((norm.double() - rnorm).abs().max() / rnorm.max()) <= 2e-6
+  assert float((term.double() - rterm).abs().max()) <= 1e-5 * max(1.0, float(rterm.max()))
+  w = torch.rand(shape[0], device=dev, generator=g)
+  (term * w).sum().backward()
+  gref = gd.clone().requires_grad_(True)
+  rn = torch.sqrt(1e-6 + (gref**2).sum(dim=(1, 2, 3)))
+  ((torch.clamp_min(rn - 1.0, 0.0)**2) * w.double()).sum().backward()
+  scale = float(gref.grad.abs().max()) + 1e-12
+  assert float((grads.grad.double() - gref.grad).abs().max()) <= 1e-5 * scale
+  if shape[0] > 8:
+    assert float((rnorm > 1).float().mean()) not in (0.0, 1.0), 'the case must cover both sides of the kink'
