@@ -63,6 +63,9 @@ SIGNATURES = {
     'expo_lrelu_bwd': (_i, [_fp, _fp, _fp, _sz, _f, _vp]),
     'expo_lrelu_bwd_bias_workspace_bytes': (_sz, [_i]),
     'expo_lrelu_bwd_bias': (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _vp, _sz, _vp]),
+    'expo_heads_regress_fwd': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i), _i, ctypes.POINTER(_f), _vp, _fp, _i, _vp]),
+    'expo_heads_regress_bwd': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i), _i,
+                                   ctypes.POINTER(_f), _vp, _fp, _i, _vp]),
     'expo_gp_inputs': (_i, [_vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
     'expo_grad_penalty_fwd': (_i, [_fp, _fp, _fp, _i, _sz, _vp]),
     'expo_grad_penalty_bwd': (_i, [_fp, _fp, _fp, _fp, _i, _sz, _vp]),
@@ -578,6 +581,42 @@ def lrelu_bwd_bias_supported(z, dz):
     return False
   return z.is_cuda and 4 <= c <= 256 and (c & (c - 1)) == 0 and z.numel() > 0 and z.data_ptr() % 16 == 0 and \
       dz.data_ptr() % 16 == 0 and z.dtype == torch.float32 and dz.dtype == torch.float32 and z.is_contiguous()
+
+
+def _heads_common(raws, abi_ids, ranges):
+  n = raws[0].shape[0]
+  for r in raws:
+    if not (r.is_cuda and r.dtype == torch.float32 and r.is_contiguous() and r.dim() == 2 and r.shape[0] == n):
+      raise ExposureHipError('exposure_amd: every head output must be a contiguous float32 (N, width) device tensor')
+  h = len(raws)
+  ptrs = (_vp * h)(*[ctypes.c_void_p(r.data_ptr()) for r in raws])
+  widths = (_i * h)(*[int(r.shape[1]) for r in raws])
+  abi = (_i * h)(*[int(v) for v in abi_ids])
+  rng = (_f * 9)(*[float(v) for v in ranges])
+  return n, h, ptrs, widths, abi, rng
+
+
+def heads_regress_fwd(raws, abi_ids, ranges, selected, params):
+  """params[n] = regressor of the head selected[n] applied to that head's raw features (EXPO_MAX_PARAMS wide, zero padded)."""
+  lib = load()
+  n, h, ptrs, widths, abi, rng = _heads_common(raws, abi_ids, ranges)
+  _ids(selected, n)
+  _f32(params, 'params', (n, EXPO_MAX_PARAMS))
+  with torch.cuda.device(params.device):
+    _check(lib.expo_heads_regress_fwd(ptrs, widths, abi, h, rng, _ptr(selected), _ptr(params), n, _stream()),
+           'expo_heads_regress_fwd')
+
+
+def heads_regress_bwd(raws, draws, abi_ids, ranges, selected, dparams):
+  lib = load()
+  n, h, ptrs, widths, abi, rng = _heads_common(raws, abi_ids, ranges)
+  assert len(draws) == h and all(d.shape == r.shape and d.is_contiguous() and d.dtype == torch.float32 for d, r in zip(draws, raws))
+  dptrs = (_vp * h)(*[ctypes.c_void_p(d.data_ptr()) for d in draws])
+  _ids(selected, n)
+  _f32(dparams, 'dparams', (n, EXPO_MAX_PARAMS))
+  with torch.cuda.device(dparams.device):
+    _check(lib.expo_heads_regress_bwd(ptrs, dptrs, widths, abi, h, rng, _ptr(selected), _ptr(dparams), n, _stream()),
+           'expo_heads_regress_bwd')
 
 
 def gp_inputs(real, fake, alpha, cat_out, interp):

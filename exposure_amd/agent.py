@@ -186,7 +186,17 @@ class Agent(nn.Module):
 
     enriched = enrich_image_input(cfg, net.float(), states)
     filter_features = self.filter_features(enriched, masks[0])
-    params, mask_params = self.regress_all(filter_features)  # 8 x reference-shaped, 8 x (N, 6)
+    # Training-time fast path (round 4): the regressors and the one-hot gather of the selected filter's parameters as
+    # ONE kernel behind the heads' second FCs (filters.heads_regress_select).  Needs what the dispatch kernels need
+    # (8-step curves, masking off) and a device; everything else takes the op-by-op path below.
+    fused_heads = (not cfg.masking and net.is_cuda and high_res is None and len(self.filters) <= 16 and
+                   not any(f.uses_generic_kernels() for f in self.filters) and
+                   all(type(f) in F.FUSED_HEAD_TYPES for f in self.filters))
+    if fused_heads:
+      raws = [filt.fc2(lrelu(filt.fc1(filter_features))) for filt in self.filters]
+      params = mask_params = None
+    else:
+      params, mask_params = self.regress_all(filter_features)  # 8 x reference-shaped, 8 x (N, 6)
 
     selector_features = self.selector_features(enriched, masks[1])
     pdf, entropy = self.action_pdf(selector_features)
@@ -200,13 +210,16 @@ class Agent(nn.Module):
     if any(f.uses_generic_kernels() for f in self.filters):
       return self._forward_generic(net, states, params, mask_params, pdf, entropy, selected_filter_id, filter_one_hot,
                                    surrogate, progress, high_res)
-    # one-hot gather of the selected filter's packed parameters -> (N, 24); same gradient
-    # routing as the reference's one-hot product over the stacked images
-    params24 = net.new_zeros((n, F._cabi.EXPO_MAX_PARAMS), dtype=torch.float32)
-    for j, (filt, p) in enumerate(zip(self.filters, params)):
-      pj = filt.pack(p).float()
-      params24 = params24 + torch.nn.functional.pad(pj, (0, F._cabi.EXPO_MAX_PARAMS - pj.shape[1])) * \
-          filter_one_hot[:, j:j + 1]
+    if fused_heads:
+      params24 = F.heads_regress_select(list(self.filters), raws, selected_filter_id)
+    else:
+      # one-hot gather of the selected filter's packed parameters -> (N, 24); same gradient
+      # routing as the reference's one-hot product over the stacked images
+      params24 = net.new_zeros((n, F._cabi.EXPO_MAX_PARAMS), dtype=torch.float32)
+      for j, (filt, p) in enumerate(zip(self.filters, params)):
+        pj = filt.pack(p).float()
+        params24 = params24 + torch.nn.functional.pad(pj, (0, F._cabi.EXPO_MAX_PARAMS - pj.shape[1])) * \
+            filter_one_hot[:, j:j + 1]
     hsv_mode = int(cfg.get('hsv_grad_mode', 0))
     abi_ids = torch.where(selected_filter_id >= 0, self.abi_filter_ids[selected_filter_id.clamp_min(0).long()],
                           torch.full_like(selected_filter_id, -1))
@@ -229,7 +242,8 @@ class Agent(nn.Module):
     debug_info = {
         'state': states,
         'selected_filter_id': selected_filter_id[0],
-        'filter_debug_info': [{'filter_parameters': p[0]} for p in params],
+        # (the fused training path regresses the SELECTED filter's parameters only: the per-filter debug list is empty there)
+        'filter_debug_info': [{'filter_parameters': p[0]} for p in params] if params is not None else [],
         'pdf': pdf[0],
         # batched extras (not in the reference dict; used by tests / the eval loop)
         'selected_filter_ids': selected_filter_id,

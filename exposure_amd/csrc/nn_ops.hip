@@ -181,6 +181,103 @@ __global__ __launch_bounds__(256) void grad_penalty_bwd_kernel(const float* __re
     dg[base + i] = g[base + i] * c;
 }
 
+// ---- the eight FC heads' tail: regressors + one-hot gather (agent.py:58-77, 119-125; filters.py:177-179, 201-203, 224-235,
+// 256-262, 306-310, 411-413, 435-436, 481-482) ------------------------------------------------------------------------
+// Every filter's second FC emits P_j raw features (+ 6 mask features); `filter_param_regressor` squashes them into the
+// filter's parameter range, and the agent keeps, per image, the parameters of the ONE filter it selected (a one-hot
+// product over the stacked results).  In torch that is ~45 element-wise launches for the regressors, 24 for the gather
+// and ~75 in the backward; here one launch each way: thread (image, slot k < 24) regresses feature k of the selected
+// head only.  tanh01(x) = tanh(x) / 2 + 1 / 2, tanh_range(l, r)(x) = tanh01(x + bias) (r - l) + l (util.py:277-294; every
+// bias of the shipped ranges is atanh(0) = 0 and is passed in anyway).
+struct HeadsArgs {
+  const float* raw[EXPO_MAX_HEADS];  // head j: [n][width_j] row-major (width_j = P_j + mask features)
+  float* draw[EXPO_MAX_HEADS];       // backward: same shapes
+  int width[EXPO_MAX_HEADS];
+  int abi[EXPO_MAX_HEADS];           // C-ABI filter id of head j (cfg.filters may be a subset / reorder)
+  int heads;
+  float exposure_range, log_gamma_range, tone_lo, tone_hi, tone_bias, color_lo, color_hi, color_bias, exposure_bias;
+};
+__device__ __forceinline__ float tanh01f(float x) { return tanhf(x) * 0.5f + 0.5f; }
+__device__ __forceinline__ float dtanh01f(float x) { const float t = tanhf(x); return 0.5f * (1.0f - t * t); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+constexpr int kHeadParams[EXPO_NUM_FILTERS] = {1, 1, 3, 1, 8, 1, 1, 24, 2};
+
+__global__ __launch_bounds__(256) void heads_regress_fwd_kernel(const HeadsArgs a, const int32_t* __restrict__ sel,
+                                                               float* __restrict__ params, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * EXPO_MAX_PARAMS) return;
+  const int img = t / EXPO_MAX_PARAMS, k = t % EXPO_MAX_PARAMS;
+  const int j = sel[img];
+  float out = 0.f;
+  if (j >= 0 && j < a.heads) {
+    const int fid = a.abi[j];
+    const int P = (fid >= 0 && fid < EXPO_NUM_FILTERS) ? kHeadParams[fid] : 0;
+    if (k < P) {
+      const float* f = a.raw[j] + size_t(img) * a.width[j];
+      const float x = f[k];
+      switch (fid) {
+        case 0: out = tanh01f(x + a.exposure_bias) * (2.0f * a.exposure_range) - a.exposure_range; break;
+        case 1: out = expf(tanh01f(x) * (2.0f * a.log_gamma_range) - a.log_gamma_range); break;
+        case 2: {  // features * (0, 1, 1); exp(tanh_range(-.5, .5)); normalised by the luminance of the scaling
+          const float s0 = expf(tanh01f(0.0f) - 0.5f), s1 = expf(tanh01f(f[1]) - 0.5f), s2 = expf(tanh01f(f[2]) - 0.5f);
+          const float inv = 1.0f / (1e-5f + 0.27f * s0 + 0.67f * s1 + 0.06f * s2);
+          out = (k == 0 ? s0 : (k == 1 ? s1 : s2)) * inv;
+        } break;
+        case 3: case 6: case 8: out = sigmoidf_(x); break;
+        case 4: out = tanh01f(x + a.tone_bias) * (a.tone_hi - a.tone_lo) + a.tone_lo; break;
+        case 5: out = tanhf(x); break;
+        case 7: out = tanh01f(x + a.color_bias) * (a.color_hi - a.color_lo) + a.color_lo; break;
+        default: break;
+      }
+    }
+  }
+  params[t] = out;
+}
+
+// d raw of EVERY head (zero outside the selected head's parameter slice)
+__global__ __launch_bounds__(256) void heads_regress_bwd_kernel(const HeadsArgs a, const int32_t* __restrict__ sel,
+                                                               const float* __restrict__ dparams, int n, int total_width) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * total_width) return;
+  const int img = t / total_width;
+  int col = t % total_width, j = 0;
+  while (col >= a.width[j]) col -= a.width[j++];
+  float g = 0.f;
+  if (j == sel[img]) {
+    const int fid = a.abi[j];
+    const int P = (fid >= 0 && fid < EXPO_NUM_FILTERS) ? kHeadParams[fid] : 0;
+    if (col < P) {
+      const float* f = a.raw[j] + size_t(img) * a.width[j];
+      const float* dp = dparams + size_t(img) * EXPO_MAX_PARAMS;
+      const float x = f[col];
+      switch (fid) {
+        case 0: g = dp[col] * dtanh01f(x + a.exposure_bias) * (2.0f * a.exposure_range); break;
+        case 1: {
+          const float y = expf(tanh01f(x) * (2.0f * a.log_gamma_range) - a.log_gamma_range);
+          g = dp[col] * y * dtanh01f(x) * (2.0f * a.log_gamma_range);
+        } break;
+        case 2:
+          if (col > 0) {  // feature 0 is masked out (features * (0, 1, 1))
+            const float s0 = expf(tanh01f(0.0f) - 0.5f), s1 = expf(tanh01f(f[1]) - 0.5f), s2 = expf(tanh01f(f[2]) - 0.5f);
+            const float inv = 1.0f / (1e-5f + 0.27f * s0 + 0.67f * s1 + 0.06f * s2);
+            const float sk = col == 1 ? s1 : s2, wk = col == 1 ? 0.67f : 0.06f;
+            const float dsk = sk * dtanh01f(f[col]);  // d s_k / d f_k
+            // out_c = s_c inv:  d out_c / d s_k = delta_ck inv - s_c inv^2 w_k
+            const float dot = dp[0] * s0 + dp[1] * s1 + dp[2] * s2;
+            g = dsk * (dp[col] * inv - dot * inv * inv * wk);
+          }
+          break;
+        case 3: case 6: case 8: { const float y = sigmoidf_(x); g = dp[col] * y * (1.0f - y); } break;
+        case 4: g = dp[col] * dtanh01f(x + a.tone_bias) * (a.tone_hi - a.tone_lo); break;
+        case 5: { const float y = tanhf(x); g = dp[col] * (1.0f - y * y); } break;
+        case 7: g = dp[col] * dtanh01f(x + a.color_bias) * (a.color_hi - a.color_lo); break;
+        default: break;
+      }
+    }
+  }
+  a.draw[j][size_t(img) * a.width[j] + col] = g;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int grid_for(size_t items) {
   const size_t blocks = (items + 255) / 256;
@@ -220,6 +317,57 @@ int expo_lrelu_bwd(const float* z, const float* dz, float* dy, size_t count, flo
   if (vec) hipLaunchKernelGGL((lrelu_bwd_kernel<true>), dim3(grid), dim3(256), 0, s, z, dz, dy, count, leak);
   else hipLaunchKernelGGL((lrelu_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, z, dz, dy, count, leak);
   HIP_TRY(hipGetLastError(), "lrelu_bwd launch");
+  return EXPO_OK;
+}
+
+static int heads_args(HeadsArgs* a, const float* const* raw, float* const* draw, const int* widths, const int* abi_ids,
+                      int heads, const float* ranges) {
+  if (heads < 1 || heads > EXPO_MAX_HEADS || !raw || !widths || !abi_ids || !ranges)
+    return fail(EXPO_E_BADARG, "bad heads arguments");
+  for (int j = 0; j < heads; ++j) {
+    if (!raw[j] || (draw && !draw[j])) return fail(EXPO_E_BADARG, "null pointer");
+    if (abi_ids[j] < 0 || abi_ids[j] >= EXPO_NUM_FILTERS) return fail(EXPO_E_BADARG, "filter_id out of range");
+    if (widths[j] < kHeadParams[abi_ids[j]]) return fail(EXPO_E_BADARG, "head narrower than its filter's parameter count");
+    a->raw[j] = raw[j];
+    a->draw[j] = draw ? draw[j] : nullptr;
+    a->width[j] = widths[j];
+    a->abi[j] = abi_ids[j];
+  }
+  a->heads = heads;
+  a->exposure_range = ranges[0]; a->log_gamma_range = ranges[1];
+  a->tone_lo = ranges[2]; a->tone_hi = ranges[3]; a->tone_bias = ranges[4];
+  a->color_lo = ranges[5]; a->color_hi = ranges[6]; a->color_bias = ranges[7]; a->exposure_bias = ranges[8];
+  return EXPO_OK;
+}
+
+int expo_heads_regress_fwd(const float* const* raw, const int* widths, const int* abi_ids, int heads, const float* ranges,
+                           const int32_t* selected, float* params, int n, void* stream) {
+  if (n < 0) return fail(EXPO_E_BADARG, "n >= 0 required");
+  HeadsArgs a{};
+  if (int rc = heads_args(&a, raw, nullptr, widths, abi_ids, heads, ranges)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!selected || !params) return fail(EXPO_E_BADARG, "null pointer");
+  const int total = n * EXPO_MAX_PARAMS;
+  hipLaunchKernelGGL(heads_regress_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                     selected, params, n);
+  HIP_TRY(hipGetLastError(), "heads_regress_fwd launch");
+  return EXPO_OK;
+}
+
+int expo_heads_regress_bwd(const float* const* raw, float* const* draw, const int* widths, const int* abi_ids, int heads,
+                           const float* ranges, const int32_t* selected, const float* dparams, int n, void* stream) {
+  if (n < 0) return fail(EXPO_E_BADARG, "n >= 0 required");
+  HeadsArgs a{};
+  if (!draw) return fail(EXPO_E_BADARG, "null pointer");
+  if (int rc = heads_args(&a, raw, draw, widths, abi_ids, heads, ranges)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!selected || !dparams) return fail(EXPO_E_BADARG, "null pointer");
+  int total_width = 0;
+  for (int j = 0; j < heads; ++j) total_width += widths[j];
+  const int total = n * total_width;
+  hipLaunchKernelGGL(heads_regress_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                     selected, dparams, n, total_width);
+  HIP_TRY(hipGetLastError(), "heads_regress_bwd launch");
   return EXPO_OK;
 }
 

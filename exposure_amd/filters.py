@@ -165,6 +165,50 @@ class _CurveFunction(torch.autograd.Function):
     return dx, dparams, None, None
 
 
+class _HeadsRegressSelect(torch.autograd.Function):
+  """params24[n] = filter_param_regressor of the head image n selected, applied to that head's raw features, zero padded
+  to EXPO_MAX_PARAMS -- ``expo_heads_regress_fwd / _bwd``: the eight regressors and the one-hot gather
+  (agent.py:58-77, 119-125) as ONE launch each way instead of ~70 forward and ~75 backward torch launches."""
+
+  @staticmethod
+  def forward(ctx, selected, abi_ids, ranges, *raws):
+    raws = tuple(r.contiguous().float() for r in raws)
+    n = raws[0].shape[0]
+    params = torch.empty((n, _cabi.EXPO_MAX_PARAMS), dtype=torch.float32, device=raws[0].device)
+    selected = selected.contiguous().to(torch.int32)
+    _cabi.heads_regress_fwd(raws, abi_ids, ranges, selected, params)
+    ctx.save_for_backward(selected, *raws)
+    ctx.meta = (tuple(abi_ids), tuple(ranges))
+    return params
+
+  @staticmethod
+  def backward(ctx, dparams):
+    selected, *raws = ctx.saved_tensors
+    abi_ids, ranges = ctx.meta
+    n = raws[0].shape[0]
+    # one flat buffer, head-major: every head's gradient is a CONTIGUOUS view (its FC's backward GEMM takes it as is)
+    widths = [r.shape[1] for r in raws]
+    flat = torch.empty((n * sum(widths),), dtype=torch.float32, device=raws[0].device)
+    draws, at = [], 0
+    for w in widths:
+      draws.append(flat[at:at + n * w].view(n, w))
+      at += n * w
+    _cabi.heads_regress_bwd(raws, draws, abi_ids, ranges, selected, dparams.contiguous().float())
+    return (None, None, None) + tuple(draws)
+
+
+def heads_regress_select(filter_modules, raws, selected):
+  """The fused tail of the FC heads (see _HeadsRegressSelect).  ``filter_modules``: the agent's Filter list (their
+  ``filter_id`` and ``cfg`` ranges), ``raws``: each head's second-FC output (N, P_j + 6), ``selected`` (N,) int32."""
+  cfg = filter_modules[0].cfg
+  tl, tr = cfg.tone_curve_range
+  cl, cr = cfg.color_curve_range
+  bias = lambda l, r, initial: math.atanh(2 * (initial - l) / (r - l) - 1) if initial is not None else 0.0
+  ranges = (float(cfg.exposure_range), math.log(cfg.gamma_range), float(tl), float(tr), 0.0, float(cl), float(cr),
+            bias(cl, cr, 1), bias(-cfg.exposure_range, cfg.exposure_range, 0))
+  return _HeadsRegressSelect.apply(selected, tuple(int(f.filter_id) for f in filter_modules), ranges, *raws)
+
+
 def pixel_filter(fid, img, packed, hsv_grad_mode=0):
   """Functional entry: filter ``fid`` (0..7, ``cfg.filters`` order) with packed (N,P) params."""
   return _PixelFilterFunction.apply(img, packed, fid, hsv_grad_mode)
@@ -607,6 +651,8 @@ class SaturationPlusFilter(Filter):
 
 ALL_FILTERS = (ExposureFilter, GammaFilter, ImprovedWhiteBalanceFilter, SaturationPlusFilter, ToneFilter,
                ContrastFilter, WNBFilter, ColorFilter)
+# the classes whose filter_param_regressor expo_heads_regress_* restates (a subclass with its own regressor does not qualify)
+FUSED_HEAD_TYPES = ALL_FILTERS + (LevelFilter,)
 
 
 class _DispatchFunction(torch.autograd.Function):

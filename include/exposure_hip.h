@@ -62,6 +62,7 @@ extern "C" {
 
 #define EXPO_NUM_FILTERS 9
 #define EXPO_MAX_PARAMS 24
+#define EXPO_MAX_HEADS 16 /* FC heads one expo_heads_regress_* call serves (cfg.filters has 8) */
 #define EXPO_CURVE_MAX_STEPS 16 /* largest cfg.curve_steps of expo_curve_fwd / _bwd */
 
 #define EXPO_FILTER_EXPOSURE 0
@@ -364,6 +365,27 @@ int expo_lrelu_bwd(const float* z, const float* dz, float* dy, size_t count, flo
 size_t expo_lrelu_bwd_bias_workspace_bytes(int channels);
 int expo_lrelu_bwd_bias(const float* z, const float* dz, float* dy, float* dbias, size_t count, int channels,
                         float leak, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * (ABI 4) The tail of the agent's FC heads: every filter's `filter_param_regressor` (filters.py:177-179 E, 201-203 G,
+ * 224-235 W, 481-482 S+, 306-310 T, 411-413 Ct, 435-436 BW, 256-262 C, 457-458 Le) followed by the one-hot selection of
+ * the chosen filter's parameters (agent.py:58-77, 119-125), per image, in one launch:
+ *   params[n][0..P) = regressor_{abi_ids[j]}(raw[j][n][0..P)),  j = selected[n];  the rest of the row, and the whole row
+ *   for j = -1, is 0.
+ * raw: HOST array of `heads` device pointers, head j holding float32 [n][widths[j]] (its second FC's output: P_j filter
+ * features followed by the mask features); abi_ids[j]: the C-ABI filter id of head j; selected: device int32 [n]
+ * (position in cfg.filters, -1 = none); params / dparams: float32 [n][EXPO_MAX_PARAMS]; ranges: HOST float[9] =
+ * {exposure_range, log(gamma_range), tone lo, tone hi, tone bias, colour lo, colour hi, colour bias, exposure bias}
+ * (cfg.exposure_range, cfg.gamma_range, cfg.tone_curve_range, cfg.color_curve_range; the biases are util.py:281-294's
+ * atanh(2 (initial - l) / (r - l) - 1), 0 for every shipped range).  The white-balance log range is the reference's
+ * constant 0.5.  expo_heads_regress_bwd writes d raw[j] for EVERY head (zeros outside the selected head's slice).
+ * 8-step curves only (cfg.curve_steps = 8: the rows hold EXPO_MAX_PARAMS values).
+ */
+int expo_heads_regress_fwd(const float* const* raw, const int* widths, const int* abi_ids, int heads,
+                           const float* ranges, const int32_t* selected, float* params, int n, void* stream);
+int expo_heads_regress_bwd(const float* const* raw, float* const* draw, const int* widths, const int* abi_ids,
+                           int heads, const float* ranges, const int32_t* selected, const float* dparams, int n,
+                           void* stream);
 
 /*
  * (ABI 4) The critic step's loss glue (net.py:126-194) -- the callers of the critic around the filter path:

@@ -596,3 +596,42 @@ def test_replay_memory_on_gpu_equals_the_round3_pool(gpu_device):
       ra, rb = a.get_replay_feed_dict(16), b.get_replay_feed_dict(16)
       for k in ra:
         assert torch.equal(ra[k], rb[k]), (it, k)
+
+
+def test_fused_heads_tail_matches_the_regressors(gpu_device):
+  """expo_heads_regress_fwd / _bwd (the eight filter_param_regressors + the one-hot gather in one launch each way)
+  against the op-by-op torch path of the same modules: parameters, and the gradients that reach every head's raw
+  features; -1 (nothing selected) gives a zero row and no gradient; against the NumPy regressors too."""
+  from exposure_amd import filters as F
+  dev = gpu_device
+  torch.manual_seed(3)
+  cfg = make_cfg()
+  ag = xagent.Agent(cfg).to(dev)
+  n = 19
+  rng = np.random.default_rng(4)
+  raws = [torch.from_numpy(rng.standard_normal((n, f.get_num_filter_parameters() + 6)).astype(np.float32) * 1.5).to(dev).requires_grad_(True)
+          for f in ag.filters]
+  sel = torch.from_numpy(((np.arange(n) % 9) - 1).astype(np.int32)).to(dev)  # -1, 0..7, -1, ...
+  p24 = F.heads_regress_select(list(ag.filters), raws, sel)
+  # op-by-op: regress every head, gather with the one-hot
+  onehot = (sel[:, None] == torch.arange(8, device=dev)[None, :]).float()
+  ref_raws = [r.detach().clone().requires_grad_(True) for r in raws]
+  ref = torch.zeros((n, 24), device=dev)
+  for j, (f, r) in enumerate(zip(ag.filters, ref_raws)):
+    pj = f.pack(f.filter_param_regressor(r[:, :f.get_num_filter_parameters()])).float()
+    ref = ref + torch.nn.functional.pad(pj, (0, 24 - pj.shape[1])) * onehot[:, j:j + 1]
+  assert float((p24 - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+  assert float(p24[sel < 0].abs().max()) == 0.0
+  for i in range(n):  # and the NumPy restatement of the regressors
+    j = int(sel[i])
+    if j >= 0:
+      fid = ag.filters[j].filter_id
+      want = fnp.regress_packed(fid, raws[j][i:i + 1, :fnp.NUM_PARAMS[fid]].detach().cpu().numpy().astype(np.float64))
+      assert np.abs(p24[i, :fnp.NUM_PARAMS[fid]].detach().cpu().numpy() - want[0]).max() <= 3e-6 * max(1.0, np.abs(want).max())
+  w = torch.from_numpy(rng.standard_normal((n, 24)).astype(np.float32)).to(dev)
+  (p24 * w).sum().backward()
+  (ref * w).sum().backward()
+  for j, (a, b) in enumerate(zip(raws, ref_raws)):
+    scale = float(b.grad.abs().max()) + 1e-12
+    assert float((a.grad - b.grad).abs().max()) <= 1e-5 * scale + 1e-7, (j, float((a.grad - b.grad).abs().max()), scale)
+    assert float(a.grad[:, ag.filters[j].get_num_filter_parameters():].abs().max()) == 0.0  # mask features: no gradient (masking off)
