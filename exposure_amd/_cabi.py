@@ -66,6 +66,8 @@ SIGNATURES = {
     'expo_heads_regress_fwd': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i), _i, ctypes.POINTER(_f), _vp, _fp, _i, _vp]),
     'expo_heads_regress_bwd': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i), _i,
                                    ctypes.POINTER(_f), _vp, _fp, _i, _vp]),
+    'expo_agent_select_fwd': (_i, [_fp, _fp, _i, _fp, _fp, ctypes.POINTER(_f), _i, _i, _i, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _i, _vp]),
+    'expo_agent_select_bwd': (_i, [_fp, _vp, _fp, ctypes.POINTER(_f), _i, _i, _fp, _fp, _fp, _i, _vp]),
     'expo_gp_inputs': (_i, [_vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
     'expo_grad_penalty_fwd': (_i, [_fp, _fp, _fp, _i, _sz, _vp]),
     'expo_grad_penalty_bwd': (_i, [_fp, _fp, _fp, _fp, _i, _sz, _vp]),
@@ -617,6 +619,38 @@ def heads_regress_bwd(raws, draws, abi_ids, ranges, selected, dparams):
   with torch.cuda.device(dparams.device):
     _check(lib.expo_heads_regress_bwd(ptrs, dptrs, widths, abi, h, rng, _ptr(selected), _ptr(dparams), n, _stream()),
            'expo_heads_regress_bwd')
+
+
+def agent_select_fwd(logits, noise, states, progress, consts, is_train, pdf, entropy, selected, onehot, surrogate, new_states,
+                     penalty_base):
+  """agent.py:87-125, 207-252 per image in one launch; ``noise``: (N, z_dim) float32, column 0 is used."""
+  lib = load()
+  n, k = logits.shape
+  _f32(logits, 'logits', (n, k)), _f32(states, 'states', (n, states.shape[1])), _f32(progress, 'progress', tuple(progress.shape))
+  assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape[0] == n and progress.numel() == 1
+  _f32(pdf, 'pdf', (n, k)), _f32(onehot, 'onehot', (n, k)), _f32(new_states, 'new_states', tuple(states.shape))
+  _ids(selected, n)
+  for t, nm in ((entropy, 'entropy'), (surrogate, 'surrogate'), (penalty_base, 'penalty_base')):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, nm
+  c = (_f * 5)(*[float(v) for v in consts])
+  with torch.cuda.device(logits.device):
+    _check(lib.expo_agent_select_fwd(_ptr(logits), _ptr(noise), int(noise.shape[1]) if noise.dim() > 1 else 1, _ptr(states),
+                                     _ptr(progress), c, k, int(states.shape[1]), int(bool(is_train)), _ptr(pdf), _ptr(entropy),
+                                     _ptr(selected), _ptr(onehot), _ptr(surrogate), _ptr(new_states), _ptr(penalty_base), n,
+                                     _stream()), 'expo_agent_select_fwd')
+
+
+def agent_select_bwd(logits, selected, progress, consts, state_dim, d_surrogate, d_penalty_base, d_logits):
+  lib = load()
+  n, k = logits.shape
+  _f32(logits, 'logits', (n, k)), _f32(d_logits, 'd_logits', (n, k))
+  _ids(selected, n)
+  for t in (d_surrogate, d_penalty_base):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+  c = (_f * 5)(*[float(v) for v in consts])
+  with torch.cuda.device(logits.device):
+    _check(lib.expo_agent_select_bwd(_ptr(logits), _ptr(selected), _ptr(progress), c, k, int(state_dim), _ptr(d_surrogate),
+                                     _ptr(d_penalty_base), _ptr(d_logits), n, _stream()), 'expo_agent_select_bwd')
 
 
 def gp_inputs(real, fake, alpha, cat_out, interp):

@@ -120,6 +120,40 @@ def pdf_sample(pdf, uniform_noise):
   return ((cdf < uniform_noise).sum(dim=1) - 1).to(torch.int32)
 
 
+class _AgentSelect(torch.autograd.Function):
+  """Action pdf, sampling, one-hot, surrogate, state update and the image-independent penalty terms of one agent step
+  (agent.py:87-125, 207-252) -- ``expo_agent_select_fwd / _bwd``: one launch each way instead of ~65 + ~35 tiny torch
+  launches.  Differentiable outputs: surrogate and penalty_base (-> logits); the rest is integer-valued, data, or (pdf,
+  entropy) reported only."""
+
+  @staticmethod
+  def forward(ctx, logits, noise, states, progress, consts, is_train):
+    logits = logits.contiguous().float()
+    n, k = logits.shape
+    dev = logits.device
+    states = states.contiguous().float()
+    noise = noise.contiguous().float()
+    pdf, onehot = torch.empty((n, k), device=dev), torch.empty((n, k), device=dev)
+    entropy, surrogate, pen = (torch.empty((n, 1), device=dev) for _ in range(3))
+    selected = torch.empty((n,), dtype=torch.int32, device=dev)
+    new_states = torch.empty_like(states)
+    F._cabi.agent_select_fwd(logits, noise, states, progress, consts, is_train, pdf, entropy, selected, onehot, surrogate,
+                             new_states, pen)
+    ctx.save_for_backward(logits, selected, progress)
+    ctx.meta = (tuple(consts), states.shape[1])
+    ctx.mark_non_differentiable(pdf, entropy, selected, onehot, new_states)
+    return pdf, entropy, selected, onehot, surrogate, new_states, pen
+
+  @staticmethod
+  def backward(ctx, _dpdf, _dent, _dsel, _doh, d_surrogate, _dns, d_pen):
+    logits, selected, progress = ctx.saved_tensors
+    consts, state_dim = ctx.meta
+    d_logits = torch.empty_like(logits)
+    F._cabi.agent_select_bwd(logits, selected, progress, consts, state_dim, d_surrogate.contiguous().float(),
+                             d_pen.contiguous().float(), d_logits)
+    return d_logits, None, None, None, None, None
+
+
 class Agent(nn.Module):
   """``agent_generator`` (agent.py:41-260) as a module.  ``forward`` mirrors its signature:
   ``inp = (net, z, states)``, ``is_train`` (0/1), ``progress`` (float), optional ``high_res``."""
@@ -199,6 +233,8 @@ class Agent(nn.Module):
       params, mask_params = self.regress_all(filter_features)  # 8 x reference-shaped, 8 x (N, 6)
 
     selector_features = self.selector_features(enriched, masks[1])
+    if fused_heads and k <= 16 and z.dtype == torch.float32 and states.shape[1] >= 3 + k:
+      return self._forward_fused(net, z, states, raws, selector_features, is_train, progress)
     pdf, entropy = self.action_pdf(selector_features)
     random_filter_id = pdf_sample(pdf, selection_noise)
     max_filter_id = torch.argmax(pdf, dim=1).to(torch.int32)
@@ -342,7 +378,39 @@ def _forward_generic(self, net, states, params, mask_params, pdf, entropy, selec
   return (out, new_states, high_res_output), debug_info, None
 
 
+def _forward_fused(self, net, z, states, raws, selector_features, is_train, progress):
+  """The training-time step on the device with the glue fused (round 4): selector FCs -> ONE selection kernel
+  (_AgentSelect) -> ONE regress-and-gather kernel (filters.heads_regress_select) -> ONE dispatch kernel with the
+  over-exposure penalty.  Same values as the op-by-op path (tests/test_hip_agent.py); cfg.masking off, 8-step curves."""
+  cfg = self.cfg
+  k = len(self.filters)
+  logits = self.selector_fc2(lrelu(self.selector_fc1(selector_features)))
+  prog = progress if torch.is_tensor(progress) else torch.full((1,), float(progress), dtype=torch.float32, device=net.device)
+  consts = (cfg.exploration, cfg.exploration_penalty, cfg.filter_usage_penalty, cfg.early_stop_penalty, cfg.test_steps)
+  pdf, entropy, selected, one_hot, surrogate, new_states, pen_base = _AgentSelect.apply(
+      logits, z, states, prog.reshape(1).float(), consts, int(is_train))
+  params24 = F.heads_regress_select(list(self.filters), raws, selected)
+  abi_ids = torch.where(selected >= 0, self.abi_filter_ids[selected.clamp_min(0).long()], torch.full_like(selected, -1))
+  out, overexposure = F.dispatch_filters(net, params24, abi_ids, int(cfg.get('hsv_grad_mode', 0)))
+  if cfg.clamp:
+    out = torch.clamp(out, 0.0, 5.0)
+    overexposure = F.overexposure_penalty(out)
+  penalty = overexposure[:, None] + pen_base
+  debug_info = {
+      'state': states,
+      'selected_filter_id': selected[0],
+      'filter_debug_info': [],  # (only the selected filter's parameters are regressed on this path)
+      'pdf': pdf[0],
+      'selected_filter_ids': selected,
+      'abi_filter_ids': abi_ids,
+      'pdf_batch': pdf,
+      'params24': params24,
+  }
+  return (out, new_states, surrogate, penalty), debug_info, None
+
+
 Agent._forward_generic = _forward_generic
+Agent._forward_fused = _forward_fused
 
 
 def agent_generator(inp, is_train, progress, cfg, high_res=None, alex_in=None, module=None, dropout_masks=None):

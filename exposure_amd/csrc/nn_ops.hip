@@ -278,6 +278,127 @@ __global__ __launch_bounds__(256) void heads_regress_bwd_kernel(const HeadsArgs 
   a.draw[j][size_t(img) * a.width[j] + col] = g;
 }
 
+// ---- action selection, state update and the non-image part of the penalty (agent.py:87-125, 207-252;
+// pdf_sample_layer.py:5-10) -- one thread per image, one launch each way instead of ~65 + ~35 tiny torch launches ------
+//   pdf = softmax(logits) + 1e-37;  pdf = pdf (1 - eps) + eps / K;  pdf /= sum(pdf) + 1e-30;  H = -sum pdf log pdf
+//   random id = #(exclusive cumsum(pdf / (rowsum(pdf) + 1e-36)) < z) - 1   (explicit association orders: the integer
+//   result must not depend on a reduction tree; K = 8 uses the packet order ((p0+p4)+(p2+p6))+((p1+p5)+(p3+p7)))
+//   id = is_train ? random id : argmax;  one_hot;  surrogate = log(pdf[id] + 1e-10) (0 for id = -1)
+//   new_states = [submitted, submitted, step + 1, max(usage, one_hot)],  submitted = |step + 1 - test_steps| < 1e-4
+//   penalty_base = (1 - progress) c_e (log K - H) + <usage, one_hot> c_u + (1 - submitted) submitted c_s
+// Backward: d logits from d surrogate and d penalty_base (through H); everything else is integer-valued or data.
+struct SelectArgs {
+  int k, state_dim, is_train;
+  float exploration, exploration_penalty, usage_penalty, early_stop_penalty, test_steps;
+};
+constexpr int kSelMaxK = 16;
+
+__device__ __forceinline__ void select_pdf(const float* __restrict__ l, int K, float eps, float* p, float* s_out) {
+  float mx = l[0];
+  for (int i = 1; i < K; ++i) mx = fmaxf(mx, l[i]);
+  float den = 0.f;
+  for (int i = 0; i < K; ++i) {
+    p[i] = expf(l[i] - mx);
+    den += p[i];
+  }
+  float tot = 0.f;
+  for (int i = 0; i < K; ++i) {
+    const float sm = p[i] / den;
+    if (s_out) s_out[i] = sm;
+    p[i] = (sm + 1e-37f) * (1.0f - eps) + eps * 1.0f / float(K);
+    tot += p[i];
+  }
+  tot += 1e-30f;
+  for (int i = 0; i < K; ++i) p[i] = p[i] / tot;
+}
+
+__global__ __launch_bounds__(64) void agent_select_fwd_kernel(const SelectArgs a, const float* __restrict__ logits,
+                                                              const float* __restrict__ noise, int noise_stride,
+                                                              const float* __restrict__ states,
+                                                              const float* __restrict__ progress, float* __restrict__ pdf,
+                                                              float* __restrict__ entropy, int32_t* __restrict__ selected,
+                                                              float* __restrict__ onehot, float* __restrict__ surrogate,
+                                                              float* __restrict__ new_states, float* __restrict__ pen_base,
+                                                              int n) {
+  const int img = blockIdx.x * blockDim.x + threadIdx.x;
+  if (img >= n) return;
+  const int K = a.k;
+  float p[kSelMaxK];
+  select_pdf(logits + size_t(img) * K, K, a.exploration, p, nullptr);
+  float H = 0.f;
+  for (int i = 0; i < K; ++i) {
+    pdf[size_t(img) * K + i] = p[i];
+    H += -p[i] * logf(p[i]);
+  }
+  entropy[img] = H;
+  // --- sampling (pdf_sample_layer.py:5-10), explicit association orders
+  float rs;
+  if (K == 8) rs = ((p[0] + p[4]) + (p[2] + p[6])) + ((p[1] + p[5]) + (p[3] + p[7]));
+  else {
+    rs = p[0];
+    for (int i = 1; i < K; ++i) rs = rs + p[i];
+  }
+  rs += 1e-36f;
+  const float z = noise[size_t(img) * noise_stride];
+  float cdf = 0.f;
+  int cnt = 0, amax = 0;
+  for (int i = 0; i < K; ++i) {
+    if (i > 0) cdf = cdf + p[i - 1] / rs;
+    cnt += (cdf < z) ? 1 : 0;
+    if (p[i] > p[amax]) amax = i;  // torch.argmax: the first maximum
+  }
+  const int id = a.is_train ? cnt - 1 : amax;
+  selected[img] = id;
+  const float* st = states + size_t(img) * a.state_dim;
+  float* ns = new_states + size_t(img) * a.state_dim;
+  const float step = st[2];
+  const float submitted = (fabsf(step + 1.0f - a.test_steps) < 1e-4f) ? 1.0f : 0.0f;
+  ns[0] = submitted;
+  ns[1] = submitted;
+  ns[2] = step + 1.0f;
+  float usage_pen = 0.f;
+  for (int i = 0; i < K; ++i) {
+    const float oh = (i == id) ? 1.0f : 0.0f;
+    onehot[size_t(img) * K + i] = oh;
+    const float u = st[3 + i];
+    usage_pen += u * oh;
+    ns[3 + i] = fmaxf(u, oh);
+  }
+  surrogate[img] = (id >= 0 && id < K) ? logf(p[id] + 1e-10f) : 0.0f;
+  const float ent_pen = (1.0f - progress[0]) * a.exploration_penalty * (-H + logf(float(K)));
+  pen_base[img] = ent_pen + usage_pen * a.usage_penalty + (1.0f - submitted) * submitted * a.early_stop_penalty;
+}
+
+__global__ __launch_bounds__(64) void agent_select_bwd_kernel(const SelectArgs a, const float* __restrict__ logits,
+                                                              const int32_t* __restrict__ selected,
+                                                              const float* __restrict__ progress,
+                                                              const float* __restrict__ d_surrogate,
+                                                              const float* __restrict__ d_pen_base,
+                                                              float* __restrict__ d_logits, int n) {
+  const int img = blockIdx.x * blockDim.x + threadIdx.x;
+  if (img >= n) return;
+  const int K = a.k;
+  float p[kSelMaxK], sm[kSelMaxK], gp[kSelMaxK];
+  select_pdf(logits + size_t(img) * K, K, a.exploration, p, sm);
+  const int id = selected[img];
+  const float gH = d_pen_base[img] * (1.0f - progress[0]) * a.exploration_penalty * -1.0f;
+  const float gs = d_surrogate[img];
+  float dot = 0.f, tot = 0.f;
+  for (int i = 0; i < K; ++i) {  // recompute the renormalisation's denominator (b = p * tot)
+    gp[i] = gH * (-(logf(p[i]) + 1.0f)) + ((i == id) ? gs / (p[i] + 1e-10f) : 0.0f);
+    dot += gp[i] * p[i];
+    tot += (sm[i] + 1e-37f) * (1.0f - a.exploration) + a.exploration * 1.0f / float(K);
+  }
+  tot += 1e-30f;
+  // p = b / tot: dL/db_j = (gp_j - sum_i gp_i p_i) / tot;  b = (s + 1e-37)(1 - eps) + eps / K;  s = softmax(l)
+  float gsm[kSelMaxK], dot2 = 0.f;
+  for (int i = 0; i < K; ++i) {
+    gsm[i] = (gp[i] - dot) / tot * (1.0f - a.exploration);
+    dot2 += gsm[i] * sm[i];
+  }
+  for (int i = 0; i < K; ++i) d_logits[size_t(img) * K + i] = sm[i] * (gsm[i] - dot2);
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int grid_for(size_t items) {
   const size_t blocks = (items + 255) / 256;
@@ -368,6 +489,47 @@ int expo_heads_regress_bwd(const float* const* raw, float* const* draw, const in
   hipLaunchKernelGGL(heads_regress_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a,
                      selected, dparams, n, total_width);
   HIP_TRY(hipGetLastError(), "heads_regress_bwd launch");
+  return EXPO_OK;
+}
+
+static int select_args(SelectArgs* a, int k, int state_dim, int is_train, const float* consts) {
+  if (k < 1 || k > kSelMaxK) return fail(EXPO_E_BADARG, "number of filters must be in [1, 16]");
+  if (state_dim < 3 + k) return fail(EXPO_E_BADARG, "state rows must hold 3 + K values (reward, stopped, step, usage)");
+  if (!consts) return fail(EXPO_E_BADARG, "null pointer");
+  *a = SelectArgs{k, state_dim, is_train ? 1 : 0, consts[0], consts[1], consts[2], consts[3], consts[4]};
+  return EXPO_OK;
+}
+
+int expo_agent_select_fwd(const float* logits, const float* noise, int noise_stride, const float* states,
+                          const float* progress, const float* consts, int k, int state_dim, int is_train, float* pdf,
+                          float* entropy, int32_t* selected, float* onehot, float* surrogate, float* new_states,
+                          float* penalty_base, int n, void* stream) {
+  SelectArgs a;
+  if (int rc = select_args(&a, k, state_dim, is_train, consts)) return rc;
+  if (n < 0 || noise_stride < 1) return fail(EXPO_E_BADARG, "n >= 0 and noise_stride >= 1 required");
+  if (n == 0) return EXPO_OK;
+  if (!logits || !noise || !states || !progress || !pdf || !entropy || !selected || !onehot || !surrogate || !new_states ||
+      !penalty_base)
+    return fail(EXPO_E_BADARG, "null pointer");
+  hipLaunchKernelGGL(agent_select_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), a, logits,
+                     noise, noise_stride, states, progress, pdf, entropy, selected, onehot, surrogate, new_states,
+                     penalty_base, n);
+  HIP_TRY(hipGetLastError(), "agent_select_fwd launch");
+  return EXPO_OK;
+}
+
+int expo_agent_select_bwd(const float* logits, const int32_t* selected, const float* progress, const float* consts, int k,
+                          int state_dim, const float* d_surrogate, const float* d_penalty_base, float* d_logits, int n,
+                          void* stream) {
+  SelectArgs a;
+  if (int rc = select_args(&a, k, state_dim, 1, consts)) return rc;
+  if (n < 0) return fail(EXPO_E_BADARG, "n >= 0 required");
+  if (n == 0) return EXPO_OK;
+  if (!logits || !selected || !progress || !d_surrogate || !d_penalty_base || !d_logits)
+    return fail(EXPO_E_BADARG, "null pointer");
+  hipLaunchKernelGGL(agent_select_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), a, logits,
+                     selected, progress, d_surrogate, d_penalty_base, d_logits, n);
+  HIP_TRY(hipGetLastError(), "agent_select_bwd launch");
   return EXPO_OK;
 }
 

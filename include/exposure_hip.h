@@ -388,6 +388,30 @@ int expo_heads_regress_bwd(const float* const* raw, float* const* draw, const in
                            void* stream);
 
 /*
+ * (ABI 4) Action selection, state update and the image-independent part of the penalty (agent.py:87-125, 207-252;
+ * pdf_sample_layer.py:5-10), per image, one launch:
+ *   pdf = softmax(logits) + 1e-37;  pdf = pdf (1 - exploration) + exploration / K;  pdf /= sum(pdf) + 1e-30
+ *   entropy = -sum pdf log pdf;  random id = #(exclusive cumsum(pdf / (rowsum(pdf) + 1e-36)) < noise) - 1 with the
+ *   explicit association orders of the reference's CPU kernels (K = 8: ((p0+p4)+(p2+p6))+((p1+p5)+(p3+p7)); the scan
+ *   left to right) -- noise 0 gives -1;  selected = is_train ? random id : argmax(pdf);  onehot;
+ *   surrogate = log(pdf[selected] + 1e-10) (0 for -1);  new_states = [submitted, submitted, step + 1, max(usage, onehot)],
+ *   submitted = |step + 1 - test_steps| < 1e-4;  penalty_base = (1 - progress) c_e (log K - entropy) + <usage, onehot> c_u
+ *   + (1 - submitted) submitted c_s.
+ * logits [n][k]; noise: element n * noise_stride (column 0 of z); states / new_states [n][state_dim] = [reward, stopped,
+ * step, usage x k, ...]; progress: DEVICE float[1] (a graph input); consts: HOST float[5] = {cfg.exploration,
+ * cfg.exploration_penalty, cfg.filter_usage_penalty, cfg.early_stop_penalty, cfg.test_steps}; outputs pdf / onehot
+ * [n][k], entropy / surrogate / penalty_base [n], selected int32 [n].  expo_agent_select_bwd: d logits from the
+ * gradients of surrogate and penalty_base (through the entropy); k <= 16.
+ */
+int expo_agent_select_fwd(const float* logits, const float* noise, int noise_stride, const float* states,
+                          const float* progress, const float* consts, int k, int state_dim, int is_train, float* pdf,
+                          float* entropy, int32_t* selected, float* onehot, float* surrogate, float* new_states,
+                          float* penalty_base, int n, void* stream);
+int expo_agent_select_bwd(const float* logits, const int32_t* selected, const float* progress, const float* consts,
+                          int k, int state_dim, const float* d_surrogate, const float* d_penalty_base, float* d_logits,
+                          int n, void* stream);
+
+/*
  * (ABI 4) The critic step's loss glue (net.py:126-194) -- the callers of the critic around the filter path:
  *   expo_gp_inputs         cat[0:n] = real, cat[n:2n] = fake (float32) and the gradient penalty's interpolation
  *                          interp = real + alpha[n] (fake - real) (net.py:170-172) in one pass; real / fake of `dtype`,

@@ -635,3 +635,60 @@ def test_fused_heads_tail_matches_the_regressors(gpu_device):
     scale = float(b.grad.abs().max()) + 1e-12
     assert float((a.grad - b.grad).abs().max()) <= 1e-5 * scale + 1e-7, (j, float((a.grad - b.grad).abs().max()), scale)
     assert float(a.grad[:, ag.filters[j].get_num_filter_parameters():].abs().max()) == 0.0  # mask features: no gradient (masking off)
+
+
+@pytest.mark.parametrize('is_train', [1, 0])
+def test_fused_agent_step_equals_the_op_by_op_step(is_train, gpu_device, monkeypatch):
+  """The training-time fast path (one selection kernel + one regress-and-gather kernel + dispatch) against the op-by-op
+  torch path of the SAME module: selected ids and new states bit-equal, pdf / surrogate / penalty / output image equal
+  to rounding, and the gradients of a scalar of all differentiable outputs with respect to every generator parameter.
+  The ids are also the NumPy sampler's for the kernel's own pdf (pdf_sample_layer.py:5-10), incl. noise 0 -> -1."""
+  dev = gpu_device
+  torch.manual_seed(5)
+  cfg = make_cfg()
+  ag = xagent.Agent(cfg).to(dev)
+  with torch.no_grad():
+    for p in ag.parameters():
+      if p.dim() == 1:
+        p.normal_(0.0, 0.3)  # non-uniform pdf
+  rng = np.random.default_rng(2)
+  n = 24
+  img = torch.from_numpy(synthetic.make_images(rng, (n, 64, 64, 3), np.float32)).to(dev)
+  states = np.zeros((n, 11), dtype=np.float32)
+  states[:, 2] = rng.integers(0, 6, n)
+  states[:, 3:] = rng.random((n, 8)) < 0.3
+  z = rng.random((n, 131), dtype=np.float32)
+  z[0, 0] = 0.0
+  masks = [torch.from_numpy((rng.random((n, 4096)) < 0.5).astype(np.float32)).to(dev) for _ in range(2)]
+  t = lambda a: torch.from_numpy(a).to(dev)
+  w_img = torch.randn(n, 64, 64, 3, device=dev) * 1e-3
+
+  def run(fused):
+    ag.zero_grad(set_to_none=True)
+    if not fused:
+      monkeypatch.setattr(xagent.Agent, '_forward_fused', None, raising=True)
+      monkeypatch.setattr(filters, 'FUSED_HEAD_TYPES', ())
+    (out, new_states, surrogate, penalty), dbg, _ = ag((img, t(z), t(states)), is_train=is_train, progress=0.3, dropout_masks=masks)
+    loss = (out.float() * w_img).sum() + (surrogate * 0.7).sum() - (penalty * 1.3).sum()
+    loss.backward()
+    grads = [p.grad.detach().clone() if p.grad is not None else None for p in ag.parameters()]
+    monkeypatch.undo()
+    return out.detach(), new_states.detach(), surrogate.detach(), penalty.detach(), dbg, grads
+
+  fo, fs, fsur, fpen, fdbg, fg = run(True)
+  ro, rs, rsur, rpen, rdbg, rg = run(False)
+  assert 'params24' in fdbg and fdbg['filter_debug_info'] == [] and len(rdbg['filter_debug_info']) == 8
+  ids = fdbg['selected_filter_ids'].cpu().numpy()
+  assert np.array_equal(ids, rdbg['selected_filter_ids'].cpu().numpy())
+  if is_train:
+    assert ids[0] == -1
+    assert np.array_equal(ids, agent_np.pdf_sample(fdbg['pdf_batch'].cpu().numpy(), z[:, 0:1]))
+  assert torch.equal(fs, rs)
+  assert float((fdbg['pdf_batch'] - rdbg['pdf_batch']).abs().max()) <= 2e-7
+  assert float((fsur - rsur).abs().max()) <= 2e-6 and float(((fpen - rpen).abs() / rpen.abs().clamp_min(1.0)).max()) <= 2e-6
+  assert float((fo - ro).abs().max()) <= 2e-5 * max(1.0, float(ro.abs().max()))
+  for (name, _), a, b in zip(ag.named_parameters(), fg, rg):
+    assert (a is None) == (b is None), name
+    if a is not None:
+      scale = float(b.abs().max()) + 1e-12
+      assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-8, (name, float((a - b).abs().max()), scale)
