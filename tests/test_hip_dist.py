@@ -104,9 +104,11 @@ def test_two_ranks_on_one_gpu_match_one_process(gpu_device, tmp_path, use_graphs
   for got, ref_g in zip(r0['grads'], want['grads']):
     scale = float(ref_g.abs().max()) + 1e-12
     # (fp32 convolutions of 4 and of 8 images, possibly through different MIOpen kernels, and the double backward of the
-    # gradient penalty on top: 1.7e-3 of a tensor's largest gradient was seen inside the full suite; a wrong reduction
-    # -- sum instead of mean, a missing shard -- would be off by a factor)
-    assert float((got - ref_g).abs().max()) <= 5e-3 * scale + 1e-8
+    # gradient penalty on top; after the first Adam step -- which moves every weight by ~lr whatever the size of its
+    # gradient, so rounding-level differences in near-zero gradients become lr-sized weight differences -- 1.7e-3 (round 3)
+    # and 7.7e-3 (round 4, fused glue kernels contract differently) of a tensor's largest gradient were seen at the
+    # second iteration; a wrong reduction -- sum instead of mean, a missing shard -- would be off by a factor)
+    assert float((got - ref_g).abs().max()) <= (5e-3 if iters == 1 else 2e-2) * scale + 1e-8
   worst = max(float((a - b).abs().max()) for a, b in zip(r0['params'], want['params']))
   assert worst < 3e-4 * iters, worst  # Adam's first steps are ~lr-sized (tests/test_dist_gloo.py)
 
