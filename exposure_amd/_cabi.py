@@ -45,6 +45,7 @@ SIGNATURES = {
     'expo_filter_dispatch_fwd': (_i, [_vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_filter_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_chain_streams': (_i, [_i, _i, _i, _i]),
+    'expo_chain_helper_stats': (_i, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
                             _vp]),
     'expo_chain_bwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
@@ -723,6 +724,14 @@ def curve_bwd(x, dy, dx, params, dparams, curves, steps, workspace=None):
 def chain_streams(n, h, w, dtype_code):
   """1 or 2: how many streams expo_chain_fwd / _bwd use for a batch of this shape."""
   return int(load().expo_chain_streams(int(n), int(h), int(w), int(dtype_code)))
+
+
+def chain_helper_stats():
+  """(probed, rejected): helper-stream pairings this process probed for a hardware queue of their own, and helpers it
+  rejected (expo_chain_helper_stats; diagnostics)."""
+  a, b = ctypes.c_int(0), ctypes.c_int(0)
+  _check(load().expo_chain_helper_stats(ctypes.byref(a), ctypes.byref(b)), 'expo_chain_helper_stats')
+  return a.value, b.value
 
 
 def apply_dispatch_fwd(ids, x, y, params, mask_params, maximum_sharpness, minimum_strength):

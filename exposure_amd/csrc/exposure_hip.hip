@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include <vector>
 #include <string>
@@ -1550,22 +1551,102 @@ struct ForkJoin {
 // One helper stream + event pair PER (device, caller stream): two host threads that drive two user streams -- one of
 // them possibly inside a hipGraph capture, which the helper then joins -- no longer meet on one helper and one event
 // pair (advisor, round 3).  Entries are created on first use and live for the process (a handful of streams).
+//
+// A helper must not share a HARDWARE queue with its caller (round 4, r04p14): the runtime multiplexes all streams of a
+// process over a few hardware queues (4 by default) in creation order, and two streams on one queue run their kernels
+// strictly one after the other -- the two lanes then cost more than one (256x512x512 chain calls: 2.63 ms aliased,
+// 2.47 one lane, 2.31 on separate queues).  Which queue a stream got cannot be asked, so the first EAGER two-lane call
+// of a caller stream probes its helper: a one-wave kernel on the caller waits (at most 0.5 ms) for a flag that a
+// one-wave kernel on the helper sets.  It sees the flag iff kernels of the two streams can run side by side.  A helper
+// that fails goes to the device's spare list (kept: releasing it would hand the same queue to the next stream created)
+// and the next candidate is tried.  Under stream capture nothing can be probed and nothing needs to be: the graph's
+// branches get their queues from the graph executor.  EXPO_CHAIN_HELPER_PROBE=0 takes the first helper unprobed.
+__device__ int g_lane_probe[2];  // [0] the flag (a generation number), [1] what the waiting kernel saw
+__global__ void lane_probe_wait_kernel(int gen, long long limit_ticks) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = wall_clock64();  // 100 MHz
+  int seen = 0;
+  do {
+    seen = __hip_atomic_load(&g_lane_probe[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen == gen) break;
+    __builtin_amdgcn_s_sleep(64);
+  } while (wall_clock64() - t0 < limit_ticks);
+  __hip_atomic_store(&g_lane_probe[1], seen == gen ? gen : -gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void lane_probe_set_kernel(int gen) {
+  if (threadIdx.x == 0) __hip_atomic_store(&g_lane_probe[0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 1: kernels of `s` and `h` ran side by side; 0: they did not; -1: could not tell (treated as "take it")
+static int lanes_run_side_by_side(hipStream_t s, hipStream_t h) {
+  static int gen = 0;
+  ++gen;
+  hipLaunchKernelGGL(lane_probe_wait_kernel, dim3(1), dim3(64), 0, s, gen, 50000LL);
+  hipLaunchKernelGGL(lane_probe_set_kernel, dim3(1), dim3(64), 0, h, gen);
+  if (hipGetLastError() != hipSuccess) return -1;
+  if (hipStreamSynchronize(h) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+  int got[2] = {0, 0};
+  if (hipMemcpyFromSymbol(got, HIP_SYMBOL(g_lane_probe), sizeof(got)) != hipSuccess) return -1;
+  return got[1] == gen ? 1 : got[1] == -gen ? 0 : -1;
+}
+static int g_helper_probes = 0, g_helper_rejected = 0;  // expo_chain_helper_stats()
+
 static ForkJoin* fork_join_for_device(hipStream_t caller = nullptr) {
-  struct Entry { int dev; hipStream_t caller; ForkJoin fj; };
+  struct Entry { int dev; hipStream_t caller; ForkJoin fj; bool probed; };
+  struct Spare { int dev; hipStream_t st; };
   static std::vector<Entry*> table;
+  static std::vector<Spare> spares;  // rejected helpers, never used again, kept so that their queue slot stays taken
   static std::mutex mu;
+  static const bool probe = !(getenv("EXPO_CHAIN_HELPER_PROBE") && atoi(getenv("EXPO_CHAIN_HELPER_PROBE")) == 0);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  for (Entry* e : table)
-    if (e->dev == dev && e->caller == caller) return &e->fj;
-  hipStream_t st;
-  hipEvent_t e0, e1;
-  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return nullptr;
-  Entry* e = new Entry{dev, caller, ForkJoin{st, e0, e1}};
-  table.push_back(e);
+  Entry* e = nullptr;
+  for (Entry* t : table)
+    if (t->dev == dev && t->caller == caller) e = t;
+  if (!e) {
+    hipStream_t st;
+    hipEvent_t e0, e1;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return nullptr;
+    e = new Entry{dev, caller, ForkJoin{st, e0, e1}, !probe};
+    table.push_back(e);
+  }
+  if (e->probed) return &e->fj;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(caller, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    return &e->fj;  // cannot tell: no probe now
+  }
+  if (cap != hipStreamCaptureStatusNone) return &e->fj;  // capturing: the helper only names a branch of the graph
+  // Eager and unprobed.  The helper is idle here: it was created above or has only been part of captures.
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;  // the probe synchronises: keep another thread's capture valid
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  hipStream_t first = e->fj.helper, cand = first;
+  bool found = false;
+  for (int attempt = 0; attempt < 8 && !found; ++attempt) {
+    ++g_helper_probes;
+    const int r = lanes_run_side_by_side(caller, cand);
+    if (r != 0) {
+      found = true;
+      break;
+    }
+    ++g_helper_rejected;
+    if (cand != first) spares.push_back(Spare{dev, cand});
+    cand = nullptr;
+    if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) {
+      cand = nullptr;
+      break;
+    }
+  }
+  if (found && cand != first) {
+    spares.push_back(Spare{dev, first});
+    e->fj.helper = cand;
+  } else if (!found && cand && cand != first) {
+    spares.push_back(Spare{dev, cand});  // nothing ran side by side (a one-queue configuration): keep the first helper
+  }
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  e->probed = true;
   return &e->fj;
 }
 // fork: helper waits for everything `s` holds; join: `s` waits for everything the helper holds.  The event is shared by
@@ -1816,6 +1897,12 @@ int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const voi
 int expo_chain_streams(int n, int h, int w, int dtype) {
   if (check_common(n, h, w, dtype) != EXPO_OK) return 0;
   return chain_plan(n, h, w, dtype).two_lanes ? 2 : 1;
+}
+
+int expo_chain_helper_stats(int* probed, int* rejected) {
+  if (probed) *probed = g_helper_probes;
+  if (rejected) *rejected = g_helper_rejected;
+  return EXPO_OK;
 }
 
 int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts, const float* const* params, int n, int h,

@@ -227,8 +227,14 @@ int expo_finish_bwd(const int* filter_ids, int steps, const float* const* params
  * -3.5 % per step at 64x512x512).  Nothing changes for the caller: all work is ordered after what `stream` held
  * before the call and before what it receives afterwards, and the pattern is capturable into a hipGraph.
  * expo_chain_streams() returns the number of streams (1 or 2) a shape gets (EXPO_CHAIN_STREAMS=1|2 overrides).
+ *
+ * The helper is chosen per (device, caller stream) and must sit on another hardware queue than `stream`: the first
+ * eager two-stream call of a caller stream synchronises that stream once and probes the pairing (two one-wave
+ * kernels, < 0.1 ms; a rejected helper costs 0.5 ms), see exposure_hip.hip.  expo_chain_helper_stats() reports how
+ * many pairings this process probed and how many helpers it rejected (diagnostics; either pointer may be NULL).
  */
 int expo_chain_streams(int n, int h, int w, int dtype);
+int expo_chain_helper_stats(int* probed, int* rejected);
 int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts,
                    const float* const* params, int n, int h, int w, int dtype,
                    void* stream);

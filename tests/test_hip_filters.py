@@ -812,3 +812,65 @@ def test_split_chain_replayed_from_a_hipgraph_equals_eager(gpu_device):
   torch.cuda.synchronize()
   for got, ref in zip([acts[8], grads[0]] + dprm, want):
     assert torch.equal(got, ref)
+
+
+def test_every_caller_stream_gets_a_helper_on_another_hardware_queue(gpu_device):
+  """The runtime multiplexes a process's streams over a few hardware queues; a helper stream that lands on its caller's
+  queue serialises the two lanes of a chain call (r04p14: 2.63 ms instead of 2.31 at 256x512x512).  The library probes
+  each (caller, helper) pairing on the caller's first eager two-lane call (exposure_hip.hip::fork_join_for_device).
+  Six caller streams -- more than there are hardware queues: every one is probed exactly once, results are identical
+  on all of them, and no caller's chain step is more than 10 % slower than the fastest caller's (an aliased pair is
+  +14 %)."""
+  dev = gpu_device
+  shape = (64, 512, 512, 3)
+  assert _cabi.chain_streams(shape[0], shape[1], shape[2], _cabi.EXPO_F16) == 2
+  ids = list(range(8))
+  g = torch.Generator(device=dev).manual_seed(21)
+  x = (torch.rand(shape, device=dev, generator=g)**2.2).half()
+  dy = torch.randn(shape, device=dev, generator=g).half()
+  rng = np.random.default_rng(21)
+  prm = [torch.from_numpy(synthetic.make_params(rng, f, shape[0])).to(dev) for f in ids]
+  acts = [x] + [torch.empty_like(x) for _ in ids]
+  grads = [torch.empty_like(x) for _ in ids] + [dy]
+  dprm = [torch.empty_like(p) for p in prm]
+  ws = _cabi.new_workspace(dev, _cabi.workspace_bytes(shape[0], shape[1], shape[2], _cabi.EXPO_F16, 8))
+
+  def step():
+    _cabi.chain_fwd(ids, acts, prm)
+    _cabi.chain_bwd(ids, acts, grads, prm, dprm, workspace=ws)
+
+  step()
+  torch.cuda.synchronize()
+  want = [acts[8].clone(), grads[0].clone()] + [d.clone() for d in dprm]
+  streams = [torch.cuda.Stream() for _ in range(6)]
+  assert len({s.cuda_stream for s in streams}) == 6
+  probed0, _ = _cabi.chain_helper_stats()
+  ms = []
+  for s in streams:
+    for t in [acts[8], grads[0]] + dprm:
+      t.fill_(3.0)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+      step()  # probes this caller's helper
+      step()
+      runs = []
+      for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+          step()
+        e1.record()
+        e1.synchronize()
+        runs.append(e0.elapsed_time(e1) / 4)
+    torch.cuda.synchronize()
+    ms.append(sorted(runs)[2])
+    for got, ref in zip([acts[8], grads[0]] + dprm, want):
+      assert torch.equal(got, ref)
+  probed1, rejected = _cabi.chain_helper_stats()
+  assert probed1 - probed0 >= 6  # one probe per new caller, more where a helper was rejected
+  with torch.cuda.stream(streams[0]):
+    step()
+  torch.cuda.synchronize()
+  assert _cabi.chain_helper_stats()[0] == probed1  # a known caller is not probed again
+  print('chain step per caller stream (ms): %s; helpers rejected so far: %d' % (' '.join('%.4f' % v for v in ms), rejected))
+  assert max(ms) <= 1.10 * min(ms), ms
