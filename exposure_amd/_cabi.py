@@ -69,6 +69,8 @@ SIGNATURES = {
                                    ctypes.POINTER(_f), _vp, _fp, _i, _vp]),
     'expo_agent_select_fwd': (_i, [_fp, _fp, _i, _fp, _fp, ctypes.POINTER(_f), _i, _i, _i, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _i, _vp]),
     'expo_agent_select_bwd': (_i, [_fp, _vp, _fp, ctypes.POINTER(_f), _i, _i, _fp, _fp, _fp, _i, _vp]),
+    'expo_adam_step': (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                           ctypes.POINTER(_sz), _fp, _fp, _vp, _f, _f, _f, _vp]),
     'expo_gp_inputs': (_i, [_vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
     'expo_grad_penalty_fwd': (_i, [_fp, _fp, _fp, _i, _sz, _vp]),
     'expo_grad_penalty_bwd': (_i, [_fp, _fp, _fp, _fp, _i, _sz, _vp]),
@@ -652,6 +654,29 @@ def agent_select_bwd(logits, selected, progress, consts, state_dim, d_surrogate,
   with torch.cuda.device(logits.device):
     _check(lib.expo_agent_select_bwd(_ptr(logits), _ptr(selected), _ptr(progress), c, k, int(state_dim), _ptr(d_surrogate),
                                      _ptr(d_penalty_base), _ptr(d_logits), n, _stream()), 'expo_agent_select_bwd')
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, ticket, beta1, beta2, eps):
+  """One Adam update of the listed fp32 tensors (expo_adam_step).  Tensor j of the four lists must share one element
+  order (same sizes and strides, dense); ``lr`` / ``step`` are device floats, ``ticket`` a device int32 (zero)."""
+  lib = load()
+  count = len(params)
+  assert len(grads) == count and len(exp_avg) == count and len(exp_avg_sq) == count
+  if count == 0:
+    return
+  dev = params[0].device
+  for quad in zip(params, grads, exp_avg, exp_avg_sq):
+    for t in quad:
+      if not (t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.size() == quad[0].size() and
+              t.stride() == quad[0].stride()):
+        raise ExposureHipError('exposure_amd: adam_step wants fp32 device tensors of one layout per parameter')
+  assert lr.is_cuda and lr.dtype == torch.float32 and step.is_cuda and step.dtype == torch.float32
+  assert ticket.is_cuda and ticket.dtype == torch.int32
+  arr = lambda ts: (_vp * count)(*[t.data_ptr() for t in ts])
+  numel = (_sz * count)(*[t.numel() for t in params])
+  with torch.cuda.device(dev):
+    _check(lib.expo_adam_step(count, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, _ptr(lr), _ptr(step),
+                              _ptr(ticket), float(beta1), float(beta2), float(eps), _stream()), 'expo_adam_step')
 
 
 def gp_inputs(real, fake, alpha, cat_out, interp):

@@ -405,6 +405,79 @@ static inline int grid_for(size_t items) {
   return int(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));  // grid-stride beyond 1 M items
 }
 
+
+// ---- Adam over a list of tensors, one launch (net.py:222-251: the three AdamOptimizers of a training iteration) -------
+// torch's fused multi-tensor Adam walks chunks of 65 536 elements with one block each: 20-75 blocks for the 1-5 M
+// parameters of one of these networks, 43 us per step on 256 CUs (profiles/r04_final_kernel_stats_train.csv).  Here a
+// block takes 1 024 elements (one float4 per thread), tensors are addressed through a table passed by value, and the
+// step counter lives on the device (read by every block, advanced by the block that finishes last), so the launch is
+// capturable and replays without host involvement.  Update rule = torch.optim.Adam (no weight decay, no amsgrad):
+//   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+constexpr int kAdamMaxTensors = EXPO_ADAM_MAX_TENSORS;
+constexpr unsigned kAdamBlockElems = 1024;
+struct AdamArgs {
+  float* p[kAdamMaxTensors];
+  const float* g[kAdamMaxTensors];
+  float* m[kAdamMaxTensors];
+  float* v[kAdamMaxTensors];
+  unsigned n[kAdamMaxTensors];
+  unsigned first_block[kAdamMaxTensors + 1];
+  int count;
+  int vec;  // every pointer 16-byte aligned
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float eps,
+                                         float step_size, float inv_sqrt_bc2) {
+  m = m + (g - m) * (1.0f - b1);
+  v = b2 * v + (1.0f - b2) * g * g;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p = p - step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, const float* __restrict__ lr, float* __restrict__ step,
+                                                   unsigned* __restrict__ ticket, float b1, float b2, float eps,
+                                                   int advance) {
+  int t = 0;
+  while (t + 1 < a.count && blockIdx.x >= a.first_block[t + 1]) ++t;  // uniform: scalar compares
+  const float st = step[0] + 1.0f;
+  const float bc1 = 1.0f - powf(b1, st), bc2 = 1.0f - powf(b2, st);
+  const float step_size = lr[0] / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  const unsigned n = a.n[t];
+  const unsigned i = (blockIdx.x - a.first_block[t]) * kAdamBlockElems + threadIdx.x * 4;
+  float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t];
+  float* __restrict__ v = a.v[t];
+  if (a.vec && i + 4 <= n) {
+    float4 pp = *reinterpret_cast<const float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i);
+    float4 mm = *reinterpret_cast<const float4*>(m + i), vv = *reinterpret_cast<const float4*>(v + i);
+    adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, eps, step_size, inv_sqrt_bc2);
+    adam_one(pp.y, gg.y, mm.y, vv.y, b1, b2, eps, step_size, inv_sqrt_bc2);
+    adam_one(pp.z, gg.z, mm.z, vv.z, b1, b2, eps, step_size, inv_sqrt_bc2);
+    adam_one(pp.w, gg.w, mm.w, vv.w, b1, b2, eps, step_size, inv_sqrt_bc2);
+    *reinterpret_cast<float4*>(p + i) = pp;
+    *reinterpret_cast<float4*>(m + i) = mm;
+    *reinterpret_cast<float4*>(v + i) = vv;
+  } else {
+    for (unsigned k = i; k < i + 4 && k < n; ++k) {
+      float pp = p[k], mm = m[k], vv = v[k];
+      adam_one(pp, g[k], mm, vv, b1, b2, eps, step_size, inv_sqrt_bc2);
+      p[k] = pp;
+      m[k] = mm;
+      v[k] = vv;
+    }
+  }
+  if (!advance) return;
+  // every block has read step[0] before it takes a ticket (its results depend on the value); the last ticket advances it
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = atomicAdd(ticket, 1u);
+    if (done == gridDim.x - 1) {
+      step[0] = st;
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 }  // namespace expo
 
 using namespace expo;
@@ -575,6 +648,48 @@ int expo_grad_penalty_bwd(const float* g, const float* norm, const float* dterm,
   hipLaunchKernelGGL(grad_penalty_bwd_kernel, dim3(unsigned(bx), n), dim3(256), 0, static_cast<hipStream_t>(stream), g, norm,
                      dterm, dg, elems_per_image);
   HIP_TRY(hipGetLastError(), "grad_penalty_bwd launch");
+  return EXPO_OK;
+}
+
+int expo_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const size_t* numel, const float* lr, float* step, void* ticket, float beta1,
+                   float beta2, float eps, void* stream) {
+  if (count < 0) return fail(EXPO_E_BADARG, "count >= 0 required");
+  if (count == 0) return EXPO_OK;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr || !step || !ticket)
+    return fail(EXPO_E_BADARG, "null pointer");
+  if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f))
+    return fail(EXPO_E_BADARG, "betas in [0, 1) and eps >= 0 required");
+  for (int j = 0; j < count; ++j) {
+    if (!params[j] || !grads[j] || !exp_avg[j] || !exp_avg_sq[j]) return fail(EXPO_E_BADARG, "null tensor pointer");
+    if (numel[j] == 0 || numel[j] > 0xffffffffull - kAdamBlockElems)
+      return fail(EXPO_E_BADARG, "tensor sizes in [1, 2^32 - 1024) required");
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // tables of at most EXPO_ADAM_MAX_TENSORS tensors per launch; only the last launch of a call advances the step
+  for (int base = 0; base < count; base += kAdamMaxTensors) {
+    AdamArgs a;
+    a.count = count - base < kAdamMaxTensors ? count - base : kAdamMaxTensors;
+    a.vec = 1;
+    unsigned blocks = 0;
+    for (int j = 0; j < a.count; ++j) {
+      a.p[j] = params[base + j];
+      a.g[j] = grads[base + j];
+      a.m[j] = exp_avg[base + j];
+      a.v[j] = exp_avg_sq[base + j];
+      a.n[j] = unsigned(numel[base + j]);
+      a.first_block[j] = blocks;
+      const unsigned nb = (a.n[j] + kAdamBlockElems - 1) / kAdamBlockElems;
+      if (blocks + nb < blocks) return fail(EXPO_E_BADARG, "too many elements for one call");
+      blocks += nb;
+      if (!aligned16(a.p[j]) || !aligned16(a.g[j]) || !aligned16(a.m[j]) || !aligned16(a.v[j])) a.vec = 0;
+    }
+    a.first_block[a.count] = blocks;
+    const int advance = base + kAdamMaxTensors >= count;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, a, lr, step, static_cast<unsigned*>(ticket), beta1, beta2,
+                       eps, advance);
+    HIP_TRY(hipGetLastError(), "adam launch");
+  }
   return EXPO_OK;
 }
 

@@ -50,9 +50,17 @@ class GAN(nn.Module):
       lr = lambda v: torch.tensor(float(v), device=device)
     else:
       lr = float
-    self.opt_g = torch.optim.Adam(self.generator.parameters(), lr=lr(cfg.lr_g(0)), **adam)
-    self.opt_v = torch.optim.Adam(self.value.parameters(), lr=lr(cfg.value_lr_mul * cfg.lr_g(0)), **adam)
-    self.opt_c = torch.optim.Adam(self.critic.parameters(), lr=lr(cfg.lr_c(0)), **adam)
+    if device is not None and torch.device(device).type == 'cuda' and os.environ.get('EXPO_HIP_ADAM', '1') == '1':
+      # one launch per optimiser step with a block per 1 024 elements (exposure_amd/optim.py; torch's fused kernel:
+      # a block per 65 536 -- 43 us for a network of these sizes); learning rate and step counter on the device
+      from .optim import HipAdam
+      make = lambda params, value: HipAdam(params, torch.tensor(float(value), device=device), betas=adam['betas'],
+                                           eps=adam['eps'])
+    else:
+      make = lambda params, value: torch.optim.Adam(params, lr=lr(value), **adam)
+    self.opt_g = make(self.generator.parameters(), cfg.lr_g(0))
+    self.opt_v = make(self.value.parameters(), cfg.value_lr_mul * cfg.lr_g(0))
+    self.opt_c = make(self.critic.parameters(), cfg.lr_c(0))
     self.process_group = process_group
     self.world_size = xdist.world_size(process_group)
     # dropout masks and the gradient penalty's alpha: drawn for the GLOBAL batch from a generator every rank seeds

@@ -452,6 +452,28 @@ int expo_curve_fwd(const void* x, void* y, const float* params, int n, int h, in
 int expo_curve_bwd(const void* x, const void* dy, void* dx, const float* params, float* dparams, int n, int h,
                    int w, int dtype, int curves, int steps, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * One Adam update of a LIST of fp32 tensors in one launch -- the three optimisers of a training iteration
+ * (net.py:222-251 `ly.optimize_loss(..., optimizer=cfg.optimizer)`; config_example.py:158
+ * `tf.train.AdamOptimizer(learning_rate=lr, beta1=0.5, beta2=0.9)`), replacing torch's fused multi-tensor Adam
+ * (one block per 65 536 elements: 43 us for the 1-5 M parameters of one network).
+ *   params / grads / exp_avg / exp_avg_sq   host arrays of `count` device pointers; tensor j has numel[j] floats,
+ *                                           all four in the same element order (tables of EXPO_ADAM_MAX_TENSORS
+ *                                           tensors per launch; more tensors -> more launches)
+ *   lr     device float        (a captured launch reads the learning rate of the replay)
+ *   step   device float        t - 1 on entry; the launch computes with t = step + 1 and stores t (the block that
+ *                              finishes last advances it: capturable, no host involvement)
+ *   ticket device uint32, zero before the first call, owned by the optimiser (restored to zero by every call)
+ * Update rule (torch.optim.Adam without weight decay / amsgrad; TF-1's differs only in where epsilon sits:
+ * sqrt(v) + eps' with eps' = eps sqrt(1 - beta2^t)):
+ *   m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ */
+#define EXPO_ADAM_MAX_TENSORS 64
+int expo_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const size_t* numel, const float* lr, float* step, void* ticket,
+                   float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,3 +166,86 @@ def test_critic_step_glue_kernels(dtype, shape, gpu_device):
   assert float((grads.grad.double() - gref.grad).abs().max()) <= 1e-5 * scale
   if shape[0] > 8:
     assert float((rnorm > 1).float().mean()) not in (0.0, 1.0), 'the case must cover both sides of the kink'
+
+
+def _adam_reference(ps, gs_per_step, lrs, b1, b2, eps):
+  """torch.optim.Adam's rule in float64 (no weight decay, no amsgrad)."""
+  ps = [p.double().clone() for p in ps]
+  ms = [torch.zeros_like(p) for p in ps]
+  vs = [torch.zeros_like(p) for p in ps]
+  for t, (gs, lr) in enumerate(zip(gs_per_step, lrs), start=1):
+    for p, g, m, v in zip(ps, gs, ms, vs):
+      g = g.double()
+      m.mul_(b1).add_(g, alpha=1 - b1)
+      v.mul_(b2).addcmul_(g, g, value=1 - b2)
+      denom = v.sqrt() / (1 - b2**t)**0.5 + eps
+      p.sub_(lr / (1 - b1**t) * m / denom)
+  return ps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('count', [7, 70])
+def test_hip_adam_matches_the_rule_in_float64(count, gpu_device):
+  """expo_adam_step (exposure_amd/optim.py) against torch.optim.Adam's update rule in float64 over six steps with a
+  changing learning rate: ragged sizes (1, 3, 1023, 1025 ...), a channels_last conv weight, a parameter without a
+  gradient (skipped), more tensors than one launch's table holds (70 > EXPO_ADAM_MAX_TENSORS), and the same six steps
+  again as ONE captured launch sequence replayed (device-side step counter and learning rate)."""
+  from exposure_amd.optim import HipAdam
+  dev = gpu_device
+  g = torch.Generator(device=dev).manual_seed(count)
+  sizes = [(1,), (3,), (7, 5), (1023,), (1025,), (64, 6, 4, 4), (100003,)]
+  sizes = (sizes * (count // len(sizes) + 1))[:count]
+  b1, b2, eps = 0.5, 0.9, 1e-8
+  lrs = [2e-3, 2e-3, 1e-3, 5e-4, 0.0, 3e-3]
+
+  def fresh():
+    ps = []
+    for i, sz in enumerate(sizes):
+      p = torch.randn(sz, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + i))
+      if len(sz) == 4:
+        p = p.contiguous(memory_format=torch.channels_last)
+      ps.append(p.requires_grad_(True))
+    idle = torch.ones(5, device=dev, requires_grad=True)  # never receives a gradient
+    return ps, idle
+
+  grads = [[torch.randn(sz, device=dev, generator=g) * (10.0**float(torch.randint(-6, 2, (1,)).item())) for sz in sizes]
+           for _ in lrs]
+  ps, idle = fresh()
+  want = _adam_reference([p.detach() for p in ps], grads, lrs, b1, b2, eps)
+
+  def check(ps):
+    for p, w, sz in zip(ps, want, sizes):
+      err = (p.detach().double() - w).abs().max().item()
+      assert err <= 4e-7 * w.abs().max().item() + 2e-6 * max(lrs) * len(lrs), (sz, err)
+
+  opt = HipAdam(ps + [idle], lr=lrs[0], betas=(b1, b2), eps=eps)
+  for gs, lr in zip(grads, lrs):
+    opt.param_groups[0]['lr'].fill_(lr)
+    for p, gr in zip(ps, gs):
+      p.grad = gr.contiguous(memory_format=torch.channels_last) if gr.dim() == 4 else gr
+    opt.step()
+  torch.cuda.synchronize()
+  check(ps)
+  assert float(opt._step) == len(lrs) and int(opt._ticket) == 0 and torch.equal(idle.detach(), torch.ones(5, device=dev))
+
+  # the same as a captured step, replayed: gradients and learning rate are static inputs of the graph
+  ps, idle = fresh()
+  opt = HipAdam(ps + [idle], lr=lrs[0], betas=(b1, b2), eps=eps)
+  static = [torch.zeros_like(p) for p in ps]
+  for p, sg in zip(ps, static):
+    p.grad = sg
+  for p in ps:
+    opt._moments(p)  # allocate the moments outside the capture
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    opt.step()
+  for p in ps:  # the capture itself does not execute
+    pass
+  for gs, lr in zip(grads, lrs):
+    opt.param_groups[0]['lr'].fill_(lr)
+    for sg, gr in zip(static, gs):
+      sg.copy_(gr)
+    graph.replay()
+  torch.cuda.synchronize()
+  check(ps)
+  assert float(opt._step) == len(lrs)
