@@ -613,6 +613,9 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
       'critic_steps_per_iteration': cfg.citers,
       'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
       'miopen_find': bool(torch.backends.cudnn.benchmark),
+      # the measured solver rankings the package ships (exposure_amd/miopen_db) or whatever the user set
+      'miopen_user_db': os.path.relpath(os.environ['MIOPEN_USER_DB_PATH'], ROOT)
+                        if os.environ.get('MIOPEN_USER_DB_PATH') else None,
       'capture_drain_verified': getattr(gan, 'capture_drain_verified', None),
       'roofline': {
           'bound': 'mfma_fp32',
@@ -624,8 +627,9 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
           'peak': MFMA_FP32_PEAK_TFLOPS,
           'unit': 'TFLOP/s',
           'frac': achieved / MFMA_FP32_PEAK_TFLOPS,
-          'note': 'the nets are fp32 like the reference\'s (MIOpen igemm on v_mfma_f32_*_f32); at batch 64 x 64x64 the '
-                  'iteration is bound by launch count, not by the matrix pipes',
+          'note': 'the nets are fp32 like the reference\'s (MIOpen / CK implicit-GEMM kernels on v_mfma_f32_*_f32); at batch '
+                  '64 x 64x64 about half of the iteration is those kernels, themselves at ~0.32 of this peak, the rest '
+                  'is ~1 200 small launches around them (DESIGN.md 3.10, profiles/r04_experiments.md r04p15)',
       },
   }
 
@@ -707,6 +711,7 @@ def run_train(args, world, rank, dev, dist):
                            'all-reduced over RCCL from backward hooks' % world,
             'launch': m['launch'],
             'miopen_find': m['miopen_find'],
+            'miopen_user_db': m['miopen_user_db'],
             'capture_drain_verified': m['capture_drain_verified'],
             'reference_note': 'README.md:43: ~0.30 s/iteration on a GTX 1080 Ti (whole run ~100 min / 20000 it)',
         },

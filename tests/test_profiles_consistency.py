@@ -54,8 +54,14 @@ def test_kernel_tables_list_every_kernel():
   # the training iteration's table (timed region only): the round's kernels are IN the graph
   train = open(os.path.join(PROF, '%s_kernel_stats_train.csv' % TAG)).read()
   assert train.startswith('# window')
+  per_iteration = int(train.split(' = ')[1].split(' per iteration')[0])
+  assert per_iteration <= 1500, per_iteration  # round-3 verdict, item 3
   for frag in ('stats_kernel', 'stats_bwd_kernel', 'stats_jvp_kernel', 'bias_lrelu_fwd_kernel', 'lrelu_bwd_kernel',
-               'dispatch_fwd_kernel', 'dispatch_bwd_kernel'):
+               'dispatch_fwd_kernel', 'dispatch_bwd_kernel',
+               # round 4: the glue of the steps
+               'lrelu_bwd_bias_kernel', 'gp_inputs_kernel', 'grad_penalty_fwd_kernel', 'grad_penalty_bwd_kernel',
+               'heads_regress_fwd_kernel', 'heads_regress_bwd_kernel', 'agent_select_fwd_kernel',
+               'agent_select_bwd_kernel', 'adam_kernel'):
     assert frag in train, frag
   infer = [r['Name'] for r in csv.DictReader(open(os.path.join(PROF, '%s_kernel_stats_infer_B.csv' % TAG)))]
   assert any('chain_fused_fwd_kernel' in n for n in infer)
