@@ -423,7 +423,7 @@ struct AdamArgs {
   unsigned n[kAdamMaxTensors];
   unsigned first_block[kAdamMaxTensors + 1];
   int count;
-  int vec;  // every pointer 16-byte aligned
+  unsigned char vec[kAdamMaxTensors];  // the tensor's four pointers are 16-byte aligned
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float eps,
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, const float* __re
   const float* __restrict__ g = a.g[t];
   float* __restrict__ m = a.m[t];
   float* __restrict__ v = a.v[t];
-  if (a.vec && i + 4 <= n) {
+  if (a.vec[t] && i + 4 <= n) {
     float4 pp = *reinterpret_cast<const float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i);
     float4 mm = *reinterpret_cast<const float4*>(m + i), vv = *reinterpret_cast<const float4*>(v + i);
     adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, eps, step_size, inv_sqrt_bc2);
@@ -670,7 +670,6 @@ int expo_adam_step(int count, float* const* params, const float* const* grads, f
   for (int base = 0; base < count; base += kAdamMaxTensors) {
     AdamArgs a;
     a.count = count - base < kAdamMaxTensors ? count - base : kAdamMaxTensors;
-    a.vec = 1;
     unsigned blocks = 0;
     for (int j = 0; j < a.count; ++j) {
       a.p[j] = params[base + j];
@@ -682,7 +681,7 @@ int expo_adam_step(int count, float* const* params, const float* const* grads, f
       const unsigned nb = (a.n[j] + kAdamBlockElems - 1) / kAdamBlockElems;
       if (blocks + nb < blocks) return fail(EXPO_E_BADARG, "too many elements for one call");
       blocks += nb;
-      if (!aligned16(a.p[j]) || !aligned16(a.g[j]) || !aligned16(a.m[j]) || !aligned16(a.v[j])) a.vec = 0;
+      a.vec[j] = aligned16(a.p[j]) && aligned16(a.g[j]) && aligned16(a.m[j]) && aligned16(a.v[j]);
     }
     a.first_block[a.count] = blocks;
     const int advance = base + kAdamMaxTensors >= count;

@@ -170,6 +170,10 @@ class _Pending:
   wait_and_scatter = wait  # round-1 name
 
 
+def _padded(numel):
+  return (numel + 3) & ~3
+
+
 class GradBucket:
   """Flat fp32 gradient storage for a parameter list; every ``p.grad`` IS a view into it.
 
@@ -184,7 +188,9 @@ class GradBucket:
 
   def __init__(self, params, on_ready=None):
     self.params = [p for p in params]
-    self.numel = sum(p.numel() for p in self.params)
+    # every parameter starts on a 16-byte boundary of the flat buffer (padding elements stay zero and ride along in the
+    # all-reduce): element-wise kernels over (parameter, gradient) pairs -- expo_adam_step -- keep their float4 path
+    self.numel = sum(_padded(p.numel()) for p in self.params)
     self.flat = None
     self.on_ready = on_ready
     self.launched = False  # set by the owner once this step's all-reduce has been issued
@@ -200,7 +206,7 @@ class GradBucket:
     for p in self.params:
       assert p.dtype == torch.float32 and _dense(p), 'bucket parameters must be dense fp32'
       p.grad = torch.as_strided(self.flat, p.size(), p.stride(), off)
-      off += p.numel()
+      off += _padded(p.numel())
     for h in self._hooks:
       h.remove()
     self._hooks = []
@@ -220,7 +226,7 @@ class GradBucket:
       if g is None or g.data_ptr() != self.flat.data_ptr() + 4 * off or g.stride() != p.stride() or \
           g.size() != p.size():
         return False
-      off += p.numel()
+      off += _padded(p.numel())
     return True
 
   def zero(self):

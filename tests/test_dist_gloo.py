@@ -102,9 +102,11 @@ def test_shard_helpers_single_process():
   ready = []
   b = xdist.GradBucket(list(conv.parameters()) + list(lin.parameters()), on_ready=ready.append)
   b.zero()
-  assert b.attached() and b.flat.numel() == sum(p.numel() for p in b.params)
+  # (every view starts on a 16-byte boundary of the flat buffer: sizes are padded to multiples of four floats)
+  assert b.attached() and b.flat.numel() == sum((p.numel() + 3) // 4 * 4 for p in b.params) == b.numel
   for p in b.params:
     assert p.grad.stride() == p.stride() and p.grad.untyped_storage().data_ptr() == b.flat.untyped_storage().data_ptr()
+    assert (p.grad.data_ptr() - b.flat.data_ptr()) % 16 == 0
   x = torch.randn(2, 3, 4, 4)
   loss = conv(x).sum() + lin(torch.randn(3, 5)).sum()
   want = torch.autograd.grad(loss, b.params, retain_graph=True)

@@ -202,6 +202,11 @@ def test_hip_adam_matches_the_rule_in_float64(count, gpu_device):
     ps = []
     for i, sz in enumerate(sizes):
       p = torch.randn(sz, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + i))
+      if sz == (1025,):  # a parameter that does not start on a 16-byte boundary: this tensor takes the scalar path
+        base = torch.empty(1026, device=dev)
+        base[1:].copy_(p)
+        p = base[1:]
+        assert p.data_ptr() % 16 == 4
       if len(sz) == 4:
         p = p.contiguous(memory_format=torch.channels_last)
       ps.append(p.requires_grad_(True))
