@@ -18,6 +18,7 @@ the selection noise (agent.py:47) and ``dropout_masks`` (two (N, 4096) 0/1 tenso
 always-on ``tf.nn.dropout`` of agent.py:36 (pass ``None`` to draw them).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -177,6 +178,7 @@ class Agent(nn.Module):
     for fc in (self.selector_fc1, self.selector_fc2):
       nn.init.xavier_uniform_(fc.weight)
       nn.init.zeros_(fc.bias)
+    self._packed_heads = None  # filters.PackedHeads, built at the first fused forward on a device
     # position in cfg.filters -> C-ABI filter id (they differ when cfg.filters is a subset/reorder)
     self.register_buffer('abi_filter_ids', torch.tensor([f.filter_id for f in self.filters], dtype=torch.int32),
                          persistent=False)
@@ -227,7 +229,15 @@ class Agent(nn.Module):
                    not any(f.uses_generic_kernels() for f in self.filters) and
                    all(type(f) in F.FUSED_HEAD_TYPES for f in self.filters))
     if fused_heads:
-      raws = [filt.fc2(lrelu(filt.fc1(filter_features))) for filt in self.filters]
+      # the K heads' two FCs as one GEMM + one batched GEMM over parameters packed in place (filters.PackedHeads);
+      # EXPO_PACKED_HEADS=0: one addmm / lrelu / addmm per head
+      if self._packed_heads is None and os.environ.get('EXPO_PACKED_HEADS', '1') == '1':
+        pack = F.PackedHeads(self.filters)
+        self._packed_heads = pack if pack.supported() else False
+      if self._packed_heads and filter_features.dtype == torch.float32:
+        raws = self._packed_heads(filter_features)
+      else:
+        raws = [filt.fc2(lrelu(filt.fc1(filter_features))) for filt in self.filters]
       params = mask_params = None
     else:
       params, mask_params = self.regress_all(filter_features)  # 8 x reference-shaped, 8 x (N, 6)

@@ -209,6 +209,119 @@ def heads_regress_select(filter_modules, raws, selected):
   return _HeadsRegressSelect.apply(selected, tuple(int(f.filter_id) for f in filter_modules), ranges, *raws)
 
 
+class _PackedHeadsFn(torch.autograd.Function):
+  """All heads' ``fc2(lrelu(fc1(features)))`` (filters.py:28-42, eight times per step: agent.py:58-69) as ONE GEMM for
+  the first layers -- features (N, F) x packed W1^T (F, K*H) --, one fused bias + lrelu launch, ONE batched GEMM for the
+  second layers (K x (N, H) x (H, 32): outputs zero-padded to 32 columns), and the transposed pair in the backward:
+  ~11 launches instead of ~90.  The packed operands ALIAS the heads' own parameters (``PackedHeads``), so nothing is
+  gathered per step; the parameters enter as inputs only so that autograd routes the gradient slices to them."""
+
+  @staticmethod
+  def forward(ctx, features, pack, *leaves):
+    n = features.shape[0]
+    k, hid, pad = pack.k, pack.hidden, pack.PAD
+    features = features.contiguous()
+    z1 = features @ pack.w1.t()  # (N, K*H)
+    h = torch.empty_like(z1)
+    _cabi.bias_lrelu_fwd(z1, pack.b1, h, 0.2)
+    h3 = h.view(n, k, hid).transpose(0, 1)  # (K, N, H): batch stride H, row stride K*H -- no copy
+    out = torch.baddbmm(pack.b2.unsqueeze(1), h3, pack.w2.transpose(1, 2))  # (K, N, 32)
+    ctx.save_for_backward(features, h)
+    ctx.pack = pack
+    return tuple(out.unbind(0))
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, *douts):
+    features, h = ctx.saved_tensors
+    pack = ctx.pack
+    n = features.shape[0]
+    k, hid, pad = pack.k, pack.hidden, pack.PAD
+    first = douts[0]
+    adjacent = all(d is not None and d.is_contiguous() and d.data_ptr() == first.data_ptr() + j * n * pad * 4
+                   for j, d in enumerate(douts))
+    if adjacent:  # the regress-and-select node hands over K slices of ONE head-major buffer (filters._HeadsRegressSelect)
+      dout = torch.as_strided(first, (k, n, pad), (n * pad, pad, 1))
+    else:
+      dout = torch.stack([d if d is not None else torch.zeros_like(first) for d in douts], dim=0)
+    h3 = h.view(n, k, hid).transpose(0, 1)
+    db2 = dout.sum(dim=1)  # (K, 32)
+    dw2 = torch.bmm(dout.transpose(1, 2), h3)  # (K, 32, H)
+    dh = torch.bmm(dout, pack.w2).transpose(0, 1).reshape(n, k * hid)  # (N, K*H): one small transposing copy
+    dz1 = torch.empty_like(dh)
+    _cabi.lrelu_bwd(h, dh, dz1, 0.2)
+    db1 = dz1.sum(dim=0)
+    dw1 = dz1.t() @ features  # (K*H, F)
+    dfeat = dz1 @ pack.w1 if ctx.needs_input_grad[0] else None
+    grads = []
+    for j, width in enumerate(pack.widths):
+      grads += [dw1[j * hid:(j + 1) * hid], db1[j * hid:(j + 1) * hid], dw2[j, :width], db2[j, :width]]
+    return (dfeat, None) + tuple(grads)
+
+
+class PackedHeads:
+  """Storage of the agent's K filter heads packed so that their first layers are ONE weight matrix (K*H, F) and their
+  second layers ONE zero-padded batch (K, 32, H): every ``filter.fc1.weight`` / ``.bias`` / ``fc2.weight`` / ``.bias``
+  keeps its identity as a Parameter (names, state dict, optimiser, gradient buckets, checkpoint import all unchanged)
+  but its ``.data`` is a view into the packed buffers -- the parameter-flattening trick of data-parallel wrappers.
+  ``ensure()`` re-packs if anything replaced the parameters' storage (``module.to(...)``, a dtype change)."""
+  PAD = 32
+
+  def __init__(self, filter_modules):
+    self.filters = list(filter_modules)
+    self.k = len(self.filters)
+    self.hidden = self.filters[0].fc1.out_features
+    self.in_dim = self.filters[0].fc1.in_features
+    self.widths = [f.fc2.out_features for f in self.filters]
+    self.w1 = self.b1 = self.w2 = self.b2 = None
+
+  def supported(self):
+    return (all(f.fc1.out_features == self.hidden and f.fc1.in_features == self.in_dim and
+                f.fc2.in_features == self.hidden and f.fc2.out_features <= self.PAD for f in self.filters) and
+            all(p.dtype == torch.float32 for p in self.leaves()))
+
+  def leaves(self):
+    out = []
+    for f in self.filters:
+      out += [f.fc1.weight, f.fc1.bias, f.fc2.weight, f.fc2.bias]
+    return out
+
+  def _aliased(self):
+    if self.w1 is None or self.w1.device != self.filters[0].fc1.weight.device:
+      return False
+    hid, f_in = self.hidden, self.in_dim
+    for j, f in enumerate(self.filters):
+      if (f.fc1.weight.data_ptr() != self.w1.data_ptr() + 4 * j * hid * f_in or
+          f.fc1.bias.data_ptr() != self.b1.data_ptr() + 4 * j * hid or
+          f.fc2.weight.data_ptr() != self.w2.data_ptr() + 4 * j * self.PAD * hid or
+          f.fc2.bias.data_ptr() != self.b2.data_ptr() + 4 * j * self.PAD):
+        return False
+    return True
+
+  @torch.no_grad()
+  def ensure(self):
+    if self._aliased():
+      return
+    dev = self.filters[0].fc1.weight.device
+    k, hid, f_in, pad = self.k, self.hidden, self.in_dim, self.PAD
+    w1 = torch.empty((k * hid, f_in), dtype=torch.float32, device=dev)
+    b1 = torch.empty((k * hid,), dtype=torch.float32, device=dev)
+    w2 = torch.zeros((k, pad, hid), dtype=torch.float32, device=dev)
+    b2 = torch.zeros((k, pad), dtype=torch.float32, device=dev)
+    for j, f in enumerate(self.filters):
+      width = self.widths[j]
+      for view, prm in ((w1[j * hid:(j + 1) * hid], f.fc1.weight), (b1[j * hid:(j + 1) * hid], f.fc1.bias),
+                        (w2[j, :width], f.fc2.weight), (b2[j, :width], f.fc2.bias)):
+        view.copy_(prm.data)
+        prm.data = view
+    self.w1, self.b1, self.w2, self.b2 = w1, b1, w2, b2
+
+  def __call__(self, features):
+    """-> K tensors (N, 32): head j's second-FC output in its first ``widths[j]`` columns, zeros behind."""
+    self.ensure()
+    return list(_PackedHeadsFn.apply(features, self, *self.leaves()))
+
+
 def pixel_filter(fid, img, packed, hsv_grad_mode=0):
   """Functional entry: filter ``fid`` (0..7, ``cfg.filters`` order) with packed (N,P) params."""
   return _PixelFilterFunction.apply(img, packed, fid, hsv_grad_mode)

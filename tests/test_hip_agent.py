@@ -692,3 +692,66 @@ def test_fused_agent_step_equals_the_op_by_op_step(is_train, gpu_device, monkeyp
     if a is not None:
       scale = float(b.abs().max()) + 1e-12
       assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-8, (name, float((a - b).abs().max()), scale)
+
+
+def test_packed_heads_equal_the_per_head_layers(gpu_device):
+  """filters.PackedHeads: the K heads' fc2(lrelu(fc1(.))) as one GEMM + one batched GEMM over parameters packed IN
+  PLACE.  Outputs (first P_j + 6 columns; zeros behind) and the gradients of every head parameter and of the features
+  against the per-head nn.Linear path on the same weights; the parameters stay the optimiser's / the state dict's:
+  an in-place update and a load_state_dict are seen by the packed operands, and .to() / a replaced storage re-packs."""
+  from exposure_amd import filters as F
+  from exposure_amd.util import lrelu
+  dev = gpu_device
+  torch.manual_seed(5)
+  cfg = make_cfg()
+  ag = xagent.Agent(cfg).to(dev)
+  with torch.no_grad():
+    for f in ag.filters:  # biases are zero-initialised: make them matter
+      f.fc1.bias.normal_(0, 0.1)
+      f.fc2.bias.normal_(0, 0.1)
+  ref_state = {k: v.detach().clone() for k, v in ag.state_dict().items()}
+  n = 13
+  feats = torch.randn(n, cfg.feature_extractor_dims, device=dev)
+  pack = F.PackedHeads(ag.filters)
+  assert pack.supported()
+
+  def compare():
+    fa = feats.clone().requires_grad_(True)
+    fb = feats.clone().requires_grad_(True)
+    for p in ag.parameters():
+      p.grad = None
+    outs = pack(fa)
+    ws = [torch.randn(n, pack.PAD, device=dev, generator=torch.Generator(device=dev).manual_seed(j)) for j in range(len(outs))]
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    got = [p.grad.clone() for p in pack.leaves()] + [fa.grad.clone()]
+    for p in ag.parameters():
+      p.grad = None
+    refs = [f.fc2(lrelu(f.fc1(fb))) for f in ag.filters]
+    sum((r * w[:, :r.shape[1]]).sum() for r, w in zip(refs, ws)).backward()
+    want = [p.grad.clone() for p in pack.leaves()] + [fb.grad.clone()]
+    for j, (o, r) in enumerate(zip(outs, refs)):
+      width = r.shape[1]
+      assert o.shape == (n, pack.PAD) and float(o[:, width:].abs().max()) == 0.0
+      assert float((o[:, :width] - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max())), j
+    for i, (a, b) in enumerate(zip(got, want)):
+      assert a.shape == b.shape
+      assert float((a - b).abs().max()) <= 2e-5 * max(1e-3, float(b.abs().max())), i
+
+  compare()
+  assert pack._aliased()
+  w1_ptr = pack.w1.data_ptr()
+  with torch.no_grad():  # an optimiser-style in-place update of the Parameters is seen by the packed operands
+    for p in pack.leaves():
+      p.add_(0.01)
+  compare()
+  assert pack.w1.data_ptr() == w1_ptr and pack._aliased()
+  ag.load_state_dict(ref_state)  # copies into the aliased storage
+  assert pack._aliased() and torch.equal(ag.filters[3].fc1.weight, ref_state['filters.3.fc1.weight'])
+  compare()
+  # names and values of the state dict are the per-filter ones
+  sd = ag.state_dict()
+  assert all(torch.equal(sd[k], v) for k, v in ref_state.items())
+  ag.filters[2].fc1.weight.data = ag.filters[2].fc1.weight.data.clone()  # someone replaced a storage: re-pack
+  assert not pack._aliased()
+  compare()
+  assert pack._aliased() and pack.w1.data_ptr() != w1_ptr
