@@ -94,8 +94,10 @@ class GAN(nn.Module):
         'c': xdist.GradBucket(self.critic.parameters(), on_ready=self._bucket_ready),
     }
     self._pending = []
-    # ExponentialMovingAverage(decay=0.99, zero_debias=True) of c_average (net.py:107-108, 165-168)
-    self.c_average_biased = 0.0
+    self._progress = None  # the step's `progress` input as a device scalar (generator_step)
+    # ExponentialMovingAverage(decay=0.99, zero_debias=True) of c_average (net.py:107-108, 165-168): the biased average
+    # lives on the device and is advanced INSIDE the critic step (one in-place lerp, part of the captured graph)
+    self._c_ema = None
     self.c_average_steps = 0
 
   # -- learning rates (config_example.py:134-158; net.py:222-251)
@@ -105,7 +107,9 @@ class GAN(nn.Module):
     def put(opt, value):
       for g in opt.param_groups:
         if torch.is_tensor(g['lr']):
-          g['lr'].fill_(value)  # in place: the captured graph reads this tensor
+          if g.get('_lr_value') != value:  # the five critic steps of an iteration repeat the G step's values: no launch
+            g['lr'].fill_(value)  # in place: the captured graph reads this tensor
+            g['_lr_value'] = value
         else:
           g['lr'] = value
 
@@ -221,7 +225,11 @@ class GAN(nn.Module):
     self.set_lrs(it, zero_g=(it == 0))
     masks = dropout_masks or self._draw_masks(fake_input.shape[0])
     if self._replay_steps:
-      prog = torch.as_tensor(float(progress), device=fake_input.device)
+      # (a device scalar filled in place: torch.as_tensor(float, device=...) is a blocking copy from pageable memory --
+      # one full drain of the queue per iteration, with the G step's graph launch behind it)
+      if self._progress is None or self._progress.device != fake_input.device:
+        self._progress = torch.zeros((), dtype=torch.float32, device=fake_input.device)
+      prog = self._progress.fill_(float(progress))
       return self._replay('g', self._generator_body_graph, (fake_input, z, states, prog, masks[0], masks[1]))
     return self._generator_body(fake_input, z, states, progress, masks)
 
@@ -348,6 +356,10 @@ class GAN(nn.Module):
     self._finish_collectives()
     self.opt_c.step()
     self.clip_critic_weights()
+    ca = out['c_average'].detach().reshape(())
+    if self._c_ema is None or self._c_ema.device != ca.device:
+      self._c_ema = torch.zeros((), dtype=ca.dtype, device=ca.device)
+    self._c_ema.lerp_(ca, 0.01)  # update_average (net.py:165-168, 267-268): 0.99 * average + 0.01 * c_average
     return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
   def critic_step(self, real_data, fake_output, it=1, alpha=None):
@@ -358,11 +370,19 @@ class GAN(nn.Module):
       out = dict(self._replay('c', self._critic_body, (real_data, fake_output, alpha)))
     else:
       out = self._critic_body(real_data, fake_output, alpha)
-    # update_average (net.py:165-168, 267-268): debiased EMA of the logit centre, kept on the device
     self.c_average_steps += 1
-    self.c_average_biased = 0.99 * self.c_average_biased + 0.01 * out['c_average']
-    out['c_average_smoothed'] = self.c_average_biased / (1.0 - 0.99**self.c_average_steps)
     return out
+
+  @property
+  def c_average_biased(self):
+    return self._c_ema if self._c_ema is not None else 0.0
+
+  def c_average_smoothed(self):
+    """The zero-debiased moving average of the logit centre (net.py:167; a reported value: nothing on the path reads
+    it), computed when asked for."""
+    if self.c_average_steps == 0:
+      return 0.0
+    return self._c_ema / (1.0 - 0.99**self.c_average_steps)
 
   # -- the training loop (net.py:298-403), minus visualisation / checkpoints / TensorBoard
   def train(self, memory, max_iter_step=None, log_every=0, log=print):
