@@ -69,6 +69,8 @@ SIGNATURES = {
                                    ctypes.POINTER(_f), _vp, _fp, _i, _vp]),
     'expo_agent_select_fwd': (_i, [_fp, _fp, _i, _fp, _fp, ctypes.POINTER(_f), _i, _i, _i, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _i, _vp]),
     'expo_agent_select_bwd': (_i, [_fp, _vp, _fp, ctypes.POINTER(_f), _i, _i, _fp, _fp, _fp, _i, _vp]),
+    'expo_planes_concat': (_i, [_vp, _fp, _fp, _i, _sz, _i, _i, _f, _vp]),
+    'expo_generator_losses': (_i, [_fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, ctypes.POINTER(_f), _i, _fp, _fp, _fp, _fp, _i, _vp]),
     'expo_adam_step': (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                            ctypes.POINTER(_sz), _fp, _fp, _vp, _f, _f, _f, _vp]),
     'expo_gp_inputs': (_i, [_vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
@@ -677,6 +679,40 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, ticket, beta1, beta2
   with torch.cuda.device(dev):
     _check(lib.expo_adam_step(count, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, _ptr(lr), _ptr(step),
                               _ptr(ticket), float(beta1), float(beta2), float(eps), _stream()), 'expo_adam_step')
+
+
+def planes_concat(images, vec, out, offset):
+  """out[n, p, c] = (c < 3 ? images[n, p, c] : vec[n, c - 3]) - offset (float32, 3 + V channels): expo_planes_concat."""
+  lib = load()
+  _img(images, 'images')
+  n = images.shape[0]
+  pixels = images[0].numel() // 3 if n else 0
+  v = 0 if vec is None else int(vec.shape[1])
+  if vec is not None:
+    _f32(vec, 'vec', (n, v))
+  assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+  assert tuple(out.shape) == tuple(images.shape[:-1]) + (3 + v,)
+  with torch.cuda.device(images.device):
+    _check(lib.expo_planes_concat(_ptr(images), _ptr(vec), _ptr(out), n, pixels, v, _dtype_code(images), float(offset),
+                                  _stream()), 'expo_planes_concat')
+
+
+def generator_losses(fake_logit, fake_input_logit, new_value, old_value, new_states, penalty, surrogate, consts, use_td,
+                     losses, reward, q_value, coef):
+  """expo_generator_losses: (g_loss, v_loss), reward, q and the five gradient coefficient rows of the G step's loss glue."""
+  lib = load()
+  n = fake_logit.numel()
+  for t in (fake_logit, fake_input_logit, new_value, old_value, surrogate, reward, q_value) + ((penalty,) if penalty is not None else ()):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+  _f32(new_states, 'new_states', (n, new_states.shape[1]))
+  assert losses.is_cuda and losses.dtype == torch.float32 and losses.numel() == 2
+  _f32(coef, 'coef', (5, n))
+  c = (_f * 5)(*[float(v) for v in consts])
+  with torch.cuda.device(fake_logit.device):
+    _check(lib.expo_generator_losses(_ptr(fake_logit), _ptr(fake_input_logit), _ptr(new_value), _ptr(old_value),
+                                     _ptr(new_states), int(new_states.shape[1]), _ptr(penalty), _ptr(surrogate), c,
+                                     int(bool(use_td)), _ptr(losses), _ptr(reward), _ptr(q_value), _ptr(coef), n, _stream()),
+           'expo_generator_losses')
 
 
 def gp_inputs(real, fake, alpha, cat_out, interp):

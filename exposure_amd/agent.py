@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from . import filters as F
-from .nn_ops import bias_lrelu, conv2d_nhwc
+from .nn_ops import bias_lrelu, conv2d_nhwc, planes_concat
 from .util import (STATE_DROPOUT_BEGIN, STATE_REWARD_DIM, STATE_STEP_DIM, STATE_STOPPED_DIM,
                    enrich_image_input, lrelu)
 
@@ -64,9 +64,11 @@ class FeatureExtractor(nn.Module):
       _xavier_conv(c)
     self.to(memory_format=torch.channels_last)
 
-  def forward(self, net_nhwc, dropout_mask=None):
-    # NHWC end to end (the convolutions see channels_last views: no copy, MIOpen picks its NHWC kernels)
-    net = net_nhwc.float() - 0.5
+  def forward(self, net_nhwc, dropout_mask=None, centered=False):
+    # NHWC end to end (the convolutions see channels_last views: no copy, MIOpen picks its NHWC kernels);
+    # `centered`: the caller has already subtracted 0.5 (Agent.forward builds the enriched input of both extractors in
+    # one launch, nn_ops.planes_concat)
+    net = net_nhwc if centered else net_nhwc.float() - 0.5
     for conv in self.convs:
       net = bias_lrelu(conv2d_nhwc(net, conv.weight), conv.bias)
     net = net.reshape(net.shape[0], self.output_dim)  # TF reshape order (H,W,C)
@@ -220,8 +222,11 @@ class Agent(nn.Module):
     selection_noise = z[:, 0:1]
     masks = dropout_masks or (None, None)
 
-    enriched = enrich_image_input(cfg, net.float(), states)
-    filter_features = self.filter_features(enriched, masks[0])
+    if net.is_cuda and cfg.img_include_states and net.shape[-1] == 3:
+      enriched, centered = planes_concat(net, states, 0.5), True  # float, concat and `- 0.5` of both extractors at once
+    else:
+      enriched, centered = enrich_image_input(cfg, net.float(), states), False
+    filter_features = self.filter_features(enriched, masks[0], centered=centered)
     # Training-time fast path (round 4): the regressors and the one-hot gather of the selected filter's parameters as
     # ONE kernel behind the heads' second FCs (filters.heads_regress_select).  Needs what the dispatch kernels need
     # (8-step curves, masking off) and a device; everything else takes the op-by-op path below.
@@ -242,7 +247,7 @@ class Agent(nn.Module):
     else:
       params, mask_params = self.regress_all(filter_features)  # 8 x reference-shaped, 8 x (N, 6)
 
-    selector_features = self.selector_features(enriched, masks[1])
+    selector_features = self.selector_features(enriched, masks[1], centered=centered)
     if fused_heads and k <= 16 and z.dtype == torch.float32 and states.shape[1] >= 3 + k:
       return self._forward_fused(net, z, states, raws, selector_features, is_train, progress)
     pdf, entropy = self.action_pdf(selector_features)

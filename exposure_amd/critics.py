@@ -18,7 +18,7 @@ from torch import nn
 from torch.autograd.function import once_differentiable
 
 from . import _cabi
-from .nn_ops import bias_lrelu, conv2d_nhwc
+from .nn_ops import bias_lrelu, conv2d_nhwc, planes_concat
 from .util import lrelu
 
 
@@ -114,10 +114,10 @@ class Critic(nn.Module):
     else:
       assert states.dim() == stat_feature.dim()
       states = torch.cat([states.float(), stat_feature], dim=1)
-    n, h, w, _ = images.shape
-    planes = states[:, None, None, :].expand(n, h, w, states.shape[1])
-    net = torch.cat([images, planes], dim=3)
-    net = net - 0.5  # NHWC; the convolutions see channels_last views
+    n = images.shape[0]
+    # image channels + state / statistics planes, minus 0.5, as ONE launch on the device (nn_ops.planes_concat);
+    # NHWC: the convolutions see channels_last views
+    net = planes_concat(images, states, 0.5)
     for conv in self.convs:
       net = bias_lrelu(conv2d_nhwc(net, conv.weight), conv.bias)
     net = net.reshape(n, self.flat)

@@ -478,6 +478,87 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, const float* __re
     }
   }
 }
+
+// ---- the input of a convnet: image channels + per-image values broadcast as constant planes, centred ------------------
+// critics.py:64-76 (`tf.concat([images, states planes, statistics planes]) - 0.5` before `cnn`) and agent.py:17-19, 47-53
+// (`enrich_image_input`, then `net - 0.5` in feature_extractor): float conversion, concatenation(s) and subtraction as one
+// launch; out[n, p, c] = (c < 3 ? image[n, p, c] : vec[n, c - 3]) - offset, float32 NHWC with 3 + V channels.
+template <typename T>
+__global__ __launch_bounds__(256) void planes_concat_kernel(const T* __restrict__ img, const float* __restrict__ vec,
+                                                            float* __restrict__ out, size_t total, unsigned hw, unsigned v,
+                                                            float offset) {
+  const unsigned C = 3 + v;
+  for (size_t e = size_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += size_t(gridDim.x) * 256) {
+    const size_t pix = e / C;
+    const unsigned c = unsigned(e - pix * C);
+    float val;
+    if (c < 3) val = img ? float(img[pix * 3 + c]) : 0.0f;
+    else val = vec[(pix / hw) * v + (c - 3)];
+    out[e] = val - offset;
+  }
+}
+
+// ---- the generator step's loss glue (net.py:92-160 as restated in gan.py::generator_losses, cfg.gan == 'w') -----------
+// per image: stopped, step from new_states;  nv = new_value [step <= max_len];  gate = a + (1 - a) stopped;
+//   reward = gate (fake_logit - fake_input_logit) m - penalty;  q = reward + (1 - stopped) gamma nv;  adv = q - old_value;
+//   TD:  g term = -q plm + surrogate (-adv);   otherwise  g term = -reward + surrogate (-reward);   v term = adv^2
+// losses = (mean g term, mean v term).  coef[5][N] holds d g_loss / d (fake_logit, new_value, surrogate, penalty) and
+// d v_loss / d old_value per image (already divided by N): the backward is coef times the upstream scalar.
+struct GLossArgs {
+  float all_reward, mult, discount, plm, max_len;
+  int use_penalty, use_td, state_dim, stopped_col, step_col;
+};
+__global__ __launch_bounds__(256) void generator_losses_kernel(GLossArgs a, const float* __restrict__ fake_logit,
+                                                               const float* __restrict__ fake_input_logit,
+                                                               const float* __restrict__ new_value,
+                                                               const float* __restrict__ old_value,
+                                                               const float* __restrict__ new_states,
+                                                               const float* __restrict__ penalty,
+                                                               const float* __restrict__ surrogate, float* __restrict__ losses,
+                                                               float* __restrict__ reward_out, float* __restrict__ q_out,
+                                                               float* __restrict__ coef, int n) {
+  float gs = 0.f, vs = 0.f;
+  const float inv_n = 1.0f / float(n);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float stopped = new_states[size_t(i) * a.state_dim + a.stopped_col];
+    const float keep = new_states[size_t(i) * a.state_dim + a.step_col] > a.max_len ? 0.0f : 1.0f;
+    const float nv = new_value[i] * keep;
+    const float gate = a.all_reward + (1.0f - a.all_reward) * stopped;
+    const float raw = gate * (fake_logit[i] - fake_input_logit[i]) * a.mult;
+    const float reward = a.use_penalty ? raw - penalty[i] : raw;
+    const float cont = (1.0f - stopped) * a.discount;
+    const float q = reward + cont * nv;
+    const float adv = q - old_value[i];
+    const float sur = surrogate[i];
+    float routine, weight, dq;  // dq = d g term / d q (TD) or / d reward
+    if (a.use_td) { routine = -q * a.plm; weight = -adv; dq = -a.plm; }
+    else { routine = -reward; weight = -reward; dq = -1.0f; }
+    gs += routine + sur * weight;
+    vs += adv * adv;
+    reward_out[i] = reward;
+    q_out[i] = q;
+    coef[i] = dq * gate * a.mult * inv_n;                            // d g_loss / d fake_logit
+    coef[n + i] = a.use_td ? dq * cont * keep * inv_n : 0.0f;        // d g_loss / d new_value
+    coef[2 * n + i] = weight * inv_n;                                // d g_loss / d surrogate
+    coef[3 * n + i] = a.use_penalty ? -dq * inv_n : 0.0f;            // d g_loss / d penalty
+    coef[4 * n + i] = -2.0f * adv * inv_n;                           // d v_loss / d old_value
+  }
+  __shared__ float pg[256], pv[256];
+  pg[threadIdx.x] = gs;
+  pv[threadIdx.x] = vs;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < unsigned(w)) {
+      pg[threadIdx.x] += pg[threadIdx.x + w];
+      pv[threadIdx.x] += pv[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    losses[0] = pg[0] * inv_n;
+    losses[1] = pv[0] * inv_n;
+  }
+}
 }  // namespace expo
 
 using namespace expo;
@@ -648,6 +729,43 @@ int expo_grad_penalty_bwd(const float* g, const float* norm, const float* dterm,
   hipLaunchKernelGGL(grad_penalty_bwd_kernel, dim3(unsigned(bx), n), dim3(256), 0, static_cast<hipStream_t>(stream), g, norm,
                      dterm, dg, elems_per_image);
   HIP_TRY(hipGetLastError(), "grad_penalty_bwd launch");
+  return EXPO_OK;
+}
+
+int expo_planes_concat(const void* images, const float* vec, float* out, int n, size_t pixels_per_image, int v, int dtype,
+                       float offset, void* stream) {
+  if (n < 0 || v < 0) return fail(EXPO_E_BADARG, "n >= 0 and v >= 0 required");
+  if (n == 0 || pixels_per_image == 0) return EXPO_OK;
+  if (!out || (v > 0 && !vec)) return fail(EXPO_E_BADARG, "null pointer");
+  if (dtype != EXPO_F16 && dtype != EXPO_F32) return fail(EXPO_E_BADDTYPE, "dtype must be EXPO_F16 or EXPO_F32");
+  if (pixels_per_image > 0xffffffffull) return fail(EXPO_E_BADARG, "image too large");
+  const size_t total = size_t(n) * pixels_per_image * size_t(3 + v);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == EXPO_F16)
+    hipLaunchKernelGGL(planes_concat_kernel<_Float16>, dim3(unsigned(blocks)), dim3(256), 0, s, (const _Float16*)images, vec,
+                       out, total, unsigned(pixels_per_image), unsigned(v), offset);
+  else
+    hipLaunchKernelGGL(planes_concat_kernel<float>, dim3(unsigned(blocks)), dim3(256), 0, s, (const float*)images, vec, out,
+                       total, unsigned(pixels_per_image), unsigned(v), offset);
+  HIP_TRY(hipGetLastError(), "planes_concat launch");
+  return EXPO_OK;
+}
+
+int expo_generator_losses(const float* fake_logit, const float* fake_input_logit, const float* new_value,
+                          const float* old_value, const float* new_states, int state_dim, const float* penalty,
+                          const float* surrogate, const float* consts, int use_td, float* losses, float* reward, float* q_value,
+                          float* coef, int n, void* stream) {
+  if (n <= 0) return fail(EXPO_E_BADARG, "n >= 1 required");
+  if (!fake_logit || !fake_input_logit || !new_value || !old_value || !new_states || !surrogate || !consts || !losses ||
+      !reward || !q_value || !coef)
+    return fail(EXPO_E_BADARG, "null pointer");
+  if (state_dim < 3) return fail(EXPO_E_BADARG, "state rows must hold reward, stopped, step");
+  GLossArgs a{consts[0], consts[1], consts[2], consts[3], consts[4], penalty ? 1 : 0, use_td ? 1 : 0, state_dim, 1, 2};
+  hipLaunchKernelGGL(generator_losses_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a, fake_logit,
+                     fake_input_logit, new_value, old_value, new_states, penalty, surrogate, losses, reward, q_value, coef, n);
+  HIP_TRY(hipGetLastError(), "generator_losses launch");
   return EXPO_OK;
 }
 

@@ -15,7 +15,8 @@ from torch import nn
 from . import dist as xdist
 from .agent import Agent
 from .critics import Critic
-from .nn_ops import critic_step_inputs, frozen_parameters, grad_penalty_term, skip_parameter_gradients
+from .nn_ops import (critic_step_inputs, frozen_parameters, generator_losses_fused, grad_penalty_term,
+                     skip_parameter_gradients)
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
 
 
@@ -137,6 +138,15 @@ class GAN(nn.Module):
     old_value = self.value(fake_input, states)
     with frozen_parameters():
       new_value = self.value(fake_output, new_states)
+    if (cfg.gan == 'w' and fake_logit.is_cuda and fake_logit.dtype == torch.float32 and STATE_STOPPED_DIM == 1 and
+        STATE_STEP_DIM == 2 and os.environ.get('EXPO_FUSED_G_LOSSES', '1') == '1'):
+      # the ~25 per-image scalar operations below (and their backward) as one launch each way
+      g_loss, v_loss, reward, q_value = generator_losses_fused(
+          fake_logit, fake_input_logit, new_value, old_value, new_states, penalty if cfg.use_penalty else None, surrogate,
+          (cfg.all_reward, cfg.critic_logit_multiplier, cfg.discount_factor, cfg.parameter_lr_mul,
+           cfg.maximum_trajectory_length), cfg.use_TD)
+      return dict(g_loss=g_loss, v_loss=v_loss, fake_output=fake_output, new_states=new_states, reward=reward,
+                  q_value=q_value, fake_logit=fake_logit, debug=debug)
     stopped = new_states[:, STATE_STOPPED_DIM:STATE_STOPPED_DIM + 1]
     clear_final = (new_states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1] > cfg.maximum_trajectory_length).float()
     new_value = new_value * (1.0 - clear_final)

@@ -16,7 +16,10 @@ library kernels run and fuses what sits between them.
 
 Tensors are NHWC float32 (the reference's layout); convolutions see them as channels_last NCHW views, no copies.
 """
+import os
+
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _cabi
 
@@ -243,6 +246,105 @@ def grad_penalty_term(gradients):
     return _GradPenaltyTerm.apply(gradients)
   norm = torch.sqrt(1e-6 + (gradients**2).sum(dim=tuple(range(1, gradients.dim()))))
   return torch.clamp_min(norm - 1.0, 0.0)**2, norm.detach()
+
+
+class _PlanesConcat(torch.autograd.Function):
+  """``cat([images, vec broadcast as planes], channel) - offset`` as float32 NHWC in one launch (``expo_planes_concat``).
+  Linear: its backward is a channel slice and a per-image sum, left to torch so that every higher derivative (the
+  gradient penalty differentiates the critic's input gradient again) comes from autograd."""
+
+  @staticmethod
+  def forward(ctx, images, vec, offset):
+    images = images.contiguous()
+    v = 0 if vec is None else vec.shape[1]
+    out = torch.empty(tuple(images.shape[:-1]) + (3 + v,), dtype=torch.float32, device=images.device)
+    _cabi.planes_concat(images, None if vec is None else vec.contiguous().float(), out, offset)
+    ctx.img_dtype = images.dtype
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    d_images = d_vec = None
+    if ctx.needs_input_grad[0]:
+      d_images = dout[..., :3].to(ctx.img_dtype)
+    if ctx.needs_input_grad[1]:
+      d_vec = dout[..., 3:].sum(dim=tuple(range(1, dout.dim() - 1)))
+    return d_images, d_vec, None
+
+
+def planes_concat(images, vec, offset=0.5):
+  """The input of ``cnn`` / ``feature_extractor``: NHWC ``images`` (3 channels) with the rows of ``vec`` (N, V) appended
+  as V constant planes, minus ``offset`` -- critics.py:64-76, agent.py:17-19 + util.py:31-36."""
+  if (images.is_cuda and images.dtype in (torch.float16, torch.float32) and images.shape[-1] == 3 and
+      os.environ.get('EXPO_PLANES_CONCAT', '1') == '1'):
+    return _PlanesConcat.apply(images, vec, float(offset))
+  net = images.float()
+  if vec is not None:
+    shape = tuple(images.shape[:-1]) + (vec.shape[1],)
+    net = torch.cat([net, vec.float().reshape((vec.shape[0],) + (1,) * (images.dim() - 2) + (vec.shape[1],)).expand(shape)],
+                    dim=images.dim() - 1)
+  return net - offset
+
+
+class _GeneratorLosses(torch.autograd.Function):
+  """(g_loss, v_loss, reward, q) of the generator step from the per-image scalars (``expo_generator_losses``: ~25 tiny
+  launches forward and as many backward become one + one).  The gradient of g_loss reaches fake_logit, new_value,
+  surrogate and penalty; old_value's path is v_loss's (``_ValueLoss``), whose backward pass runs on its own."""
+
+  @staticmethod
+  def forward(ctx, fake_logit, fake_input_logit, new_value, old_value, new_states, penalty, surrogate, consts, use_td):
+    n = fake_logit.numel()
+    flat = lambda t: t.detach().reshape(n).contiguous().float()
+    dev = fake_logit.device
+    losses = torch.empty((2,), dtype=torch.float32, device=dev)
+    reward = torch.empty((n,), dtype=torch.float32, device=dev)
+    q = torch.empty((n,), dtype=torch.float32, device=dev)
+    coef = torch.empty((5, n), dtype=torch.float32, device=dev)
+    _cabi.generator_losses(flat(fake_logit), flat(fake_input_logit), flat(new_value), flat(old_value),
+                           new_states.detach().contiguous().float(), None if penalty is None else flat(penalty),
+                           flat(surrogate), consts, use_td, losses, reward, q, coef)
+    ctx.save_for_backward(coef)
+    ctx.shapes = (fake_logit.shape, new_value.shape, None if penalty is None else penalty.shape, surrogate.shape)
+    # only g_loss carries this node: v_loss's own backward pass (which runs first, _ValueLoss) must not traverse it
+    g_loss, v_val = losses[0], losses[1]
+    ctx.mark_non_differentiable(v_val, reward, q, coef)
+    return g_loss, v_val, reward, q, coef
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, dg, _dv, _dr, _dq, _dc):
+    coef, = ctx.saved_tensors
+    s_fl, s_nv, s_pen, s_sur = ctx.shapes
+    g = coef[:4] * dg  # one launch: the four gradient rows
+    return (g[0].reshape(s_fl), None, g[1].reshape(s_nv), None, None, None if s_pen is None else g[3].reshape(s_pen),
+            g[2].reshape(s_sur), None, None)
+
+
+class _ValueLoss(torch.autograd.Function):
+  """v_loss = mean((q - old_value)^2) with q a constant (net.py:131-134): the value computed by ``_GeneratorLosses`` tied to
+  ``old_value`` -- d v_loss / d old_value = -2 adv / N (row 4 of its coefficients)."""
+
+  @staticmethod
+  def forward(ctx, old_value, v_loss, coef):
+    ctx.save_for_backward(coef)
+    ctx.shape = old_value.shape
+    return v_loss.clone()
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, dv):
+    coef, = ctx.saved_tensors
+    return (coef[4] * dv).reshape(ctx.shape), None, None
+
+
+def generator_losses_fused(fake_logit, fake_input_logit, new_value, old_value, new_states, penalty, surrogate, consts,
+                           use_td):
+  """-> (g_loss, v_loss, reward (N, 1), q_value (N, 1)); see ``_GeneratorLosses``.  ``consts`` = (all_reward,
+  critic_logit_multiplier, discount_factor, parameter_lr_mul, maximum_trajectory_length)."""
+  g_loss, v_val, reward, q, coef = _GeneratorLosses.apply(fake_logit, fake_input_logit, new_value, old_value.detach(),
+                                                          new_states, penalty, surrogate, tuple(consts), bool(use_td))
+  v_loss = _ValueLoss.apply(old_value, v_val, coef)
+  return g_loss, v_loss, reward.reshape(fake_logit.shape), q.reshape(fake_logit.shape)
 
 
 def critic_step_inputs(real_data, fake_output, alpha):

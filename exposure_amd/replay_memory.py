@@ -56,7 +56,7 @@ class _PinnedRing:
   """Host staging buffers for small host -> device transfers that must not wait for the stream.  A buffer is reused
   only after the copy that read it has completed (its event; in steady state that was many calls ago)."""
 
-  def __init__(self, device, slots=16):
+  def __init__(self, device, slots=64):
     self.device = torch.device(device)
     self.cuda = self.device.type == 'cuda'
     self.slots, self.bufs, self.events, self.at = slots, {}, {}, 0

@@ -474,6 +474,38 @@ int expo_adam_step(int count, float* const* params, const float* const* grads, f
                    float* const* exp_avg_sq, const size_t* numel, const float* lr, float* step, void* ticket,
                    float beta1, float beta2, float eps, void* stream);
 
+/*
+ * The input tensor of a convnet: image channels + per-image values broadcast as constant planes, minus `offset` --
+ * critics.py:64-76 (`tf.concat([images, state planes, statistics planes], axis=3) - 0.5` in front of `cnn`) and
+ * agent.py:17-19, 47-53 (`enrich_image_input`, then `net - 0.5` in feature_extractor): dtype conversion,
+ * concatenation and subtraction in one launch.
+ *   images  device [N][pixels][3] in `dtype` (NULL: zeros -- the adjoint's own adjoint has no image part)
+ *   vec     device float32 [N][V] (V may be 0)
+ *   out     device float32 [N][pixels][3 + V] = (c < 3 ? images : vec[n][c - 3]) - offset
+ * Linear, so its derivative is slicing / a per-image sum (the host side leaves those to autograd).
+ */
+int expo_planes_concat(const void* images, const float* vec, float* out, int n, size_t pixels_per_image, int v,
+                       int dtype, float offset, void* stream);
+
+/*
+ * The generator step's loss glue (net.py:92-160 with cfg.gan == 'w'; util.py:13-16 state columns): per image
+ *   stopped = new_states[1], step = new_states[2];  nv = new_value * [step <= max_len];  gate = a + (1 - a) stopped
+ *   reward = gate (fake_logit - fake_input_logit) m - penalty;  q = reward + (1 - stopped) gamma nv;  adv = q - old_value
+ *   use_td:  g term = -q plm - surrogate adv      (net.py:135-140, 152-157)
+ *   else:    g term = -reward - surrogate reward
+ *   losses[0] = g_loss = mean g term,  losses[1] = v_loss = mean adv^2
+ * consts = host float[5] {a = all_reward, m = critic_logit_multiplier, gamma = discount_factor,
+ * plm = parameter_lr_mul, max_len = maximum_trajectory_length}; penalty may be NULL (cfg.use_penalty off).
+ * All vectors float32 [N]; new_states [N][state_dim].  reward / q_value [N] are reported values;
+ * coef float32 [5][N] receives d g_loss / d {fake_logit, new_value, surrogate, penalty} and d v_loss / d old_value
+ * (stop-gradients of the reference applied: the weight of the surrogate and q inside adv are constants), so the
+ * backward pass is coef times the upstream scalar.  One block; N is a minibatch.
+ */
+int expo_generator_losses(const float* fake_logit, const float* fake_input_logit, const float* new_value,
+                          const float* old_value, const float* new_states, int state_dim, const float* penalty,
+                          const float* surrogate, const float* consts, int use_td, float* losses, float* reward,
+                          float* q_value, float* coef, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,3 +254,93 @@ def test_hip_adam_matches_the_rule_in_float64(count, gpu_device):
   torch.cuda.synchronize()
   check(ps)
   assert float(opt._step) == len(lrs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('v', [0, 3, 14])
+def test_planes_concat_matches_torch(dtype, v, gpu_device):
+  """expo_planes_concat == cat([images.float(), vec planes], 3) - 0.5, with autograd's first derivative (channel slice in
+  the image's dtype, per-image sum for the planes) and the second one (the penalty path differentiates the input
+  gradient again: a function of the upstream gradient only, checked through autograd.grad with create_graph)."""
+  dev = gpu_device
+  g = torch.Generator(device=dev).manual_seed(v)
+  n, h, w = 5, 16, 12
+  img = torch.rand((n, h, w, 3), device=dev, generator=g).to(dtype).requires_grad_(True)
+  vec = torch.randn((n, v), device=dev, generator=g).requires_grad_(True) if v else None
+  out = nn_ops.planes_concat(img, vec, 0.5)
+  ref_img = img.detach().clone().requires_grad_(True)
+  ref_vec = vec.detach().clone().requires_grad_(True) if v else None
+  ref = ref_img.float()
+  if v:
+    ref = torch.cat([ref, ref_vec[:, None, None, :].expand(n, h, w, v)], dim=3)
+  ref = ref - 0.5
+  assert out.dtype == torch.float32 and out.shape == (n, h, w, 3 + v) and torch.equal(out, ref)
+  wgt = torch.randn(out.shape, device=dev, generator=g)
+  (out * wgt).sum().backward()
+  (ref * wgt).sum().backward()
+  assert img.grad.dtype == dtype and torch.equal(img.grad, ref_img.grad)
+  if v:
+    assert float((vec.grad - ref_vec.grad).abs().max()) <= 1e-5 * float(ref_vec.grad.abs().max())
+  if dtype == torch.float32 and v:  # second order: d/dw of <grad_img(w), u> + <grad_vec(w), s>
+    w2 = wgt.clone().requires_grad_(True)
+    img2 = img.detach().clone().requires_grad_(True)
+    vec2 = vec.detach().clone().requires_grad_(True)
+    gi, gv = torch.autograd.grad((nn_ops.planes_concat(img2, vec2, 0.5) * w2).sum(), [img2, vec2], create_graph=True)
+    u, s = torch.randn_like(gi), torch.randn_like(gv)
+    gw, = torch.autograd.grad((gi * u).sum() + (gv * s).sum(), w2)
+    want = torch.cat([u, s[:, None, None, :].expand(n, h, w, v)], dim=3)
+    assert float((gw - want).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('use_td', [True, False])
+@pytest.mark.parametrize('use_penalty', [True, False])
+def test_generator_loss_glue_matches_the_op_by_op_formula(use_td, use_penalty, gpu_device):
+  """expo_generator_losses (nn_ops.generator_losses_fused) against the op-by-op restatement of net.py:92-160 in
+  gan.py::generator_losses -- g_loss, v_loss, reward, q and the gradients that reach fake_logit, new_value, old_value,
+  penalty and surrogate from the two separate backward passes of a generator step; trajectories past the maximum length
+  lose their bootstrap value, stopped ones their continuation."""
+  dev = gpu_device
+  g = torch.Generator(device=dev).manual_seed(11)
+  n, d = 37, 11
+  consts = dict(all_reward=0.3, mult=0.05, discount=0.98, plm=1.7, max_len=7)
+  mk = lambda: torch.randn((n, 1), device=dev, generator=g)
+  base = dict(fake_logit=mk(), fake_input_logit=mk(), new_value=mk(), old_value=mk(), penalty=mk().abs(), surrogate=mk())
+  states = torch.zeros((n, d), device=dev)
+  states[:, 1] = (torch.rand(n, device=dev, generator=g) < 0.4).float()
+  states[:, 2] = torch.randint(1, 10, (n,), device=dev, generator=g).float()
+  assert float(states[:, 2].max()) > consts['max_len'] and float(states[:, 1].sum()) > 0
+
+  def leaves():
+    return {k: v.clone().requires_grad_(k != 'fake_input_logit') for k, v in base.items()}
+
+  a = leaves()
+  g_loss, v_loss, reward, q = nn_ops.generator_losses_fused(
+      a['fake_logit'], a['fake_input_logit'], a['new_value'], a['old_value'], states, a['penalty'] if use_penalty else None,
+      a['surrogate'], (consts['all_reward'], consts['mult'], consts['discount'], consts['plm'], consts['max_len']), use_td)
+  b = leaves()
+  stopped = states[:, 1:2]
+  clear_final = (states[:, 2:3] > consts['max_len']).float()
+  nv = b['new_value'] * (1.0 - clear_final)
+  gate = consts['all_reward'] + (1 - consts['all_reward']) * stopped
+  raw = gate * (b['fake_logit'] - b['fake_input_logit']) * consts['mult']
+  r_ref = raw - b['penalty'] if use_penalty else raw
+  q_ref = r_ref + (1.0 - stopped) * consts['discount'] * nv
+  adv = q_ref.detach() - b['old_value']
+  v_ref = (adv**2).mean()
+  routine, weight = (-q_ref * consts['plm'], -adv) if use_td else (-r_ref, -r_ref)
+  g_ref = (routine + b['surrogate'] * weight.detach()).mean()
+  close = lambda x, y, tol=2e-6: float((x - y).abs().max()) <= tol * max(1.0, float(y.abs().max()))
+  assert close(g_loss, g_ref) and close(v_loss, v_ref) and close(reward, r_ref) and close(q, q_ref)
+  assert reward.shape == (n, 1) and q.shape == (n, 1) and not reward.requires_grad
+  v_loss.backward()  # the value net's backward runs first, on its own (gan.py::_generator_body)
+  g_loss.backward()
+  v_ref.backward()
+  g_ref.backward()
+  for k in ('fake_logit', 'new_value', 'old_value', 'penalty', 'surrogate'):
+    ga, gb = a[k].grad, b[k].grad
+    if gb is None or float(gb.abs().max()) == 0.0:
+      assert ga is None or float(ga.abs().max()) == 0.0, k
+    else:
+      assert ga is not None and close(ga, gb, 3e-6), k
