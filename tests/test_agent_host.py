@@ -231,3 +231,59 @@ def test_evaluate_loop_two_filter_config():
       ref_hi = fnp.process_packed(fid, ref_hi, p)
       lo, st = lo2, st2
   np.testing.assert_allclose(out_hi.numpy(), ref_hi, rtol=2e-5, atol=2e-6)
+
+
+def test_packed_heads_host_logic_on_cpu():
+  """filters.PackedHeads with the C-ABI mocked: the heads' Parameters become views of the packed matrices without
+  changing a value or a state-dict entry, the fused node reproduces the per-head layers and their gradients, deepcopy
+  keeps the aliasing inside the copy, and a replaced storage is detected and re-packed."""
+  import copy
+  from exposure_amd import filters as F
+  from exposure_amd.util import lrelu
+  torch.manual_seed(2)
+  cfg = make_cfg()
+  ag = xagent.Agent(cfg)
+  with torch.no_grad():
+    for f in ag.filters:
+      f.fc1.bias.normal_(0, 0.1)
+      f.fc2.bias.normal_(0, 0.1)
+  before = {k: v.clone() for k, v in ag.state_dict().items()}
+  pack = F.PackedHeads(ag.filters)
+  assert pack.supported() and not pack._aliased()
+  pack.ensure()
+  assert pack._aliased()
+  after = ag.state_dict()
+  assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
+  assert all(isinstance(p, torch.nn.Parameter) and p.is_leaf for p in pack.leaves())
+  feats = torch.randn(6, cfg.feature_extractor_dims)
+  with fake_hip():
+    fa = feats.clone().requires_grad_(True)
+    outs = pack(fa)
+    sum((o * (j + 1)).sum() for j, o in enumerate(outs)).backward()
+    got = [p.grad.clone() for p in pack.leaves()] + [fa.grad.clone()]
+    for p in ag.parameters():
+      p.grad = None
+    fb = feats.clone().requires_grad_(True)
+    refs = [f.fc2(lrelu(f.fc1(fb))) for f in ag.filters]
+    sum((r * (j + 1)).sum() for j, r in enumerate(refs)).backward()
+    want = [p.grad.clone() for p in pack.leaves()] + [fb.grad.clone()]
+  for o, r in zip(outs, refs):
+    assert torch.allclose(o[:, :r.shape[1]], r, rtol=1e-5, atol=1e-6) and float(o[:, r.shape[1]:].abs().max()) == 0.0
+  for a, b in zip(got, want):
+    assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+  # a deep copy's Parameters own fresh storage (nn.Parameter.__deepcopy__ clones): its pack notices and re-packs from
+  # the PARAMETERS (the source of truth), never from its stale packed copy
+  ag._packed_heads = pack
+  twin = copy.deepcopy(ag)
+  with torch.no_grad():
+    twin.filters[0].fc1.weight.add_(1.0)
+  assert not twin._packed_heads._aliased()
+  twin._packed_heads.ensure()
+  assert twin._packed_heads._aliased() and twin._packed_heads.w1.data_ptr() != pack.w1.data_ptr()
+  assert torch.equal(twin._packed_heads.w1[:128], before['filters.0.fc1.weight'] + 1.0)
+  assert torch.equal(pack.w1[:128], before['filters.0.fc1.weight'])
+  # anything that replaces a parameter's storage is noticed at the next call
+  ag.filters[5].fc2.bias.data = ag.filters[5].fc2.bias.data.clone()
+  assert not pack._aliased()
+  pack.ensure()
+  assert pack._aliased() and all(torch.equal(ag.state_dict()[k], before[k]) for k in before)
