@@ -2022,8 +2022,12 @@ int expo_chain_bwd(const int* filter_ids, int steps, void* const* acts, void* co
     hipStream_t sp = ck.lane ? fj->helper : s;
     const size_t ioff = size_t(ck.nb) * h * w * 3 * esz;
     for (int i = steps - 1; i >= 0 && !rc; --i) {
-      // the forward chain ended descending (or ascending) on step steps-1; the backward starts where it ended
-      const int rev = plan.snake ? ((steps - i) & 1) : 0;
+      // the forward launch of step steps-1 walked in direction (steps-1) & 1 and ENDED on the other side: the backward
+      // starts there, i.e. walks the opposite way, and alternates down to step 0, whose direction (1) is again the
+      // opposite of the next forward call's first launch (0).  (Until r04p22 this read (steps - i) & 1, which is the
+      // same thing for an odd number of steps only: with 8 steps the first backward launch started on the images its
+      // predecessor had touched FIRST -- the read-latency counters of profiles/r04_p22_cold_counters.md show it.)
+      const int rev = plan.snake ? ((i + 1) & 1) : 0;
       const int bx = geom_bx(bwd_geom_kind(filter_ids[i]), n, h, w, dtype);  // records per image of this step's kernel
       float* rec = records + size_t(i) * step_floats + size_t(ck.nb) * bx * kWsSlots;
       const void* xin = static_cast<const char*>(acts[i]) + ioff;
