@@ -415,10 +415,12 @@ class GAN(nn.Module):
       for _ in range(citers):
         feed = memory.get_replay_feed_dict(cfg.batch_size)
         c_out = self.critic_step(feed['real_data'], feed['fake_output'], it=it)
-      rec = dict(iter=it, g_loss=float(g_out['g_loss']), v_loss=float(g_out['v_loss']), emd=float(c_out['emd']),
-                 cgn=float(c_out['gradient_norm']))
-      history.append(rec)
+      # the four reported scalars stay on the device (one small launch; the steps' outputs are static graph buffers that
+      # the next replay overwrites): the host reads them when it logs and once at the end, not four times per iteration
+      history.append(torch.stack([g_out['g_loss'].reshape(()), g_out['v_loss'].reshape(()), c_out['emd'].reshape(()),
+                                  c_out['gradient_norm'].reshape(())]).float())
       if log_every and it % log_every == 0:
-        log('it%6d, g_loss=%.2f, v_loss=%.2f, EMD=%.3f, cgn=%.2f  %s' %
-            (it, rec['g_loss'], rec['v_loss'], rec['emd'], rec['cgn'], memory.debug()))
-    return history
+        g_loss, v_loss, emd, cgn = history[-1].tolist()
+        log('it%6d, g_loss=%.2f, v_loss=%.2f, EMD=%.3f, cgn=%.2f  %s' % (it, g_loss, v_loss, emd, cgn, memory.debug()))
+    values = torch.stack(history).cpu().tolist() if history else []
+    return [dict(iter=it, g_loss=v[0], v_loss=v[1], emd=v[2], cgn=v[3]) for it, v in enumerate(values)]
