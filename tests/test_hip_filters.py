@@ -717,9 +717,10 @@ def test_dispatch_streaming_policy_equals_cached_policy(gpu_device):
 
 
 def test_chain_calls_on_two_user_streams_share_the_helper_stream(gpu_device):
-  """expo_chain_fwd / _bwd fork to ONE library-owned helper stream per device.  Two chains enqueued
-  from two user streams (own workspaces) must each be ordered only through their own stream: results bit-identical to
-  the same chains run one after the other, and the split must actually be on for this shape."""
+  """expo_chain_fwd / _bwd fork to a library-owned helper stream (since round 4 one per device AND caller
+  stream -- the name of this test is round 3's).  Two chains enqueued from two user streams (own workspaces) must each
+  be ordered only through their own stream: results bit-identical to the same chains run one after the other, and the
+  split must actually be on for this shape."""
   dev = gpu_device
   shape = (28, 512, 512, 3)  # 44 MB per tensor: inside the [40 MiB, 256 MiB) gate
   assert _cabi.chain_streams(shape[0], shape[1], shape[2], _cabi.EXPO_F16) == 2
