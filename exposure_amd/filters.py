@@ -242,8 +242,9 @@ class _PackedHeadsFn(torch.autograd.Function):
                    for j, d in enumerate(douts))
     if adjacent:  # the regress-and-select node hands over K slices of ONE head-major buffer (filters._HeadsRegressSelect)
       dout = torch.as_strided(first, (k, n, pad), (n * pad, pad, 1))
-    else:
-      dout = torch.stack([d if d is not None else torch.zeros_like(first) for d in douts], dim=0)
+    else:  # any other consumer: heads nobody used arrive as None
+      like = next(d for d in douts if d is not None)
+      dout = torch.stack([d if d is not None else torch.zeros_like(like) for d in douts], dim=0)
     h3 = h.view(n, k, hid).transpose(0, 1)
     db2 = dout.sum(dim=1)  # (K, 32)
     dw2 = torch.bmm(dout.transpose(1, 2), h3)  # (K, 32, H)

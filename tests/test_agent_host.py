@@ -271,6 +271,12 @@ def test_packed_heads_host_logic_on_cpu():
     assert torch.allclose(o[:, :r.shape[1]], r, rtol=1e-5, atol=1e-6) and float(o[:, r.shape[1]:].abs().max()) == 0.0
   for a, b in zip(got, want):
     assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+  with fake_hip():  # a consumer that uses ONE head: the other heads' upstream gradients arrive as None
+    for p in ag.parameters():
+      p.grad = None
+    outs = pack(feats.clone().requires_grad_(True))
+    (outs[3].sum() * 2.0).backward()
+  assert float(ag.filters[3].fc2.weight.grad.abs().sum()) > 0 and float(ag.filters[0].fc2.weight.grad.abs().sum()) == 0.0
   # a deep copy's Parameters own fresh storage (nn.Parameter.__deepcopy__ clones): its pack notices and re-packs from
   # the PARAMETERS (the source of truth), never from its stale packed copy
   ag._packed_heads = pack
