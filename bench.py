@@ -614,8 +614,9 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
       'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
       'miopen_find': bool(torch.backends.cudnn.benchmark),
       # the measured solver rankings the package ships (exposure_amd/miopen_db) or whatever the user set
-      'miopen_user_db': os.path.relpath(os.environ['MIOPEN_USER_DB_PATH'], ROOT)
-                        if os.environ.get('MIOPEN_USER_DB_PATH') else None,
+      # (MIOpen reads and writes a private per-rank COPY of the shipped files: exposure_amd/__init__.py)
+      'miopen_user_db': ('private copy of %s' % os.path.relpath(os.environ['EXPO_MIOPEN_DB_ACTIVE'], ROOT))
+                        if os.environ.get('EXPO_MIOPEN_DB_ACTIVE') else os.environ.get('MIOPEN_USER_DB_PATH'),
       'capture_drain_verified': getattr(gan, 'capture_drain_verified', None),
       'roofline': {
           'bound': 'mfma_fp32',

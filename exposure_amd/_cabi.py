@@ -46,6 +46,8 @@ SIGNATURES = {
     'expo_filter_dispatch_bwd': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_chain_streams': (_i, [_i, _i, _i, _i]),
     'expo_chain_helper_stats': (_i, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    'expo_chain_prepare': (_i, [_vp]),
+    'expo_chain_release': (_i, [_vp]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
                             _vp]),
     'expo_chain_bwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
@@ -793,6 +795,19 @@ def chain_helper_stats():
   a, b = ctypes.c_int(0), ctypes.c_int(0)
   _check(load().expo_chain_helper_stats(ctypes.byref(a), ctypes.byref(b)), 'expo_chain_helper_stats')
   return a.value, b.value
+
+
+def chain_prepare(stream=None):
+  """Probe the helper-stream pairing of ``stream`` (default: torch's current stream) now, so that the first eager
+  two-stream chain call does not stall it (expo_chain_prepare; idempotent)."""
+  s = _stream() if stream is None else ctypes.c_void_p(int(getattr(stream, 'cuda_stream', stream)))
+  _check(load().expo_chain_prepare(s), 'expo_chain_prepare')
+
+
+def chain_release(stream):
+  """Forget the helper-stream pairing of a stream that is about to be destroyed (expo_chain_release)."""
+  s = ctypes.c_void_p(int(getattr(stream, 'cuda_stream', stream)))
+  _check(load().expo_chain_release(s), 'expo_chain_release')
 
 
 def apply_dispatch_fwd(ids, x, y, params, mask_params, maximum_sharpness, minimum_strength):

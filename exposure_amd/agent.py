@@ -185,6 +185,19 @@ class Agent(nn.Module):
     self.register_buffer('abi_filter_ids', torch.tensor([f.filter_id for f in self.filters], dtype=torch.int32),
                          persistent=False)
 
+  def pack_heads(self, now=True):
+    """Builds the packed storage of the K filter heads (filters.PackedHeads) and, with ``now``, moves the parameters
+    into it right away -- what ``gan.GAN`` does once at construction, after ``.to(device)`` and BEFORE optimisers,
+    gradient buckets and hipGraphs take pointers to the parameters.  -> the pack, or None when the heads do not fit it
+    (EXPO_PACKED_HEADS=0, unequal layer sizes, not fp32, not on a device)."""
+    if self._packed_heads is None:
+      pack = F.PackedHeads(self.filters) if os.environ.get('EXPO_PACKED_HEADS', '1') == '1' else None
+      self._packed_heads = pack if pack is not None and pack.supported() else False
+    pack = self._packed_heads or None
+    if pack is not None and now and self.filters[0].fc1.weight.is_cuda:
+      pack.ensure()
+    return pack
+
   def regress_all(self, filter_features):
     """Per-filter FC heads + range squashing -> (reference-shaped parameter tensors, raw mask parameters)."""
     out, mask_params = [], []
@@ -236,9 +249,8 @@ class Agent(nn.Module):
     if fused_heads:
       # the K heads' two FCs as one GEMM + one batched GEMM over parameters packed in place (filters.PackedHeads);
       # EXPO_PACKED_HEADS=0: one addmm / lrelu / addmm per head
-      if self._packed_heads is None and os.environ.get('EXPO_PACKED_HEADS', '1') == '1':
-        pack = F.PackedHeads(self.filters)
-        self._packed_heads = pack if pack.supported() else False
+      if self._packed_heads is None:
+        self.pack_heads(now=False)
       if self._packed_heads and filter_features.dtype == torch.float32:
         raws = self._packed_heads(filter_features)
       else:

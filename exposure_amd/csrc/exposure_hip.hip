@@ -20,6 +20,7 @@
 // chunk of the image; each thread walks 48-byte pixel groups with a block stride.
 // Cache policy: tensors >= EXPO_STREAM_MIN_BYTES run the IoStream instantiations (nt loads,
 // write-through stores), smaller ones IoCached -- pixel_io.h.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -1590,64 +1591,131 @@ static int lanes_run_side_by_side(hipStream_t s, hipStream_t h) {
 }
 static int g_helper_probes = 0, g_helper_rejected = 0;  // expo_chain_helper_stats()
 
-static ForkJoin* fork_join_for_device(hipStream_t caller = nullptr) {
-  struct Entry { int dev; hipStream_t caller; ForkJoin fj; bool probed; };
-  struct Spare { int dev; hipStream_t st; };
-  static std::vector<Entry*> table;
-  static std::vector<Spare> spares;  // rejected helpers, never used again, kept so that their queue slot stays taken
-  static std::mutex mu;
+// Table of (device, caller stream) -> helper.  A stream HANDLE can come back for a new stream after
+// hipStreamDestroy, so an entry also remembers the runtime's stream id (hipStreamGetId): a recreated stream gets a
+// fresh entry -- and is probed again -- while the stale entry's helper is recycled (advisor, round 4).
+// Locking: `mu` guards the table and the spare list only; the probe (which launches a kernel that may wait up to
+// 0.5 ms on the caller's stream and synchronises both streams) runs under the ENTRY's mutex, so callers on other
+// streams are never held up by it.  At most kMaxProbeAttempts candidates are tried per pairing and at most
+// kMaxSpares rejected streams are parked per process (beyond that a rejected stream is destroyed: its queue slot may
+// then be handed out again, which only costs later probes an attempt).
+constexpr int kMaxProbeAttempts = 4;
+constexpr size_t kMaxSpares = 8;
+struct HelperEntry {
+  int dev;
+  hipStream_t caller;
+  unsigned long long caller_id;
+  ForkJoin fj;
+  bool probed;
+  std::mutex mu;
+};
+static std::vector<HelperEntry*> g_helper_table;
+static std::vector<hipStream_t> g_helper_spares;  // rejected helpers, never used again, kept so that their queue slot stays taken
+static std::mutex g_helper_mu;
+static bool helper_probe_enabled() {
   static const bool probe = !(getenv("EXPO_CHAIN_HELPER_PROBE") && atoi(getenv("EXPO_CHAIN_HELPER_PROBE")) == 0);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  Entry* e = nullptr;
-  for (Entry* t : table)
-    if (t->dev == dev && t->caller == caller) e = t;
-  if (!e) {
-    hipStream_t st;
-    hipEvent_t e0, e1;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return nullptr;
-    e = new Entry{dev, caller, ForkJoin{st, e0, e1}, !probe};
-    table.push_back(e);
-  }
-  if (e->probed) return &e->fj;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(caller, &cap) != hipSuccess) {
+  return probe;
+}
+// hipStreamGetId entered the runtime with HIP 7.1; the process may run on an older libamdhip64 (PyTorch ships its own
+// 7.0), so the symbol is looked up at run time -- without it a reused handle cannot be told from the old stream and
+// keeps the old pairing (expo_chain_release is the way to drop it then).
+static unsigned long long stream_id_of(hipStream_t s) {
+  using GetId = hipError_t (*)(hipStream_t, unsigned long long*);
+  static const GetId get_id = reinterpret_cast<GetId>(dlsym(RTLD_DEFAULT, "hipStreamGetId"));
+  unsigned long long id = 0;
+  if (!get_id) return 0;
+  if (get_id(s, &id) != hipSuccess) {
     (void)hipGetLastError();
-    return &e->fj;  // cannot tell: no probe now
+    id = 0;
   }
-  if (cap != hipStreamCaptureStatusNone) return &e->fj;  // capturing: the helper only names a branch of the graph
-  // Eager and unprobed.  The helper is idle here: it was created above or has only been part of captures.
+  return id;
+}
+static void park_or_destroy(hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_helper_mu);
+  if (g_helper_spares.size() < kMaxSpares)
+    g_helper_spares.push_back(st);
+  else
+    (void)hipStreamDestroy(st);
+}
+// the probe of one pairing; the caller holds e->mu and `e` is eager (not capturing)
+static void probe_helper(HelperEntry* e) {
   hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;  // the probe synchronises: keep another thread's capture valid
   (void)hipThreadExchangeStreamCaptureMode(&mode);
   hipStream_t first = e->fj.helper, cand = first;
   bool found = false;
-  for (int attempt = 0; attempt < 8 && !found; ++attempt) {
-    ++g_helper_probes;
-    const int r = lanes_run_side_by_side(caller, cand);
+  for (int attempt = 0; attempt < kMaxProbeAttempts; ++attempt) {
+    {
+      std::lock_guard<std::mutex> lock(g_helper_mu);
+      ++g_helper_probes;
+    }
+    const int r = lanes_run_side_by_side(e->caller, cand);
     if (r != 0) {
       found = true;
       break;
     }
-    ++g_helper_rejected;
-    if (cand != first) spares.push_back(Spare{dev, cand});
+    {
+      std::lock_guard<std::mutex> lock(g_helper_mu);
+      ++g_helper_rejected;
+    }
+    if (cand != first) park_or_destroy(cand);
     cand = nullptr;
+    if (attempt + 1 == kMaxProbeAttempts) break;
     if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
       cand = nullptr;
       break;
     }
   }
   if (found && cand != first) {
-    spares.push_back(Spare{dev, first});
+    park_or_destroy(first);
     e->fj.helper = cand;
-  } else if (!found && cand && cand != first) {
-    spares.push_back(Spare{dev, cand});  // nothing ran side by side (a one-queue configuration): keep the first helper
-  }
+  }  // (!found: nothing ran side by side -- a one-queue configuration -- and the first helper stays)
   (void)hipThreadExchangeStreamCaptureMode(&mode);
   e->probed = true;
-  return &e->fj;
+}
+
+// -> the (device, caller) entry, created on first use; `probe_now`: probe it if that has not happened and the caller
+// is not capturing.  nullptr on a HIP error.
+static HelperEntry* helper_entry(hipStream_t caller, bool probe_now) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+  const unsigned long long id = stream_id_of(caller);
+  HelperEntry* e = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_helper_mu);
+    for (HelperEntry* t : g_helper_table)
+      if (t->dev == dev && t->caller == caller) e = t;
+    if (e && e->caller_id != id) {
+      // the handle names a NEW stream: the pairing has to be probed again (the helper itself is reusable -- it is idle,
+      // every chain call joins it before returning)
+      e->caller_id = id;
+      e->probed = !helper_probe_enabled();
+    }
+    if (!e) {
+      hipStream_t st;
+      hipEvent_t e0, e1;
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return nullptr;
+      e = new HelperEntry{dev, caller, id, ForkJoin{st, e0, e1}, !helper_probe_enabled(), {}};
+      g_helper_table.push_back(e);
+    }
+  }
+  if (!probe_now) return e;
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (e->probed) return e;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(caller, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    return e;  // cannot tell: no probe now
+  }
+  if (cap != hipStreamCaptureStatusNone) return e;  // capturing: the helper only names a branch of the graph
+  probe_helper(e);  // eager and unprobed; the helper is idle: it was created above or has only been part of captures
+  return e;
+}
+static ForkJoin* fork_join_for_device(hipStream_t caller = nullptr) {
+  HelperEntry* e = helper_entry(caller, true);
+  return e ? &e->fj : nullptr;
 }
 // fork: helper waits for everything `s` holds; join: `s` waits for everything the helper holds.  The event is shared by
 // all callers of a device, so record + wait must not interleave with another host thread's pair (its record would
@@ -1897,6 +1965,42 @@ int expo_filter_dispatch_bwd(const int32_t* filter_ids, const void* x, const voi
 int expo_chain_streams(int n, int h, int w, int dtype) {
   if (check_common(n, h, w, dtype) != EXPO_OK) return 0;
   return chain_plan(n, h, w, dtype).two_lanes ? 2 : 1;
+}
+
+int expo_chain_prepare(void* stream) {
+  // The probe of DESIGN.md 3.5 as an explicit initialisation step: an integrator who does not want the first eager
+  // two-stream chain call of `stream` to stall that stream (one one-wave kernel waiting <= 0.5 ms per candidate, two
+  // stream synchronisations) calls this once after creating the stream.  Idempotent; a no-op while `stream` is
+  // capturing or with EXPO_CHAIN_HELPER_PROBE=0.
+  return helper_entry(static_cast<hipStream_t>(stream), true) ? EXPO_OK : fail(EXPO_E_HIP, "chain helper stream");
+}
+
+int expo_chain_release(void* stream) {
+  // Forget the pairing of a caller stream that is about to be destroyed: its helper stream and events are destroyed
+  // (the helper is idle between chain calls: every call joins it before it returns).  Returns EXPO_OK whether or not
+  // the stream had a pairing.  Must not race with a chain call on the same stream.
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+  HelperEntry* found = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_helper_mu);
+    for (size_t i = 0; i < g_helper_table.size(); ++i)
+      if (g_helper_table[i]->dev == dev && g_helper_table[i]->caller == static_cast<hipStream_t>(stream)) {
+        found = g_helper_table[i];
+        g_helper_table.erase(g_helper_table.begin() + i);
+        break;
+      }
+  }
+  if (!found) return EXPO_OK;
+  {
+    std::lock_guard<std::mutex> lock(found->mu);
+    (void)hipStreamSynchronize(found->fj.helper);
+    (void)hipEventDestroy(found->fj.fork);
+    (void)hipEventDestroy(found->fj.join);
+    (void)hipStreamDestroy(found->fj.helper);
+  }
+  delete found;
+  return EXPO_OK;
 }
 
 int expo_chain_helper_stats(int* probed, int* rejected) {

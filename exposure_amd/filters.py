@@ -275,6 +275,7 @@ class PackedHeads:
     self.in_dim = self.filters[0].fc1.in_features
     self.widths = [f.fc2.out_features for f in self.filters]
     self.w1 = self.b1 = self.w2 = self.b2 = None
+    self.generation = 0  # bumped by every (re)pack: holders of pointers into the packed buffers compare it
 
   def supported(self):
     return (all(f.fc1.out_features == self.hidden and f.fc1.in_features == self.in_dim and
@@ -299,10 +300,27 @@ class PackedHeads:
         return False
     return True
 
+  def quick_aliased(self):
+    """The first and the last leaf still live in the packed buffers (two pointer comparisons: what a graph-replaying
+    caller can afford per step; ``module.to()`` / a dtype change / a restore that replaces storages moves them all)."""
+    if self.w1 is None:
+      return False
+    first, last = self.filters[0].fc1.weight, self.filters[-1].fc2.bias
+    return (first.data_ptr() == self.w1.data_ptr() and
+            last.data_ptr() == self.b2.data_ptr() + 4 * (self.k - 1) * self.PAD)
+
   @torch.no_grad()
   def ensure(self):
+    """Packs on first use; packs AGAIN when the parameters were re-allocated since.  A re-pack moves every head
+    parameter to new storage: hipGraphs captured before keep reading and updating the OLD buffers -- whoever captured
+    them must compare ``generation`` (``gan.GAN._check_heads`` drops its graphs); inside a capture it is refused."""
     if self._aliased():
       return
+    if self.filters[0].fc1.weight.is_cuda and torch.cuda.is_current_stream_capturing():
+      raise RuntimeError('exposure_amd: the filter heads\' parameters were re-allocated (module.to(), a dtype change, a '
+                         'restore that replaces storages) and would have to be re-packed INSIDE a hipGraph capture; run '
+                         'one eager step (or Agent.pack_heads()) first')
+    self.generation += 1
     dev = self.filters[0].fc1.weight.device
     k, hid, f_in, pad = self.k, self.hidden, self.in_dim, self.PAD
     w1 = torch.empty((k * hid, f_in), dtype=torch.float32, device=dev)

@@ -41,6 +41,12 @@ class GAN(nn.Module):
     self.value = Critic(cfg, num_state_dim=cfg.num_state_dim)
     if device is not None:
       self.to(device)
+    # the filter heads' parameters move into their packed storage NOW -- before the optimisers, the gradient buckets
+    # and any captured step take pointers to them (a lazy pack inside the first forward would be fine, a later re-pack
+    # behind captured graphs is not: _check_heads)
+    fused_path = not cfg.masking and device is not None and torch.device(device).type == 'cuda'
+    self._heads_pack = self.generator.pack_heads() if fused_path else None
+    self._heads_generation = self._heads_pack.generation if self._heads_pack is not None else 0
     adam = dict(betas=(cfg.adam_beta1, cfg.adam_beta2), eps=1e-8)  # config_example.py:158
     if device is not None and torch.device(device).type == 'cuda' and os.environ.get('EXPO_FUSED_ADAM', '1') == '1':
       adam['fused'] = True  # one multi-tensor kernel per optimiser step instead of ~10 foreach launches
@@ -101,16 +107,44 @@ class GAN(nn.Module):
     self._c_ema = None
     self.c_average_steps = 0
 
+  # -- optimiser state (the Adam slots and the logit-centre average a ``tf.train.Saver`` keeps beside the weights,
+  #    net.py:271, 380-384): ``torch.save({'model': gan.state_dict(), 'optim': gan.optimizer_state_dict()}, path)``
+  def optimizer_state_dict(self):
+    return dict(opt_g=self.opt_g.state_dict(), opt_v=self.opt_v.state_dict(), opt_c=self.opt_c.state_dict(),
+                c_ema=None if self._c_ema is None else self._c_ema.detach().clone(),
+                c_average_steps=self.c_average_steps)
+
+  @torch.no_grad()
+  def load_optimizer_state_dict(self, sd):
+    """Restores moments, step counters and learning rates IN PLACE (captured step graphs keep reading the same
+    buffers); the next ``set_lrs`` refills the learning-rate scalars for its iteration."""
+    self.opt_g.load_state_dict(sd['opt_g'])
+    self.opt_v.load_state_dict(sd['opt_v'])
+    self.opt_c.load_state_dict(sd['opt_c'])
+    for opt in (self.opt_g, self.opt_v, self.opt_c):
+      for g in opt.param_groups:
+        g.pop('_lr_value', None)
+    if sd.get('c_ema') is not None:
+      if self._c_ema is None:
+        self._c_ema = sd['c_ema'].detach().clone().to(next(self.parameters()).device)
+      else:
+        self._c_ema.copy_(sd['c_ema'])
+    self.c_average_steps = int(sd.get('c_average_steps', 0))
+
   # -- learning rates (config_example.py:134-158; net.py:222-251)
   def set_lrs(self, it, zero_g=False):
     lr_g = 0.0 if zero_g else self.cfg.lr_g(it)  # net.py:327-328: lr_g = 0 at iter 0
 
     def put(opt, value):
       for g in opt.param_groups:
-        if torch.is_tensor(g['lr']):
-          if g.get('_lr_value') != value:  # the five critic steps of an iteration repeat the G step's values: no launch
-            g['lr'].fill_(value)  # in place: the captured graph reads this tensor
-            g['_lr_value'] = value
+        lr = g['lr']
+        if torch.is_tensor(lr):
+          # the five critic steps of an iteration repeat the G step's values: no launch.  The note is only trusted for
+          # the tensor it was made for and while nobody else wrote to it (tensor version counter): a scalar replaced or
+          # refilled from outside (a restored optimiser state) is filled again.
+          if g.get('_lr_value') != (value, id(lr), lr._version):
+            lr.fill_(value)  # in place: the captured graph reads this tensor
+            g['_lr_value'] = (value, id(lr), lr._version)
         else:
           g['lr'] = value
 
@@ -246,6 +280,22 @@ class GAN(nn.Module):
   def _generator_body_graph(self, fake_input, z, states, progress, m0, m1):
     return self._generator_body(fake_input, z, states, progress, [m0, m1])
 
+  def _check_heads(self):
+    """A replayed step never runs ``Agent.forward``, so nothing would notice head parameters that were re-allocated
+    behind the captured graphs (``gan.to(...)``, ``.half()``, a restore that replaces storages): the graphs would go on
+    reading and updating the old packed buffers.  Two pointer comparisons per step; on a mismatch the heads are packed
+    again (eagerly, here) and every captured step is dropped -- the next calls warm up and capture afresh."""
+    pack = self._heads_pack
+    if pack is None or (pack.quick_aliased() and pack.generation == self._heads_generation):
+      return
+    pack.ensure()
+    self._heads_generation = pack.generation
+    if any(entry != 'warm' for entry in self._graphs.values()):
+      import warnings
+      warnings.warn('exposure_amd: the filter heads\' parameters were re-allocated after step graphs had been captured; '
+                    'the captured steps are dropped and will be captured again')
+    self._graphs.clear()
+
   # ---- hipGraph capture / replay of a whole optimisation step --------------------------------
   def _replay(self, key, body, inputs):
     """hipGraph execution of one optimisation step.  Per (step kind, input shapes): the FIRST call
@@ -254,6 +304,7 @@ class GAN(nn.Module):
     hipGraph, and from then on the inputs are copied into the static buffers and the graph is
     replayed: ~6 000 eager launches (~10 us of host time each) become one graph launch.  Returned
     tensors are the graph's static outputs (valid until the next replay of the same graph)."""
+    self._check_heads()
     sig = (key,) + tuple((tuple(t.shape), t.dtype) for t in inputs)
     entry = self._graphs.get(sig)
     if entry is None:

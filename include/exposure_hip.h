@@ -228,13 +228,23 @@ int expo_finish_bwd(const int* filter_ids, int steps, const float* const* params
  * before the call and before what it receives afterwards, and the pattern is capturable into a hipGraph.
  * expo_chain_streams() returns the number of streams (1 or 2) a shape gets (EXPO_CHAIN_STREAMS=1|2 overrides).
  *
- * The helper is chosen per (device, caller stream) and must sit on another hardware queue than `stream`: the first
- * eager two-stream call of a caller stream synchronises that stream once and probes the pairing (two one-wave
- * kernels, < 0.1 ms; a rejected helper costs 0.5 ms), see exposure_hip.hip.  expo_chain_helper_stats() reports how
- * many pairings this process probed and how many helpers it rejected (diagnostics; either pointer may be NULL).
+ * The helper is chosen per (device, caller stream) and must sit on another hardware queue than `stream`: the pairing
+ * is probed ONCE per caller stream (two one-wave kernels, < 0.1 ms; a rejected helper costs 0.5 ms -- the kernel on
+ * `stream` waits that long for the helper's -- at most 4 candidates; both streams are synchronised), see
+ * exposure_hip.hip.  By default the first EAGER two-stream chain call of a caller stream does that; an integrator who
+ * does not want a stall inside a data-path call runs it at set-up time with expo_chain_prepare(stream) (idempotent;
+ * nothing to do under stream capture, where the graph executor assigns the queues).  EXPO_CHAIN_HELPER_PROBE=0 in the
+ * environment switches the probe off altogether (the first helper stream is taken as it comes).  Only callers on the
+ * SAME stream wait for a probe.  expo_chain_release(stream) forgets a pairing and destroys its helper stream -- call it
+ * before hipStreamDestroy of a stream that made chain calls (where the runtime has hipStreamGetId -- HIP >= 7.1 -- a destroyed
+ * stream whose handle is reused is recognised and probed again either way).  Rejected helper streams stay parked (at most 8 per process) so
+ * that their hardware queue is not handed out again.  expo_chain_helper_stats() reports how many pairings this
+ * process probed and how many helpers it rejected (diagnostics; either pointer may be NULL).
  */
 int expo_chain_streams(int n, int h, int w, int dtype);
 int expo_chain_helper_stats(int* probed, int* rejected);
+int expo_chain_prepare(void* stream);
+int expo_chain_release(void* stream);
 int expo_chain_fwd(const int* filter_ids, int steps, void* const* acts,
                    const float* const* params, int n, int h, int w, int dtype,
                    void* stream);

@@ -329,6 +329,61 @@ def test_graphed_steps_match_eager(gpu_device):
   assert worst < 3e-4, worst  # Adam steps are ~lr-sized; see tests/test_dist_gloo.py
 
 
+def test_heads_are_packed_at_construction_and_a_repack_drops_the_captured_steps(gpu_device):
+  """the filter heads' parameters live in the packed buffers from GAN construction on (optimisers, buckets
+  and graphs are built over the final storage).  Parameters re-allocated behind captured step graphs -- here one head's
+  weight replaced, as ``module.to(dtype)`` or a storage-replacing restore would -- are noticed at the next step: the
+  heads are packed again, the captured steps dropped (warning) and captured afresh, and training goes on updating the
+  parameters the module actually holds -- the same values as a run that never re-allocated."""
+  import warnings
+  dev = gpu_device
+  cfg = make_cfg()
+  rng = np.random.default_rng(9)
+  n = 8
+  t = lambda a: torch.from_numpy(a).to(dev)
+  img = t(synthetic.make_images(rng, (n, 64, 64, 3), np.float16))
+  real = t(synthetic.make_images(rng, (n, 64, 64, 3), np.float16))
+  states = torch.zeros(n, 11, device=dev)
+  z = t(rng.random((n, 131), dtype=np.float32))
+  masks = [t((rng.random((n, 4096)) < 0.5).astype(np.float32)) for _ in range(2)]
+  alpha = t(rng.random((n, 1, 1, 1), dtype=np.float32))
+  finals = []
+  for disturb in (False, True):
+    torch.manual_seed(21)
+    gan = GAN(cfg, device=dev, use_graphs=True)
+    pack = gan.generator._packed_heads
+    assert pack and pack is gan._heads_pack and pack.generation == 1 and pack.quick_aliased()
+    head0 = gan.generator.filters[0].fc1.weight
+    assert head0.data_ptr() == pack.w1.data_ptr()  # packed before the first forward
+    for it in (3, 4, 5):  # eager warm-up, capture + replay, replay
+      g = gan.generator_step(img, z, states, progress=0.2, it=it, dropout_masks=masks)
+      gan.critic_step(real, g['fake_output'].clone(), it=it, alpha=alpha)
+    assert any(e != 'warm' for e in gan._graphs.values())
+    if disturb:
+      head0.data = head0.data.clone()  # new storage, same values
+      last = gan.generator.filters[-1].fc2.bias
+      last.data = last.data.clone()
+      assert not pack.quick_aliased()
+      with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        g = gan.generator_step(img, z, states, progress=0.2, it=6, dropout_masks=masks)
+      assert any('re-allocated' in str(w.message) for w in caught)
+      assert pack.generation == 2 and pack.quick_aliased() and head0.data_ptr() == pack.w1.data_ptr()
+      assert all(e == 'warm' for e in gan._graphs.values())  # every captured step dropped; this call ran eagerly
+    else:
+      g = gan.generator_step(img, z, states, progress=0.2, it=6, dropout_masks=masks)
+    gan.critic_step(real, g['fake_output'].clone(), it=6, alpha=alpha)
+    before = head0.detach().clone()
+    for it in (7, 8):  # (capture +) replay over the current storage
+      g = gan.generator_step(img, z, states, progress=0.2, it=it, dropout_masks=masks)
+      gan.critic_step(real, g['fake_output'].clone(), it=it, alpha=alpha)
+    torch.cuda.synchronize()
+    assert not torch.equal(before, head0.detach())  # Adam keeps updating the tensor the module holds
+    finals.append([p.detach().clone() for p in gan.parameters()])
+  worst = max(float((a - b).abs().max()) for a, b in zip(*finals))
+  assert worst < 3e-4, worst  # (eager vs replayed steps differ at Adam's step size at most: test_graphed_steps_match_eager)
+
+
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
 @pytest.mark.parametrize('shape', [(4, 96, 128, 3), (3, 7, 9, 3)])
 @pytest.mark.parametrize('steps', [8, 5, 1, 0])

@@ -67,11 +67,17 @@ def _worker(rank, world, port, out_dir, use_graphs, iters):
   img, real, states, z = _inputs(dev)
   sh = xdist.shard
   import warnings
+  after_first = None
   with warnings.catch_warnings(record=True) as caught:
     warnings.simplefilter('always')
-    g, c = _run_steps(gan, sh(img), sh(real), sh(states), sh(z), iters)
+    for k in range(iters):
+      g, c = _run_steps(gan, sh(img), sh(real), sh(states), sh(z), 1)
+      if k == 0 and iters > 1:
+        torch.cuda.synchronize()
+        after_first = [p.detach().cpu().clone() for p in gan.parameters()]
   torch.cuda.synchronize()
   snap = _snapshot(gan, g, c)
+  snap['params_after_first'] = after_first
   snap['still_graphs'] = bool(gan.use_graphs)
   snap['warned'] = any('stay eager' in str(w.message) for w in caught)
   torch.save(snap, os.path.join(out_dir, 'rank%d.pt' % rank))
@@ -86,14 +92,31 @@ def test_two_ranks_on_one_gpu_match_one_process(gpu_device, tmp_path, use_graphs
   of each step kind must NOT capture -- it warns and stays eager (GAN._replay) -- and the results are the same."""
   from exposure_amd.config import make_cfg
   from exposure_amd.gan import GAN
-  torch.manual_seed(123)
-  ref = GAN(make_cfg(), device=gpu_device, seed=77)
-  g, c = _run_steps(ref, *_inputs(gpu_device), iters=iters)
-  torch.cuda.synchronize()
-  want = _snapshot(ref, g, c)
   mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), use_graphs, iters), nprocs=2, join=True)
   r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
   r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
+  torch.manual_seed(123)
+  ref = GAN(make_cfg(), device=gpu_device, seed=77)
+  inputs = _inputs(gpu_device)
+  g, c = _run_steps(ref, *inputs, iters=1)
+  if iters > 1:
+    # The gradients of iteration k are a function of the weights after iteration k - 1 (and of the shared noise
+    # stream).  After an Adam step -- which moves every weight by ~lr whatever the size of its gradient, so
+    # rounding-level differences in near-zero gradients become lr-sized weight differences -- the two runs' weights
+    # differ at the 1e-4 level and iteration-2 gradients by up to 8e-3 of a tensor's largest (measured, round 4): that
+    # divergence is Adam's, not the exchange's.  So the one-process run CONTINUES FROM THE RANKS' WEIGHTS (checked first
+    # to be within Adam's first-step size of its own): iteration 2 is then compared from identical weights under the
+    # same bound as iteration 1.
+    torch.cuda.synchronize()
+    worst = max(float((a - p.detach().cpu()).abs().max()) for a, p in zip(r0['params_after_first'], ref.parameters()))
+    assert worst < 3e-4, worst
+    with torch.no_grad():
+      for p, a in zip(ref.parameters(), r0['params_after_first']):
+        p.copy_(a.to(p.device))  # in place: captured graphs and the packed heads keep their storage
+    for _ in range(iters - 1):
+      g, c = _run_steps(ref, *inputs, iters=1)
+  torch.cuda.synchronize()
+  want = _snapshot(ref, g, c)
   if use_graphs:
     assert r0['warned'] and not r0['still_graphs']  # the eager fallback was taken, loudly
   for a, b in zip(r0['params'], r1['params']):
@@ -104,13 +127,12 @@ def test_two_ranks_on_one_gpu_match_one_process(gpu_device, tmp_path, use_graphs
   for got, ref_g in zip(r0['grads'], want['grads']):
     scale = float(ref_g.abs().max()) + 1e-12
     # (fp32 convolutions of 4 and of 8 images, possibly through different MIOpen kernels, and the double backward of the
-    # gradient penalty on top; after the first Adam step -- which moves every weight by ~lr whatever the size of its
-    # gradient, so rounding-level differences in near-zero gradients become lr-sized weight differences -- 1.7e-3 (round 3)
-    # and 7.7e-3 (round 4, fused glue kernels contract differently) of a tensor's largest gradient were seen at the
-    # second iteration; a wrong reduction -- sum instead of mean, a missing shard -- would be off by a factor)
-    assert float((got - ref_g).abs().max()) <= (5e-3 if iters == 1 else 2e-2) * scale + 1e-8
+    # gradient penalty on top: 1.7e-3 of a tensor's largest gradient seen; a wrong reduction -- sum instead of mean, a
+    # missing shard -- would be off by a factor)
+    assert float((got - ref_g).abs().max()) <= 5e-3 * scale + 1e-8
   worst = max(float((a - b).abs().max()) for a, b in zip(r0['params'], want['params']))
-  assert worst < 3e-4 * iters, worst  # Adam's first steps are ~lr-sized (tests/test_dist_gloo.py)
+  # Adam's steps are ~lr-sized (tests/test_dist_gloo.py); the moments of iteration 1 differ at rounding level
+  assert worst < 3e-4, worst
 
 
 def test_bench_launches_two_ranks_that_share_the_gpu(gpu_device):

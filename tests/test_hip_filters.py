@@ -875,3 +875,25 @@ def test_every_caller_stream_gets_a_helper_on_another_hardware_queue(gpu_device)
   assert _cabi.chain_helper_stats()[0] == probed1  # a known caller is not probed again
   print('chain step per caller stream (ms): %s; helpers rejected so far: %d' % (' '.join('%.4f' % v for v in ms), rejected))
   assert max(ms) <= 1.10 * min(ms), ms
+  # expo_chain_prepare: the probe as an explicit set-up call -- the first chain call of that stream finds it done;
+  # idempotent; expo_chain_release forgets a pairing (the next call of that stream starts over)
+  fresh = torch.cuda.Stream()
+  base = _cabi.chain_helper_stats()[0]
+  _cabi.chain_prepare(fresh)
+  after = _cabi.chain_helper_stats()[0]
+  assert after > base
+  _cabi.chain_prepare(fresh)
+  with torch.cuda.stream(fresh):
+    step()
+  torch.cuda.synchronize()
+  assert _cabi.chain_helper_stats()[0] == after
+  for got, ref in zip([acts[8], grads[0]] + dprm, want):
+    assert torch.equal(got, ref)
+  _cabi.chain_release(fresh)
+  _cabi.chain_release(fresh)  # (unknown now: still OK)
+  with torch.cuda.stream(fresh):
+    step()
+  torch.cuda.synchronize()
+  assert _cabi.chain_helper_stats()[0] > after
+  for got, ref in zip([acts[8], grads[0]] + dprm, want):
+    assert torch.equal(got, ref)

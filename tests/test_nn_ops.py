@@ -257,6 +257,98 @@ def test_hip_adam_matches_the_rule_in_float64(count, gpu_device):
 
 
 @pytest.mark.gpu
+def test_hip_adam_state_dict_round_trip_and_torch_interop(gpu_device):
+  """HipAdam's ``state_dict`` is torch.optim.Optimizer's: (1) three steps, save, a FRESH HipAdam over copies of the
+  parameters loads it and both take three more steps -> identical parameters, moments and step counter; (2) the same
+  state loads into ``torch.optim.Adam`` (capturable: tensor step) and the next steps agree to fp32 rounding, and a
+  state written by torch's Adam loads back; (3) two parameter groups with their own learning rates, ``add_param_group``;
+  (4) a mismatching state is refused; restoring writes the learning-rate scalar IN PLACE (a captured graph reads it)."""
+  from exposure_amd.optim import HipAdam
+  dev = gpu_device
+  sizes = [(5,), (33, 7), (8, 3, 4, 4), (1025,)]
+
+  def fresh(seed=0):
+    ps = []
+    for i, sz in enumerate(sizes):
+      p = torch.randn(sz, device=dev, generator=torch.Generator(device=dev).manual_seed(seed + i))
+      if len(sz) == 4:
+        p = p.contiguous(memory_format=torch.channels_last)
+      ps.append(p.requires_grad_(True))
+    return ps
+
+  def grads(k):
+    g = torch.Generator(device=dev).manual_seed(1000 + k)
+    out = [torch.randn(sz, device=dev, generator=g) for sz in sizes]
+    return [t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t for t in out]
+
+  def steps(opt, ps, ks):
+    for k in ks:
+      for p, g in zip(ps, grads(k)):
+        p.grad = g
+      opt.step()
+
+  a = fresh()
+  opt_a = HipAdam(a, lr=1e-2, betas=(0.5, 0.9))
+  steps(opt_a, a, range(3))
+  sd = opt_a.state_dict()
+  assert sorted(sd['state']) == [0, 1, 2, 3] and float(sd['state'][0]['step']) == 3.0
+  assert sd['param_groups'][0]['params'] == [0, 1, 2, 3]
+  # (1) resume in a fresh optimiser
+  b = [p.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for p in a]
+  opt_b = HipAdam(b, lr=123.0, betas=(0.9, 0.999))
+  lr_tensor = opt_b.param_groups[0]['lr']
+  opt_b.load_state_dict(sd)
+  assert opt_b.param_groups[0]['lr'] is lr_tensor and float(lr_tensor) == pytest.approx(1e-2)
+  assert opt_b.param_groups[0]['betas'] == (0.5, 0.9) and float(opt_b._step) == 3.0
+  steps(opt_a, a, range(3, 6))
+  steps(opt_b, b, range(3, 6))
+  for p, q in zip(a, b):
+    assert torch.equal(p, q)
+    assert torch.equal(opt_a.state[p][0], opt_b.state[q][0]) and torch.equal(opt_a.state[p][1], opt_b.state[q][1])
+  assert float(opt_b._step) == 6.0
+  # (2) torch.optim.Adam takes the same state and continues alike; its own state loads back
+  c = [p.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for p in a]
+  opt_c = torch.optim.Adam(c, lr=1.0, betas=(0.1, 0.2), capturable=True)
+  opt_c.load_state_dict(opt_a.state_dict())
+  assert float(opt_c.param_groups[0]['lr']) == pytest.approx(1e-2) and tuple(opt_c.param_groups[0]['betas']) == (0.5, 0.9)
+  steps(opt_a, a, range(6, 8))
+  steps(opt_c, c, range(6, 8))
+  for p, q in zip(a, c):
+    assert (p - q).abs().max().item() <= 1e-6 * max(1.0, p.abs().max().item())
+  d = [p.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for p in c]
+  opt_d = HipAdam(d, lr=0.0)
+  opt_d.load_state_dict(opt_c.state_dict())
+  steps(opt_c, c, range(8, 10))
+  steps(opt_d, d, range(8, 10))
+  for p, q in zip(c, d):
+    assert (p - q).abs().max().item() <= 1e-6 * max(1.0, p.abs().max().item())
+  assert float(opt_d._step) == 10.0
+  # (3) two groups, each with its own learning rate and step counter
+  e = fresh(7)
+  f = [p.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for p in e]
+  opt_e = HipAdam([dict(params=e[:2], lr=1e-2), dict(params=e[2:3], lr=1e-3)], lr=5e-3, betas=(0.5, 0.9))
+  opt_e.add_param_group(dict(params=e[3:]))  # -> the default 5e-3
+  opt_f = torch.optim.Adam([dict(params=f[:2], lr=1e-2), dict(params=f[2:3], lr=1e-3), dict(params=f[3:], lr=5e-3)],
+                           betas=(0.5, 0.9))
+  assert [float(g['lr']) for g in opt_e.param_groups] == pytest.approx([1e-2, 1e-3, 5e-3])
+  steps(opt_e, e, range(4))
+  steps(opt_f, f, range(4))
+  for p, q in zip(e, f):
+    assert (p - q).abs().max().item() <= 1e-6 * max(1.0, p.abs().max().item())
+  sd_e = opt_e.state_dict()
+  assert [g['params'] for g in sd_e['param_groups']] == [[0, 1], [2], [3]] and len(opt_e.params) == 4
+  # (4) refusals
+  with pytest.raises(ValueError):
+    opt_a.load_state_dict(sd_e)  # three groups into one
+  bad = opt_a.state_dict()
+  bad['state'][1]['exp_avg'] = bad['state'][1]['exp_avg'][:5]
+  with pytest.raises(ValueError):
+    opt_b.load_state_dict(bad)
+  with pytest.raises(AssertionError):
+    opt_e.add_param_group(dict(params=e[:1]))  # already in a group
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
 @pytest.mark.parametrize('v', [0, 3, 14])
 def test_planes_concat_matches_torch(dtype, v, gpu_device):
