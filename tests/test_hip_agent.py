@@ -373,12 +373,13 @@ def test_heads_are_packed_at_construction_and_a_repack_drops_the_captured_steps(
     else:
       g = gan.generator_step(img, z, states, progress=0.2, it=6, dropout_masks=masks)
     gan.critic_step(real, g['fake_output'].clone(), it=6, alpha=alpha)
-    before = head0.detach().clone()
+    before = pack.w1.detach().clone()
     for it in (7, 8):  # (capture +) replay over the current storage
       g = gan.generator_step(img, z, states, progress=0.2, it=it, dropout_masks=masks)
       gan.critic_step(real, g['fake_output'].clone(), it=it, alpha=alpha)
     torch.cuda.synchronize()
-    assert not torch.equal(before, head0.detach())  # Adam keeps updating the tensor the module holds
+    # Adam keeps updating the storage the module's parameters live in (the heads some image of the batch selected)
+    assert head0.data_ptr() == pack.w1.data_ptr() and not torch.equal(before, pack.w1.detach())
     finals.append([p.detach().clone() for p in gan.parameters()])
   worst = max(float((a - b).abs().max()) for a, b in zip(*finals))
   assert worst < 3e-4, worst  # (eager vs replayed steps differ at Adam's step size at most: test_graphed_steps_match_eager)
