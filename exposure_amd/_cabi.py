@@ -47,6 +47,7 @@ SIGNATURES = {
     'expo_chain_streams': (_i, [_i, _i, _i, _i]),
     'expo_chain_helper_stats': (_i, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     'expo_chain_prepare': (_i, [_vp]),
+    'expo_conv4x4s2_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_chain_release': (_i, [_vp]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
                             _vp]),
@@ -795,6 +796,22 @@ def chain_helper_stats():
   a, b = ctypes.c_int(0), ctypes.c_int(0)
   _check(load().expo_chain_helper_stats(ctypes.byref(a), ctypes.byref(b)), 'expo_chain_helper_stats')
   return a.value, b.value
+
+
+def conv4x4s2_fwd(x, w, bias, y, act, leak=0.2):
+  """y = f(conv(x, w) + bias): NHWC float32 ``x`` (N, H, W, Cin), ``w`` an nn.Conv2d weight (Cout, Cin, 4, 4) in
+  channels_last memory order, ``y`` (N, H/2, W/2, Cout); ``act`` 1 -> lrelu(., leak) (expo_conv4x4s2_fwd)."""
+  lib = load()
+  n, h, wd, cin = x.shape
+  cout = w.shape[0]
+  assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+  assert w.dtype == torch.float32 and tuple(w.shape) == (cout, cin, 4, 4) and w.permute(0, 2, 3, 1).is_contiguous()
+  assert y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (n, h // 2, wd // 2, cout)
+  if bias is not None:
+    _f32(bias, 'bias', (cout,))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_conv4x4s2_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, h, wd, cin, cout, int(act), float(leak),
+                                  _stream()), 'expo_conv4x4s2_fwd')
 
 
 def chain_prepare(stream=None):

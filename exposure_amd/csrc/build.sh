@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build libexposure_hip.so for gfx950 in-tree (the .so is git-ignored but travels with gpurun).
-# Five translation units (curve_generic.hip: Tone / Color for cfg.curve_steps other than 8): the streaming kernels (default flags), the VALU-bound fused inference kernel
+# Six translation units (conv_ops.hip: the convnets' 4x4 / stride-2 convolution on the f32 matrix cores; curve_generic.hip: Tone / Color for cfg.curve_steps other than 8): the streaming kernels (default flags), the VALU-bound fused inference kernel
 # (-fno-slp-vectorize -fno-honor-nans, see chain_fused.hip), the convnets' activation (nn_ops.hip) and the one-pass
 # backward of a fixed sequence (chain_fused_bwd.hip; -fno-slp-vectorize: the packed-fp32 pairs cost it ~100 VGPRs); extra
 # arguments go to every compile step.
@@ -21,11 +21,14 @@ p3=$!
 p4=$!
 "$HIPCC" "${FLAGS[@]}" "$@" -c "$HERE/curve_generic.hip" -o "$TMP/curve_generic.o" &
 p5=$!
+"$HIPCC" "${FLAGS[@]}" "$@" -c "$HERE/conv_ops.hip" -o "$TMP/conv_ops.o" &
+p6=$!
 # (a bare `wait` returns 0 whatever the jobs did: wait for each PID so a failed compile stops the script here)
 wait $p1
 wait $p2
 wait $p3
 wait $p4
 wait $p5
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$TMP/exposure_hip.o" "$TMP/chain_fused.o" "$TMP/nn_ops.o" "$TMP/chain_fused_bwd.o" "$TMP/curve_generic.o" -o "$OUT"
+wait $p6
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$TMP/exposure_hip.o" "$TMP/chain_fused.o" "$TMP/nn_ops.o" "$TMP/chain_fused_bwd.o" "$TMP/curve_generic.o" "$TMP/conv_ops.o" -o "$OUT"
 echo "built $OUT"

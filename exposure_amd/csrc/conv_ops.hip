@@ -1,0 +1,515 @@
+// conv_ops.hip -- the one convolution of the convnets around the filter path (feature_extractor agent.py:21-32, cnn
+// critics.py:13-35: `ly.conv2d(kernel_size=4, stride=2)` SAME, NHWC float32) as hand-written implicit-GEMM kernels on
+// the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, 157 TFLOP/s chip peak), with the layer's bias + lrelu
+// (util.py:225-229) in the epilogue.
+//
+// Why in-house: the layers are SMALL -- batch 64 / 128 of 64x64 proxies give GEMMs of ~1 GFLOP (M x Cout x K =
+// 65536 x 32 x 224 ... 1024 x 256 x 2048) -- and the library kernels MIOpen picks for them (asm igemm / CK grouped
+// xdlops, tuned for large problems) take 17-46 us each, 0.2-0.5 of the f32 matrix peak, plus a zero-fill launch in
+// front of every split-K kernel and a bias / activation launch behind every forward (profiles/r04_final_kernel_
+// stats_train.csv: 228 convolution launches = 5.1 ms of a 9.5 ms training iteration, 191 fills = 1.0 ms).  A tile
+// decomposition chosen for THESE sizes -- 1024 wave-tasks of 32x32 output elements each, one per SIMD, whatever the
+// layer -- runs them at a multiple of that.
+//
+// Forward as a GEMM:  Y[m][co] = sum_k A[m][k] W[co][k],  m = (n, oh, ow),  k = (kh, kw, ci),  K = 16 Cin
+//   A[m][k] = X[n][2 oh - 1 + kh][2 ow - 1 + kw][ci]  (0 outside the image)
+//   * for a fixed kh the (kw, ci) range is 4 Cin CONTIGUOUS floats of X (NHWC: w and c adjacent), so a K-chunk of 4
+//     floats is one 16-byte load whatever Cin is (14, 6, 17 for the first layers);
+//   * W is the nn.Conv2d weight (Cout, Cin, 4, 4) in channels_last memory order = [co][kh][kw][ci] = [co][k].
+// Block tile BM x BN, K step 32 per wave group; WM x WN x WK waves: WM x WN tile the block tile, WK wave groups split
+// every K step between them (intra-block split-K, reduced through LDS at the end -- no atomics, no zero fill, a fixed
+// summation order).  Operand tiles go global -> registers -> LDS (K-minor rows padded by 4 floats: conflict-free
+// ds_read_b128 / ds_write_b128), one K step ahead of the MFMAs; each lane reads its A / B fragment as ONE b128 per 8
+// k: lane l holds row l & 31 and k = 8c + 4 (l >> 5) + j for the j-th MFMA of the chunk (any pairing of k between the
+// two lane halves is a valid order of the K sum as long as A and B use the same one).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/exposure_hip.h"
+#include "host_common.h"
+
+namespace expo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct __attribute__((packed, aligned(4))) F4U { float v[4]; };  // a 4-float chunk that is only dword-aligned
+
+struct ConvDims {
+  int n, h, w, cin, cout;  // h, w: the LARGER spatial size (forward input / data-gradient output), even
+  int ho, wo;              // h / 2, w / 2
+  int kdim;                // 16 cin
+  int m;                   // n ho wo
+};
+
+__device__ __forceinline__ float lrelu_v(float v, float leak) { return v > 0.f ? v : v * leak; }
+
+constexpr int kConvPad = 4;  // floats of row padding in LDS
+
+// ---- forward ---------------------------------------------------------------------------------------------------
+// One 4-float K-chunk of the implicit im2col matrix: row (n, oh, ow) at k..k+3.
+struct FwdRow {
+  int img;       // n H W Cin: element offset of the image
+  int ih0, c0;   // 2 oh - 1;  (2 ow - 1) Cin  (may be negative)
+  bool ok;
+};
+__device__ __forceinline__ FwdRow fwd_row(const ConvDims& d, int m) {
+  FwdRow r;
+  r.ok = m < d.m;
+  const int mm = r.ok ? m : 0;
+  const int n = mm / (d.ho * d.wo), rem = mm - n * (d.ho * d.wo);
+  const int oh = rem / d.wo, ow = rem - oh * d.wo;
+  r.img = n * d.h * d.w * d.cin;
+  r.ih0 = 2 * oh - 1;
+  r.c0 = (2 * ow - 1) * d.cin;
+  return r;
+}
+// Branch-free: a load sits in straight-line code behind a clamped address and its result is masked afterwards.  (The
+// first version put the image-edge cases in branches; the compiler closes such a branch with s_waitcnt vmcnt(0), every
+// 64-pixel tile has edge pixels, so every wave waited out its loads right after issuing them: 3.7x the MFMA time.)
+// CIN4: Cin % 4 == 0 -- a chunk never straddles a pixel, so it is inside the image row or outside it as a whole (one
+// 16-byte load); otherwise the four elements are loaded and masked one by one (the first layers: K is small there).
+// Loads go through raw buffer resources (SRD over the whole tensor): an element outside the image gets a byte offset
+// beyond the buffer, for which the hardware returns 0 without touching memory -- no select BEHIND the load either (a
+// v_cndmask on the loaded value is a use, and the compiler waits for the load right there; a pointer select between the
+// tensor and a block of zeros turns the loads into flat_load, which must be waited out before any LDS access).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kConvRsrcFlags = 0x00020000;  // gfx9-family raw buffer descriptor word 3 (DATA_FORMAT = 32-bit); stride 0
+constexpr int kConvOob = -16;               // 0xFFFFFFF0 as a byte offset: beyond any buffer this code accepts (< 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const float* p, size_t floats) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, int(floats * 4), kConvRsrcFlags);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, int elem_off, bool ok) {
+  const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? elem_off * 4 : kConvOob, 0, 0);
+  // (bit_cast of a vector-element lvalue reads element 0 -- clang quirk, pixel_io.h: copy to scalars first)
+  const uint32_t u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3];
+  return make_float4(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1), __builtin_bit_cast(float, u2),
+                     __builtin_bit_cast(float, u3));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int elem_off, bool ok) {
+  const uint32_t u = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? elem_off * 4 : kConvOob, 0, 0);
+  return __builtin_bit_cast(float, u);
+}
+// A 4-float chunk of an image row: row_off = element offset of the row's start, c = offset inside the row (may be < 0).
+// Cin % 4 == 0 (CIN4): a chunk never straddles a pixel, so it lies inside the row or outside it as a whole -- one
+// 16-byte load.  Otherwise (the first layers: 14, 6, 17 planes) the image's left / right edge can cut THROUGH a chunk:
+// the 16-byte load serves the chunks that lie inside as a whole, four 4-byte loads serve the elements of the cut ones
+// (out of range -- free -- in every other lane), and the two are added where the chunk is CONSUMED (one of them is zero),
+// not behind the loads.  (Element-wise loads for every chunk cost 4x the vector-L1 line look-ups: 27 us for the first
+// generator layer against 17 for the deeper ones with the same FLOPs.)
+template <bool CIN4> struct Chunk;
+template <> struct Chunk<true> {
+  float4 v;
+  __device__ __forceinline__ float4 get() const { return v; }
+};
+template <> struct Chunk<false> {
+  float4 v, p;
+  __device__ __forceinline__ float4 get() const { return make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w); }
+};
+template <bool CIN4>
+__device__ __forceinline__ Chunk<CIN4> row_chunk(__amdgpu_buffer_rsrc_t rx, int row_off, int c, int lim, bool ok) {
+  Chunk<CIN4> r;
+  const bool whole = ok && c >= 0 && c + 3 < lim;
+  r.v = buf_load4(rx, row_off + c, whole);
+  if constexpr (!CIN4) {
+    const bool cut = ok && !whole;
+    r.p = make_float4(buf_load1(rx, row_off + c + 0, cut && c + 0 >= 0 && c + 0 < lim),
+                      buf_load1(rx, row_off + c + 1, cut && c + 1 >= 0 && c + 1 < lim),
+                      buf_load1(rx, row_off + c + 2, cut && c + 2 >= 0 && c + 2 < lim),
+                      buf_load1(rx, row_off + c + 3, cut && c + 3 >= 0 && c + 3 < lim));
+  }
+  return r;
+}
+template <bool CIN4>
+__device__ __forceinline__ Chunk<CIN4> fwd_load_a(__amdgpu_buffer_rsrc_t rx, const FwdRow& r, const ConvDims& d, int k) {
+  const int rr = 4 * d.cin;
+  const int kh = (k >= rr) + (k >= 2 * rr) + (k >= 3 * rr);
+  const int ih = r.ih0 + kh;
+  const bool ok = r.ok && k < d.kdim && unsigned(ih) < unsigned(d.h);
+  const int lim = d.w * d.cin;  // valid offsets inside an image row: [0, lim)
+  return row_chunk<CIN4>(rx, r.img + ih * lim, r.c0 + (k - kh * rr), lim, ok);
+}
+
+template <int BM, int BN, int WM, int WN, int WK, int BKS, bool CIN4>
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_fwd_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ w,
+                                                                      const float* __restrict__ bias,
+                                                                      float* __restrict__ y, ConvDims d, int act,
+                                                                      float leak) {
+  constexpr int T = 64 * WM * WN * WK;
+  static_assert(BKS % 8 == 0, "a wave group's K slice is consumed in chunks of 8");
+  constexpr int BKT = BKS * WK;         // k per block step (BKS per wave group)
+  constexpr int LDK = BKT + kConvPad;   // LDS row length
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tiles are multiples of the 32x32 MFMA tile");
+  constexpr int QK = BKT / 4;            // float4 chunks per tile row
+  static_assert((BM * QK) % T == 0 && (BN * QK) % T == 0, "every thread moves the same number of chunks");
+  constexpr int NA = BM * QK / T, NB = BN * QK / T;  // chunks per thread
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
+  float* const As = lds;
+  float* const Bs = lds + 2 * BM * LDK;
+
+  // XCD-aware tile order: consecutive block ids go round-robin over the 8 XCDs; blocks that share an M tile (the
+  // same image rows, all N tiles) get the same XCD so that its L2 serves the re-reads
+  const int tiles_n = (d.cout + BN - 1) / BN, tiles_m = (d.m + BM - 1) / BM;
+  const int nblocks = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  if (nblocks % 8 == 0) bid = (bid % 8) * (nblocks / 8) + bid / 8;
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WM * WN), wmn = wave - wk * (WM * WN), wm = wmn / WN, wn = wmn - wm * WN;
+
+  // per-thread chunk slots
+  FwdRow arow[NA];
+  int a_r[NA], a_q[NA], b_r[NB], b_q[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int f = tid + j * T;
+    a_r[j] = f / QK;
+    a_q[j] = f - a_r[j] * QK;
+    arow[j] = fwd_row(d, m0 + a_r[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int f = tid + j * T;
+    b_r[j] = f / QK;
+    b_q[j] = f - b_r[j] * QK;
+  }
+  const __amdgpu_buffer_rsrc_t rx = conv_rsrc(x, size_t(d.n) * d.h * d.w * d.cin);
+  const __amdgpu_buffer_rsrc_t rw = conv_rsrc(w, size_t(d.cout) * d.kdim);
+  Chunk<CIN4> ra[NA];
+  float4 rb[NB];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) ra[j] = fwd_load_a<CIN4>(rx, arow[j], d, k0 + 4 * a_q[j]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int co = n0 + b_r[j], k = k0 + 4 * b_q[j];
+      const bool ok = co < d.cout && k < d.kdim;
+      rb[j] = buf_load4(rw, co * d.kdim + k, ok);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      *reinterpret_cast<float4*>(As + (buf * BM + a_r[j]) * LDK + 4 * a_q[j]) = ra[j].get();
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      *reinterpret_cast<float4*>(Bs + (buf * BN + b_r[j]) * LDK + 4 * b_q[j]) = rb[j];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int steps = (d.kdim + BKT - 1) / BKT;
+  load_tiles(0);
+  store_tiles(0);
+  load_tiles(BKT);
+  __syncthreads();
+  const int lrow = lane & 31, lk = (lane >> 5) * 4;
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    // (unconditional -- one basic block per step: chunks past K come back as zeros without touching memory, and the
+    // last step's store lands in the buffer nobody reads again)
+    store_tiles(buf ^ 1);            // data of step s + 1 (loaded during step s - 1's MFMAs)
+    load_tiles((s + 2) * BKT);       // lands while this step computes
+    __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler sinks these loads behind the step's MFMAs, where
+                                        // nothing hides their latency from the next step's ds_write)
+    const float* a_base = As + (buf * BM + wm * TM + lrow) * LDK + wk * BKS + lk;
+    const float* b_base = Bs + (buf * BN + wn * TN + lrow) * LDK + wk * BKS + lk;
+#pragma unroll
+    for (int c = 0; c < BKS / 8; ++c) {
+      float4 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDK + c * 8);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDK + c * 8);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: sum the WK partial tiles (LDS, fixed order), bias + lrelu, store NHWC ----
+  // C / D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  if constexpr (WK > 1) {
+    // partial tiles of groups 1 .. WK-1 -> LDS [wk - 1][wmn][MI][NI][16][64]; group 0 adds them in order
+    constexpr int per_wave = MI * NI * 16 * 64;
+    static_assert((WK - 1) * WM * WN * per_wave <= 2 * (BM + BN) * LDK, "partials fit the operand buffers");
+    if (wk > 0) {
+      float* dst = lds + ((wk - 1) * WM * WN + wmn) * per_wave;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) dst[((i * NI + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int g = 1; g < WK; ++g) {
+      const float* src = lds + ((g - 1) * WM * WN + wmn) * per_wave;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += src[((i * NI + j) * 16 + e) * 64 + lane];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn * TN + j * 32 + (lane & 31);
+    const float b = (bias && co < d.cout) ? bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < d.m && co < d.cout) {
+          float v = acc[i][j][e] + b;
+          if (act) v = lrelu_v(v, leak);
+          y[size_t(m) * d.cout + co] = v;
+        }
+      }
+  }
+}
+
+// ---- forward, flat decomposition (v2) ------------------------------------------------------------------------------
+// One WAVE = one 32 x 32 output tile over one K slice; no LDS staging, no barrier in the main loop: every lane loads its
+// own A / B fragments straight from global memory (16 bytes per lane and operand per 8 k: lane l -> row / column l & 31,
+// k = 8c + 4 (l >> 5) .. + 3; four consecutive chunks walk one 128-byte line per row, so the vector L1 sees every line
+// once), and 4-8 waves per SIMD hide each other's load latency.  A block = the S K-slices (x NT column tiles sharing the
+// A rows through the L1) of one tile; the S partial tiles meet in LDS once, at the end, and are summed in slice order.
+// K slices are cut along the (kh, r) structure of K = 4 rows x R floats (R = 4 Cin): G = 4 S2 segments (kh, j) of
+// RS = roundup8(R / S2) floats, G / S consecutive segments per slice.
+struct FlatPlan {
+  int s;     // K slices (waves per tile), divides g
+  int s2;    // segments per kh row
+  int rs;    // floats per segment (multiple of 8)
+  int tiles_m, tiles_n;
+};
+
+template <int NT, bool CIN4>
+__global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             ConvDims d, FlatPlan pl, int act, float leak) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [s][NT][16][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sl = wave / NT, nt = wave - sl * NT;  // K slice, column tile inside the block
+  const int groups_n = (pl.tiles_n + NT - 1) / NT;
+  const int nblocks = pl.tiles_m * groups_n;
+  int bid = blockIdx.x;
+  if (nblocks % 8 == 0) bid = (bid % 8) * (nblocks / 8) + bid / 8;  // neighbouring tiles on one XCD (shared L2)
+  const int tm = bid / groups_n, tn = (bid - tm * groups_n) * NT + nt;
+  const int row = lane & 31, half = lane >> 5;
+  const int m = tm * 32 + row, co = tn * 32 + row;  // this lane's A row (output pixel) and B row (output channel)
+  const int rr = 4 * d.cin, lim = d.w * d.cin;
+  const bool m_ok = m < d.m, co_ok = co < d.cout;
+  const int mm = m_ok ? m : 0;
+  const int n = mm / (d.ho * d.wo), rem = mm - n * (d.ho * d.wo);
+  const int oh = rem / d.wo, ow = rem - oh * d.wo;
+  const int img = n * d.h * lim;
+  const int ih0 = 2 * oh - 1, c0 = (2 * ow - 1) * d.cin + 4 * half;
+  const int wrow = (co_ok ? co : 0) * d.kdim + 4 * half;
+  const __amdgpu_buffer_rsrc_t rx = conv_rsrc(x, size_t(d.n) * d.h * d.w * d.cin);
+  const __amdgpu_buffer_rsrc_t rw = conv_rsrc(w, size_t(d.cout) * d.kdim);
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+  auto load_a = [&](int prow, bool row_ok, int off, int seg_end) -> Chunk<CIN4> {
+    // off: this lane's chunk offset inside the kh row (without the lane half's 4, which c0 carries)
+    return row_chunk<CIN4>(rx, prow, c0 + off, lim, row_ok && off + 4 * half < seg_end);
+  };
+  auto load_b = [&](int pw, int off, int seg_end) -> float4 {
+    return buf_load4(rw, pw + off, co_ok && off + 4 * half < seg_end);
+  };
+  auto mma = [&](const float4& a, const float4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  };
+
+  const int g = 4 * pl.s2, per = g / pl.s;
+  for (int seg = sl * per; seg < (sl + 1) * per; ++seg) {
+    const int kh = seg / pl.s2, j = seg - kh * pl.s2;
+    const int r0 = j * pl.rs;
+    const int seg_end = min(r0 + pl.rs, rr);
+    const int ih = ih0 + kh;
+    const bool row_ok = m_ok && unsigned(ih) < unsigned(d.h);
+    const int prow = img + ih * lim;
+    const int pw = wrow + kh * rr;
+    // chunks of 8 k, four at a time: the next four's loads are in flight while these MFMAs issue (loads past the
+    // segment's end come back as zeros without touching memory, so the pipeline needs no tail case)
+    constexpr int U = CIN4 ? 4 : 2;  // (the cut-chunk fix-ups double a chunk's registers)
+    Chunk<CIN4> ac[U], an[U];
+    float4 bc[U], bn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ac[u] = load_a(prow, row_ok, r0 + 8 * u, seg_end);
+      bc[u] = load_b(pw, r0 + 8 * u, seg_end);
+    }
+#pragma unroll 2
+    for (int r = r0; r < seg_end; r += 8 * U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        an[u] = load_a(prow, row_ok, r + 8 * (U + u), seg_end);
+        bn[u] = load_b(pw, r + 8 * (U + u), seg_end);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of the MFMAs that hide them
+#pragma unroll
+      for (int u = 0; u < U; ++u) mma(ac[u].get(), bc[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ac[u] = an[u];
+        bc[u] = bn[u];
+      }
+    }
+  }
+
+  // ---- the S partial tiles meet in LDS; wave (sl, nt) finishes accumulator registers e = sl, sl + S, ... ----
+  const int col = tn * 32 + (lane & 31);
+  const float bv = (bias && col < d.cout) ? bias[col] : 0.f;
+  if (pl.s > 1) {
+    float* mine = part + (sl * NT + nt) * 1024;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mine[e * 64 + lane] = acc[e];
+    __syncthreads();
+    for (int e = sl; e < 16; e += pl.s) {
+      float v = part[nt * 1024 + e * 64 + lane];
+      for (int q = 1; q < pl.s; ++q) v += part[(q * NT + nt) * 1024 + e * 64 + lane];
+      const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      if (mo < d.m && col < d.cout) {
+        v += bv;
+        if (act) v = lrelu_v(v, leak);
+        y[size_t(mo) * d.cout + col] = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      if (mo < d.m && col < d.cout) {
+        float v = acc[e] + bv;
+        if (act) v = lrelu_v(v, leak);
+        y[size_t(mo) * d.cout + col] = v;
+      }
+    }
+  }
+}
+
+// K slicing for a target of ~16 waves per CU: S in {1, 2, 4, 8, 16} (S <= 16: one accumulator register per slice at
+// least in the final sum), S2 = segments per kh row (S <= 4: whole rows)
+static FlatPlan flat_plan(const ConvDims& d, int nt, int forced_s) {
+  FlatPlan p;
+  p.tiles_m = (d.m + 31) / 32;
+  p.tiles_n = (d.cout + 31) / 32;
+  const long tiles = long(p.tiles_m) * p.tiles_n;
+  int s = 1;
+  while (s < 16 && tiles * s * 2 <= 4096 + 2048) s *= 2;  // the power of two that brings tiles * s closest to 4096
+  const int rr = 4 * d.cin;
+  while (s > 4 && (rr + (s / 4) - 1) / (s / 4) < 8) s /= 2;  // a segment holds at least one chunk
+  if (forced_s > 0) s = forced_s;
+  while (s * nt > 16) s /= 2;
+  p.s = s;
+  p.s2 = s <= 4 ? 1 : s / 4;
+  p.rs = ((rr + p.s2 - 1) / p.s2 + 7) / 8 * 8;
+  return p;
+}
+
+template <int BM, int BN, int WM, int WN, int WK, int BKS>
+static void launch_fwd(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, int act,
+                       float leak, hipStream_t s) {
+  const int blocks = ((d.m + BM - 1) / BM) * ((d.cout + BN - 1) / BN);
+  if (d.cin % 4 == 0)
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WK, BKS, true>), dim3(blocks), dim3(64 * WM * WN * WK), 0, s, x, w,
+                       bias, y, d, act, leak);
+  else
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WK, BKS, false>), dim3(blocks), dim3(64 * WM * WN * WK), 0, s, x, w,
+                       bias, y, d, act, leak);
+}
+
+static int conv_dims(ConvDims* d, int n, int h, int w, int cin, int cout) {
+  if (n < 0 || h < 2 || w < 2 || (h & 1) || (w & 1) || cin < 1 || cout < 1)
+    return fail(EXPO_E_BADARG, "conv4x4s2: n >= 0, even h, w >= 2, cin, cout >= 1 required");
+  // tensors are addressed through 32-bit byte offsets (raw buffer resources)
+  if (double(n) * h * w * cin * 4 > 2.0e9 || double(n) * (h / 2) * (w / 2) * cout * 4 > 2.0e9 || double(cout) * 16 * cin * 4 > 2.0e9)
+    return fail(EXPO_E_BADARG, "conv4x4s2: a tensor of 2 GB or more is not supported");
+  d->n = n; d->h = h; d->w = w; d->cin = cin; d->cout = cout;
+  d->ho = h / 2; d->wo = w / 2; d->kdim = 16 * cin; d->m = n * d->ho * d->wo;
+  return EXPO_OK;
+}
+
+// tile shape by problem size: the largest tile that still yields >= kMinBlocks blocks (one per CU and then some);
+// EXPO_CONV_TILE=1..4 forces a shape (probes)
+constexpr int kMinBlocks = 200;
+
+}  // namespace expo
+
+using namespace expo;
+
+extern "C" {
+
+int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cin,
+                       int cout, int act, float leak, void* stream) {
+  ConvDims d;
+  if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!x || !w || !y) return fail(EXPO_E_BADARG, "null pointer");
+  if ((reinterpret_cast<uintptr_t>(w) & 15) != 0) return fail(EXPO_E_BADARG, "conv4x4s2: weight must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int forced = env_int("EXPO_CONV_TILE", 0);  // (read per call: the probes and tests switch it; 5 = flat)
+  auto blocks = [&](int bm, int bn) { return ((d.m + bm - 1) / bm) * ((d.cout + bn - 1) / bn); };
+  int shape = forced;
+  // Measured on MI355X (tools/r05/conv_bench.py, profiles/r05_conv_*.txt): the LDS-tiled shapes win where 64 x 64
+  // tiles still give every CU a block or two (the second layer; the third at batch 128), the flat decomposition
+  // everywhere else (first layers: K is short; deep layers: few rows, long K)
+  if (shape == 0 && d.cout > 32 && env_int("EXPO_CONV_NT", 0) == 0 && env_int("EXPO_CONV_SLICES", 0) == 0) {
+    const int b64 = blocks(64, 64);
+    if (b64 >= 512) shape = 2;
+    else if (b64 >= 256) shape = 3;
+  }
+  if (shape < 1 || shape > 4) {
+    // the flat decomposition (default); EXPO_CONV_TILE=1..4 selects the LDS-tiled shapes of the first version (probes),
+    // EXPO_CONV_SLICES forces the K slice count, EXPO_CONV_NT the column tiles per block
+    int nt = env_int("EXPO_CONV_NT", 1);
+    if (nt != 1 && nt != 2) nt = 1;
+    const FlatPlan pl = flat_plan(d, nt, env_int("EXPO_CONV_SLICES", 0));
+    const int nblocks = pl.tiles_m * ((pl.tiles_n + nt - 1) / nt);
+    const size_t lds = pl.s > 1 ? size_t(pl.s) * nt * 4096 : 0;
+#define EXPO_FLAT(NT, C4) \
+  hipLaunchKernelGGL((conv_fwd_flat_kernel<NT, C4>), dim3(nblocks), dim3(64 * pl.s * NT), lds, s, x, w, bias, y, d, pl, act, leak)
+    if (nt == 2) { if (d.cin % 4 == 0) EXPO_FLAT(2, true); else EXPO_FLAT(2, false); }
+    else { if (d.cin % 4 == 0) EXPO_FLAT(1, true); else EXPO_FLAT(1, false); }
+#undef EXPO_FLAT
+    HIP_TRY(hipGetLastError(), "conv4x4s2_fwd launch");
+    return EXPO_OK;
+  }
+  (void)blocks;
+  switch (shape) {
+    case 1: launch_fwd<64, 32, 2, 1, 2, 32>(x, w, bias, y, d, act, leak, s); break;
+    case 2: launch_fwd<64, 64, 2, 2, 1, 32>(x, w, bias, y, d, act, leak, s); break;
+    case 3: launch_fwd<32, 64, 1, 2, 2, 32>(x, w, bias, y, d, act, leak, s); break;
+    default: launch_fwd<32, 32, 1, 1, 4, 16>(x, w, bias, y, d, act, leak, s); break;
+  }
+  HIP_TRY(hipGetLastError(), "conv4x4s2_fwd launch");
+  return EXPO_OK;
+}
+
+}  // extern "C"

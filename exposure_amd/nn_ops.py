@@ -71,13 +71,37 @@ def _nhwc(x_nchw):
   return y if y.is_contiguous() else y.contiguous()
 
 
+def _hip_conv(x, w):
+  """The in-house implicit-GEMM kernels (csrc/conv_ops.hip) take float32 NHWC tensors on a device and a weight in
+  channels_last memory order ([co][kh][kw][ci]); EXPO_HIP_CONV=0 sends every convolution to MIOpen as before."""
+  return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 4 and
+          tuple(w.shape[2:]) == (4, 4) and w.permute(0, 2, 3, 1).is_contiguous() and
+          os.environ.get('EXPO_HIP_CONV', '1') == '1')
+
+
+def _conv_fwd(x, w, bias=None, act=0, leak=0.2):
+  """conv (+ bias + lrelu) of an NHWC tensor: ``expo_conv4x4s2_fwd`` or the library pair it replaces."""
+  if _hip_conv(x, w):
+    n, h, wd, _ = x.shape
+    y = torch.empty((n, h // 2, wd // 2, w.shape[0]), dtype=torch.float32, device=x.device)
+    _cabi.conv4x4s2_fwd(x, w, bias, y, act, leak)
+    return y
+  y = _nhwc(torch.ops.aten.convolution(_nchw(x), w, None, _STRIDE, _PAD, _DIL, False, [0, 0], 1))
+  if act or bias is not None:
+    assert act, 'a bias without the activation is not a layer of these nets'
+    z = torch.empty_like(y)
+    _cabi.bias_lrelu_fwd(y, bias, z, leak)
+    return z
+  return y
+
+
 class _ConvF(torch.autograd.Function):
   """y = conv(x, W), NHWC in / NHWC out, kernel 4, stride 2, padding 1, no bias."""
 
   @staticmethod
   def forward(ctx, x, w):
     ctx.save_for_backward(x, w)
-    return _nhwc(torch.ops.aten.convolution(_nchw(x), w, None, _STRIDE, _PAD, _DIL, False, [0, 0], 1))
+    return _conv_fwd(x, w)
 
   @staticmethod
   def backward(ctx, gy):
@@ -204,6 +228,46 @@ class _BiasLrelu(torch.autograd.Function):
     gy = _LreluGrad.apply(z, gz, ctx.leak)
     gb = gy.reshape(-1, gy.shape[-1]).sum(dim=0) if want_gb else None
     return gy, gb, None
+
+
+class _ConvBiasLrelu(torch.autograd.Function):
+  """z = lrelu(conv(x, W) + b): one layer of ``feature_extractor`` / ``cnn`` (agent.py:21-32, critics.py:13-35) as ONE
+  launch (``expo_conv4x4s2_fwd`` with the bias and the activation in its epilogue).  The backward is the composition
+  the two separate nodes had -- activation gradient (+ bias gradient in the same pass), data gradient, weight gradient
+  -- built from Functions that are themselves differentiable, so the gradient penalty's double backward goes through."""
+
+  @staticmethod
+  def forward(ctx, x, w, b, leak):
+    z = _conv_fwd(x, w, b, 1, leak)
+    ctx.save_for_backward(x, w, z)
+    ctx.leak = leak
+    return z
+
+  @staticmethod
+  def backward(ctx, gz):
+    x, w, z = ctx.saved_tensors
+    want_gb = ctx.needs_input_grad[2] and not _SKIP_PARAM_GRADS
+    gz = gz.contiguous()
+    if want_gb and _cabi.lrelu_bwd_bias_supported(z, gz):
+      gy, gb = _LreluGradBias.apply(z, gz, ctx.leak)
+    else:
+      gy = _LreluGrad.apply(z, gz, ctx.leak)
+      gb = gy.reshape(-1, gy.shape[-1]).sum(dim=0) if want_gb else None
+    gx = _ConvD.apply(gy, w) if ctx.needs_input_grad[0] else None
+    gw = _ConvG.apply(x, gy, w) if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS else None
+    return gx, gw, gb, None
+
+
+def conv_bias_lrelu(x, weight, bias, leak=0.2):
+  """``lrelu(ly.conv2d(x, C_out, kernel_size=4, stride=2) + bias)`` for NHWC float32 ``x``: fused where the in-house
+  kernel runs, the ``conv2d_nhwc`` + ``bias_lrelu`` pair elsewhere (CPU, EXPO_HIP_CONV=0, other dtypes)."""
+  assert x.dim() == 4 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and tuple(weight.shape[2:]) == (4, 4)
+  x = x.contiguous()
+  if _hip_conv(x, weight) and bias is not None:
+    if _FROZEN:
+      weight, bias = weight.detach(), bias.detach()
+    return _ConvBiasLrelu.apply(x, weight, bias, leak)
+  return bias_lrelu(conv2d_nhwc(x, weight), bias, leak)
 
 
 def bias_lrelu(y, bias=None, leak=0.2):

@@ -516,6 +516,19 @@ int expo_generator_losses(const float* fake_logit, const float* fake_input_logit
                           const float* surrogate, const float* consts, int use_td, float* losses, float* reward,
                           float* q_value, float* coef, int n, void* stream);
 
+/* ---- the convnets' convolution (round 5) ------------------------------------------------------------------------
+ * `ly.conv2d(net, C_out, kernel_size=4, stride=2)` (SAME padding; agent.py:21-32, critics.py:13-35) on NHWC float32
+ * tensors as implicit-GEMM kernels on the f32 matrix cores (csrc/conv_ops.hip), with the layer's bias + lrelu
+ * (util.py:225-229) in the epilogue:
+ *   y[n][oh][ow][co] = f(bias[co] + sum_{kh,kw,ci} x[n][2 oh - 1 + kh][2 ow - 1 + kw][ci] w[co][kh][kw][ci])
+ *   x     float32 [n][h][w][cin] (h, w even)      w     float32 [cout][4][4][cin] (16-byte aligned: the channels_last
+ *   y     float32 [n][h/2][w/2][cout]                    memory order of an nn.Conv2d weight (cout, cin, 4, 4))
+ *   bias  float32 [cout] or NULL                  act   0: f = identity, 1: f = lrelu(., leak)
+ * Deterministic (fixed summation order, no atomics), no workspace.  Replaces aten::miopen_convolution +
+ * expo_bias_lrelu_fwd for these layers. */
+int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cin,
+                       int cout, int act, float leak, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -436,3 +436,74 @@ def test_generator_loss_glue_matches_the_op_by_op_formula(use_td, use_penalty, g
       assert ga is None or float(ga.abs().max()) == 0.0, k
     else:
       assert ga is not None and close(ga, gb, 3e-6), k
+
+
+# ---- the in-house convolution kernels (csrc/conv_ops.hip, round 5) ---------------------------------------------------
+CONV_CASES = [(3, 8, 5, 7), (2, 16, 14, 32), (5, 12, 6, 32), (2, 64, 17, 32), (9, 8, 32, 64), (4, 16, 64, 128),
+              (16, 8, 128, 256), (1, 2, 3, 1), (7, 4, 4, 33), (8, 64, 14, 32), (32, 32, 32, 64)]
+CONV_ENVS = ('EXPO_CONV_TILE', 'EXPO_CONV_NT', 'EXPO_CONV_SLICES')
+
+
+def _conv_case(n, h, cin, cout, dev, seed):
+  g = torch.Generator(device=dev).manual_seed(seed)
+  x = torch.randn((n, h, h, cin), device=dev, generator=g)
+  w = (torch.randn((cout, cin, 4, 4), device=dev, generator=g) / (16 * cin)**0.5).contiguous(memory_format=torch.channels_last)
+  b = torch.randn((cout,), device=dev, generator=g) * 0.1
+  return x, w, b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_hip_conv_forward_matches_float64(case, gpu_device, monkeypatch):
+  """expo_conv4x4s2_fwd (implicit GEMM on v_mfma_f32_32x32x2_f32) against a float64 convolution on the CPU, plain and
+  with the bias + lrelu epilogue, for EVERY decomposition the library can pick -- the flat one under 1 / 2 column tiles
+  per block and 1 .. 16 K slices, the four LDS-tiled shapes -- on shapes with ragged tiles (M, Cout not multiples of
+  32), the first layers' channel counts (14, 6, 17: chunks cut by the image edge), one-pixel outputs.  f32 MFMA is an
+  exact fmaf chain: the error is f32 summation rounding, 2e-6 of the largest output; MIOpen's own error on the same
+  operands is printed beside it."""
+  from exposure_amd import _cabi
+  n, h, cin, cout = case
+  dev = gpu_device
+  x, w, b = _conv_case(n, h, cin, cout, dev, seed=n + h)
+  ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), None, 2, 1).permute(0, 2, 3, 1)
+  scale = float(ref.abs().max())
+  lib = float((ref_conv(x, w).double().cpu() - ref).abs().max()) / scale
+  variants = ([('0', '0', '0')] + [('5', nt, sl) for nt in ('1', '2') for sl in ('0', '1', '2', '4', '8', '16')] +
+              [(t, '0', '0') for t in '1234'])
+  y = torch.empty((n, h // 2, h // 2, cout), device=dev)
+  worst = 0.0
+  for tile, nt, sl in variants:
+    for k, v in zip(CONV_ENVS, (tile, nt, sl)):
+      monkeypatch.setenv(k, v)
+    for act in (0, 1):
+      y.fill_(float('nan'))
+      _cabi.conv4x4s2_fwd(x, w, b if act else None, y, act, 0.2)
+      want = ref + b.double().cpu() if act else ref
+      if act:
+        want = torch.where(want > 0, want, want * 0.2)
+      err = float((y.double().cpu() - want).abs().max()) / scale
+      assert err < 2e-6, (case, tile, nt, sl, act, err)
+      worst = max(worst, err)
+  print('conv fwd %s: worst %.2e of max |y| over %d variants (MIOpen %.2e)' % (case, worst, len(variants), lib))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,cout,n,h', [(14, 32, 6, 16), (64, 128, 5, 8)])
+def test_fused_conv_layer_autograd_matches_the_library_pair(cin, cout, n, h, gpu_device, monkeypatch):
+  """nn_ops.conv_bias_lrelu (one launch forward) == bias_lrelu(conv2d_nhwc(.)) through MIOpen (EXPO_HIP_CONV=0):
+  value, first derivatives with respect to input / weight / bias, and the gradient-penalty pattern -- the derivative of
+  ||d out / d x||^2 with respect to the weight (double backward through the layer)."""
+  dev = gpu_device
+  x0, w0, b0 = _conv_case(n, h, cin, cout, dev, seed=3)
+  c = torch.randn((n, h // 2, h // 2, cout), device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+  res = []
+  for hip in ('1', '0'):
+    monkeypatch.setenv('EXPO_HIP_CONV', hip)
+    x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    z = nn_ops.conv_bias_lrelu(x, w, b)
+    gx, gw, gb = torch.autograd.grad((z * c).sum(), [x, w, b], create_graph=True)
+    ggw, = torch.autograd.grad((gx**2).sum(), [w])
+    res.append([t.detach() for t in (z, gx, gw, gb, ggw)])
+  for name, a, r in zip(('z', 'gx', 'gw', 'gb', 'ggw'), *res):
+    tol = 2e-5 * float(r.abs().max()) + 1e-7
+    assert float((a - r).abs().max()) <= tol, (name, float((a - r).abs().max()), tol)
