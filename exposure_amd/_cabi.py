@@ -48,6 +48,7 @@ SIGNATURES = {
     'expo_chain_helper_stats': (_i, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     'expo_chain_prepare': (_i, [_vp]),
     'expo_conv4x4s2_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'expo_conv4x4s2_bwd_data': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     'expo_chain_release': (_i, [_vp]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
                             _vp]),
@@ -812,6 +813,20 @@ def conv4x4s2_fwd(x, w, bias, y, act, leak=0.2):
   with torch.cuda.device(x.device):
     _check(lib.expo_conv4x4s2_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, h, wd, cin, cout, int(act), float(leak),
                                   _stream()), 'expo_conv4x4s2_fwd')
+
+
+def conv4x4s2_bwd_data(dy, w, dx):
+  """dx = the data gradient of conv4x4s2 for upstream ``dy`` (N, H/2, W/2, Cout): NHWC float32 ``dx`` (N, H, W, Cin),
+  every element written (expo_conv4x4s2_bwd_data)."""
+  lib = load()
+  n, h, wd, cin = dx.shape
+  cout = w.shape[0]
+  assert dy.is_cuda and dy.dtype == torch.float32 and dy.is_contiguous() and tuple(dy.shape) == (n, h // 2, wd // 2, cout)
+  assert w.dtype == torch.float32 and tuple(w.shape) == (cout, cin, 4, 4) and w.permute(0, 2, 3, 1).is_contiguous()
+  assert dx.dtype == torch.float32 and dx.is_contiguous()
+  with torch.cuda.device(dy.device):
+    _check(lib.expo_conv4x4s2_bwd_data(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, cin, cout, _stream()),
+           'expo_conv4x4s2_bwd_data')
 
 
 def chain_prepare(stream=None):

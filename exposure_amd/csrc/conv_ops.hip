@@ -433,6 +433,130 @@ static FlatPlan flat_plan(const ConvDims& d, int nt, int forced_s) {
   return p;
 }
 
+// ---- data gradient (transposed convolution), flat decomposition -----------------------------------------------------
+//   dX[n][ih][iw][ci] = sum_{kh, kw, co} dY[n][oh][ow][co] W[co][kh][kw][ci]   over the taps with ih = 2 oh - 1 + kh
+// An input pixel of parity (ph, pw) = (ih & 1, iw & 1) is reached by 2 x 2 of the 4 x 4 taps: kh = 1 - ph + 2 th,
+// oh = a + ph - th for ih = 2 a + ph (th = 0, 1), the same in w.  So the data gradient is FOUR dense GEMMs, one per parity
+// class:  M' = N Ho Wo pixels (a, b),  N' = Cin,  K' = 4 taps x Cout:
+//   A[m'][(t, co)] = dY[n][a + ph - th][b + pw - tw][co]      co contiguous: one 16-byte load per 4 k (Cout % 4 == 0)
+//   B[(t, co)][ci] = W[co][kh_t][kw_t][ci]                     ci contiguous: lane l reads column l & 31 of FOUR rows co
+//                                                              (4-byte loads; 32 lanes cover one 128-byte line)
+// One wave = one 32 x 32 tile (pixels of one class x input channels) over one K' slice, like the forward; K' slices are
+// cut along (tap, co range): G = 4 S2 segments of RS = roundup8(Cout / S2) channels.
+__global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             float* __restrict__ dx, ConvDims d, FlatPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [s][16][64]
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int per_class = pl.tiles_m * pl.tiles_n, nblocks = 4 * per_class;
+  int bid = blockIdx.x;
+  if (nblocks % 8 == 0) bid = (bid % 8) * (nblocks / 8) + bid / 8;
+  const int cls = bid / per_class, rem_b = bid - cls * per_class;
+  const int tm = rem_b / pl.tiles_n, tn = rem_b - tm * pl.tiles_n;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int row = lane & 31, half = lane >> 5;
+  const int m = tm * 32 + row, ci = tn * 32 + row;  // this lane's A row (input pixel of the class) and B column
+  const bool m_ok = m < d.m, ci_ok = ci < d.cin;
+  const int mm = m_ok ? m : 0;
+  const int n = mm / (d.ho * d.wo), rem = mm - n * (d.ho * d.wo);
+  const int a = rem / d.wo, b = rem - a * d.wo;
+  const __amdgpu_buffer_rsrc_t rg = conv_rsrc(dy, size_t(d.n) * d.ho * d.wo * d.cout);
+  const __amdgpu_buffer_rsrc_t rw = conv_rsrc(w, size_t(d.cout) * d.kdim);
+  const int wstride = d.kdim;  // floats between two output channels of W
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  auto mma = [&](const float4& fa, const float4& fb) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+  };
+
+  const int g = 4 * pl.s2, per = g / pl.s;
+  for (int seg = sl * per; seg < (sl + 1) * per; ++seg) {
+    const int t = seg / pl.s2, j = seg - t * pl.s2;
+    const int th = t >> 1, tw = t & 1;
+    const int oh = a + ph - th, ow = b + pw - tw;
+    const int kh = 1 - ph + 2 * th, kw = 1 - pw + 2 * tw;
+    const bool pix_ok = m_ok && unsigned(oh) < unsigned(d.ho) && unsigned(ow) < unsigned(d.wo);
+    const int abase = ((n * d.ho + oh) * d.wo + ow) * d.cout + 4 * half;        // + co
+    const int bbase = (4 * half) * wstride + (kh * 4 + kw) * d.cin + ci;        // + co * wstride
+    const int r0 = j * pl.rs, seg_end = min(r0 + pl.rs, d.cout);
+    auto load_a = [&](int co) -> float4 { return buf_load4(rg, abase + co, pix_ok && co + 4 * half < seg_end); };
+    auto load_b = [&](int co) -> float4 {
+      const bool ok = ci_ok && co + 4 * half < seg_end;  // (Cout % 4 == 0: the four rows exist together)
+      const int o = bbase + co * wstride;
+      return make_float4(buf_load1(rw, o, ok), buf_load1(rw, o + wstride, ok), buf_load1(rw, o + 2 * wstride, ok),
+                         buf_load1(rw, o + 3 * wstride, ok));
+    };
+    constexpr int U = 4;
+    float4 ac[U], an[U], bc[U], bn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ac[u] = load_a(r0 + 8 * u);
+      bc[u] = load_b(r0 + 8 * u);
+    }
+#pragma unroll 2
+    for (int r = r0; r < seg_end; r += 8 * U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        an[u] = load_a(r + 8 * (U + u));
+        bn[u] = load_b(r + 8 * (U + u));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) mma(ac[u], bc[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ac[u] = an[u];
+        bc[u] = bn[u];
+      }
+    }
+  }
+
+  // the S partial tiles meet in LDS; wave sl finishes accumulator registers e = sl, sl + S, ...
+  auto store = [&](int e, float v) {
+    const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;  // the pixel of accumulator register e
+    if (mo < d.m && ci_ok) {
+      const int no = mo / (d.ho * d.wo), ro = mo - no * (d.ho * d.wo);
+      const int ao = ro / d.wo, bo = ro - ao * d.wo;
+      dx[(size_t(no * d.h + 2 * ao + ph) * d.w + 2 * bo + pw) * d.cin + ci] = v;
+    }
+  };
+  if (pl.s > 1) {
+    float* mine = part + sl * 1024;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mine[e * 64 + lane] = acc[e];
+    __syncthreads();
+    for (int e = sl; e < 16; e += pl.s) {
+      float v = part[e * 64 + lane];
+      for (int q = 1; q < pl.s; ++q) v += part[q * 1024 + e * 64 + lane];
+      store(e, v);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) store(e, acc[e]);
+  }
+}
+
+// K' slicing of the data gradient: tiles = 4 classes x pixel tiles x channel tiles; segments along (tap, co range)
+static FlatPlan bwd_plan(const ConvDims& d, int forced_s) {
+  FlatPlan p;
+  p.tiles_m = (d.m + 31) / 32;
+  p.tiles_n = (d.cin + 31) / 32;
+  const long tiles = 4L * p.tiles_m * p.tiles_n;
+  int s = 1;
+  while (s < 16 && tiles * s * 2 <= 4096 + 2048) s *= 2;
+  while (s > 4 && (d.cout + (s / 4) - 1) / (s / 4) < 8) s /= 2;
+  if (forced_s > 0) s = forced_s;
+  if (s > 16) s = 16;
+  p.s = s;
+  p.s2 = s <= 4 ? 1 : s / 4;
+  p.rs = ((d.cout + p.s2 - 1) / p.s2 + 7) / 8 * 8;
+  return p;
+}
+
 template <int BM, int BN, int WM, int WN, int WK, int BKS>
 static void launch_fwd(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, int act,
                        float leak, hipStream_t s) {
@@ -509,6 +633,22 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
     default: launch_fwd<32, 32, 1, 1, 4, 16>(x, w, bias, y, d, act, leak, s); break;
   }
   HIP_TRY(hipGetLastError(), "conv4x4s2_fwd launch");
+  return EXPO_OK;
+}
+
+int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, int h, int wd, int cin, int cout,
+                            void* stream) {
+  ConvDims d;
+  if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!dy || !w || !dx) return fail(EXPO_E_BADARG, "null pointer");
+  if (cout % 4 != 0) return fail(EXPO_E_BADARG, "conv4x4s2_bwd_data: cout must be a multiple of 4");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const FlatPlan pl = bwd_plan(d, env_int("EXPO_CONV_SLICES", 0));
+  const int nblocks = 4 * pl.tiles_m * pl.tiles_n;
+  const size_t lds = pl.s > 1 ? size_t(pl.s) * 4096 : 0;
+  hipLaunchKernelGGL(conv_bwd_flat_kernel, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, dx, d, pl);
+  HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data launch");
   return EXPO_OK;
 }
 

@@ -123,6 +123,13 @@ class _ConvD(torch.autograd.Function):
   def forward(ctx, g, w):
     ctx.save_for_backward(g, w)
     n, h, wd, _ = g.shape
+    # (not for the first layers: with 6 / 14 / 17 input planes a 32-wide tile of input channels is mostly padding and
+    # MIOpen's kernel is faster -- 28-45 against 50 us at batch 64, profiles/r05_p3_conv_bwd_wrw.txt)
+    if (_hip_conv(g, w) and w.shape[0] % 4 == 0 and w.shape[1] >= 24 and
+        os.environ.get('EXPO_HIP_CONV_BWD', '1') == '1'):
+      dx = torch.empty((n, 2 * h, 2 * wd, w.shape[1]), dtype=torch.float32, device=g.device)
+      _cabi.conv4x4s2_bwd_data(g, w, dx)  # four parity-class GEMMs on the f32 matrix cores, no zero fill
+      return dx
     x_like = torch.empty((n, w.shape[1], 2 * h, 2 * wd), dtype=g.dtype, device=g.device,
                          memory_format=torch.channels_last)
     return _nhwc(torch.ops.aten.convolution_backward(_nchw(g), x_like, w, None, _STRIDE, _PAD, _DIL, False, [0, 0], 1,

@@ -528,7 +528,12 @@ int expo_generator_losses(const float* fake_logit, const float* fake_input_logit
  * expo_bias_lrelu_fwd for these layers. */
 int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cin,
                        int cout, int act, float leak, void* stream);
-
+/* The data gradient of the same convolution (the transposed convolution of dy): four dense GEMMs, one per parity
+ * class of the input pixel.  Replaces aten::convolution_backward(input gradient only) and the zero fill in front of
+ * MIOpen's split-K kernel.
+ *   dy  float32 [n][h/2][w/2][cout] (cout % 4 == 0)     dx  float32 [n][h][w][cin], every element written */
+int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, int h, int wd, int cin, int cout,
+                            void* stream);
 #ifdef __cplusplus
 }
 #endif

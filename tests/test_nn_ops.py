@@ -507,3 +507,29 @@ def test_fused_conv_layer_autograd_matches_the_library_pair(cin, cout, n, h, gpu
   for name, a, r in zip(('z', 'gx', 'gw', 'gb', 'ggw'), *res):
     tol = 2e-5 * float(r.abs().max()) + 1e-7
     assert float((a - r).abs().max()) <= tol, (name, float((a - r).abs().max()), tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 8, 5, 8), (2, 16, 14, 32), (2, 64, 17, 32), (9, 8, 32, 64), (4, 16, 64, 128),
+                                  (16, 8, 128, 256), (7, 4, 4, 36), (32, 32, 32, 64), (3, 4, 3, 4)])
+def test_hip_conv_data_gradient_matches_float64(case, gpu_device, monkeypatch):
+  """expo_conv4x4s2_bwd_data (four parity-class GEMMs on the f32 matrix cores) against the float64 autograd gradient
+  of a convolution on the CPU, under every K' slice count (1 .. 16 waves per tile); ragged pixel / channel tiles,
+  channel counts below one tile, the smallest image.  Every element of dx is written (the buffer starts as NaN)."""
+  from exposure_amd import _cabi
+  n, h, cin, cout = case
+  dev = gpu_device
+  x, w, _ = _conv_case(n, h, cin, cout, dev, seed=n + h)
+  g = torch.randn((n, h // 2, h // 2, cout), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+  xd = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+  yd = F.conv2d(xd, w.double().cpu(), None, 2, 1)
+  ref, = torch.autograd.grad(yd, [xd], g.double().cpu().permute(0, 3, 1, 2))
+  ref = ref.permute(0, 2, 3, 1)
+  scale = float(ref.abs().max())
+  dx = torch.empty((n, h, h, cin), device=dev)
+  for sl in ('0', '1', '2', '4', '8', '16'):
+    monkeypatch.setenv('EXPO_CONV_SLICES', sl)
+    dx.fill_(float('nan'))
+    _cabi.conv4x4s2_bwd_data(g, w, dx)
+    err = float((dx.double().cpu() - ref).abs().max()) / scale
+    assert err < 3e-6, (case, sl, err)

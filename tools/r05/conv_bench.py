@@ -122,6 +122,81 @@ def bench_fwd(dev, reps):
   print('sum: MIOpen + bias_lrelu %.1f us, ours fused (auto) %.1f us' % (tot_lib, tot_ours))
 
 
+def ref_bwd(g, w, n, h, cin):
+  x_like = torch.empty((n, cin, h, h), device=g.device, memory_format=torch.channels_last)
+  return torch.ops.aten.convolution_backward(g.permute(0, 3, 1, 2), x_like, w, None, STRIDE, PAD, DIL, False, [0, 0], 1,
+                                             [True, False, False])[0].permute(0, 2, 3, 1).contiguous()
+
+
+def ref_wrw(x, g, w):
+  return torch.ops.aten.convolution_backward(g.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, None, STRIDE, PAD, DIL, False,
+                                             [0, 0], 1, [False, True, False])[1]
+
+
+def clear_env():
+  for k in ('EXPO_CONV_TILE', 'EXPO_CONV_NT', 'EXPO_CONV_SLICES', 'EXPO_CONV_PARTS', 'EXPO_CONV_WRW_TILE'):
+    os.environ.pop(k, None)
+
+
+def check_bwd_wrw(dev):
+  cases = [(3, 8, 5, 8), (2, 16, 14, 32), (5, 12, 6, 32), (2, 64, 17, 32), (9, 8, 32, 64), (4, 16, 64, 128),
+           (16, 8, 128, 256), (7, 4, 4, 36), (8, 64, 14, 32), (32, 32, 32, 64), (3, 4, 3, 4)]
+  for (n, h, cin, cout) in cases:
+    x, w, b = make(n, h, cin, cout, dev, seed=n + h)
+    g = torch.randn((n, h // 2, h // 2, cout), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    xd = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = w.double().cpu().requires_grad_(True)
+    yd = torch.nn.functional.conv2d(xd, wd, None, 2, 1)
+    gx_ref, gw_ref = torch.autograd.grad(yd, [xd, wd], g.double().cpu().permute(0, 3, 1, 2))
+    gx_ref = gx_ref.permute(0, 2, 3, 1)
+    sx, sw = float(gx_ref.abs().max()), float(gw_ref.abs().max())
+    lib_x = float((ref_bwd(g, w, n, h, cin).double().cpu() - gx_ref).abs().max()) / sx
+    lib_w = float((ref_wrw(x, g, w).double().cpu() - gw_ref).abs().max()) / sw
+    worst_x = worst_w = 0.0
+    dx = torch.empty((n, h, h, cin), device=dev)
+    for sl in ('0', '1', '2', '4', '8', '16'):
+      clear_env()
+      os.environ['EXPO_CONV_SLICES'] = sl
+      dx.fill_(float('nan'))
+      _cabi.conv4x4s2_bwd_data(g, w, dx)
+      err = float((dx.double().cpu() - gx_ref).abs().max()) / sx
+      assert err < 3e-6, ('bwd_data mismatch', n, h, cin, cout, sl, err)
+      worst_x = max(worst_x, err)
+    clear_env()
+    print('bwd check n=%d h=%d cin=%d cout=%d: dx err %.2e (MIOpen %.2e)' % (n, h, cin, cout, worst_x, lib_x))
+  print('bwd/wrw check OK')
+
+
+def bench_bwd_wrw(dev, reps):
+  print('data gradient / weight gradient, us per launch (graph replay): MIOpen | ours by setting')
+  tot = {'bwd_lib': 0.0, 'bwd': 0.0, 'wrw_lib': 0.0, 'wrw': 0.0}
+  for n in (64, 128):
+    for (cin, h, cout) in LAYERS:
+      x, w, b = make(n, h, cin, cout, dev)
+      g = torch.randn((n, h // 2, h // 2, cout), device=dev)
+      dx = torch.empty((n, h, h, cin), device=dev)
+      dw = torch.empty_like(w)
+      fl = 2.0 * n * (h // 2)**2 * cout * 16 * cin
+      clear_env()
+      t_bl = timeit(lambda: ref_bwd(g, w, n, h, cin), reps)
+      t_wl = timeit(lambda: ref_wrw(x, g, w), reps)
+      rb = {}
+      for sl in (0, 1, 2, 4, 8, 16):
+        clear_env()
+        if sl:
+          os.environ['EXPO_CONV_SLICES'] = str(sl)
+        rb['s%d' % sl] = timeit(lambda: _cabi.conv4x4s2_bwd_data(g, w, dx), reps)
+      clear_env()
+      bb = min(rb, key=rb.get)
+      print('n=%3d cin=%3d h=%2d cout=%3d  bwd %6.1f | auto %6.1f best %s %6.1f (%.0f TF) | %s' %
+            (n, cin, h, cout, t_bl, rb['s0'], bb, rb[bb], fl / rb[bb] / 1e6, ' '.join('%s=%.1f' % kv for kv in rb.items())))
+      tot['bwd_lib'] += t_bl
+      tot['bwd'] += rb['s0']
+      tot['wrw_lib'] += t_wl
+  print('sums (auto): bwd MIOpen %.1f ours %.1f | wrw MIOpen %.1f (kept: an in-house flat wrw kernel measured 2-8x slower, profiles/r05_p3_conv_bwd_wrw.txt)' %
+        (tot['bwd_lib'], tot['bwd'], tot['wrw_lib']))
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('what', nargs='?', default='all')
@@ -132,6 +207,9 @@ def main():
   if args.what in ('fwd', 'all'):
     check_fwd(dev)
     bench_fwd(dev, args.reps)
+  if args.what in ('bwd', 'all'):
+    check_bwd_wrw(dev)
+    bench_bwd_wrw(dev, args.reps)
 
 
 if __name__ == '__main__':
