@@ -18,4 +18,12 @@ TensorFlow image ops the reference calls but does not contain
 own unit test applies to them: agreement with Python's ``colorsys`` tuple by
 tuple (plus matplotlib as a second implementation) -- see
 ``tests/test_oracle_*.py`` and DESIGN.md section 1(c).
+
+Since round 5 ONE part is pinned by the reference itself: the forward
+arithmetic of Exposure, Gamma (x >= 0.001) and WhiteBalance (regressor
+normalisation + process), ``rgb2lum`` and ``lerp`` are checked against vectors
+produced by running the reference's own NumPy code (``user_study_ui/filters.py``,
+``util.py``) in the build container -- ``tests/golden/make_reference_vectors.py``,
+``tests/test_reference_vectors.py``.  Everything that lives in TensorFlow (the
+other five filters, every gradient, the tie conventions) stays unpinned.
 """
