@@ -628,9 +628,10 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
           'peak': MFMA_FP32_PEAK_TFLOPS,
           'unit': 'TFLOP/s',
           'frac': achieved / MFMA_FP32_PEAK_TFLOPS,
-          'note': 'the nets are fp32 like the reference\'s (MIOpen / CK implicit-GEMM kernels on v_mfma_f32_*_f32); at batch '
-                  '64 x 64x64 about half of the iteration is those kernels, themselves at ~0.32 of this peak, the rest '
-                  'is ~1 200 small launches around them (DESIGN.md 3.10, profiles/r04_experiments.md r04p15)',
+          'note': 'the nets are fp32 like the reference\'s; forward convolutions (+ bias + lrelu) and the data gradients '
+                  'of the deeper layers run on the in-house implicit-GEMM kernels (csrc/conv_ops.hip, v_mfma_f32_32x32x2_f32: '
+                  '45-80 TFLOP/s inside those kernels), weight gradients on MIOpen; at batch 64 x 64x64 about half of the '
+                  'iteration is convolution kernels, the rest ~900 small launches around them (DESIGN.md 3.10, 3.11)',
       },
   }
 

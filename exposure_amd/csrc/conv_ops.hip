@@ -303,47 +303,56 @@ struct FlatPlan {
   int tiles_m, tiles_n;
 };
 
-template <int NT, bool CIN4>
+template <int NI, bool CIN4>
 __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              ConvDims d, FlatPlan pl, int act, float leak) {
-  extern __shared__ __attribute__((aligned(16))) float part[];  // [s][NT][16][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sl = wave / NT, nt = wave - sl * NT;  // K slice, column tile inside the block
-  const int groups_n = (pl.tiles_n + NT - 1) / NT;
-  const int nblocks = pl.tiles_m * groups_n;
+  // NI = column tiles per WAVE (32 x 32 NI outputs): the A fragment is loaded once and feeds NI MFMAs -- 3 operand
+  // loads per 8 MFMAs instead of 2 per 4 for NI = 2
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [s][NI][16][64]
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;  // wave = K slice
+  const int nblocks = pl.tiles_m * pl.tiles_n;
   int bid = blockIdx.x;
   if (nblocks % 8 == 0) bid = (bid % 8) * (nblocks / 8) + bid / 8;  // neighbouring tiles on one XCD (shared L2)
-  const int tm = bid / groups_n, tn = (bid - tm * groups_n) * NT + nt;
+  const int tm = bid / pl.tiles_n, tn = bid - tm * pl.tiles_n;
   const int row = lane & 31, half = lane >> 5;
-  const int m = tm * 32 + row, co = tn * 32 + row;  // this lane's A row (output pixel) and B row (output channel)
+  const int m = tm * 32 + row;  // this lane's A row (output pixel); its B rows (output channels): co[ni]
   const int rr = 4 * d.cin, lim = d.w * d.cin;
-  const bool m_ok = m < d.m, co_ok = co < d.cout;
+  const bool m_ok = m < d.m;
   const int mm = m_ok ? m : 0;
   const int n = mm / (d.ho * d.wo), rem = mm - n * (d.ho * d.wo);
   const int oh = rem / d.wo, ow = rem - oh * d.wo;
   const int img = n * d.h * lim;
   const int ih0 = 2 * oh - 1, c0 = (2 * ow - 1) * d.cin + 4 * half;
-  const int wrow = (co_ok ? co : 0) * d.kdim + 4 * half;
+  int wrow[NI];
+  bool co_ok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int co = (tn * NI + i) * 32 + row;
+    co_ok[i] = co < d.cout;
+    wrow[i] = (co_ok[i] ? co : 0) * d.kdim + 4 * half;
+  }
   const __amdgpu_buffer_rsrc_t rx = conv_rsrc(x, size_t(d.n) * d.h * d.w * d.cin);
   const __amdgpu_buffer_rsrc_t rw = conv_rsrc(w, size_t(d.cout) * d.kdim);
 
-  f32x16 acc;
+  f32x16 acc[NI];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
   auto load_a = [&](int prow, bool row_ok, int off, int seg_end) -> Chunk<CIN4> {
     // off: this lane's chunk offset inside the kh row (without the lane half's 4, which c0 carries)
     return row_chunk<CIN4>(rx, prow, c0 + off, lim, row_ok && off + 4 * half < seg_end);
   };
-  auto load_b = [&](int pw, int off, int seg_end) -> float4 {
-    return buf_load4(rw, pw + off, co_ok && off + 4 * half < seg_end);
-  };
-  auto mma = [&](const float4& a, const float4& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  auto mma = [&](const float4& a, const float4 (&b)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[i].x, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[i].y, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[i].z, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[i].w, acc[i], 0, 0, 0);
+    }
   };
 
   const int g = 4 * pl.s2, per = g / pl.s;
@@ -354,23 +363,26 @@ __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __rest
     const int ih = ih0 + kh;
     const bool row_ok = m_ok && unsigned(ih) < unsigned(d.h);
     const int prow = img + ih * lim;
-    const int pw = wrow + kh * rr;
-    // chunks of 8 k, four at a time: the next four's loads are in flight while these MFMAs issue (loads past the
-    // segment's end come back as zeros without touching memory, so the pipeline needs no tail case)
-    constexpr int U = CIN4 ? 4 : 2;  // (the cut-chunk fix-ups double a chunk's registers)
+    auto load_b = [&](int off, float4 (&b)[NI]) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) b[i] = buf_load4(rw, wrow[i] + kh * rr + off, co_ok[i] && off + 4 * half < seg_end);
+    };
+    // chunks of 8 k, U at a time: the next U's loads are in flight while these MFMAs issue (loads past the segment's
+    // end come back as zeros without touching memory, so the pipeline needs no tail case)
+    constexpr int U = (CIN4 && NI == 1) ? 4 : 2;  // (cut-chunk fix-ups / a second column tile double the registers)
     Chunk<CIN4> ac[U], an[U];
-    float4 bc[U], bn[U];
+    float4 bc[U][NI], bn[U][NI];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       ac[u] = load_a(prow, row_ok, r0 + 8 * u, seg_end);
-      bc[u] = load_b(pw, r0 + 8 * u, seg_end);
+      load_b(r0 + 8 * u, bc[u]);
     }
 #pragma unroll 2
     for (int r = r0; r < seg_end; r += 8 * U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         an[u] = load_a(prow, row_ok, r + 8 * (U + u), seg_end);
-        bn[u] = load_b(pw, r + 8 * (U + u), seg_end);
+        load_b(r + 8 * (U + u), bn[u]);
       }
       __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of the MFMAs that hide them
 #pragma unroll
@@ -378,55 +390,56 @@ __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __rest
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         ac[u] = an[u];
-        bc[u] = bn[u];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bc[u][i] = bn[u][i];
       }
     }
   }
 
-  // ---- the S partial tiles meet in LDS; wave (sl, nt) finishes accumulator registers e = sl, sl + S, ... ----
-  const int col = tn * 32 + (lane & 31);
-  const float bv = (bias && col < d.cout) ? bias[col] : 0.f;
+  // ---- the S partial tiles meet in LDS; wave sl finishes accumulator slots v = sl, sl + S, ... (v = ni 16 + e) ----
+  auto store = [&](int v, float val) {
+    const int i = v >> 4, e = v & 15;
+    const int col = (tn * NI + i) * 32 + (lane & 31);
+    const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+    if (mo < d.m && col < d.cout) {
+      if (bias) val += bias[col];
+      if (act) val = lrelu_v(val, leak);
+      y[size_t(mo) * d.cout + col] = val;
+    }
+  };
   if (pl.s > 1) {
-    float* mine = part + (sl * NT + nt) * 1024;
+    float* mine = part + sl * (NI * 1024);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) mine[e * 64 + lane] = acc[e];
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mine[(i * 16 + e) * 64 + lane] = acc[i][e];
     __syncthreads();
-    for (int e = sl; e < 16; e += pl.s) {
-      float v = part[nt * 1024 + e * 64 + lane];
-      for (int q = 1; q < pl.s; ++q) v += part[(q * NT + nt) * 1024 + e * 64 + lane];
-      const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      if (mo < d.m && col < d.cout) {
-        v += bv;
-        if (act) v = lrelu_v(v, leak);
-        y[size_t(mo) * d.cout + col] = v;
-      }
+    for (int v = sl; v < NI * 16; v += pl.s) {
+      float val = part[v * 64 + lane];
+      for (int q = 1; q < pl.s; ++q) val += part[q * (NI * 1024) + v * 64 + lane];
+      store(v, val);
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      if (mo < d.m && col < d.cout) {
-        float v = acc[e] + bv;
-        if (act) v = lrelu_v(v, leak);
-        y[size_t(mo) * d.cout + col] = v;
-      }
-    }
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) store(i * 16 + e, acc[i][e]);
   }
 }
 
 // K slicing for a target of ~16 waves per CU: S in {1, 2, 4, 8, 16} (S <= 16: one accumulator register per slice at
 // least in the final sum), S2 = segments per kh row (S <= 4: whole rows)
-static FlatPlan flat_plan(const ConvDims& d, int nt, int forced_s) {
+static FlatPlan flat_plan(const ConvDims& d, int ni, int forced_s) {
   FlatPlan p;
   p.tiles_m = (d.m + 31) / 32;
-  p.tiles_n = (d.cout + 31) / 32;
+  p.tiles_n = (d.cout + 32 * ni - 1) / (32 * ni);
   const long tiles = long(p.tiles_m) * p.tiles_n;
+  const long target = 4096 / ni;  // wave count: ~4096 MFMA streams' worth of work chip-wide
   int s = 1;
-  while (s < 16 && tiles * s * 2 <= 4096 + 2048) s *= 2;  // the power of two that brings tiles * s closest to 4096
+  while (s < 16 && tiles * s * 2 <= target + target / 2) s *= 2;  // the power of two that brings tiles * s closest
   const int rr = 4 * d.cin;
   while (s > 4 && (rr + (s / 4) - 1) / (s / 4) < 8) s /= 2;  // a segment holds at least one chunk
-  if (forced_s > 0) s = forced_s;
-  while (s * nt > 16) s /= 2;
+  if (forced_s > 0) s = forced_s > 16 ? 16 : forced_s;
   p.s = s;
   p.s2 = s <= 4 ? 1 : s / 4;
   p.rs = ((rr + p.s2 - 1) / p.s2 + 7) / 8 * 8;
@@ -443,9 +456,11 @@ static FlatPlan flat_plan(const ConvDims& d, int nt, int forced_s) {
 //                                                              (4-byte loads; 32 lanes cover one 128-byte line)
 // One wave = one 32 x 32 tile (pixels of one class x input channels) over one K' slice, like the forward; K' slices are
 // cut along (tap, co range): G = 4 S2 segments of RS = roundup8(Cout / S2) channels.
+template <int NI>
 __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              float* __restrict__ dx, ConvDims d, FlatPlan pl) {
-  extern __shared__ __attribute__((aligned(16))) float part[];  // [s][16][64]
+  // NI = input-channel tiles per wave (32 pixels x 32 NI channels): the dY fragment is loaded once for NI MFMAs
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [s][NI][16][64]
   const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int per_class = pl.tiles_m * pl.tiles_n, nblocks = 4 * per_class;
   int bid = blockIdx.x;
@@ -454,23 +469,35 @@ __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __rest
   const int tm = rem_b / pl.tiles_n, tn = rem_b - tm * pl.tiles_n;
   const int ph = cls >> 1, pw = cls & 1;
   const int row = lane & 31, half = lane >> 5;
-  const int m = tm * 32 + row, ci = tn * 32 + row;  // this lane's A row (input pixel of the class) and B column
-  const bool m_ok = m < d.m, ci_ok = ci < d.cin;
+  const int m = tm * 32 + row;  // this lane's A row (input pixel of the class); its B columns: ci[i]
+  const bool m_ok = m < d.m;
   const int mm = m_ok ? m : 0;
   const int n = mm / (d.ho * d.wo), rem = mm - n * (d.ho * d.wo);
   const int a = rem / d.wo, b = rem - a * d.wo;
   const __amdgpu_buffer_rsrc_t rg = conv_rsrc(dy, size_t(d.n) * d.ho * d.wo * d.cout);
   const __amdgpu_buffer_rsrc_t rw = conv_rsrc(w, size_t(d.cout) * d.kdim);
   const int wstride = d.kdim;  // floats between two output channels of W
-
-  f32x16 acc;
+  int ci[NI];
+  bool ci_ok[NI];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  auto mma = [&](const float4& fa, const float4& fb) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+  for (int i = 0; i < NI; ++i) {
+    ci[i] = (tn * NI + i) * 32 + row;
+    ci_ok[i] = ci[i] < d.cin;
+  }
+
+  f32x16 acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  auto mma = [&](const float4& fa, const float4 (&fb)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[i].x, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[i].y, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[i].z, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[i].w, acc[i], 0, 0, 0);
+    }
   };
 
   const int g = 4 * pl.s2, per = g / pl.s;
@@ -481,28 +508,32 @@ __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __rest
     const int kh = 1 - ph + 2 * th, kw = 1 - pw + 2 * tw;
     const bool pix_ok = m_ok && unsigned(oh) < unsigned(d.ho) && unsigned(ow) < unsigned(d.wo);
     const int abase = ((n * d.ho + oh) * d.wo + ow) * d.cout + 4 * half;        // + co
-    const int bbase = (4 * half) * wstride + (kh * 4 + kw) * d.cin + ci;        // + co * wstride
+    const int bbase = (4 * half) * wstride + (kh * 4 + kw) * d.cin;             // + co * wstride + ci
     const int r0 = j * pl.rs, seg_end = min(r0 + pl.rs, d.cout);
     auto load_a = [&](int co) -> float4 { return buf_load4(rg, abase + co, pix_ok && co + 4 * half < seg_end); };
-    auto load_b = [&](int co) -> float4 {
-      const bool ok = ci_ok && co + 4 * half < seg_end;  // (Cout % 4 == 0: the four rows exist together)
-      const int o = bbase + co * wstride;
-      return make_float4(buf_load1(rw, o, ok), buf_load1(rw, o + wstride, ok), buf_load1(rw, o + 2 * wstride, ok),
-                         buf_load1(rw, o + 3 * wstride, ok));
+    auto load_b = [&](int co, float4 (&fb)[NI]) {
+      const bool in = co + 4 * half < seg_end;  // (Cout % 4 == 0: the four rows exist together)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const bool ok = ci_ok[i] && in;
+        const int o = bbase + co * wstride + ci[i];
+        fb[i] = make_float4(buf_load1(rw, o, ok), buf_load1(rw, o + wstride, ok), buf_load1(rw, o + 2 * wstride, ok),
+                            buf_load1(rw, o + 3 * wstride, ok));
+      }
     };
-    constexpr int U = 4;
-    float4 ac[U], an[U], bc[U], bn[U];
+    constexpr int U = NI == 1 ? 4 : 2;
+    float4 ac[U], an[U], bc[U][NI], bn[U][NI];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       ac[u] = load_a(r0 + 8 * u);
-      bc[u] = load_b(r0 + 8 * u);
+      load_b(r0 + 8 * u, bc[u]);
     }
 #pragma unroll 2
     for (int r = r0; r < seg_end; r += 8 * U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         an[u] = load_a(r + 8 * (U + u));
-        bn[u] = load_b(r + 8 * (U + u));
+        load_b(r + 8 * (U + u), bn[u]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -510,44 +541,52 @@ __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __rest
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         ac[u] = an[u];
-        bc[u] = bn[u];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bc[u][i] = bn[u][i];
       }
     }
   }
 
-  // the S partial tiles meet in LDS; wave sl finishes accumulator registers e = sl, sl + S, ...
-  auto store = [&](int e, float v) {
+  // the S partial tiles meet in LDS; wave sl finishes accumulator slots v = sl, sl + S, ... (v = ni 16 + e)
+  auto store = [&](int v, float val) {
+    const int i = v >> 4, e = v & 15;
     const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;  // the pixel of accumulator register e
-    if (mo < d.m && ci_ok) {
+    const int c = (tn * NI + i) * 32 + (lane & 31);
+    if (mo < d.m && c < d.cin) {
       const int no = mo / (d.ho * d.wo), ro = mo - no * (d.ho * d.wo);
       const int ao = ro / d.wo, bo = ro - ao * d.wo;
-      dx[(size_t(no * d.h + 2 * ao + ph) * d.w + 2 * bo + pw) * d.cin + ci] = v;
+      dx[(size_t(no * d.h + 2 * ao + ph) * d.w + 2 * bo + pw) * d.cin + c] = val;
     }
   };
   if (pl.s > 1) {
-    float* mine = part + sl * 1024;
+    float* mine = part + sl * (NI * 1024);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) mine[e * 64 + lane] = acc[e];
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mine[(i * 16 + e) * 64 + lane] = acc[i][e];
     __syncthreads();
-    for (int e = sl; e < 16; e += pl.s) {
-      float v = part[e * 64 + lane];
-      for (int q = 1; q < pl.s; ++q) v += part[q * 1024 + e * 64 + lane];
-      store(e, v);
+    for (int v = sl; v < NI * 16; v += pl.s) {
+      float val = part[v * 64 + lane];
+      for (int q = 1; q < pl.s; ++q) val += part[q * (NI * 1024) + v * 64 + lane];
+      store(v, val);
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) store(e, acc[e]);
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) store(i * 16 + e, acc[i][e]);
   }
 }
 
 // K' slicing of the data gradient: tiles = 4 classes x pixel tiles x channel tiles; segments along (tap, co range)
-static FlatPlan bwd_plan(const ConvDims& d, int forced_s) {
+static FlatPlan bwd_plan(const ConvDims& d, int ni, int forced_s) {
   FlatPlan p;
   p.tiles_m = (d.m + 31) / 32;
-  p.tiles_n = (d.cin + 31) / 32;
+  p.tiles_n = (d.cin + 32 * ni - 1) / (32 * ni);
   const long tiles = 4L * p.tiles_m * p.tiles_n;
+  const long target = 4096 / ni;
   int s = 1;
-  while (s < 16 && tiles * s * 2 <= 4096 + 2048) s *= 2;
+  while (s < 16 && tiles * s * 2 <= target + target / 2) s *= 2;
   while (s > 4 && (d.cout + (s / 4) - 1) / (s / 4) < 8) s /= 2;
   if (forced_s > 0) s = forced_s;
   if (s > 16) s = 16;
@@ -612,14 +651,18 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
   if (shape < 1 || shape > 4) {
     // the flat decomposition (default); EXPO_CONV_TILE=1..4 selects the LDS-tiled shapes of the first version (probes),
     // EXPO_CONV_SLICES forces the K slice count, EXPO_CONV_NT the column tiles per block
-    int nt = env_int("EXPO_CONV_NT", 1);
-    if (nt != 1 && nt != 2) nt = 1;
-    const FlatPlan pl = flat_plan(d, nt, env_int("EXPO_CONV_SLICES", 0));
-    const int nblocks = pl.tiles_m * ((pl.tiles_n + nt - 1) / nt);
-    const size_t lds = pl.s > 1 ? size_t(pl.s) * nt * 4096 : 0;
-#define EXPO_FLAT(NT, C4) \
-  hipLaunchKernelGGL((conv_fwd_flat_kernel<NT, C4>), dim3(nblocks), dim3(64 * pl.s * NT), lds, s, x, w, bias, y, d, pl, act, leak)
-    if (nt == 2) { if (d.cin % 4 == 0) EXPO_FLAT(2, true); else EXPO_FLAT(2, false); }
+    int ni = env_int("EXPO_CONV_NT", 0);  // column tiles per wave (0: the library's choice)
+    // two column tiles per wave (A fragment shared in registers) where that still leaves >= 256 tiles: the third layer,
+    // the fourth at batch 128 (17.3 vs 20.0 us, 26.3 vs 31.5 us)
+    if (ni == 0) ni = (long((d.m + 31) / 32) * ((d.cout + 63) / 64) >= 256) ? 2 : 1;
+    if (ni != 1 && ni != 2) ni = 1;
+    if (d.cout <= 32) ni = 1;
+    const FlatPlan pl = flat_plan(d, ni, env_int("EXPO_CONV_SLICES", 0));
+    const int nblocks = pl.tiles_m * pl.tiles_n;
+    const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
+#define EXPO_FLAT(NI, C4) \
+  hipLaunchKernelGGL((conv_fwd_flat_kernel<NI, C4>), dim3(nblocks), dim3(64 * pl.s), lds, s, x, w, bias, y, d, pl, act, leak)
+    if (ni == 2) { if (d.cin % 4 == 0) EXPO_FLAT(2, true); else EXPO_FLAT(2, false); }
     else { if (d.cin % 4 == 0) EXPO_FLAT(1, true); else EXPO_FLAT(1, false); }
 #undef EXPO_FLAT
     HIP_TRY(hipGetLastError(), "conv4x4s2_fwd launch");
@@ -644,10 +687,15 @@ int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, i
   if (!dy || !w || !dx) return fail(EXPO_E_BADARG, "null pointer");
   if (cout % 4 != 0) return fail(EXPO_E_BADARG, "conv4x4s2_bwd_data: cout must be a multiple of 4");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const FlatPlan pl = bwd_plan(d, env_int("EXPO_CONV_SLICES", 0));
+  int ni = env_int("EXPO_CONV_NT", 0);  // input-channel tiles per wave (0: the library's choice)
+  if (ni == 0) ni = d.cin >= 64 ? 2 : 1;  // (two tiles share the dY fragment: 2-10 % on the deeper layers)
+  if (ni != 1 && ni != 2) ni = 1;
+  if (d.cin <= 32) ni = 1;
+  const FlatPlan pl = bwd_plan(d, ni, env_int("EXPO_CONV_SLICES", 0));
   const int nblocks = 4 * pl.tiles_m * pl.tiles_n;
-  const size_t lds = pl.s > 1 ? size_t(pl.s) * 4096 : 0;
-  hipLaunchKernelGGL(conv_bwd_flat_kernel, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, dx, d, pl);
+  const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
+  if (ni == 2) hipLaunchKernelGGL(conv_bwd_flat_kernel<2>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, dx, d, pl);
+  else hipLaunchKernelGGL(conv_bwd_flat_kernel<1>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, dx, d, pl);
   HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data launch");
   return EXPO_OK;
 }

@@ -457,7 +457,7 @@ def _conv_case(n, h, cin, cout, dev, seed):
 def test_hip_conv_forward_matches_float64(case, gpu_device, monkeypatch):
   """expo_conv4x4s2_fwd (implicit GEMM on v_mfma_f32_32x32x2_f32) against a float64 convolution on the CPU, plain and
   with the bias + lrelu epilogue, for EVERY decomposition the library can pick -- the flat one under 1 / 2 column tiles
-  per block and 1 .. 16 K slices, the four LDS-tiled shapes -- on shapes with ragged tiles (M, Cout not multiples of
+  per wave and 1 .. 16 K slices, the four LDS-tiled shapes -- on shapes with ragged tiles (M, Cout not multiples of
   32), the first layers' channel counts (14, 6, 17: chunks cut by the image edge), one-pixel outputs.  f32 MFMA is an
   exact fmaf chain: the error is f32 summation rounding, 2e-6 of the largest output; MIOpen's own error on the same
   operands is printed beside it."""
@@ -527,9 +527,11 @@ def test_hip_conv_data_gradient_matches_float64(case, gpu_device, monkeypatch):
   ref = ref.permute(0, 2, 3, 1)
   scale = float(ref.abs().max())
   dx = torch.empty((n, h, h, cin), device=dev)
-  for sl in ('0', '1', '2', '4', '8', '16'):
-    monkeypatch.setenv('EXPO_CONV_SLICES', sl)
-    dx.fill_(float('nan'))
-    _cabi.conv4x4s2_bwd_data(g, w, dx)
-    err = float((dx.double().cpu() - ref).abs().max()) / scale
-    assert err < 3e-6, (case, sl, err)
+  for nt in ('0', '1', '2'):  # input-channel tiles per wave (0: the library's choice)
+    for sl in ('0', '1', '2', '4', '8', '16'):
+      monkeypatch.setenv('EXPO_CONV_NT', nt)
+      monkeypatch.setenv('EXPO_CONV_SLICES', sl)
+      dx.fill_(float('nan'))
+      _cabi.conv4x4s2_bwd_data(g, w, dx)
+      err = float((dx.double().cpu() - ref).abs().max()) / scale
+      assert err < 3e-6, (case, nt, sl, err)

@@ -4,11 +4,11 @@
 set -euo pipefail
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/final
-TAG=${1:-r04_final}
+TAG=${1:-r05_final}
 for f in bench_chain bench_chain_1stream bench_chain_A bench_chain_B bench_chain_f32 bench_chain_cold bench_chain_cold_untiled bench_infer_B bench_infer_C bench_chain_fused bench_chain_fused_B bench_chain_fused_f32_B bench_train bench_train_find_on bench_train_eager bench_extra; do
   [ -s $SRC/$f.json ] && cp $SRC/$f.json profiles/${TAG}_$f.json
 done
-for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt; do
+for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt $SRC/conv_bench.txt; do
   cp $f profiles/${TAG}_$(basename $f)
 done
 # bench.py quotes, beside its own figure, rocprofv3's duration of the dominant kernel from the table committed WHEN IT

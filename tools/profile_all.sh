@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every measured artefact under profiles/ in ONE gpurun call:
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/profile_all.sh'
-# then, back in the container:  tools/collect_profiles.sh r04_final
+# then, back in the container:  tools/collect_profiles.sh r05_final
 # (an 8-GPU lease additionally runs tools/scale_all.sh: the section 8(e) scaling table)
 # rocprofv3 passes: --kernel-trace alone (durations) and one --pmc counter per pass (never combined
 # with sys/runtime tracing); the rocpd databases stay on the GPU box, only CSV summaries come back.
@@ -31,6 +31,7 @@ python $R/bench.py --workload train --steps 20 --warmup 3 > $OUT/bench_train.jso
 python $R/bench.py --workload train --steps 20 --warmup 3 --miopen-find on > $OUT/bench_train_find_on.json 2>/dev/null
 python $R/bench.py --workload train --steps 10 --warmup 3 --graph off > $OUT/bench_train_eager.json 2>/dev/null
 python $R/tools/bench_extra.py > $OUT/bench_extra.json 2>/dev/null
+python $R/tools/r05/conv_bench.py all --reps 20 > $OUT/conv_bench.txt 2>&1  # the in-house convolution kernels against MIOpen, per layer
 for sz in 96 512 1024; do
   reps=20; [ $sz -ge 512 ] && reps=8
   $R/tools/membench $sz 9 $reps pol > $OUT/membench_${sz}.txt 2>&1

@@ -154,9 +154,10 @@ def check_bwd_wrw(dev):
     lib_w = float((ref_wrw(x, g, w).double().cpu() - gw_ref).abs().max()) / sw
     worst_x = worst_w = 0.0
     dx = torch.empty((n, h, h, cin), device=dev)
-    for sl in ('0', '1', '2', '4', '8', '16'):
+    for nt, sl in [(nt, sl) for nt in ('0', '1', '2') for sl in ('0', '1', '2', '4', '8', '16')]:
       clear_env()
       os.environ['EXPO_CONV_SLICES'] = sl
+      os.environ['EXPO_CONV_NT'] = nt
       dx.fill_(float('nan'))
       _cabi.conv4x4s2_bwd_data(g, w, dx)
       err = float((dx.double().cpu() - gx_ref).abs().max()) / sx
@@ -181,17 +182,19 @@ def bench_bwd_wrw(dev, reps):
       t_bl = timeit(lambda: ref_bwd(g, w, n, h, cin), reps)
       t_wl = timeit(lambda: ref_wrw(x, g, w), reps)
       rb = {}
-      for sl in (0, 1, 2, 4, 8, 16):
+      for nt, sl in ((0, 0), (1, 0), (2, 0), (1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (2, 8), (2, 16)):
         clear_env()
+        if nt:
+          os.environ['EXPO_CONV_NT'] = str(nt)
         if sl:
           os.environ['EXPO_CONV_SLICES'] = str(sl)
-        rb['s%d' % sl] = timeit(lambda: _cabi.conv4x4s2_bwd_data(g, w, dx), reps)
+        rb['n%ds%d' % (nt, sl)] = timeit(lambda: _cabi.conv4x4s2_bwd_data(g, w, dx), reps)
       clear_env()
       bb = min(rb, key=rb.get)
       print('n=%3d cin=%3d h=%2d cout=%3d  bwd %6.1f | auto %6.1f best %s %6.1f (%.0f TF) | %s' %
-            (n, cin, h, cout, t_bl, rb['s0'], bb, rb[bb], fl / rb[bb] / 1e6, ' '.join('%s=%.1f' % kv for kv in rb.items())))
+            (n, cin, h, cout, t_bl, rb['n0s0'], bb, rb[bb], fl / rb[bb] / 1e6, ' '.join('%s=%.1f' % kv for kv in rb.items())))
       tot['bwd_lib'] += t_bl
-      tot['bwd'] += rb['s0']
+      tot['bwd'] += rb['n0s0']
       tot['wrw_lib'] += t_wl
   print('sums (auto): bwd MIOpen %.1f ours %.1f | wrw MIOpen %.1f (kept: an in-house flat wrw kernel measured 2-8x slower, profiles/r05_p3_conv_bwd_wrw.txt)' %
         (tot['bwd_lib'], tot['bwd'], tot['wrw_lib']))
