@@ -49,6 +49,7 @@ SIGNATURES = {
     'expo_chain_prepare': (_i, [_vp]),
     'expo_conv4x4s2_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_bwd_data': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    'expo_conv_tuning': (_i, [_i, _i, _i]),
     'expo_chain_release': (_i, [_vp]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
                             _vp]),
@@ -827,6 +828,11 @@ def conv4x4s2_bwd_data(dy, w, dx):
   with torch.cuda.device(dy.device):
     _check(lib.expo_conv4x4s2_bwd_data(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, cin, cout, _stream()),
            'expo_conv4x4s2_bwd_data')
+
+
+def conv_tuning(tile=0, nt=0, slices=0):
+  """Probes / tests: force the decomposition of the convolution kernels (expo_conv_tuning; 0 = the library's choice)."""
+  _check(load().expo_conv_tuning(int(tile), int(nt), int(slices)), 'expo_conv_tuning')
 
 
 def chain_prepare(stream=None):

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/exposure_hip.h"
 #include "host_common.h"
 
@@ -619,9 +621,18 @@ static int conv_dims(ConvDims* d, int n, int h, int w, int cin, int cout) {
   return EXPO_OK;
 }
 
-// tile shape by problem size: the largest tile that still yields >= kMinBlocks blocks (one per CU and then some);
-// EXPO_CONV_TILE=1..4 forces a shape (probes)
-constexpr int kMinBlocks = 200;
+// Decomposition overrides (probes and tests; 0 = the library's own choice): read from the environment ONCE --
+// EXPO_CONV_TILE (1-4: an LDS-tiled forward shape, 5: the flat kernel), EXPO_CONV_NT (column tiles per wave, 1 | 2),
+// EXPO_CONV_SLICES (K slices) -- and settable through expo_conv_tuning() afterwards (no getenv on the launch path: the
+// backward kernels are launched from autograd's worker thread while the host thread may be in putenv).
+struct ConvTuning {
+  std::atomic<int> tile, nt, slices;
+  ConvTuning() : tile(env_int("EXPO_CONV_TILE", 0)), nt(env_int("EXPO_CONV_NT", 0)), slices(env_int("EXPO_CONV_SLICES", 0)) {}
+};
+static ConvTuning& conv_tuning() {
+  static ConvTuning t;
+  return t;
+}
 
 }  // namespace expo
 
@@ -637,27 +648,26 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
   if (!x || !w || !y) return fail(EXPO_E_BADARG, "null pointer");
   if ((reinterpret_cast<uintptr_t>(w) & 15) != 0) return fail(EXPO_E_BADARG, "conv4x4s2: weight must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int forced = env_int("EXPO_CONV_TILE", 0);  // (read per call: the probes and tests switch it; 5 = flat)
+  const int forced = conv_tuning().tile.load(), forced_nt = conv_tuning().nt.load(), forced_s = conv_tuning().slices.load();
   auto blocks = [&](int bm, int bn) { return ((d.m + bm - 1) / bm) * ((d.cout + bn - 1) / bn); };
   int shape = forced;
   // Measured on MI355X (tools/r05/conv_bench.py, profiles/r05_conv_*.txt): the LDS-tiled shapes win where 64 x 64
   // tiles still give every CU a block or two (the second layer; the third at batch 128), the flat decomposition
   // everywhere else (first layers: K is short; deep layers: few rows, long K)
-  if (shape == 0 && d.cout > 32 && env_int("EXPO_CONV_NT", 0) == 0 && env_int("EXPO_CONV_SLICES", 0) == 0) {
+  if (shape == 0 && d.cout > 32 && forced_nt == 0 && forced_s == 0) {
     const int b64 = blocks(64, 64);
     if (b64 >= 512) shape = 2;
     else if (b64 >= 256) shape = 3;
   }
   if (shape < 1 || shape > 4) {
-    // the flat decomposition (default); EXPO_CONV_TILE=1..4 selects the LDS-tiled shapes of the first version (probes),
-    // EXPO_CONV_SLICES forces the K slice count, EXPO_CONV_NT the column tiles per block
-    int ni = env_int("EXPO_CONV_NT", 0);  // column tiles per wave (0: the library's choice)
+    // the flat decomposition (default)
+    int ni = forced_nt;  // column tiles per wave (0: the library's choice)
     // two column tiles per wave (A fragment shared in registers) where that still leaves >= 256 tiles: the third layer,
     // the fourth at batch 128 (17.3 vs 20.0 us, 26.3 vs 31.5 us)
     if (ni == 0) ni = (long((d.m + 31) / 32) * ((d.cout + 63) / 64) >= 256) ? 2 : 1;
     if (ni != 1 && ni != 2) ni = 1;
     if (d.cout <= 32) ni = 1;
-    const FlatPlan pl = flat_plan(d, ni, env_int("EXPO_CONV_SLICES", 0));
+    const FlatPlan pl = flat_plan(d, ni, forced_s);
     const int nblocks = pl.tiles_m * pl.tiles_n;
     const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
 #define EXPO_FLAT(NI, C4) \
@@ -679,6 +689,15 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
   return EXPO_OK;
 }
 
+int expo_conv_tuning(int tile, int nt, int slices) {
+  // probes / tests: override the decomposition of the convolution kernels (negative: leave as is; 0: the library's choice)
+  if (tile > 5 || nt > 2 || slices > 16) return fail(EXPO_E_BADARG, "conv tuning: tile <= 5, nt <= 2, slices <= 16");
+  if (tile >= 0) conv_tuning().tile.store(tile);
+  if (nt >= 0) conv_tuning().nt.store(nt);
+  if (slices >= 0) conv_tuning().slices.store(slices);
+  return EXPO_OK;
+}
+
 int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, int h, int wd, int cin, int cout,
                             void* stream) {
   ConvDims d;
@@ -687,11 +706,11 @@ int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, i
   if (!dy || !w || !dx) return fail(EXPO_E_BADARG, "null pointer");
   if (cout % 4 != 0) return fail(EXPO_E_BADARG, "conv4x4s2_bwd_data: cout must be a multiple of 4");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int ni = env_int("EXPO_CONV_NT", 0);  // input-channel tiles per wave (0: the library's choice)
+  int ni = conv_tuning().nt.load();  // input-channel tiles per wave (0: the library's choice)
   if (ni == 0) ni = d.cin >= 64 ? 2 : 1;  // (two tiles share the dY fragment: 2-10 % on the deeper layers)
   if (ni != 1 && ni != 2) ni = 1;
   if (d.cin <= 32) ni = 1;
-  const FlatPlan pl = bwd_plan(d, ni, env_int("EXPO_CONV_SLICES", 0));
+  const FlatPlan pl = bwd_plan(d, ni, conv_tuning().slices.load());
   const int nblocks = 4 * pl.tiles_m * pl.tiles_n;
   const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
   if (ni == 2) hipLaunchKernelGGL(conv_bwd_flat_kernel<2>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, dx, d, pl);

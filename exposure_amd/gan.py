@@ -288,6 +288,8 @@ class GAN(nn.Module):
     pack = self._heads_pack
     if pack is None or (pack.quick_aliased() and pack.generation == self._heads_generation):
       return
+    # the last replay may still be RUNNING: neither move the parameters under it nor destroy its graph exec in flight
+    torch.cuda.current_stream().synchronize()
     pack.ensure()
     self._heads_generation = pack.generation
     if any(entry != 'warm' for entry in self._graphs.values()):

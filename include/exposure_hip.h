@@ -534,6 +534,10 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
  *   dy  float32 [n][h/2][w/2][cout] (cout % 4 == 0)     dx  float32 [n][h][w][cin], every element written */
 int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, int h, int wd, int cin, int cout,
                             void* stream);
+/* Probes and tests: override how the two kernels above decompose a problem (process-wide; negative = leave as is,
+ * 0 = the library's own choice).  tile 1-4: an LDS-tiled forward shape, 5: the flat kernel; nt 1 | 2: column tiles per
+ * wave; slices 1-16: K slices per tile.  The initial values come from EXPO_CONV_TILE / _NT / _SLICES, read once. */
+int expo_conv_tuning(int tile, int nt, int slices);
 #ifdef __cplusplus
 }
 #endif

@@ -441,7 +441,6 @@ def test_generator_loss_glue_matches_the_op_by_op_formula(use_td, use_penalty, g
 # ---- the in-house convolution kernels (csrc/conv_ops.hip, round 5) ---------------------------------------------------
 CONV_CASES = [(3, 8, 5, 7), (2, 16, 14, 32), (5, 12, 6, 32), (2, 64, 17, 32), (9, 8, 32, 64), (4, 16, 64, 128),
               (16, 8, 128, 256), (1, 2, 3, 1), (7, 4, 4, 33), (8, 64, 14, 32), (32, 32, 32, 64)]
-CONV_ENVS = ('EXPO_CONV_TILE', 'EXPO_CONV_NT', 'EXPO_CONV_SLICES')
 
 
 def _conv_case(n, h, cin, cout, dev, seed):
@@ -473,8 +472,7 @@ def test_hip_conv_forward_matches_float64(case, gpu_device, monkeypatch):
   y = torch.empty((n, h // 2, h // 2, cout), device=dev)
   worst = 0.0
   for tile, nt, sl in variants:
-    for k, v in zip(CONV_ENVS, (tile, nt, sl)):
-      monkeypatch.setenv(k, v)
+    _cabi.conv_tuning(int(tile), int(nt), int(sl))
     for act in (0, 1):
       y.fill_(float('nan'))
       _cabi.conv4x4s2_fwd(x, w, b if act else None, y, act, 0.2)
@@ -484,6 +482,7 @@ def test_hip_conv_forward_matches_float64(case, gpu_device, monkeypatch):
       err = float((y.double().cpu() - want).abs().max()) / scale
       assert err < 2e-6, (case, tile, nt, sl, act, err)
       worst = max(worst, err)
+  _cabi.conv_tuning(0, 0, 0)
   print('conv fwd %s: worst %.2e of max |y| over %d variants (MIOpen %.2e)' % (case, worst, len(variants), lib))
 
 
@@ -529,9 +528,9 @@ def test_hip_conv_data_gradient_matches_float64(case, gpu_device, monkeypatch):
   dx = torch.empty((n, h, h, cin), device=dev)
   for nt in ('0', '1', '2'):  # input-channel tiles per wave (0: the library's choice)
     for sl in ('0', '1', '2', '4', '8', '16'):
-      monkeypatch.setenv('EXPO_CONV_NT', nt)
-      monkeypatch.setenv('EXPO_CONV_SLICES', sl)
+      _cabi.conv_tuning(0, int(nt), int(sl))
       dx.fill_(float('nan'))
       _cabi.conv4x4s2_bwd_data(g, w, dx)
       err = float((dx.double().cpu() - ref).abs().max()) / scale
       assert err < 3e-6, (case, nt, sl, err)
+  _cabi.conv_tuning(0, 0, 0)

@@ -71,7 +71,7 @@ def check_fwd(dev):
     # tiles 1-4: the LDS-tiled shapes
     variants = [('0', nt, sl) for nt in ('1', '2') for sl in ('0', '1', '2', '4', '8', '16')] + [(t, '0', '0') for t in '1234']
     for tile, nt, sl in variants:
-      os.environ['EXPO_CONV_TILE'], os.environ['EXPO_CONV_NT'], os.environ['EXPO_CONV_SLICES'] = tile, nt, sl
+      _cabi.conv_tuning(int(tile), int(nt), int(sl))
       errs = []
       for act in (0, 1):
         y.fill_(float('nan'))
@@ -85,8 +85,7 @@ def check_fwd(dev):
       worst = max(worst, max(errs))
     print('fwd check n=%d h=%d cin=%d cout=%d: %d variants OK, worst err %.2e (MIOpen %.2e) of max |y| %.2f' %
           (n, h, cin, cout, len(variants), worst, err_lib, scale))
-    for k in ('EXPO_CONV_TILE', 'EXPO_CONV_NT', 'EXPO_CONV_SLICES'):
-      os.environ.pop(k, None)
+    _cabi.conv_tuning(0, 0, 0)
   print('fwd check OK, worst %.2e' % worst)
 
 
@@ -106,12 +105,9 @@ def bench_fwd(dev, reps):
       t_lib_act = timeit(lambda: _cabi.bias_lrelu_fwd(ref_fwd(x, w), b, z, 0.2), reps)
       res = {}
       for name, env in settings:
-        for k in ('EXPO_CONV_TILE', 'EXPO_CONV_NT', 'EXPO_CONV_SLICES'):
-          os.environ.pop(k, None)
-        os.environ.update(env)
+        _cabi.conv_tuning(int(env.get('EXPO_CONV_TILE', 0)), int(env.get('EXPO_CONV_NT', 0)), int(env.get('EXPO_CONV_SLICES', 0)))
         res[name] = timeit(lambda: _cabi.conv4x4s2_fwd(x, w, b, y, 1, 0.2), reps)
-      for k in ('EXPO_CONV_TILE', 'EXPO_CONV_NT', 'EXPO_CONV_SLICES'):
-        os.environ.pop(k, None)
+      _cabi.conv_tuning(0, 0, 0)
       fl = 2.0 * n * (h // 2)**2 * cout * 16 * cin
       best = min(res, key=res.get)
       print('n=%3d cin=%3d h=%2d cout=%3d  %6.1f | %6.1f | auto %6.1f  best %s %6.1f (%.0f TFLOP/s, x%.2f) | %s' %
@@ -134,8 +130,7 @@ def ref_wrw(x, g, w):
 
 
 def clear_env():
-  for k in ('EXPO_CONV_TILE', 'EXPO_CONV_NT', 'EXPO_CONV_SLICES', 'EXPO_CONV_PARTS', 'EXPO_CONV_WRW_TILE'):
-    os.environ.pop(k, None)
+  _cabi.conv_tuning(0, 0, 0)
 
 
 def check_bwd_wrw(dev):
@@ -155,9 +150,7 @@ def check_bwd_wrw(dev):
     worst_x = worst_w = 0.0
     dx = torch.empty((n, h, h, cin), device=dev)
     for nt, sl in [(nt, sl) for nt in ('0', '1', '2') for sl in ('0', '1', '2', '4', '8', '16')]:
-      clear_env()
-      os.environ['EXPO_CONV_SLICES'] = sl
-      os.environ['EXPO_CONV_NT'] = nt
+      _cabi.conv_tuning(0, int(nt), int(sl))
       dx.fill_(float('nan'))
       _cabi.conv4x4s2_bwd_data(g, w, dx)
       err = float((dx.double().cpu() - gx_ref).abs().max()) / sx
@@ -183,11 +176,7 @@ def bench_bwd_wrw(dev, reps):
       t_wl = timeit(lambda: ref_wrw(x, g, w), reps)
       rb = {}
       for nt, sl in ((0, 0), (1, 0), (2, 0), (1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (2, 8), (2, 16)):
-        clear_env()
-        if nt:
-          os.environ['EXPO_CONV_NT'] = str(nt)
-        if sl:
-          os.environ['EXPO_CONV_SLICES'] = str(sl)
+        _cabi.conv_tuning(0, nt, sl)
         rb['n%ds%d' % (nt, sl)] = timeit(lambda: _cabi.conv4x4s2_bwd_data(g, w, dx), reps)
       clear_env()
       bb = min(rb, key=rb.get)
