@@ -8,7 +8,7 @@ DECISIONS instead of its seed: ``torch.randperm`` / ``torch.rand`` on the memory
 permutation / coin flips.  Under the same decisions the round-3 specification pool (tests/_replay_r03.py) and the
 product's slot pool (exposure_amd/replay_memory.py) must return the same records -- ids, (reward, stopped, step) -- for
 every pop / replace / replay of the trace, and hold the same pool in the same order afterwards: 60 generator batches
-incl. terminated records dropped in front of a pop, refills, over-length trajectories with their keep coin flips, 44
+incl. terminated records dropped in front of a pop, refills, over-length trajectories with their keep coin flips, 54
 critic replays with repetition."""
 import json
 import os
