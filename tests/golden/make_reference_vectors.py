@@ -8,6 +8,8 @@ TensorFlow / cv2 / PyQt5:
   util.py                    linearize_ProPhotoRGB (495-501), lerp (307-308)
   histogram_intersection.py  hist_intersection, calc_hist (11-12, 23-25) and the luminance half of
                              get_statistics (15-20; its saturation needs cv2.cvtColor and is NOT covered)
+  filters.py                 the NumPy statements inside Filter.get_mask / VignetFilter.get_mask that build the constant
+                             coordinate grid of the spatial masks (124-133, 371-380)
 
 Neither module can be IMPORTED here (module-level ``import cv2`` / ``PyQt5`` / ``tensorflow``; util.py:658 is a syntax
 error on Python >= 3.7), so the named definitions are cut out of the files -- by ``ast`` where the file parses, by
@@ -152,6 +154,40 @@ def main():
   edge = np.array([0.0, 1.0, 0.5, 0.03125, 0.96875, -0.1, 1.1, 0.999999, 0.25, 0.25])
   out['hi_edge_values'] = edge
   out['hi_edge_hist'] = hi['calc_hist'](edge, 32, (0.0, 1.0))
+
+  # ---- filters.py: the NumPy statements of Filter.get_mask / VignetFilter.get_mask that build the coordinate grid ----
+  # (the methods themselves are TensorFlow graph code; the grid is a constant they compute with plain NumPy loops:
+  # filters.py:124-133 and 371-380.  Those statements -- the np.zeros, shorter_edge and the nested for loop -- are taken
+  # from the method's AST and executed with `size` given.)
+  f_path = os.path.join(REF, 'filters.py')
+  ftree = ast.parse(open(f_path).read(), filename=f_path)
+  prov.append(('filters.py', sha256(f_path)))
+
+  def grid_statements(cls_name):
+    cls = next(n for n in ftree.body if isinstance(n, ast.ClassDef) and n.name == cls_name)
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'get_mask')
+    stmts = []
+    for node in ast.walk(fn):
+      if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name):
+        name = node.targets[0].id
+        src = ast.unparse(node.value)
+        if (name == 'grid' and src.startswith('np.zeros')) or name == 'shorter_edge':
+          stmts.append(node)
+      elif isinstance(node, ast.For) and isinstance(node.target, ast.Name) and node.target.id == 'i':
+        stmts.append(node)
+    stmts.sort(key=lambda n: n.lineno)
+    assert [type(n).__name__ for n in stmts] == ['Assign', 'Assign', 'For'], [ast.unparse(n)[:40] for n in stmts]
+    return ast.Module(body=stmts, type_ignores=[])
+
+  sizes = [(64, 64), (5, 9), (9, 7), (16, 24), (2, 2)]
+  out['mask_grid_sizes'] = np.array(sizes)
+  for cls_name, key in (('Filter', 'mask_grid'), ('VignetFilter', 'vignet_grid')):
+    code = compile(grid_statements(cls_name), '<reference filters.%s.get_mask grid>' % cls_name, 'exec')
+    for (gh, gw) in sizes:
+      gns = {'np': np, 'size': [gh, gw]}
+      exec(code, gns)
+      assert gns['grid'].dtype == np.float32 and gns['grid'].shape == (1, gh, gw, 2)
+      out['%s_%dx%d' % (key, gh, gw)] = gns['grid']
 
   out['provenance'] = np.array(['%s sha256=%s' % p for p in prov])
   path = os.path.join(HERE, 'reference_numpy.npz')

@@ -4,7 +4,7 @@ executed with numpy + math only; the fixture holds data and the source files' sh
 this repository that does not come from the build's own restatements: CPU -- the three filter oracles, the host helpers
 and the metric reproduce it; GPU -- the HIP kernels do.  Covered: Exposure, Gamma (x >= 0.001), WhiteBalance (regressor
 normalisation + process), rgb2lum, lerp, the ProPhoto linearisation, the metric's luminance statistics and histogram
-arithmetic.  NOT covered (no executable statement in /root/reference): everything that lives in TensorFlow."""
+arithmetic, the coordinate grid of the spatial masks.  NOT covered (no executable statement in /root/reference): everything that lives in TensorFlow."""
 import os
 
 import numpy as np
@@ -42,7 +42,7 @@ def cases(ref):
 
 def test_fixture_names_its_sources(ref):
   prov = [str(p) for p in ref['provenance']]
-  assert len(prov) == 3 and all('sha256=' in p and len(p.split('sha256=')[1]) == 64 for p in prov)
+  assert len(prov) == 4 and all('sha256=' in p and len(p.split('sha256=')[1]) == 64 for p in prov)
   assert prov[0].startswith('user_study_ui/filters.py') and prov[1].startswith('util.py')
   # the generated parameters lie inside the ranges the TF path's regressors can produce
   assert np.abs(ref['ui_exposure_ev']).max() <= 3.5 and (ref['ui_gamma_g'] >= 1 / 3).all() and (ref['ui_gamma_g'] <= 3).all()
@@ -103,6 +103,35 @@ def test_metric_reproduces_the_reference_run(ref):
   h = metrics.calc_hist(torch.from_numpy(ref['hi_edge_values'])).double().numpy()
   np.testing.assert_allclose(h, ref['hi_edge_hist'], atol=1e-7)
   assert abs(ref['hi_edge_hist'].sum() - 0.8) < 1e-12
+
+
+def test_mask_grid_equals_the_reference_statements(ref):
+  """The constant coordinate grid of the spatial masks: the NumPy statements inside ``Filter.get_mask`` and
+  ``VignetFilter.get_mask`` (filters.py:124-133, 371-380), executed in the build container for square, portrait,
+  landscape and minimal sizes, against the oracle's closed form -- bit for bit in float32 (what the reference feeds to
+  ``tf.constant``); the two reference methods build the same grid."""
+  from oracle import filters_torch
+  sizes = [tuple(int(v) for v in s) for s in ref['mask_grid_sizes']]
+  assert (5, 9) in sizes and (9, 7) in sizes  # non-square both ways: the shorter-edge centring
+  for h, w in sizes:
+    want = ref['mask_grid_%dx%d' % (h, w)]
+    assert want.dtype == np.float32 and want.shape == (1, h, w, 2)
+    assert np.array_equal(ref['vignet_grid_%dx%d' % (h, w)], want)
+    assert np.array_equal(fnp.mask_grid(h, w, np.float32), want), (h, w)
+    # the float64 oracle's grid IS the float32 one widened
+    assert np.array_equal(fnp.mask_grid(h, w, np.float64), want.astype(np.float64))
+  # through the masks themselves: a mask that depends on the row only / the column only reproduces the grid's values
+  img = np.zeros((1, 5, 9, 3))
+  mp = np.zeros((1, 6))
+  mp[0, 0], mp[0, 4], mp[0, 5] = 0.3, 0.7, 0.2  # A (row coefficient), sharpness, strength; B = C = D = 0
+  m = fnp.get_mask(img, mp)
+  t = lambda v: np.tanh(v) * 5.0  # tanh_range(-5, 5, initial=0)
+  g = ref['mask_grid_5x9'].astype(np.float64)
+  inp = (g[..., 0:1] * t(0.3) + t(0.0) * (0.0 - 0.5)) * (1 * t(0.7) / 5)
+  want = 1 / (1 + np.exp(-inp)) * (t(0.2) / 5 * 0.5 + 0.5) * (1 - 0.3) + 0.3
+  np.testing.assert_allclose(m, want, rtol=1e-12)
+  tm = filters_torch.get_mask(torch.from_numpy(img), torch.from_numpy(mp)).numpy()
+  np.testing.assert_allclose(tm, want, rtol=1e-12)
 
 
 @pytest.mark.gpu
