@@ -598,6 +598,167 @@ static FlatPlan bwd_plan(const ConvDims& d, int ni, int forced_s) {
   return p;
 }
 
+// ---- weight gradient -----------------------------------------------------------------------------------------------------
+//   dW[co][k2] = sum_m dY[m][co] A[m][k2],   m = (n, oh, ow),  k2 = (kh, kw, ci),  A = the forward's im2col matrix
+// A GEMM with the PIXELS as its K dimension (65536 ... 1024 of them at batch 64) and a small output (Cout x 16 Cin).
+// One wave = a 32 (co) x 128 (k2) tile of dW over a range of pixel pairs: per pair (MFMA k = 2: lane half h <-> pixel
+// 2 q + h) a lane loads ONE float of dY (row co0 + (l & 31): 32 lanes cover one 128-byte line) and ONE 16-byte chunk of
+// the im2col row (k2 = k2_0 + 4 (l & 31) .. + 3: 32 lanes cover 512 contiguous bytes of the image row) -- and that
+// chunk's four elements are the B operands of FOUR MFMAs on four interleaved 32 x 32 tiles (tile r holds the columns
+// k2 = 4 j + r): 2 loads per 4 MFMAs, and accumulator register e of the four tiles is one float4 of dW[co][4 j .. 4 j + 3],
+// so the stores are whole 512-byte rows.  (The first version, r05p3, loaded 4 bytes per operand and MFMA: 2-8x slower
+// than MIOpen.)  The pixel range of a tile is spread over P blocks x S waves: the S partial tiles of a block meet in
+// LDS, the P block partials are written as P full-size copies of dW into a workspace and summed in block order by a
+// second, element-wise launch (P = 1: straight to dW).  No atomics, no zero fill, no fence; a fixed summation order.
+struct WrwPlan {
+  int tiles_co, tiles_k;  // 32 x 128 tiles of dW
+  int s, p;               // waves per block, blocks per tile
+  int pairs_per_wave;     // pixel pairs (2 consecutive ow of one row) per wave
+};
+
+template <bool CIN4>
+__global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ out, ConvDims d, WrwPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [s][64][64]: slot v = e * 4 + r
+  const int lane = threadIdx.x & 63;
+  const int sl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tiles = pl.tiles_co * pl.tiles_k;
+  const int tile = blockIdx.x % tiles, pb = blockIdx.x / tiles;
+  const int tc = tile / pl.tiles_k, tk = tile - tc * pl.tiles_k;
+  const int col = lane & 31, half = lane >> 5;
+  const int rr = 4 * d.cin, lim = d.w * d.cin;
+  const __amdgpu_buffer_rsrc_t rx = conv_rsrc(x, size_t(d.n) * d.h * d.w * d.cin);
+  const __amdgpu_buffer_rsrc_t rg = conv_rsrc(dy, size_t(d.n) * d.ho * d.wo * d.cout);
+  // A operand: dY column co (this lane's output row); B operand: the im2col chunk k2 .. k2 + 3 (its output columns)
+  const int co = tc * 32 + col;
+  const bool co_ok = co < d.cout;
+  const int k2 = tk * 128 + 4 * col;
+  const bool k2_ok = k2 < d.kdim;  // (kdim = 16 cin is a multiple of 4: a chunk exists as a whole or not at all)
+  const int kk = k2_ok ? k2 : 0;
+  const int kh = (kk >= rr) + (kk >= 2 * rr) + (kk >= 3 * rr);
+  const int b_c = (2 * half - 1) * d.cin + (kk - kh * rr);  // + 4 owp cin: offset inside the image row
+  const int a_off = half * d.cout + co;                      // + (the pair's first pixel) * cout
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+  const int wpairs = d.wo / 2, total_pairs = d.m / 2;  // (wo is even: see the host side)
+  const int q0 = (pb * pl.s + sl) * pl.pairs_per_wave;
+  const int q1 = min(q0 + pl.pairs_per_wave, total_pairs);
+  // wave-uniform walk over the pixel pairs (scalar registers), advanced without divisions
+  int it_row = q0 / wpairs;  // n ho + oh
+  int it_owp = q0 - it_row * wpairs;
+  int it_n = it_row / d.ho;
+  int it_oh = it_row - it_n * d.ho;
+  int it_q = q0;
+  auto load_pair = [&](float& fa, Chunk<CIN4>& fb) {
+    const bool q_ok = it_q < q1;
+    fa = buf_load1(rg, (it_row * d.wo + 2 * it_owp) * d.cout + a_off, q_ok && co_ok);
+    const int ih = 2 * it_oh - 1 + kh;
+    fb = row_chunk<CIN4>(rx, (it_n * d.h + ih) * lim, b_c + 4 * it_owp * d.cin, lim,
+                         q_ok && k2_ok && unsigned(ih) < unsigned(d.h));
+    ++it_q;
+    if (++it_owp == wpairs) {
+      it_owp = 0;
+      ++it_row;
+      if (++it_oh == d.ho) {
+        it_oh = 0;
+        ++it_n;
+      }
+    }
+  };
+  constexpr int U = CIN4 ? 4 : 2;
+  float ac[U], an[U];
+  Chunk<CIN4> bc[U], bn[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) load_pair(ac[u], bc[u]);
+#pragma unroll 2
+  for (int q = q0; q < q1; q += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_pair(an[u], bn[u]);
+    __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of the MFMAs that hide them
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float4 b = bc[u].get();
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b.w, acc[3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ac[u] = an[u];
+      bc[u] = bn[u];
+    }
+  }
+
+  // accumulator register e of tile r, lane l: row (co) = (e & 3) + 8 (e >> 2) + 4 (l >> 5), column (k2) = 4 (l & 31) + r
+  // -> the four tiles' register e is dW[row][k2_0 + 4 (l & 31) .. + 3]: one float4 per lane, 512 contiguous bytes per row
+  float* const dst = out + size_t(pb) * d.cout * d.kdim;  // this block's copy of dW (P = 1: dW itself)
+  auto store_row = [&](int e, const float4& v) {
+    const int r_co = tc * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+    if (r_co < d.cout && k2_ok) *reinterpret_cast<float4*>(dst + size_t(r_co) * d.kdim + k2) = v;
+  };
+  if (pl.s > 1) {
+    float* mine = part + sl * 4096;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      *reinterpret_cast<float4*>(mine + (e * 64 + lane) * 4) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+    __syncthreads();
+    for (int e = sl; e < 16; e += pl.s) {
+      float4 v = *reinterpret_cast<const float4*>(part + (e * 64 + lane) * 4);
+      for (int q = 1; q < pl.s; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(part + q * 4096 + (e * 64 + lane) * 4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      store_row(e, v);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) store_row(e, make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]));
+  }
+}
+
+// dW = the sum of the P block copies, in block order (one float4 per thread)
+__global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                              size_t count4, int p) {
+  const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= count4) return;
+  const float4* src = reinterpret_cast<const float4*>(ws);
+  float4 v = src[i];
+  for (int q = 1; q < p; ++q) {
+    const float4 t = src[size_t(q) * count4 + i];
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  reinterpret_cast<float4*>(dw)[i] = v;
+}
+
+static WrwPlan wrw_plan(const ConvDims& d, int forced_s, int forced_p) {
+  WrwPlan p;
+  p.tiles_co = (d.cout + 31) / 32;
+  p.tiles_k = (d.kdim + 127) / 128;
+  const long tiles = long(p.tiles_co) * p.tiles_k;
+  const int total_pairs = d.m / 2;
+  const int batch = 4;
+  long waves = (1024 + tiles - 1) / tiles;  // per tile: one wave of 4 MFMA streams per SIMD chip-wide
+  if (waves > (total_pairs + 2 * batch - 1) / (2 * batch)) waves = (total_pairs + 2 * batch - 1) / (2 * batch);
+  if (waves < 1) waves = 1;
+  int s = 1;
+  while (s < 4 && s * 2 <= waves) s *= 2;
+  if (forced_s > 0) s = forced_s > 4 ? 4 : forced_s;
+  int pb = int((waves + s - 1) / s);
+  if (forced_p > 0) pb = forced_p;
+  p.s = s;
+  p.pairs_per_wave = (total_pairs + pb * s - 1) / (pb * s);
+  p.pairs_per_wave = (p.pairs_per_wave + batch - 1) / batch * batch;
+  p.p = (total_pairs + p.pairs_per_wave * s - 1) / (p.pairs_per_wave * s);  // no empty blocks
+  if (p.p < 1) p.p = 1;
+  return p;
+}
+
 template <int BM, int BN, int WM, int WN, int WK, int BKS>
 static void launch_fwd(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, int act,
                        float leak, hipStream_t s) {
@@ -626,8 +787,9 @@ static int conv_dims(ConvDims* d, int n, int h, int w, int cin, int cout) {
 // EXPO_CONV_SLICES (K slices) -- and settable through expo_conv_tuning() afterwards (no getenv on the launch path: the
 // backward kernels are launched from autograd's worker thread while the host thread may be in putenv).
 struct ConvTuning {
-  std::atomic<int> tile, nt, slices;
-  ConvTuning() : tile(env_int("EXPO_CONV_TILE", 0)), nt(env_int("EXPO_CONV_NT", 0)), slices(env_int("EXPO_CONV_SLICES", 0)) {}
+  std::atomic<int> tile, nt, slices, parts;
+  ConvTuning() : tile(env_int("EXPO_CONV_TILE", 0)), nt(env_int("EXPO_CONV_NT", 0)), slices(env_int("EXPO_CONV_SLICES", 0)),
+                 parts(env_int("EXPO_CONV_PARTS", 0)) {}
 };
 static ConvTuning& conv_tuning() {
   static ConvTuning t;
@@ -716,6 +878,55 @@ int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, i
   if (ni == 2) hipLaunchKernelGGL(conv_bwd_flat_kernel<2>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, dx, d, pl);
   else hipLaunchKernelGGL(conv_bwd_flat_kernel<1>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, dx, d, pl);
   HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data launch");
+  return EXPO_OK;
+}
+
+int expo_conv_wrw_tuning(int slices, int parts) {
+  // probes / tests: waves per block (1-4) and blocks per tile of the weight-gradient kernel (negative: leave; 0: auto)
+  if (slices > 4) return fail(EXPO_E_BADARG, "conv wrw tuning: slices <= 4");
+  if (slices >= 0) conv_tuning().slices.store(slices);
+  if (parts >= 0) conv_tuning().parts.store(parts);
+  return EXPO_OK;
+}
+
+size_t expo_conv4x4s2_wrw_workspace_bytes(int n, int h, int wd, int cin, int cout) {
+  ConvDims d;
+  if (conv_dims(&d, n, h, wd, cin, cout) != EXPO_OK || n == 0) return 0;
+  const int fs = conv_tuning().slices.load();
+  const WrwPlan pl = wrw_plan(d, fs > 4 ? 4 : fs, conv_tuning().parts.load());
+  return pl.p > 1 ? size_t(pl.p) * cout * d.kdim * 4 : 0;
+}
+
+int expo_conv4x4s2_wrw(const float* x, const float* dy, float* dw, int n, int h, int wd, int cin, int cout,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  ConvDims d;
+  if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
+  if (!dw) return fail(EXPO_E_BADARG, "null pointer");
+  if ((reinterpret_cast<uintptr_t>(dw) & 15) != 0) return fail(EXPO_E_BADARG, "conv4x4s2_wrw: dw must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    HIP_TRY(hipMemsetAsync(dw, 0, size_t(cout) * d.kdim * 4, s), "conv4x4s2_wrw (empty batch)");
+    return EXPO_OK;
+  }
+  if (!x || !dy) return fail(EXPO_E_BADARG, "null pointer");
+  if (d.wo & 1) return fail(EXPO_E_BADARG, "conv4x4s2_wrw: w / 2 must be even (pixels are consumed in pairs)");
+  const int fs = conv_tuning().slices.load();
+  const WrwPlan pl = wrw_plan(d, fs > 4 ? 4 : fs, conv_tuning().parts.load());
+  const size_t count = size_t(cout) * d.kdim;
+  if (pl.p > 1 && (!workspace || workspace_bytes < size_t(pl.p) * count * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)))
+    return fail(EXPO_E_BADARG, "conv4x4s2_wrw: workspace too small or not 16-byte aligned (expo_conv4x4s2_wrw_workspace_bytes)");
+  float* out = pl.p > 1 ? static_cast<float*>(workspace) : dw;
+  const dim3 grid(unsigned(pl.tiles_co * pl.tiles_k) * pl.p), block(64 * pl.s);
+  const size_t lds = pl.s > 1 ? size_t(pl.s) * 16384 : 0;
+  if (d.cin % 4 == 0) hipLaunchKernelGGL(conv_wrw_kernel<true>, grid, block, lds, s, x, dy, out, d, pl);
+  else hipLaunchKernelGGL(conv_wrw_kernel<false>, grid, block, lds, s, x, dy, out, d, pl);
+  HIP_TRY(hipGetLastError(), "conv4x4s2_wrw launch");
+  if (pl.p > 1) {
+    const size_t count4 = count / 4;
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(unsigned((count4 + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), dw, count4, pl.p);
+    HIP_TRY(hipGetLastError(), "conv4x4s2_wrw reduce launch");
+  }
   return EXPO_OK;
 }
 

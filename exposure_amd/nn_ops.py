@@ -150,6 +150,14 @@ class _ConvG(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, g, w_like):
     ctx.save_for_backward(x, g)
+    # OFF by default: measured on par with MIOpen's kernel + its zero fill for the deeper layers (21-27 vs 24-26 us, two
+    # launches either way) and 2-3x slower for the first layers (profiles/r05_p7_conv_wrw_v2.txt).  What it offers is a
+    # fixed summation order (MIOpen's split-K kernels add with float atomics): EXPO_HIP_CONV_WRW=1.
+    if (os.environ.get('EXPO_HIP_CONV_WRW', '0') == '1' and _hip_conv(x, w_like) and g.dtype == torch.float32 and
+        g.shape[2] % 2 == 0):
+      dw = torch.empty_like(w_like, memory_format=torch.preserve_format)  # the weight's own (channels_last) layout
+      _cabi.conv4x4s2_wrw(x, g.contiguous(), dw)  # deterministic split over the pixels, no zero fill
+      return dw
     return torch.ops.aten.convolution_backward(_nchw(g), _nchw(x), w_like, None, _STRIDE, _PAD, _DIL, False, [0, 0], 1,
                                                [False, True, False])[1]
 

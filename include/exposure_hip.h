@@ -534,7 +534,19 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
  *   dy  float32 [n][h/2][w/2][cout] (cout % 4 == 0)     dx  float32 [n][h][w][cin], every element written */
 int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, int h, int wd, int cin, int cout,
                             void* stream);
-/* Probes and tests: override how the two kernels above decompose a problem (process-wide; negative = leave as is,
+/* The weight gradient: dw[co][kh][kw][ci] = sum over the batch's output pixels of dy[.][co] x[.][kh][kw][ci], written in
+ * the weight's own memory order, every element (dw 16-byte aligned).  The pixel sum of a 32 x 128 tile of dw is spread
+ * over P blocks; for P > 1 the blocks write P full-size copies of dw into `workspace` (caller-owned scratch, no
+ * initialisation needed, at least expo_conv4x4s2_wrw_workspace_bytes(...) bytes, 16-byte aligned) and a second,
+ * element-wise launch adds them in block order: deterministic, no atomics, no zero fill of dw.  w / 2 must be even.
+ * Replaces aten::convolution_backward(weight gradient only) + the zero fill in front of MIOpen's split-K kernel. */
+size_t expo_conv4x4s2_wrw_workspace_bytes(int n, int h, int wd, int cin, int cout);
+int expo_conv4x4s2_wrw(const float* x, const float* dy, float* dw, int n, int h, int wd, int cin, int cout,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* Probes and tests: waves per block (1-4) and blocks per tile of the weight-gradient kernel (negative = leave as is,
+ * 0 = the library's choice; initial values from EXPO_CONV_SLICES / EXPO_CONV_PARTS). */
+int expo_conv_wrw_tuning(int slices, int parts);
+/* Probes and tests: override how the forward / data-gradient kernels decompose a problem (process-wide; negative = leave as is,
  * 0 = the library's own choice).  tile 1-4: an LDS-tiled forward shape, 5: the flat kernel; nt 1 | 2: column tiles per
  * wave; slices 1-16: K slices per tile.  The initial values come from EXPO_CONV_TILE / _NT / _SLICES, read once. */
 int expo_conv_tuning(int tile, int nt, int slices);

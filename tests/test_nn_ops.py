@@ -534,3 +534,36 @@ def test_hip_conv_data_gradient_matches_float64(case, gpu_device, monkeypatch):
       err = float((dx.double().cpu() - ref).abs().max()) / scale
       assert err < 3e-6, (case, nt, sl, err)
   _cabi.conv_tuning(0, 0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 8, 5, 8), (2, 16, 14, 32), (2, 64, 17, 32), (9, 8, 32, 64), (4, 16, 64, 128),
+                                  (16, 8, 128, 256), (7, 4, 4, 36), (32, 32, 32, 64), (3, 4, 3, 4)])
+def test_hip_conv_weight_gradient_matches_float64(case, gpu_device):
+  """expo_conv4x4s2_wrw (opt-in: EXPO_HIP_CONV_WRW=1) against the float64 autograd weight gradient on the CPU, under
+  several (waves per block, blocks per tile) splits of the pixel sum incl. P = 1 (no reduce launch) and an odd P, twice
+  in a row through the same scratch; every element of dw is written (the buffer starts as NaN); the result of a given
+  split is bit-reproducible (fixed summation order: no atomics)."""
+  from exposure_amd import _cabi
+  n, h, cin, cout = case
+  dev = gpu_device
+  x, w, _ = _conv_case(n, h, cin, cout, dev, seed=n + h)
+  g = torch.randn((n, h // 2, h // 2, cout), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+  wd = w.double().cpu().requires_grad_(True)
+  yd = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wd, None, 2, 1)
+  ref, = torch.autograd.grad(yd, [wd], g.double().cpu().permute(0, 3, 1, 2))
+  scale = float(ref.abs().max())
+  dw = torch.empty_like(w)
+  try:
+    for sl, parts in ((0, 0), (1, 1), (2, 3), (4, 0), (4, 7), (3, 2)):
+      _cabi.conv_wrw_tuning(sl, parts)
+      runs = []
+      for _ in range(2):
+        dw.fill_(float('nan'))
+        _cabi.conv4x4s2_wrw(x, g, dw)
+        err = float((dw.double().cpu() - ref).abs().max()) / scale
+        assert err < 1e-5, (case, sl, parts, err)  # (P = S = 1: one wave alone sums up to 16 384 terms in f32)
+        runs.append(dw.clone())
+      assert torch.equal(runs[0], runs[1])
+  finally:
+    _cabi.conv_wrw_tuning(0, 0)

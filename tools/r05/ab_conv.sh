@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for rep in 1 2; do
   for hip in 0 1; do
     echo "== EXPO_HIP_CONV=$hip (repeat $rep)"
-    EXPO_HIP_CONV=$hip EXPO_HIP_CONV_BWD=$hip EXPO_HIP_CONV_WRW=$hip timeout 300 python bench.py --workload train --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+    EXPO_HIP_CONV=$hip EXPO_HIP_CONV_BWD=$hip timeout 300 python bench.py --workload train --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
   if l.startswith('{'):

@@ -156,7 +156,19 @@ def check_bwd_wrw(dev):
       err = float((dx.double().cpu() - gx_ref).abs().max()) / sx
       assert err < 3e-6, ('bwd_data mismatch', n, h, cin, cout, sl, err)
       worst_x = max(worst_x, err)
+    dw = torch.empty_like(w)
+    if (h // 2) % 2 == 0:
+      for sl, parts in ((0, 0), (1, 1), (2, 3), (4, 0), (4, 7), (3, 2)):
+        _cabi.conv_wrw_tuning(sl, parts)
+        for rep in range(2):
+          dw.fill_(float('nan'))
+          _cabi.conv4x4s2_wrw(x, g, dw)
+          err = float((dw.double().cpu() - gw_ref).abs().max()) / sw
+          assert err < 1e-5, ('wrw mismatch', n, h, cin, cout, sl, parts, rep, err)
+          worst_w = max(worst_w, err)
+      _cabi.conv_wrw_tuning(0, 0)
     clear_env()
+    print('wrw check: dw err %.2e (MIOpen %.2e)' % (worst_w, lib_w))
     print('bwd check n=%d h=%d cin=%d cout=%d: dx err %.2e (MIOpen %.2e)' % (n, h, cin, cout, worst_x, lib_x))
   print('bwd/wrw check OK')
 
@@ -178,15 +190,24 @@ def bench_bwd_wrw(dev, reps):
       for nt, sl in ((0, 0), (1, 0), (2, 0), (1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (2, 8), (2, 16)):
         _cabi.conv_tuning(0, nt, sl)
         rb['n%ds%d' % (nt, sl)] = timeit(lambda: _cabi.conv4x4s2_bwd_data(g, w, dx), reps)
+      rw = {}
+      for sl, parts in ((0, 0), (4, 0), (2, 0), (1, 0), (4, 8), (4, 32), (4, 128), (2, 64)):
+        _cabi.conv_wrw_tuning(sl, parts)
+        rw['s%dp%d' % (sl, parts)] = timeit(lambda: _cabi.conv4x4s2_wrw(x, g, dw), reps)
+      _cabi.conv_wrw_tuning(0, 0)
+      bw = min(rw, key=rw.get)
       clear_env()
       bb = min(rb, key=rb.get)
       print('n=%3d cin=%3d h=%2d cout=%3d  bwd %6.1f | auto %6.1f best %s %6.1f (%.0f TF) | %s' %
             (n, cin, h, cout, t_bl, rb['n0s0'], bb, rb[bb], fl / rb[bb] / 1e6, ' '.join('%s=%.1f' % kv for kv in rb.items())))
+      print('%28s  wrw %6.1f | auto %6.1f best %s %6.1f (%.0f TF) | %s' %
+            ('', t_wl, rw['s0p0'], bw, rw[bw], fl / rw[bw] / 1e6, ' '.join('%s=%.1f' % kv for kv in rw.items())))
+      tot['wrw'] += rw['s0p0']
       tot['bwd_lib'] += t_bl
       tot['bwd'] += rb['n0s0']
       tot['wrw_lib'] += t_wl
-  print('sums (auto): bwd MIOpen %.1f ours %.1f | wrw MIOpen %.1f (kept: an in-house flat wrw kernel measured 2-8x slower, profiles/r05_p3_conv_bwd_wrw.txt)' %
-        (tot['bwd_lib'], tot['bwd'], tot['wrw_lib']))
+  print('sums (auto): bwd MIOpen %.1f ours %.1f | wrw MIOpen %.1f (+ a zero fill each) ours %.1f (incl. the reduce launch)' %
+        (tot['bwd_lib'], tot['bwd'], tot['wrw_lib'], tot['wrw']))
 
 
 def main():
