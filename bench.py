@@ -143,7 +143,8 @@ class Chain:
     # thread_local: with a process group alive, RCCL's watchdog thread may poll events while this
     # thread captures; under the default "global" mode such a call aborts the process
     try:
-      with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+      from exposure_amd.util import capture_without_gc  # no cyclic garbage collection inside a capture
+      with capture_without_gc(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
         for _ in range(unroll):
           self.launch()
     except RuntimeError as e:  # never lose the run over the launch method

@@ -17,7 +17,7 @@ from .agent import Agent
 from .critics import Critic
 from .nn_ops import (critic_step_inputs, frozen_parameters, generator_losses_fused, grad_penalty_term,
                      skip_parameter_gradients)
-from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
+from .util import STATE_STEP_DIM, STATE_STOPPED_DIM, capture_without_gc
 
 
 class GAN(nn.Module):
@@ -337,7 +337,8 @@ class GAN(nn.Module):
       # default "global" mode such a call from another thread aborts the process
       mode = 'thread_local' if xdist.world_size(self.process_group) > 1 or self.force_collectives else 'global'
       try:
-        with torch.cuda.graph(graph, capture_error_mode=mode):
+        # (no cyclic garbage collection inside the capture: util.capture_without_gc)
+        with capture_without_gc(), torch.cuda.graph(graph, capture_error_mode=mode):
           static_out = body(*static_in)
       except RuntimeError as e:  # e.g. a collective that refuses capture: keep training, eagerly
         import warnings

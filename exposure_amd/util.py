@@ -78,3 +78,28 @@ def enrich_image_input(cfg, net, states):
     planes = states[:, None, None, :].to(net.dtype).expand(n, h, w, states.shape[1])
     net = torch.cat([net, planes], dim=3)
   return net
+
+
+class capture_without_gc:
+  """Around a hipGraph capture: collect Python garbage FIRST, keep the cyclic collector off while the stream captures.
+
+  A dead reference cycle that owns device resources -- an earlier ``GAN`` with captured step graphs is one: module ->
+  gradient buckets -> their ready callback -> module -- is freed whenever the cyclic collector happens to run.  If that
+  is in the middle of a capture, destroying its ``CUDAGraph`` objects (hipGraphExecDestroy, the graph's memory pool) is
+  an operation the runtime refuses while a stream captures; the error is thrown from a destructor and the process
+  ABORTS (found by a gpu-suite run that died inside ``test_train_cli_runs``, "Garbage-collecting" on top of the fault
+  handler's stack: round 5).  ``torch.cuda.graph`` used to collect before every capture; since it became optional
+  (``torch.compiler.config.force_cudagraph_gc``, off by default) nothing does."""
+
+  def __enter__(self):
+    import gc
+    gc.collect()
+    self._was_enabled = gc.isenabled()
+    gc.disable()
+    return self
+
+  def __exit__(self, *exc):
+    import gc
+    if self._was_enabled:
+      gc.enable()
+    return False

@@ -36,3 +36,15 @@ def gpu_device():
   if not torch.cuda.is_available():
     pytest.fail('test marked gpu but no GPU is visible')
   return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _collect_device_garbage_between_tests(request):
+  """After every gpu test: free dead reference cycles that own device resources NOW (a ``GAN`` with captured step graphs
+  is such a cycle) instead of whenever the cyclic collector next runs -- possibly inside a later test's hipGraph capture,
+  where destroying a graph aborts the process (exposure_amd/util.py::capture_without_gc; one gpu-suite run in fifteen
+  died that way in round 5 before this fixture and the guards around the captures existed)."""
+  yield
+  if request.node.get_closest_marker('gpu') is not None:
+    import gc
+    gc.collect()

@@ -385,6 +385,25 @@ def test_heads_are_packed_at_construction_and_a_repack_drops_the_captured_steps(
   assert worst < 3e-4, worst  # (eager vs replayed steps differ at Adam's step size at most: test_graphed_steps_match_eager)
 
 
+def test_capture_survives_dead_graph_owners(gpu_device):
+  """Round-5 incident: three DEAD GANs whose captured step graphs are only reachable through a reference cycle, then a
+  live GAN captures its steps while the cyclic collector is as eager as it can be.  The product collects BEFORE the
+  capture and keeps the collector off inside it (util.capture_without_gc), so the run finishes; without the guard the
+  collector destroys the dead graphs inside the capture -- "operation not permitted when stream is capturing", thrown
+  from a destructor -- and the process aborts (tools/r05/gc_capture_repro.py; the unguarded leg is run for the record:
+  its outcome depends on the runtime and is reported, not asserted)."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = os.path.join(root, 'tools', 'r05', 'gc_capture_repro.py')
+  guarded = subprocess.run([sys.executable, script], cwd=root, capture_output=True, text=True, timeout=600)
+  assert guarded.returncode == 0 and 'OK: captured' in guarded.stdout, guarded.stderr[-2000:]
+  unguarded = subprocess.run([sys.executable, script, 'unguarded'], cwd=root, capture_output=True, text=True, timeout=600)
+  print('unguarded run: rc=%d%s' % (unguarded.returncode, ' (' + unguarded.stderr.strip().splitlines()[1].strip() + ')'
+                                     if unguarded.returncode and len(unguarded.stderr.strip().splitlines()) > 1 else ''))
+
+
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
 @pytest.mark.parametrize('shape', [(4, 96, 128, 3), (3, 7, 9, 3)])
 @pytest.mark.parametrize('steps', [8, 5, 1, 0])

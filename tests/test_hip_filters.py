@@ -797,7 +797,8 @@ def test_split_chain_replayed_from_a_hipgraph_equals_eager(gpu_device):
   torch.cuda.current_stream().wait_stream(side)
   torch.cuda.synchronize()
   graph = torch.cuda.CUDAGraph()
-  with torch.cuda.graph(graph):
+  from exposure_amd.util import capture_without_gc
+  with capture_without_gc(), torch.cuda.graph(graph):
     step()
     step()
   for _ in range(3):

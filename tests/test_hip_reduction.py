@@ -241,7 +241,8 @@ def test_dispatch_backward_on_streaming_sized_tensors_and_in_a_graph(gpu_device)
   torch.cuda.current_stream().wait_stream(side)
   torch.cuda.synchronize()
   graph = torch.cuda.CUDAGraph()
-  with torch.cuda.graph(graph):
+  from exposure_amd.util import capture_without_gc
+  with capture_without_gc(), torch.cuda.graph(graph):
     _cabi.dispatch_bwd(tids, tx, tdy, dx_g, tp24, dp_g, None)
   for _ in range(3):
     dx_g.fill_(float('nan'))

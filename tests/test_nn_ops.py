@@ -242,7 +242,8 @@ def test_hip_adam_matches_the_rule_in_float64(count, gpu_device):
   for p in ps:
     opt._moments(p)  # allocate the moments outside the capture
   graph = torch.cuda.CUDAGraph()
-  with torch.cuda.graph(graph):
+  from exposure_amd.util import capture_without_gc
+  with capture_without_gc(), torch.cuda.graph(graph):
     opt.step()
   for p in ps:  # the capture itself does not execute
     pass
