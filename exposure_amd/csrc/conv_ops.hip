@@ -7,9 +7,12 @@
 // 65536 x 32 x 224 ... 1024 x 256 x 2048) -- and the library kernels MIOpen picks for them (asm igemm / CK grouped
 // xdlops, tuned for large problems) take 17-46 us each, 0.2-0.5 of the f32 matrix peak, plus a zero-fill launch in
 // front of every split-K kernel and a bias / activation launch behind every forward (profiles/r04_final_kernel_
-// stats_train.csv: 228 convolution launches = 5.1 ms of a 9.5 ms training iteration, 191 fills = 1.0 ms).  A tile
-// decomposition chosen for THESE sizes -- 1024 wave-tasks of 32x32 output elements each, one per SIMD, whatever the
-// layer -- runs them at a multiple of that.
+// stats_train.csv: 228 convolution launches = 5.1 ms of a 9.5 ms training iteration, 191 fills = 1.0 ms).  Decompositions
+// chosen for THESE sizes run the forward (+ bias + lrelu, one launch) 1.2-1.7x and the deeper layers' data gradient
+// 1.2-1.6x faster (45-80 TFLOP/s; DESIGN.md 3.11 says what bounds them).  In this file, in order: the LDS-tiled forward
+// (conv_fwd_kernel, four shapes), the flat forward (conv_fwd_flat_kernel: the default except where 64 x 64 tiles still
+// give every CU a block or two), the data gradient as four parity-class GEMMs (conv_bwd_flat_kernel), the weight
+// gradient (conv_wrw_kernel + its reduce launch: parity-green and deterministic, on par with MIOpen at best -> opt-in).
 //
 // Forward as a GEMM:  Y[m][co] = sum_k A[m][k] W[co][k],  m = (n, oh, ow),  k = (kh, kw, ci),  K = 16 Cin
 //   A[m][k] = X[n][2 oh - 1 + kh][2 ow - 1 + kw][ci]  (0 outside the image)
@@ -813,7 +816,7 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
   const int forced = conv_tuning().tile.load(), forced_nt = conv_tuning().nt.load(), forced_s = conv_tuning().slices.load();
   auto blocks = [&](int bm, int bn) { return ((d.m + bm - 1) / bm) * ((d.cout + bn - 1) / bn); };
   int shape = forced;
-  // Measured on MI355X (tools/r05/conv_bench.py, profiles/r05_conv_*.txt): the LDS-tiled shapes win where 64 x 64
+  // Measured on MI355X (tools/r05/conv_bench.py, profiles/r05_final_conv_bench.txt): the LDS-tiled shapes win where 64 x 64
   // tiles still give every CU a block or two (the second layer; the third at batch 128), the flat decomposition
   // everywhere else (first layers: K is short; deep layers: few rows, long K)
   if (shape == 0 && d.cout > 32 && forced_nt == 0 && forced_s == 0) {
@@ -840,7 +843,6 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
     HIP_TRY(hipGetLastError(), "conv4x4s2_fwd launch");
     return EXPO_OK;
   }
-  (void)blocks;
   switch (shape) {
     case 1: launch_fwd<64, 32, 2, 1, 2, 32>(x, w, bias, y, d, act, leak, s); break;
     case 2: launch_fwd<64, 64, 2, 2, 1, 32>(x, w, bias, y, d, act, leak, s); break;
