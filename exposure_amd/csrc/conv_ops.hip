@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
       }
     }
   };
-  constexpr int U = CIN4 ? 4 : 2;
+  constexpr int U = 4;
   float ac[U], an[U];
   Chunk<CIN4> bc[U], bn[U];
 #pragma unroll
@@ -725,18 +725,34 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
   }
 }
 
-// dW = the sum of the P block copies, in block order (one float4 per thread)
+// dW = the sum of the P block copies.  A block owns 16 float4 elements; its 16 thread groups each add every 16th copy
+// (g, g + 16, ...), then the 16 group sums are added in group order through LDS: a fixed order, and P / 16 loads deep
+// instead of P (the first layers' dW is 7 168 floats under 128 copies: one thread per element walked 128 dependent-ish
+// loads in 7 blocks -- most of that layer's 59 us).
 __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                               size_t count4, int p) {
-  const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= count4) return;
+  __shared__ float4 part[16][16];
+  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const size_t i = size_t(blockIdx.x) * 16 + el;
   const float4* src = reinterpret_cast<const float4*>(ws);
-  float4 v = src[i];
-  for (int q = 1; q < p; ++q) {
-    const float4 t = src[size_t(q) * count4 + i];
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < count4) {
+    for (int q = grp; q < p; q += 16) {
+      const float4 t = src[size_t(q) * count4 + i];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
   }
-  reinterpret_cast<float4*>(dw)[i] = v;
+  part[grp][el] = v;
+  __syncthreads();
+  if (grp == 0 && i < count4) {
+    float4 r = part[0][el];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) {
+      const float4 t = part[g][el];
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = r;
+  }
 }
 
 static WrwPlan wrw_plan(const ConvDims& d, int forced_s, int forced_p) {
@@ -746,13 +762,14 @@ static WrwPlan wrw_plan(const ConvDims& d, int forced_s, int forced_p) {
   const long tiles = long(p.tiles_co) * p.tiles_k;
   const int total_pairs = d.m / 2;
   const int batch = 4;
-  long waves = (1024 + tiles - 1) / tiles;  // per tile: one wave of 4 MFMA streams per SIMD chip-wide
+  long waves = (2048 + tiles - 1) / tiles;  // per tile: two waves of 4 MFMA streams per SIMD chip-wide
   if (waves > (total_pairs + 2 * batch - 1) / (2 * batch)) waves = (total_pairs + 2 * batch - 1) / (2 * batch);
   if (waves < 1) waves = 1;
   int s = 1;
   while (s < 4 && s * 2 <= waves) s *= 2;
   if (forced_s > 0) s = forced_s > 4 ? 4 : forced_s;
   int pb = int((waves + s - 1) / s);
+  if (pb > 256) pb = 256;  // beyond 256 copies of dW the reduce launch costs more than the shorter pixel ranges save
   if (forced_p > 0) pb = forced_p;
   p.s = s;
   p.pairs_per_wave = (total_pairs + pb * s - 1) / (pb * s);
@@ -925,7 +942,7 @@ int expo_conv4x4s2_wrw(const float* x, const float* dy, float* dw, int n, int h,
   HIP_TRY(hipGetLastError(), "conv4x4s2_wrw launch");
   if (pl.p > 1) {
     const size_t count4 = count / 4;
-    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(unsigned((count4 + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(unsigned((count4 + 15) / 16)), dim3(256), 0, s,
                        static_cast<const float*>(workspace), dw, count4, pl.p);
     HIP_TRY(hipGetLastError(), "conv4x4s2_wrw reduce launch");
   }

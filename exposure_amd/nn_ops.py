@@ -150,11 +150,12 @@ class _ConvG(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, g, w_like):
     ctx.save_for_backward(x, g)
-    # OFF by default: measured on par with MIOpen's kernel + its zero fill for the deeper layers (21-27 vs 24-26 us, two
-    # launches either way) and 2-3x slower for the first layers (profiles/r05_p7_conv_wrw_v2.txt).  What it offers is a
-    # fixed summation order (MIOpen's split-K kernels add with float atomics): EXPO_HIP_CONV_WRW=1.
-    if (os.environ.get('EXPO_HIP_CONV_WRW', '0') == '1' and _hip_conv(x, w_like) and g.dtype == torch.float32 and
-        g.shape[2] % 2 == 0):
+    # EXPO_HIP_CONV_WRW: 0 = MIOpen's kernel for every layer (default), 1 = expo_conv4x4s2_wrw for every layer (a fixed
+    # summation order; MIOpen's split-K kernels add with float atomics), auto = in-house where it measured faster than
+    # MIOpen's kernel + the zero fill that one needs: 24 <= C_in < 128 (profiles/r05_p8_conv_wrw_reduce.txt).
+    mode = os.environ.get('EXPO_HIP_CONV_WRW', '0')
+    if ((mode == '1' or (mode == 'auto' and 24 <= x.shape[3] < 128)) and _hip_conv(x, w_like) and
+        g.dtype == torch.float32 and g.shape[2] % 2 == 0):
       dw = torch.empty_like(w_like, memory_format=torch.preserve_format)  # the weight's own (channels_last) layout
       _cabi.conv4x4s2_wrw(x, g.contiguous(), dw)  # deterministic split over the pixels, no zero fill
       return dw
