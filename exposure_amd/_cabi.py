@@ -838,22 +838,6 @@ def conv_tuning(tile=0, nt=0, slices=0):
   _check(load().expo_conv_tuning(int(tile), int(nt), int(slices)), 'expo_conv_tuning')
 
 
-_CONV_WS = {}  # device index -> scratch of the weight-gradient kernel (the P block copies of dW)
-
-
-def conv_wrw_workspace(device, nbytes):
-  """The device's weight-gradient scratch, at least ``nbytes`` large (no initialisation needed).  It cannot be
-  (re)allocated during a hipGraph capture -- the eager warm-up step of a captured training step has already sized it."""
-  key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-  ws = _CONV_WS.get(key)
-  if ws is None or ws.numel() < nbytes:
-    if torch.cuda.is_current_stream_capturing():
-      raise ExposureHipError('exposure_amd: the weight-gradient workspace must exist before a hipGraph capture starts '
-                             '(run the step once eagerly)')
-    ws = _CONV_WS[key] = torch.empty(max(int(nbytes), 8 << 20), dtype=torch.uint8, device=device)
-  return ws
-
-
 def conv4x4s2_wrw(x, dy, dw):
   """dw = the weight gradient of conv4x4s2: NHWC float32 ``x`` (N, H, W, Cin), ``dy`` (N, H/2, W/2, Cout), ``dw`` a
   (Cout, Cin, 4, 4) tensor in channels_last memory order, every element written (expo_conv4x4s2_wrw)."""
@@ -864,7 +848,9 @@ def conv4x4s2_wrw(x, dy, dw):
   assert dy.dtype == torch.float32 and dy.is_contiguous() and tuple(dy.shape) == (n, h // 2, wd // 2, cout)
   assert dw.dtype == torch.float32 and tuple(dw.shape) == (cout, cin, 4, 4) and dw.permute(0, 2, 3, 1).is_contiguous()
   need = int(lib.expo_conv4x4s2_wrw_workspace_bytes(n, h, wd, cin, cout))
-  ws = conv_wrw_workspace(x.device, need) if need else None
+  # the P block copies of dW: scratch from torch's caching allocator per call (stream-ordered reuse; inside a hipGraph
+  # capture it comes from the graph's private pool) -- a buffer cached per device would be shared between streams
+  ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
   with torch.cuda.device(x.device):
     _check(lib.expo_conv4x4s2_wrw(_ptr(x), _ptr(dy), _ptr(dw), n, h, wd, cin, cout,
                                   ctypes.c_void_p(ws.data_ptr() if ws is not None else 0),
