@@ -770,6 +770,9 @@ static WrwPlan wrw_plan(const ConvDims& d, int forced_s, int forced_p) {
   if (forced_s > 0) s = forced_s > 4 ? 4 : forced_s;
   int pb = int((waves + s - 1) / s);
   if (pb > 256) pb = 256;  // beyond 256 copies of dW the reduce launch costs more than the shorter pixel ranges save
+  // one round of blocks: a 4-wave block holds 64 KB of LDS for its reduction, so a CU takes two and the chip 512 --
+  // 3 tiles x 171 parts = 513 blocks ran the 17-plane layer in two rounds (49.6 us; 39.3 with 128 parts)
+  if (long(pb) * tiles > 512) pb = int(512 / tiles) > 0 ? int(512 / tiles) : 1;
   if (forced_p > 0) pb = forced_p;
   p.s = s;
   p.pairs_per_wave = (total_pairs + pb * s - 1) / (pb * s);

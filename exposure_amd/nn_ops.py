@@ -152,7 +152,7 @@ class _ConvG(torch.autograd.Function):
     ctx.save_for_backward(x, g)
     # EXPO_HIP_CONV_WRW: 0 = MIOpen's kernel for every layer (default), 1 = expo_conv4x4s2_wrw for every layer (a fixed
     # summation order; MIOpen's split-K kernels add with float atomics), auto = in-house where it measured faster than
-    # MIOpen's kernel + the zero fill that one needs: 24 <= C_in < 128 (profiles/r05_p8_conv_wrw_reduce.txt).
+    # MIOpen's zero fill + kernel pair: 24 <= C_in < 128 (19.4 / 19.5 vs 21.3 / 20.4 us, profiles/r05_final_conv_bench.txt).
     mode = os.environ.get('EXPO_HIP_CONV_WRW', '0')
     if ((mode == '1' or (mode == 'auto' and 24 <= x.shape[3] < 128)) and _hip_conv(x, w_like) and
         g.dtype == torch.float32 and g.shape[2] % 2 == 0):

@@ -191,7 +191,7 @@ def bench_bwd_wrw(dev, reps):
         _cabi.conv_tuning(0, nt, sl)
         rb['n%ds%d' % (nt, sl)] = timeit(lambda: _cabi.conv4x4s2_bwd_data(g, w, dx), reps)
       rw = {}
-      for sl, parts in ((0, 0), (4, 0), (2, 0), (1, 0), (4, 8), (4, 32), (4, 128), (2, 64)):
+      for sl, parts in ((0, 0), (4, 0), (2, 0), (1, 0), (4, 8), (4, 32), (4, 128), (4, 256), (2, 64)):
         _cabi.conv_wrw_tuning(sl, parts)
         rw['s%dp%d' % (sl, parts)] = timeit(lambda: _cabi.conv4x4s2_wrw(x, g, dw), reps)
       _cabi.conv_wrw_tuning(0, 0)
@@ -206,7 +206,7 @@ def bench_bwd_wrw(dev, reps):
       tot['bwd_lib'] += t_bl
       tot['bwd'] += rb['n0s0']
       tot['wrw_lib'] += t_wl
-  print('sums (auto): bwd MIOpen %.1f ours %.1f | wrw MIOpen %.1f (+ a zero fill each) ours %.1f (incl. the reduce launch)' %
+  print('sums (auto): bwd MIOpen %.1f ours %.1f | wrw MIOpen %.1f ours %.1f (each incl. everything the call launches: the zero fill of MIOpen, the reduce launch here)' %
         (tot['bwd_lib'], tot['bwd'], tot['wrw_lib'], tot['wrw']))
 
 
