@@ -7,8 +7,8 @@ import conv_bench as cb
 from exposure_amd import _cabi
 
 dev = torch.device('cuda:0')
-SETS = {0: ((0, 0), (4, 128), (4, 256)), 1: ((0, 0), (4, 256)), 2: ((0, 0), (4, 128), (4, 192)), 3: ((0, 0), (4, 32), (4, 64)),
-        4: ((0, 0), (4, 8), (4, 16), (4, 32), (2, 16)), 5: ((0, 0), (4, 2), (4, 4), (4, 8), (2, 8))}
+SETS = {0: ((0, 0), (4, 128), (4, 256), (4, 384)), 1: ((0, 0), (4, 256), (4, 512), (4, 768)), 2: ((0, 0), (4, 128), (4, 170), (4, 256)),
+        3: ((0, 0), (4, 64), (4, 96), (4, 128)), 4: ((0, 0), (4, 16), (4, 24), (4, 32)), 5: ((0, 0), (4, 4), (4, 6), (4, 8))}
 for n in (64, 128):
   for li, (cin, h, cout) in enumerate(cb.LAYERS):
     x, w, b = cb.make(n, h, cin, cout, dev)
