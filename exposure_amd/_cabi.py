@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # never a non-HIP implementation.
 LIB_PATH = os.environ.get('EXPO_HIP_LIB') or os.path.join(_HERE, 'libexposure_hip.so')
 
-EXPO_ABI_VERSION = 4
+EXPO_ABI_VERSION = 6
 EXPO_CURVE_MAX_STEPS = 16
 EXPO_F16, EXPO_F32 = 0, 1
 EXPO_MAX_PARAMS = 24
@@ -28,6 +28,7 @@ _vp, _i, _fp, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c
 SIGNATURES = {
     'expo_version': (_i, []),
     'expo_last_error': (ctypes.c_char_p, []),
+    'expo_build_info': (ctypes.c_char_p, []),
     'expo_num_filter_params': (_i, [_i]),
     'expo_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'expo_filter_fwd': (_i, [_i, _vp, _vp, _fp, _i, _i, _i, _i, _vp]),
@@ -53,6 +54,13 @@ SIGNATURES = {
     'expo_conv4x4s2_wrw_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'expo_conv4x4s2_wrw': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_conv_wrw_tuning': (_i, [_i, _i]),
+    'expo_conv4x4s2_bwd_data_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
+    'expo_conv4x4s2_fwd_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
+    'expo_conv4x4s2_wrw_bias': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_critic_head_fwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _fp, _vp]),
+    'expo_critic_head_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
+    'expo_plane_sums': (_i, [_fp, _fp, _i, _sz, _i, _i, _vp]),
+    'expo_gp_direct': (_i, [_fp, _i, _fp, _f, _fp, _fp, _fp, _i, _sz, _vp]),
     'expo_chain_release': (_i, [_vp]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
                             _vp]),
@@ -113,8 +121,35 @@ def load():
   ver = lib.expo_version()
   if ver != EXPO_ABI_VERSION:
     raise ExposureHipError('exposure_amd: ABI version mismatch (library %d, binding %d)' % (ver, EXPO_ABI_VERSION))
+  # the binary must come from THESE sources (it is git-ignored and travels prebuilt): csrc/build.sh bakes the digest in
+  built, tree = (lib.expo_build_info() or b'').decode(), source_digest()
+  if tree is not None and built != tree and os.environ.get('EXPO_ALLOW_STALE_LIB') != '1' and not os.environ.get('EXPO_HIP_LIB'):
+    raise ExposureHipError(
+        'exposure_amd: %s was built from other sources (binary %s, tree %s) -- rebuild with exposure_amd/csrc/build.sh '
+        '(EXPO_ALLOW_STALE_LIB=1 loads it anyway)' % (LIB_PATH, built[:16], tree[:16]))
   _lib = lib
   return lib
+
+
+def source_digest():
+  """sha256 over csrc/*.hip, csrc/*.h, csrc/build.sh (byte order of the names) behind include/exposure_hip.h -- what
+  csrc/build.sh passes to the compiler as EXPO_SOURCE_DIGEST; None when the sources are not there (an installed copy)."""
+  import hashlib
+  csrc = os.path.join(_HERE, 'csrc')
+  header = os.path.join(_HERE, '..', 'include', 'exposure_hip.h')
+  if not (os.path.isdir(csrc) and os.path.exists(header)):
+    return None
+  names = sorted(f for f in os.listdir(csrc) if f.endswith(('.hip', '.h')) or f == 'build.sh')
+  h = hashlib.sha256()
+  for path in [header] + [os.path.join(csrc, f) for f in names]:
+    with open(path, 'rb') as fh:
+      h.update(fh.read())
+  return h.hexdigest()
+
+
+def build_info():
+  """The source digest baked into the loaded binary (expo_build_info)."""
+  return (load().expo_build_info() or b'').decode()
 
 
 def _check(rc, what):
@@ -855,6 +890,114 @@ def conv4x4s2_wrw(x, dy, dw):
     _check(lib.expo_conv4x4s2_wrw(_ptr(x), _ptr(dy), _ptr(dw), n, h, wd, cin, cout,
                                   ctypes.c_void_p(ws.data_ptr() if ws is not None else 0),
                                   ctypes.c_size_t(ws.numel() if ws is not None else 0), _stream()), 'expo_conv4x4s2_wrw')
+
+
+def _conv_args(x_shape, w):
+  n, h, wd, cin = x_shape
+  cout = w.shape[0]
+  assert w.dtype == torch.float32 and tuple(w.shape) == (cout, cin, 4, 4) and w.permute(0, 2, 3, 1).is_contiguous()
+  return n, h, wd, cin, cout
+
+
+def conv4x4s2_bwd_data_mask(dy, w, zmask, dx, leak=0.2):
+  """dx = D(dy, w) * slope(zmask): the data gradient with the lrelu backward of the layer below in its epilogue
+  (expo_conv4x4s2_bwd_data_mask); ``zmask`` = that layer's activation, shaped like ``dx``."""
+  lib = load()
+  n, h, wd, cin, cout = _conv_args(dx.shape, w)
+  assert dy.is_cuda and dy.dtype == torch.float32 and dy.is_contiguous() and tuple(dy.shape) == (n, h // 2, wd // 2, cout)
+  assert dx.dtype == torch.float32 and dx.is_contiguous()
+  assert zmask.dtype == torch.float32 and zmask.is_contiguous() and zmask.shape == dx.shape
+  with torch.cuda.device(dy.device):
+    _check(lib.expo_conv4x4s2_bwd_data_mask(_ptr(dy), _ptr(w), _ptr(zmask), _ptr(dx), n, h, wd, cin, cout, float(leak),
+                                            _stream()), 'expo_conv4x4s2_bwd_data_mask')
+
+
+def conv4x4s2_fwd_mask(x, w, zmask, y, leak=0.2):
+  """y = conv(x, w) * slope(zmask) (expo_conv4x4s2_fwd_mask); ``y`` may be ``zmask`` itself (written in place)."""
+  lib = load()
+  n, h, wd, cin, cout = _conv_args(x.shape, w)
+  assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+  for t in (y, zmask):
+    assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (n, h // 2, wd // 2, cout)
+  with torch.cuda.device(x.device):
+    _check(lib.expo_conv4x4s2_fwd_mask(_ptr(x), _ptr(w), _ptr(zmask), _ptr(y), n, h, wd, cin, cout, float(leak),
+                                       _stream()), 'expo_conv4x4s2_fwd_mask')
+
+
+def conv4x4s2_wrw_bias(x, dy, dw, dbias, bias_images=None):
+  """conv4x4s2_wrw and, in the same pass, ``dbias[co]`` = the sum of ``dy[..., co]`` over the first ``bias_images``
+  images (default: all) -- expo_conv4x4s2_wrw_bias."""
+  lib = load()
+  n, h, wd, cin = x.shape
+  cout = dy.shape[-1]
+  assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+  assert dy.dtype == torch.float32 and dy.is_contiguous() and tuple(dy.shape) == (n, h // 2, wd // 2, cout)
+  assert dw.dtype == torch.float32 and tuple(dw.shape) == (cout, cin, 4, 4) and dw.permute(0, 2, 3, 1).is_contiguous()
+  _f32(dbias, 'dbias', (cout,))
+  need = int(lib.expo_conv4x4s2_wrw_workspace_bytes(n, h, wd, cin, cout))
+  ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
+  with torch.cuda.device(x.device):
+    _check(lib.expo_conv4x4s2_wrw_bias(_ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), n if bias_images is None else int(bias_images),
+                                       n, h, wd, cin, cout, ctypes.c_void_p(ws.data_ptr() if ws is not None else 0),
+                                       ctypes.c_size_t(ws.numel() if ws is not None else 0), _stream()),
+           'expo_conv4x4s2_wrw_bias')
+
+
+def critic_head_fwd(hpre, w2, b2, n_real, n_fake, n_interp, inv_n, logits, h, dh, scalars, leak=0.2):
+  """expo_critic_head_fwd: fc1 activation, fc2, the rows' upstream gradients and the mean logits of the batched critic pass."""
+  lib = load()
+  m, hidden = hpre.shape
+  assert m == n_real + n_fake + n_interp
+  for t in (hpre, h, dh):
+    _f32(t, 'hpre / h / dh', (m, hidden))
+  assert w2.is_cuda and w2.dtype == torch.float32 and w2.is_contiguous() and w2.numel() == hidden
+  assert b2.is_cuda and b2.dtype == torch.float32 and b2.numel() == 1
+  _f32(logits, 'logits', (m,))
+  assert scalars.is_cuda and scalars.dtype == torch.float32 and scalars.is_contiguous() and scalars.numel() >= 2
+  with torch.cuda.device(hpre.device):
+    _check(lib.expo_critic_head_fwd(_ptr(hpre), _ptr(w2), _ptr(b2), int(n_real), int(n_fake), int(n_interp), hidden,
+                                    float(inv_n), float(leak), _ptr(logits), _ptr(h), _ptr(dh), _ptr(scalars), _stream()),
+           'expo_critic_head_fwd')
+
+
+def critic_head_bwd(dh, h, thpre, n_real, n_fake, n_interp, inv_n, gb1, gw2, gb2, leak=0.2):
+  """expo_critic_head_bwd: fc1 bias / fc2 weight / fc2 bias gradients of the loss rows and of the penalty's tangent."""
+  lib = load()
+  m, hidden = h.shape
+  assert m == n_real + n_fake + n_interp
+  _f32(dh, 'dh', (m, hidden)), _f32(h, 'h', (m, hidden))
+  if n_interp:
+    _f32(thpre, 'thpre', (n_interp, hidden))
+  for t, k in ((gb1, hidden), (gw2, hidden), (gb2, 1)):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == k
+  with torch.cuda.device(h.device):
+    _check(lib.expo_critic_head_bwd(_ptr(dh), _ptr(h), _ptr(thpre), int(n_real), int(n_fake), int(n_interp), hidden,
+                                    float(inv_n), float(leak), _ptr(gb1), _ptr(gw2), _ptr(gb2), _stream()),
+           'expo_critic_head_bwd')
+
+
+def plane_sums(x, sums, first):
+  """sums[n, c - first] = x[n, ..., c] summed over the pixels, first <= c < C (expo_plane_sums)."""
+  lib = load()
+  n, c = x.shape[0], x.shape[-1]
+  assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+  _f32(sums, 'sums', (n, c - first))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_plane_sums(_ptr(x), _ptr(sums), n, x[0].numel() // c if n else 0, c, int(first), _stream()),
+           'expo_plane_sums')
+
+
+def gp_direct(u, ds, scale, v, norm, term):
+  """g = u[..., :3] + ds; per image norm / penalty term and v = scale * d term / d g in one launch (expo_gp_direct)."""
+  lib = load()
+  n, c = u.shape[0], u.shape[-1]
+  assert u.is_cuda and u.dtype == torch.float32 and u.is_contiguous() and c >= 3
+  for t in (ds, v):
+    assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(u.shape[:-1]) + (3,)
+  _f32(norm, 'norm', (n,)), _f32(term, 'term', (n,))
+  with torch.cuda.device(u.device):
+    _check(lib.expo_gp_direct(_ptr(u), c, _ptr(ds), float(scale), _ptr(v), _ptr(norm), _ptr(term), n,
+                              u[0].numel() // c if n else 0, _stream()), 'expo_gp_direct')
 
 
 def conv_wrw_tuning(slices=0, parts=0):

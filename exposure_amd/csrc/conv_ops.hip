@@ -46,6 +46,10 @@ struct ConvDims {
 };
 
 __device__ __forceinline__ float lrelu_v(float v, float leak) { return v > 0.f ? v : v * leak; }
+// d lrelu / d (its argument), read from the OUTPUT z (nn_ops.hip: lrelu keeps sign and zero; TF's sub-gradient at 0)
+__device__ __forceinline__ float lrelu_slope_v(float z, float leak) {
+  return z > 0.f ? 1.0f : (z < 0.f ? leak : 0.5f * (1.0f + leak));
+}
 
 constexpr int kConvPad = 4;  // floats of row padding in LDS
 
@@ -137,8 +141,10 @@ template <int BM, int BN, int WM, int WN, int WK, int BKS, bool CIN4>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_fwd_kernel(const float* __restrict__ x,
                                                                       const float* __restrict__ w,
                                                                       const float* __restrict__ bias,
-                                                                      float* __restrict__ y, ConvDims d, int act,
-                                                                      float leak) {
+                                                                      const float* zmask, float* y, ConvDims d,
+                                                                      int act, float leak) {
+  // zmask (nullable, may alias y): the result is multiplied by the lrelu slope read from zmask at the same position --
+  // the tangent pass of the gradient penalty's double backward, t_l = F(t_{l-1}, W_l) * slope(z_l), written over z_l
   constexpr int T = 64 * WM * WN * WK;
   static_assert(BKS % 8 == 0, "a wave group's K slice is consumed in chunks of 8");
   constexpr int BKT = BKS * WK;         // k per block step (BKS per wave group)
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_fwd_kernel(const float
         if (m < d.m && co < d.cout) {
           float v = acc[i][j][e] + b;
           if (act) v = lrelu_v(v, leak);
+          if (zmask) v *= lrelu_slope_v(zmask[size_t(m) * d.cout + co], leak);
           y[size_t(m) * d.cout + co] = v;
         }
       }
@@ -310,8 +317,8 @@ struct FlatPlan {
 
 template <int NI, bool CIN4>
 __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ y,
-                                                             ConvDims d, FlatPlan pl, int act, float leak) {
+                                                             const float* __restrict__ bias, const float* zmask,
+                                                             float* y, ConvDims d, FlatPlan pl, int act, float leak) {
   // NI = column tiles per WAVE (32 x 32 NI outputs): the A fragment is loaded once and feeds NI MFMAs -- 3 operand
   // loads per 8 MFMAs instead of 2 per 4 for NI = 2
   extern __shared__ __attribute__((aligned(16))) float part[];  // [s][NI][16][64]
@@ -409,6 +416,7 @@ __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __rest
     if (mo < d.m && col < d.cout) {
       if (bias) val += bias[col];
       if (act) val = lrelu_v(val, leak);
+      if (zmask) val *= lrelu_slope_v(zmask[size_t(mo) * d.cout + col], leak);
       y[size_t(mo) * d.cout + col] = val;
     }
   };
@@ -463,7 +471,10 @@ static FlatPlan flat_plan(const ConvDims& d, int ni, int forced_s) {
 // cut along (tap, co range): G = 4 S2 segments of RS = roundup8(Cout / S2) channels.
 template <int NI>
 __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                             float* __restrict__ dx, ConvDims d, FlatPlan pl) {
+                                                             const float* __restrict__ zmask, float* __restrict__ dx,
+                                                             ConvDims d, FlatPlan pl, float leak) {
+  // zmask (nullable, the layer BELOW's activation z, shaped like dx): dx *= slope(z) -- the activation gradient of the
+  // layer below in this kernel's epilogue instead of a launch of its own
   // NI = input-channel tiles per wave (32 pixels x 32 NI channels): the dY fragment is loaded once for NI MFMAs
   extern __shared__ __attribute__((aligned(16))) float part[];  // [s][NI][16][64]
   const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -560,7 +571,9 @@ __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __rest
     if (mo < d.m && c < d.cin) {
       const int no = mo / (d.ho * d.wo), ro = mo - no * (d.ho * d.wo);
       const int ao = ro / d.wo, bo = ro - ao * d.wo;
-      dx[(size_t(no * d.h + 2 * ao + ph) * d.w + 2 * bo + pw) * d.cin + c] = val;
+      const size_t o = (size_t(no * d.h + 2 * ao + ph) * d.w + 2 * bo + pw) * d.cin + c;
+      if (zmask) val *= lrelu_slope_v(zmask[o], leak);
+      dx[o] = val;
     }
   };
   if (pl.s > 1) {
@@ -601,6 +614,66 @@ static FlatPlan bwd_plan(const ConvDims& d, int ni, int forced_s) {
   return p;
 }
 
+// ---- data gradient of the FIRST layers (6 / 17 input planes: critic, value net) on the vector ALUs ----------------------
+// With Cin = 6 a 32-wide tile of input channels is 81 % padding: the matrix-core kernel above takes 47 us for 0.4 GFLOP.
+// Here a THREAD owns one input pixel of one parity class (ph, pw) -- blockIdx.y, so the taps and the weights are
+// wave-uniform -- and all CIN channels of it: per 4 output channels it loads one 16-byte chunk of dY for each of its 4
+// taps' pixels and issues 16 CIN FMAs whose weight operand is a SCALAR register (the weight index depends on loop
+// counters only: s_load through the scalar cache, no LDS, no vector loads for W).  No padding work: 768 FMAs per thread
+// for Cin = 6 (2.6 us chip-wide at batch 64), 2176 for Cin = 17.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             const float* __restrict__ zmask, float* __restrict__ dx,
+                                                             ConvDims d, float leak) {
+  const int cls = blockIdx.y, ph = cls >> 1, pw = cls & 1;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const bool m_ok = m < d.m;
+  const int mm = m_ok ? m : 0;
+  const int n = mm / (d.ho * d.wo), rem = mm - n * (d.ho * d.wo);
+  const int a = rem / d.wo, b = rem - a * d.wo;
+  const __amdgpu_buffer_rsrc_t rg = conv_rsrc(dy, size_t(d.n) * d.ho * d.wo * d.cout);
+  int goff[4];
+  bool gok[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int oh = a + ph - (t >> 1), ow = b + pw - (t & 1);
+    gok[t] = m_ok && unsigned(oh) < unsigned(d.ho) && unsigned(ow) < unsigned(d.wo);
+    goff[t] = ((n * d.ho + oh) * d.wo + ow) * d.cout;
+  }
+  float acc[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
+  float4 g[4], gn[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) g[t] = buf_load4(rg, goff[t], gok[t]);
+  for (int co = 0; co < d.cout; co += 4) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gn[t] = buf_load4(rg, goff[t] + co + 4, gok[t] && co + 4 < d.cout);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kh = 1 - ph + 2 * (t >> 1), kw = 1 - pw + 2 * (t & 1);
+      const float gv[4] = {g[t].x, g[t].y, g[t].z, g[t].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* wp = w + (size_t(co + j) * 16 + kh * 4 + kw) * CIN;  // wave-uniform: scalar loads
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) acc[c] = fmaf(gv[j], wp[c], acc[c]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) g[t] = gn[t];
+  }
+  if (m_ok) {
+    const size_t o = (size_t(n * d.h + 2 * a + ph) * d.w + 2 * b + pw) * CIN;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      float v = acc[c];
+      if (zmask) v *= lrelu_slope_v(zmask[o + c], leak);
+      dx[o + c] = v;
+    }
+  }
+}
+
 // ---- weight gradient -----------------------------------------------------------------------------------------------------
 //   dW[co][k2] = sum_m dY[m][co] A[m][k2],   m = (n, oh, ow),  k2 = (kh, kw, ci),  A = the forward's im2col matrix
 // A GEMM with the PIXELS as its K dimension (65536 ... 1024 of them at batch 64) and a small output (Cout x 16 Cin).
@@ -619,10 +692,16 @@ struct WrwPlan {
   int pairs_per_wave;     // pixel pairs (2 consecutive ow of one row) per wave
 };
 
+// Bias gradient in the same pass (db_out non-null): db[co] = the column sums of dY over the pixel pairs below `bias_pairs`
+// (the critic step batches passes whose bias gradients differ: only the first images' rows count) -- the waves of the
+// tiles with tk = 0 add up the dY values they feed to the matrix cores anyway; one float per block copy and channel.
 template <bool CIN4>
 __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       float* __restrict__ out, ConvDims d, WrwPlan pl) {
+                                                       float* __restrict__ out, size_t out_stride,
+                                                       float* __restrict__ db_out, size_t db_stride, int bias_pairs,
+                                                       ConvDims d, WrwPlan pl) {
   extern __shared__ __attribute__((aligned(16))) float part[];  // [s][64][64]: slot v = e * 4 + r
+  __shared__ float bpart[4][32];
   const int lane = threadIdx.x & 63;
   const int sl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tiles = pl.tiles_co * pl.tiles_k;
@@ -676,6 +755,8 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
   constexpr int U = 4;
   float ac[U], an[U];
   Chunk<CIN4> bc[U], bn[U];
+  const bool want_bias = db_out != nullptr && tk == 0;
+  float bsum = 0.f;
 #pragma unroll
   for (int u = 0; u < U; ++u) load_pair(ac[u], bc[u]);
 #pragma unroll 2
@@ -685,6 +766,7 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
     __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of the MFMAs that hide them
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      if (want_bias && q + u < bias_pairs) bsum += ac[u];  // (pairs past q1 were loaded as zeros)
       const float4 b = bc[u].get();
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b.x, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], b.y, acc[1], 0, 0, 0);
@@ -700,7 +782,17 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
 
   // accumulator register e of tile r, lane l: row (co) = (e & 3) + 8 (e >> 2) + 4 (l >> 5), column (k2) = 4 (l & 31) + r
   // -> the four tiles' register e is dW[row][k2_0 + 4 (l & 31) .. + 3]: one float4 per lane, 512 contiguous bytes per row
-  float* const dst = out + size_t(pb) * d.cout * d.kdim;  // this block's copy of dW (P = 1: dW itself)
+  if (want_bias) {  // (block-uniform) the two pixels of a pair sit in the two lane halves; waves are added in order
+    bsum += __shfl_xor(bsum, 32);
+    if (half == 0) bpart[sl][col] = bsum;
+    __syncthreads();
+    if (sl == 0 && half == 0 && co_ok) {
+      float v = bpart[0][col];
+      for (int q = 1; q < pl.s; ++q) v += bpart[q][col];
+      db_out[size_t(pb) * db_stride + co] = v;
+    }
+  }
+  float* const dst = out + size_t(pb) * out_stride;  // this block's copy of dW (P = 1: dW itself)
   auto store_row = [&](int e, const float4& v) {
     const int r_co = tc * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
     if (r_co < d.cout && k2_ok) *reinterpret_cast<float4*>(dst + size_t(r_co) * d.kdim + k2) = v;
@@ -730,7 +822,9 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
 // instead of P (the first layers' dW is 7 168 floats under 128 copies: one thread per element walked 128 dependent-ish
 // loads in 7 blocks -- most of that layer's 59 us).
 __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                              size_t count4, int p) {
+                                                              float* __restrict__ dbias, size_t dw4, size_t count4,
+                                                              size_t stride4, int p) {
+  // a copy = stride4 float4 elements of which count4 are summed: the first dw4 dW, the rest (if any) the bias gradient
   __shared__ float4 part[16][16];
   const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const size_t i = size_t(blockIdx.x) * 16 + el;
@@ -738,7 +832,7 @@ __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __res
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < count4) {
     for (int q = grp; q < p; q += 16) {
-      const float4 t = src[size_t(q) * count4 + i];
+      const float4 t = src[size_t(q) * stride4 + i];
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
   }
@@ -751,7 +845,8 @@ __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __res
       const float4 t = part[g][el];
       r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
     }
-    reinterpret_cast<float4*>(dw)[i] = r;
+    if (i < dw4) reinterpret_cast<float4*>(dw)[i] = r;
+    else reinterpret_cast<float4*>(dbias)[i - dw4] = r;
   }
 }
 
@@ -783,15 +878,15 @@ static WrwPlan wrw_plan(const ConvDims& d, int forced_s, int forced_p) {
 }
 
 template <int BM, int BN, int WM, int WN, int WK, int BKS>
-static void launch_fwd(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, int act,
-                       float leak, hipStream_t s) {
+static void launch_fwd(const float* x, const float* w, const float* bias, const float* zmask, float* y,
+                       const ConvDims& d, int act, float leak, hipStream_t s) {
   const int blocks = ((d.m + BM - 1) / BM) * ((d.cout + BN - 1) / BN);
   if (d.cin % 4 == 0)
     hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WK, BKS, true>), dim3(blocks), dim3(64 * WM * WN * WK), 0, s, x, w,
-                       bias, y, d, act, leak);
+                       bias, zmask, y, d, act, leak);
   else
     hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WK, BKS, false>), dim3(blocks), dim3(64 * WM * WN * WK), 0, s, x, w,
-                       bias, y, d, act, leak);
+                       bias, zmask, y, d, act, leak);
 }
 
 static int conv_dims(ConvDims* d, int n, int h, int w, int cin, int cout) {
@@ -807,26 +902,27 @@ static int conv_dims(ConvDims* d, int n, int h, int w, int cin, int cout) {
 
 // Decomposition overrides (probes and tests; 0 = the library's own choice): read from the environment ONCE --
 // EXPO_CONV_TILE (1-4: an LDS-tiled forward shape, 5: the flat kernel), EXPO_CONV_NT (column tiles per wave, 1 | 2),
-// EXPO_CONV_SLICES (K slices) -- and settable through expo_conv_tuning() afterwards (no getenv on the launch path: the
-// backward kernels are launched from autograd's worker thread while the host thread may be in putenv).
+// EXPO_CONV_SLICES (K slices of the forward / data-gradient kernels: 1, 2, 4, 8 or 16), EXPO_CONV_WRW_SLICES (waves per
+// block of the weight-gradient kernel: 1 .. 4), EXPO_CONV_PARTS (its block copies) -- and settable through
+// expo_conv_tuning() / expo_conv_wrw_tuning() afterwards (no getenv on the launch path: the backward kernels are launched
+// from autograd's worker thread while the host thread may be in putenv).
+static bool pow2_upto(int v, int hi) { return v >= 1 && v <= hi && (v & (v - 1)) == 0; }
 struct ConvTuning {
-  std::atomic<int> tile, nt, slices, parts;
+  std::atomic<int> tile, nt, slices, wrw_slices, parts;
   ConvTuning() : tile(env_int("EXPO_CONV_TILE", 0)), nt(env_int("EXPO_CONV_NT", 0)), slices(env_int("EXPO_CONV_SLICES", 0)),
-                 parts(env_int("EXPO_CONV_PARTS", 0)) {}
+                 wrw_slices(env_int("EXPO_CONV_WRW_SLICES", 0)), parts(env_int("EXPO_CONV_PARTS", 0)) {
+    // the kernels cut K into 4 S2 segments, S | 4 S2: anything but a power of two would silently drop segments
+    if (slices.load() != 0 && !pow2_upto(slices.load(), 16)) slices.store(0);
+    if (wrw_slices.load() > 4) wrw_slices.store(4);  // (the weight-gradient kernel takes any 1 .. 4 waves per block)
+  }
 };
 static ConvTuning& conv_tuning() {
   static ConvTuning t;
   return t;
 }
 
-}  // namespace expo
-
-using namespace expo;
-
-extern "C" {
-
-int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cin,
-                       int cout, int act, float leak, void* stream) {
+static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* zmask, float* y, int n, int h,
+                         int wd, int cin, int cout, int act, float leak, void* stream) {
   ConvDims d;
   if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
   if (n == 0) return EXPO_OK;
@@ -856,7 +952,7 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
     const int nblocks = pl.tiles_m * pl.tiles_n;
     const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
 #define EXPO_FLAT(NI, C4) \
-  hipLaunchKernelGGL((conv_fwd_flat_kernel<NI, C4>), dim3(nblocks), dim3(64 * pl.s), lds, s, x, w, bias, y, d, pl, act, leak)
+  hipLaunchKernelGGL((conv_fwd_flat_kernel<NI, C4>), dim3(nblocks), dim3(64 * pl.s), lds, s, x, w, bias, zmask, y, d, pl, act, leak)
     if (ni == 2) { if (d.cin % 4 == 0) EXPO_FLAT(2, true); else EXPO_FLAT(2, false); }
     else { if (d.cin % 4 == 0) EXPO_FLAT(1, true); else EXPO_FLAT(1, false); }
 #undef EXPO_FLAT
@@ -864,18 +960,113 @@ int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float*
     return EXPO_OK;
   }
   switch (shape) {
-    case 1: launch_fwd<64, 32, 2, 1, 2, 32>(x, w, bias, y, d, act, leak, s); break;
-    case 2: launch_fwd<64, 64, 2, 2, 1, 32>(x, w, bias, y, d, act, leak, s); break;
-    case 3: launch_fwd<32, 64, 1, 2, 2, 32>(x, w, bias, y, d, act, leak, s); break;
-    default: launch_fwd<32, 32, 1, 1, 4, 16>(x, w, bias, y, d, act, leak, s); break;
+    case 1: launch_fwd<64, 32, 2, 1, 2, 32>(x, w, bias, zmask, y, d, act, leak, s); break;
+    case 2: launch_fwd<64, 64, 2, 2, 1, 32>(x, w, bias, zmask, y, d, act, leak, s); break;
+    case 3: launch_fwd<32, 64, 1, 2, 2, 32>(x, w, bias, zmask, y, d, act, leak, s); break;
+    default: launch_fwd<32, 32, 1, 1, 4, 16>(x, w, bias, zmask, y, d, act, leak, s); break;
   }
   HIP_TRY(hipGetLastError(), "conv4x4s2_fwd launch");
   return EXPO_OK;
 }
 
+static int conv_bwd_data_impl(const float* dy, const float* w, const float* zmask, float* dx, int n, int h, int wd,
+                              int cin, int cout, float leak, void* stream) {
+  ConvDims d;
+  if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!dy || !w || !dx) return fail(EXPO_E_BADARG, "null pointer");
+  if (cout % 4 != 0) return fail(EXPO_E_BADARG, "conv4x4s2_bwd_data: cout must be a multiple of 4");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int ni = conv_tuning().nt.load();  // input-channel tiles per wave (0: the library's choice)
+  const int forced_s = conv_tuning().slices.load();
+  // the first layers (6 / 17 input planes) on the vector ALUs (conv_bwd_small_kernel), unless a probe forces a plan
+  if (ni == 0 && forced_s == 0 && (cin == 6 || cin == 17) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+    const dim3 grid(unsigned((d.m + 255) / 256), 4);
+    if (cin == 6) hipLaunchKernelGGL(conv_bwd_small_kernel<6>, grid, dim3(256), 0, s, dy, w, zmask, dx, d, leak);
+    else hipLaunchKernelGGL(conv_bwd_small_kernel<17>, grid, dim3(256), 0, s, dy, w, zmask, dx, d, leak);
+    HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data (small) launch");
+    return EXPO_OK;
+  }
+  if (ni == 0) ni = d.cin >= 64 ? 2 : 1;  // (two tiles share the dY fragment: 2-10 % on the deeper layers)
+  if (ni != 1 && ni != 2) ni = 1;
+  if (d.cin <= 32) ni = 1;
+  const FlatPlan pl = bwd_plan(d, ni, forced_s);
+  const int nblocks = 4 * pl.tiles_m * pl.tiles_n;
+  const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
+  if (ni == 2) hipLaunchKernelGGL(conv_bwd_flat_kernel<2>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, zmask, dx, d, pl, leak);
+  else hipLaunchKernelGGL(conv_bwd_flat_kernel<1>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, zmask, dx, d, pl, leak);
+  HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data launch");
+  return EXPO_OK;
+}
+
+// a block copy of the weight-gradient workspace: dW (cout x 16 cin floats) followed by the bias gradient (cout floats,
+// padded to whole float4s)
+static size_t wrw_copy_floats(const ConvDims& d) { return size_t(d.cout) * d.kdim + size_t((d.cout + 3) / 4 * 4); }
+
+static int conv_wrw_impl(const float* x, const float* dy, float* dw, float* dbias, int bias_images, int n, int h, int wd,
+                         int cin, int cout, void* workspace, size_t workspace_bytes, void* stream) {
+  ConvDims d;
+  if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
+  if (!dw) return fail(EXPO_E_BADARG, "null pointer");
+  if ((reinterpret_cast<uintptr_t>(dw) & 15) != 0) return fail(EXPO_E_BADARG, "conv4x4s2_wrw: dw must be 16-byte aligned");
+  if (dbias && ((reinterpret_cast<uintptr_t>(dbias) & 15) != 0 || cout % 4 != 0))
+    return fail(EXPO_E_BADARG, "conv4x4s2_wrw: dbias must be 16-byte aligned and cout a multiple of 4");
+  if (bias_images < 0 || bias_images > n) return fail(EXPO_E_BADARG, "conv4x4s2_wrw: 0 <= bias_images <= n");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    HIP_TRY(hipMemsetAsync(dw, 0, size_t(cout) * d.kdim * 4, s), "conv4x4s2_wrw (empty batch)");
+    if (dbias) HIP_TRY(hipMemsetAsync(dbias, 0, size_t(cout) * 4, s), "conv4x4s2_wrw (empty batch)");
+    return EXPO_OK;
+  }
+  if (!x || !dy) return fail(EXPO_E_BADARG, "null pointer");
+  if (d.wo & 1) return fail(EXPO_E_BADARG, "conv4x4s2_wrw: w / 2 must be even (pixels are consumed in pairs)");
+  const WrwPlan pl = wrw_plan(d, conv_tuning().wrw_slices.load(), conv_tuning().parts.load());
+  const size_t count = size_t(cout) * d.kdim, copy = wrw_copy_floats(d);
+  if (pl.p > 1 && (!workspace || workspace_bytes < size_t(pl.p) * copy * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)))
+    return fail(EXPO_E_BADARG, "conv4x4s2_wrw: workspace too small or not 16-byte aligned (expo_conv4x4s2_wrw_workspace_bytes)");
+  float* const ws = static_cast<float*>(workspace);
+  float* out = pl.p > 1 ? ws : dw;
+  float* db_out = !dbias ? nullptr : (pl.p > 1 ? ws + count : dbias);
+  const size_t stride = pl.p > 1 ? copy : 0;
+  const int bias_pairs = bias_images * d.ho * (d.wo / 2);
+  const dim3 grid(unsigned(pl.tiles_co * pl.tiles_k) * pl.p), block(64 * pl.s);
+  const size_t lds = pl.s > 1 ? size_t(pl.s) * 16384 : 0;
+  if (d.cin % 4 == 0)
+    hipLaunchKernelGGL(conv_wrw_kernel<true>, grid, block, lds, s, x, dy, out, stride, db_out, stride, bias_pairs, d, pl);
+  else
+    hipLaunchKernelGGL(conv_wrw_kernel<false>, grid, block, lds, s, x, dy, out, stride, db_out, stride, bias_pairs, d, pl);
+  HIP_TRY(hipGetLastError(), "conv4x4s2_wrw launch");
+  if (pl.p > 1) {
+    const size_t dw4 = count / 4, count4 = dbias ? copy / 4 : dw4;
+    // (the copies' stride is `copy` floats either way: without a bias gradient the tail of a copy is not read)
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(unsigned((count4 + 15) / 16)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), dw, dbias, dw4, count4, copy / 4, pl.p);
+    HIP_TRY(hipGetLastError(), "conv4x4s2_wrw reduce launch");
+  }
+  return EXPO_OK;
+}
+
+}  // namespace expo
+
+using namespace expo;
+
+extern "C" {
+
+int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cin,
+                       int cout, int act, float leak, void* stream) {
+  return conv_fwd_impl(x, w, bias, nullptr, y, n, h, wd, cin, cout, act, leak, stream);
+}
+
+int expo_conv4x4s2_fwd_mask(const float* x, const float* w, const float* zmask, float* y, int n, int h, int wd, int cin,
+                            int cout, float leak, void* stream) {
+  if (!zmask) return fail(EXPO_E_BADARG, "null pointer");
+  return conv_fwd_impl(x, w, nullptr, zmask, y, n, h, wd, cin, cout, 0, leak, stream);
+}
+
 int expo_conv_tuning(int tile, int nt, int slices) {
   // probes / tests: override the decomposition of the convolution kernels (negative: leave as is; 0: the library's choice)
-  if (tile > 5 || nt > 2 || slices > 16) return fail(EXPO_E_BADARG, "conv tuning: tile <= 5, nt <= 2, slices <= 16");
+  if (tile > 5 || nt > 2 || (slices > 0 && !pow2_upto(slices, 16)))
+    return fail(EXPO_E_BADARG, "conv tuning: tile <= 5, nt <= 2, slices in {1, 2, 4, 8, 16}");
   if (tile >= 0) conv_tuning().tile.store(tile);
   if (nt >= 0) conv_tuning().nt.store(nt);
   if (slices >= 0) conv_tuning().slices.store(slices);
@@ -884,29 +1075,19 @@ int expo_conv_tuning(int tile, int nt, int slices) {
 
 int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, int h, int wd, int cin, int cout,
                             void* stream) {
-  ConvDims d;
-  if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
-  if (n == 0) return EXPO_OK;
-  if (!dy || !w || !dx) return fail(EXPO_E_BADARG, "null pointer");
-  if (cout % 4 != 0) return fail(EXPO_E_BADARG, "conv4x4s2_bwd_data: cout must be a multiple of 4");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  int ni = conv_tuning().nt.load();  // input-channel tiles per wave (0: the library's choice)
-  if (ni == 0) ni = d.cin >= 64 ? 2 : 1;  // (two tiles share the dY fragment: 2-10 % on the deeper layers)
-  if (ni != 1 && ni != 2) ni = 1;
-  if (d.cin <= 32) ni = 1;
-  const FlatPlan pl = bwd_plan(d, ni, conv_tuning().slices.load());
-  const int nblocks = 4 * pl.tiles_m * pl.tiles_n;
-  const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
-  if (ni == 2) hipLaunchKernelGGL(conv_bwd_flat_kernel<2>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, dx, d, pl);
-  else hipLaunchKernelGGL(conv_bwd_flat_kernel<1>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, dx, d, pl);
-  HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data launch");
-  return EXPO_OK;
+  return conv_bwd_data_impl(dy, w, nullptr, dx, n, h, wd, cin, cout, 0.f, stream);
+}
+
+int expo_conv4x4s2_bwd_data_mask(const float* dy, const float* w, const float* zmask, float* dx, int n, int h, int wd,
+                                 int cin, int cout, float leak, void* stream) {
+  if (!zmask) return fail(EXPO_E_BADARG, "null pointer");
+  return conv_bwd_data_impl(dy, w, zmask, dx, n, h, wd, cin, cout, leak, stream);
 }
 
 int expo_conv_wrw_tuning(int slices, int parts) {
-  // probes / tests: waves per block (1-4) and blocks per tile of the weight-gradient kernel (negative: leave; 0: auto)
+  // probes / tests: waves per block (1 .. 4) and blocks per tile of the weight-gradient kernel (negative: leave; 0: auto)
   if (slices > 4) return fail(EXPO_E_BADARG, "conv wrw tuning: slices <= 4");
-  if (slices >= 0) conv_tuning().slices.store(slices);
+  if (slices >= 0) conv_tuning().wrw_slices.store(slices);
   if (parts >= 0) conv_tuning().parts.store(parts);
   return EXPO_OK;
 }
@@ -914,42 +1095,19 @@ int expo_conv_wrw_tuning(int slices, int parts) {
 size_t expo_conv4x4s2_wrw_workspace_bytes(int n, int h, int wd, int cin, int cout) {
   ConvDims d;
   if (conv_dims(&d, n, h, wd, cin, cout) != EXPO_OK || n == 0) return 0;
-  const int fs = conv_tuning().slices.load();
-  const WrwPlan pl = wrw_plan(d, fs > 4 ? 4 : fs, conv_tuning().parts.load());
-  return pl.p > 1 ? size_t(pl.p) * cout * d.kdim * 4 : 0;
+  const WrwPlan pl = wrw_plan(d, conv_tuning().wrw_slices.load(), conv_tuning().parts.load());
+  return pl.p > 1 ? size_t(pl.p) * wrw_copy_floats(d) * 4 : 0;
 }
 
 int expo_conv4x4s2_wrw(const float* x, const float* dy, float* dw, int n, int h, int wd, int cin, int cout,
                        void* workspace, size_t workspace_bytes, void* stream) {
-  ConvDims d;
-  if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
-  if (!dw) return fail(EXPO_E_BADARG, "null pointer");
-  if ((reinterpret_cast<uintptr_t>(dw) & 15) != 0) return fail(EXPO_E_BADARG, "conv4x4s2_wrw: dw must be 16-byte aligned");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (n == 0) {
-    HIP_TRY(hipMemsetAsync(dw, 0, size_t(cout) * d.kdim * 4, s), "conv4x4s2_wrw (empty batch)");
-    return EXPO_OK;
-  }
-  if (!x || !dy) return fail(EXPO_E_BADARG, "null pointer");
-  if (d.wo & 1) return fail(EXPO_E_BADARG, "conv4x4s2_wrw: w / 2 must be even (pixels are consumed in pairs)");
-  const int fs = conv_tuning().slices.load();
-  const WrwPlan pl = wrw_plan(d, fs > 4 ? 4 : fs, conv_tuning().parts.load());
-  const size_t count = size_t(cout) * d.kdim;
-  if (pl.p > 1 && (!workspace || workspace_bytes < size_t(pl.p) * count * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15)))
-    return fail(EXPO_E_BADARG, "conv4x4s2_wrw: workspace too small or not 16-byte aligned (expo_conv4x4s2_wrw_workspace_bytes)");
-  float* out = pl.p > 1 ? static_cast<float*>(workspace) : dw;
-  const dim3 grid(unsigned(pl.tiles_co * pl.tiles_k) * pl.p), block(64 * pl.s);
-  const size_t lds = pl.s > 1 ? size_t(pl.s) * 16384 : 0;
-  if (d.cin % 4 == 0) hipLaunchKernelGGL(conv_wrw_kernel<true>, grid, block, lds, s, x, dy, out, d, pl);
-  else hipLaunchKernelGGL(conv_wrw_kernel<false>, grid, block, lds, s, x, dy, out, d, pl);
-  HIP_TRY(hipGetLastError(), "conv4x4s2_wrw launch");
-  if (pl.p > 1) {
-    const size_t count4 = count / 4;
-    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(unsigned((count4 + 15) / 16)), dim3(256), 0, s,
-                       static_cast<const float*>(workspace), dw, count4, pl.p);
-    HIP_TRY(hipGetLastError(), "conv4x4s2_wrw reduce launch");
-  }
-  return EXPO_OK;
+  return conv_wrw_impl(x, dy, dw, nullptr, 0, n, h, wd, cin, cout, workspace, workspace_bytes, stream);
+}
+
+int expo_conv4x4s2_wrw_bias(const float* x, const float* dy, float* dw, float* dbias, int bias_images, int n, int h,
+                            int wd, int cin, int cout, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dbias) return fail(EXPO_E_BADARG, "null pointer");
+  return conv_wrw_impl(x, dy, dw, dbias, bias_images, n, h, wd, cin, cout, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,227 @@
+// critic_step.hip -- the small kernels between the convolutions and GEMMs of the hand-scheduled WGAN-GP critic update
+// (net.py:126-199, 245-251; critics.py:42-98): exposure_amd/critic_direct.py runs the real, fake and interpolated
+// images as ONE batch through the critic, forms every first- and second-order quantity of
+//     c_loss = mean(D(fake) - D(real)) + lambda mean(max(||grad_x^ D(x^)|| - 1, 0)^2)
+// explicitly (no autograd graph), and needs a handful of per-row / per-image reductions on the way.  Each is one launch
+// with a fixed summation order.
+//
+//   expo_critic_head_fwd    fc1's pre-activation [M][hidden] -> h = lrelu(.), logit = h . w2 + b2, the upstream gradient
+//                           of every row's pre-activation (real rows -1/N, fake rows +1/N, interpolated rows 1: the
+//                           inner gradient d D(x^) / d x^ starts from ones, net.py:174-183), mean logits
+//   expo_critic_head_bwd    bias / fc2 gradients from the rows of the loss and from the penalty's tangent
+//   expo_plane_sums         per-image sums of the trailing planes of an NHWC tensor (the gradient that reaches the
+//                           statistics planes the critic appends to its input, critics.py:64-76)
+//   expo_gp_direct          g = u[..., :3] + ds; norm = sqrt(1e-6 + sum g^2); term = max(norm - 1, 0)^2 (net.py:185-187)
+//                           and the penalty's gradient with respect to g in the same launch
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/exposure_hip.h"
+#include "host_common.h"
+
+namespace expo {
+
+__device__ __forceinline__ float cs_lrelu(float v, float leak) { return v > 0.f ? v : v * leak; }
+__device__ __forceinline__ float cs_slope(float z, float leak) {
+  return z > 0.f ? 1.0f : (z < 0.f ? leak : 0.5f * (1.0f + leak));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// One block of 16 waves; wave w takes rows w, w + 16, ...  Row order of the batch: [real | fake | interpolated].
+__global__ __launch_bounds__(1024) void critic_head_fwd_kernel(const float* __restrict__ hpre, const float* __restrict__ w2,
+                                                               const float* __restrict__ b2, int n_real, int n_fake,
+                                                               int n_interp, int hidden, float inv_n, float leak,
+                                                               float* __restrict__ logits, float* __restrict__ h,
+                                                               float* __restrict__ dh, float* __restrict__ scalars) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = n_real + n_fake + n_interp;
+  const float bias = b2[0];
+  for (int m = wave; m < rows; m += 16) {
+    const float dl = m < n_real ? -inv_n : (m < n_real + n_fake ? inv_n : 1.0f);
+    float dot = 0.f;
+    for (int j = lane; j < hidden; j += 64) {
+      const float z = cs_lrelu(hpre[size_t(m) * hidden + j], leak);
+      const float wj = w2[j];
+      h[size_t(m) * hidden + j] = z;
+      dh[size_t(m) * hidden + j] = dl * wj * cs_slope(z, leak);
+      dot = fmaf(z, wj, dot);
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) logits[m] = dot + bias;
+  }
+  __syncthreads();  // (logits were written by this block: visible after the barrier)
+  if (threadIdx.x == 0) {
+    float sr = 0.f, sf = 0.f;
+    for (int m = 0; m < n_real; ++m) sr += logits[m];
+    for (int m = 0; m < n_fake; ++m) sf += logits[n_real + m];
+    scalars[0] = n_real > 0 ? sr / float(n_real) : 0.f;  // mean real logit (this rank's rows)
+    scalars[1] = n_fake > 0 ? sf / float(n_fake) : 0.f;  // mean fake logit
+  }
+}
+
+// gb1[j] = sum over the loss rows of dh; gw2[j] = sum over the loss rows of dlogit h + sum over the interpolated rows of
+// thpre slope(h); gb2 = sum of dlogit.  1024 threads = 8 row groups x 128 columns (hidden <= 128 per pass), LDS-reduced in
+// group order.
+__global__ __launch_bounds__(1024) void critic_head_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                               const float* __restrict__ thpre, int n_real, int n_fake,
+                                                               int n_interp, int hidden, float inv_n, float leak,
+                                                               float* __restrict__ gb1, float* __restrict__ gw2,
+                                                               float* __restrict__ gb2) {
+  __shared__ float p1[8][128], p2[8][128];
+  const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
+  const int n_loss = n_real + n_fake;
+  for (int j0 = 0; j0 < hidden; j0 += 128) {
+    const int j = j0 + col;
+    float s1 = 0.f, s2 = 0.f;
+    if (j < hidden) {
+      for (int m = grp; m < n_loss; m += 8) {
+        const float dl = m < n_real ? -inv_n : inv_n;
+        s1 += dh[size_t(m) * hidden + j];
+        s2 = fmaf(dl, h[size_t(m) * hidden + j], s2);
+      }
+      for (int m = grp; m < n_interp; m += 8)
+        s2 = fmaf(thpre[size_t(m) * hidden + j], cs_slope(h[size_t(n_loss + m) * hidden + j], leak), s2);
+    }
+    p1[grp][col] = s1;
+    p2[grp][col] = s2;
+    __syncthreads();
+    if (grp == 0 && j < hidden) {
+      float a = p1[0][col], b = p2[0][col];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) { a += p1[g][col]; b += p2[g][col]; }
+      gb1[j] = a;
+      gw2[j] = b;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gb2[0] = float(n_fake) * inv_n - float(n_real) * inv_n;
+}
+
+// sums[n][c - c0] = sum over the pixels of x[n][p][c], c0 <= c < ct: one block per image, block-reduced in a fixed order
+__global__ __launch_bounds__(1024) void plane_sums_kernel(const float* __restrict__ x, float* __restrict__ sums,
+                                                          unsigned pixels, int ct, int c0) {
+  __shared__ float part[16][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* xi = x + size_t(blockIdx.x) * pixels * ct;
+  const int v = ct - c0;  // <= 16
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  for (unsigned p = threadIdx.x; p < pixels; p += 1024) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < v) acc[c] += xi[size_t(p) * ct + c0 + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c < v) {
+      const float s = wave_sum(acc[c]);
+      if (lane == 0) part[wave][c] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < unsigned(v)) {
+    float s = part[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) s += part[w][threadIdx.x];
+    sums[size_t(blockIdx.x) * v + threadIdx.x] = s;
+  }
+}
+
+// One block per image: pass 1 the squared norm of g = u[..., :3] + ds, pass 2 the penalty's gradient
+//   v = scale 2 max(norm - 1, 0) / norm g       (scale = lambda / N: the mean over the GLOBAL batch)
+__global__ __launch_bounds__(1024) void gp_direct_kernel(const float* __restrict__ u, int ct, const float* __restrict__ ds,
+                                                         float scale, float* __restrict__ v, float* __restrict__ norm,
+                                                         float* __restrict__ term, unsigned pixels) {
+  __shared__ float part[16];
+  __shared__ float coef;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* ui = u + size_t(blockIdx.x) * pixels * ct;
+  const float* di = ds + size_t(blockIdx.x) * pixels * 3;
+  float* vi = v + size_t(blockIdx.x) * pixels * 3;
+  float s = 0.f;
+  for (unsigned p = threadIdx.x; p < pixels; p += 1024) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float g = ui[size_t(p) * ct + c] + di[size_t(p) * 3 + c];
+      s = fmaf(g, g, s);
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) part[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = part[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += part[w];
+    const float nm = sqrtf(1e-6f + t);
+    const float over = fmaxf(nm - 1.0f, 0.0f);
+    norm[blockIdx.x] = nm;
+    term[blockIdx.x] = over * over;
+    coef = scale * 2.0f * over / nm;
+  }
+  __syncthreads();
+  const float c = coef;
+  for (unsigned p = threadIdx.x; p < pixels; p += 1024) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vi[size_t(p) * 3 + k] = (ui[size_t(p) * ct + k] + di[size_t(p) * 3 + k]) * c;
+  }
+}
+
+}  // namespace expo
+
+using namespace expo;
+
+extern "C" {
+
+int expo_critic_head_fwd(const float* hpre, const float* w2, const float* b2, int n_real, int n_fake, int n_interp,
+                         int hidden, float inv_n, float leak, float* logits, float* h, float* dh, float* scalars,
+                         void* stream) {
+  if (n_real < 0 || n_fake < 0 || n_interp < 0 || hidden < 1) return fail(EXPO_E_BADARG, "row counts >= 0, hidden >= 1 required");
+  if (n_real + n_fake + n_interp == 0) return EXPO_OK;
+  if (!hpre || !w2 || !b2 || !logits || !h || !dh || !scalars) return fail(EXPO_E_BADARG, "null pointer");
+  hipLaunchKernelGGL(critic_head_fwd_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), hpre, w2, b2, n_real,
+                     n_fake, n_interp, hidden, inv_n, leak, logits, h, dh, scalars);
+  HIP_TRY(hipGetLastError(), "critic_head_fwd launch");
+  return EXPO_OK;
+}
+
+int expo_critic_head_bwd(const float* dh, const float* h, const float* thpre, int n_real, int n_fake, int n_interp,
+                         int hidden, float inv_n, float leak, float* gb1, float* gw2, float* gb2, void* stream) {
+  if (n_real < 0 || n_fake < 0 || n_interp < 0 || hidden < 1) return fail(EXPO_E_BADARG, "row counts >= 0, hidden >= 1 required");
+  if (!dh || !h || (n_interp > 0 && !thpre) || !gb1 || !gw2 || !gb2) return fail(EXPO_E_BADARG, "null pointer");
+  hipLaunchKernelGGL(critic_head_bwd_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), dh, h, thpre, n_real,
+                     n_fake, n_interp, hidden, inv_n, leak, gb1, gw2, gb2);
+  HIP_TRY(hipGetLastError(), "critic_head_bwd launch");
+  return EXPO_OK;
+}
+
+int expo_plane_sums(const float* x, float* sums, int n, size_t pixels_per_image, int channels, int first, void* stream) {
+  if (n < 0 || channels < 1 || first < 0 || first >= channels || channels - first > 16)
+    return fail(EXPO_E_BADARG, "plane_sums: n >= 0, 0 <= first < channels, at most 16 planes");
+  if (n == 0) return EXPO_OK;
+  if (!x || !sums) return fail(EXPO_E_BADARG, "null pointer");
+  if (pixels_per_image > 0xffffffffull) return fail(EXPO_E_BADARG, "image too large");
+  hipLaunchKernelGGL(plane_sums_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), x, sums,
+                     unsigned(pixels_per_image), channels, first);
+  HIP_TRY(hipGetLastError(), "plane_sums launch");
+  return EXPO_OK;
+}
+
+int expo_gp_direct(const float* u, int u_channels, const float* ds, float scale, float* v, float* norm, float* term, int n,
+                   size_t pixels_per_image, void* stream) {
+  if (n < 0 || u_channels < 3) return fail(EXPO_E_BADARG, "gp_direct: n >= 0, u_channels >= 3 required");
+  if (n == 0 || pixels_per_image == 0) return EXPO_OK;
+  if (!u || !ds || !v || !norm || !term) return fail(EXPO_E_BADARG, "null pointer");
+  if (pixels_per_image > 0xffffffffull) return fail(EXPO_E_BADARG, "image too large");
+  hipLaunchKernelGGL(gp_direct_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), u, u_channels, ds, scale, v,
+                     norm, term, unsigned(pixels_per_image));
+  HIP_TRY(hipGetLastError(), "gp_direct launch");
+  return EXPO_OK;
+}
+
+}  // extern "C"

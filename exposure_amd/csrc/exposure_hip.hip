@@ -1809,6 +1809,11 @@ int expo_version(void) { return EXPO_ABI_VERSION; }
 
 const char* expo_last_error(void) { return g_err.c_str(); }
 
+#ifndef EXPO_SOURCE_DIGEST
+#define EXPO_SOURCE_DIGEST "unknown"
+#endif
+const char* expo_build_info(void) { return EXPO_SOURCE_DIGEST; }
+
 int expo_num_filter_params(int filter_id) {
   if (filter_id < 0 || filter_id >= EXPO_NUM_FILTERS) return -1;
   return kNumParams[filter_id];

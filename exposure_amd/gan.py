@@ -12,6 +12,7 @@ import os
 import torch
 from torch import nn
 
+from . import critic_direct
 from . import dist as xdist
 from .agent import Agent
 from .critics import Critic
@@ -22,10 +23,14 @@ from .util import STATE_STEP_DIM, STATE_STOPPED_DIM, capture_without_gc
 
 class GAN(nn.Module):
 
-  def __init__(self, cfg, device=None, process_group=None, use_graphs=False, seed=0):
+  def __init__(self, cfg, device=None, process_group=None, use_graphs=False, seed=0, direct_critic=True):
     super().__init__()
     self.cfg = cfg
     self.use_graphs = bool(use_graphs)
+    # the critic update as a hand-scheduled launch sequence (exposure_amd/critic_direct.py) wherever it applies -- the
+    # default Wasserstein critic with the gradient penalty on a ROCm device; False keeps every step on autograd (the
+    # path the direct schedule is tested against, and the one every other configuration takes)
+    self.direct_critic = bool(direct_critic)
     self._graphs = {}
     # MIOpen kernel selection: EXPO_MIOPEN_FIND=1 switches on its benchmark ("find") mode, 0 keeps the immediate-mode
     # heuristic.  (Rounds 1-2 needed find mode: torch's generic double backward of the gradient penalty runs forward
@@ -411,8 +416,12 @@ class GAN(nn.Module):
       torch._foreach_clamp_max_(params, float(cfg.clamp_critic))
 
   def _critic_body(self, real_data, fake_output, alpha):
-    out = self.critic_losses(real_data, fake_output, alpha)
-    self._backward_into(out['c_loss'], ['c'])
+    if self.direct_critic and critic_direct.supported(self, real_data, fake_output):
+      out = critic_direct.critic_losses_and_grads(self, real_data, fake_output, alpha)
+      self._bucket_ready(self.buckets['c'])  # (a no-op on one rank: the gradients already sit in p.grad)
+    else:
+      out = self.critic_losses(real_data, fake_output, alpha)
+      self._backward_into(out['c_loss'], ['c'])
     if self._collectives():
       ca = out['c_average'].clone()
       xdist.all_reduce_mean_(ca, self.process_group, force=self.force_collectives)

@@ -48,9 +48,11 @@
 extern "C" {
 #endif
 
-#define EXPO_ABI_VERSION 4 /* 2: caller-owned reduction workspace (no float atomics, no fills); 3: derivatives of the
+#define EXPO_ABI_VERSION 6 /* 2: caller-owned reduction workspace (no float atomics, no fills); 3: derivatives of the
                               critic statistics and of the penalty, VignetFilter, bias + lrelu, masked per-image dispatch;
-                              4: Tone / Color curves of any cfg.curve_steps (expo_curve_*) */
+                              4: Tone / Color curves of any cfg.curve_steps (expo_curve_*); 5: the convnets' convolution
+                              (expo_conv4x4s2_*); 6: its mask / bias variants, the hand-scheduled critic update's
+                              kernels, expo_build_info */
 
 #define EXPO_OK 0
 #define EXPO_E_BADARG (-1)
@@ -86,6 +88,12 @@ int expo_version(void);
 
 /* Message of the last error raised on the calling thread ("" if none). */
 const char* expo_last_error(void);
+
+/* (ABI 6) The sha256 (hex) of the sources this binary was built from -- csrc/build.sh hashes include/exposure_hip.h and
+ * the .hip / .h files and build.sh of csrc/ (byte order of their names) and passes the digest to the compiler.  The
+ * Python binding recomputes it from the tree and refuses a stale binary (EXPO_ALLOW_STALE_LIB=1 overrides); "unknown"
+ * for a build that bypassed build.sh. */
+const char* expo_build_info(void);
 
 /* Replaces Filter.get_num_filter_parameters() (filters.py:24-26); -1 on bad id. */
 int expo_num_filter_params(int filter_id);
@@ -543,13 +551,60 @@ int expo_conv4x4s2_bwd_data(const float* dy, const float* w, float* dx, int n, i
 size_t expo_conv4x4s2_wrw_workspace_bytes(int n, int h, int wd, int cin, int cout);
 int expo_conv4x4s2_wrw(const float* x, const float* dy, float* dw, int n, int h, int wd, int cin, int cout,
                        void* workspace, size_t workspace_bytes, void* stream);
-/* Probes and tests: waves per block (1-4) and blocks per tile of the weight-gradient kernel (negative = leave as is,
- * 0 = the library's choice; initial values from EXPO_CONV_SLICES / EXPO_CONV_PARTS). */
+/* (ABI 6) The same three primitives with the ACTIVATION'S gradient and the BIAS gradient folded in -- what a layer
+ * `z = lrelu(conv(x, w) + b)` (agent.py:21-32, critics.py:13-35; util.py:225-229) needs around its convolutions in the
+ * backward and in the gradient penalty's double backward (net.py:174-194), without launches of their own:
+ *   slope(z) = 1 (z > 0), leak (z < 0), (1 + leak) / 2 (z == 0: TF's sub-gradient of f1 x + f2 |x|)
+ *   expo_conv4x4s2_bwd_data_mask   dx = D(dy, w) * slope(zmask):  zmask float32 [n][h][w][cin] = the activation of the
+ *                                  layer BELOW -- its lrelu backward in this kernel's epilogue
+ *   expo_conv4x4s2_fwd_mask        y = F(x, w) * slope(zmask):    zmask float32 [n][h/2][w/2][cout]; y MAY ALIAS zmask --
+ *                                  the tangent of the double backward, t_l = F(t_{l-1}, w_l) slope(z_l), written over z_l
+ *   expo_conv4x4s2_wrw_bias        expo_conv4x4s2_wrw and dbias[co] = sum of dy[.][co] over the output pixels of the
+ *                                  first `bias_images` images (0 <= bias_images <= n; cout % 4 == 0, dbias 16-byte
+ *                                  aligned): the column sums come from the values the kernel feeds to the matrix cores
+ *                                  anyway.  Same workspace as expo_conv4x4s2_wrw (the bias copies are part of it).
+ * The data gradient of the layers with 6 or 17 input planes (critic, value net) runs on the vector ALUs with the weights
+ * in scalar registers (conv_bwd_small_kernel: a 32-wide matrix-core tile would be 81 % / 47 % padding). */
+int expo_conv4x4s2_bwd_data_mask(const float* dy, const float* w, const float* zmask, float* dx, int n, int h, int wd,
+                                 int cin, int cout, float leak, void* stream);
+int expo_conv4x4s2_fwd_mask(const float* x, const float* w, const float* zmask, float* y, int n, int h, int wd, int cin,
+                            int cout, float leak, void* stream);
+int expo_conv4x4s2_wrw_bias(const float* x, const float* dy, float* dw, float* dbias, int bias_images, int n, int h,
+                            int wd, int cin, int cout, void* workspace, size_t workspace_bytes, void* stream);
+/* Probes and tests: waves per block (1 .. 4) and blocks per tile of the weight-gradient kernel (negative = leave as
+ * is, 0 = the library's choice; initial values from EXPO_CONV_WRW_SLICES / EXPO_CONV_PARTS).  Independent of
+ * expo_conv_tuning's `slices`. */
 int expo_conv_wrw_tuning(int slices, int parts);
 /* Probes and tests: override how the forward / data-gradient kernels decompose a problem (process-wide; negative = leave as is,
  * 0 = the library's own choice).  tile 1-4: an LDS-tiled forward shape, 5: the flat kernel; nt 1 | 2: column tiles per
- * wave; slices 1-16: K slices per tile.  The initial values come from EXPO_CONV_TILE / _NT / _SLICES, read once. */
+ * wave; slices 1, 2, 4, 8 or 16: K slices per tile (any other value is rejected: the kernels cut K into 4 S2 segments).
+ * The initial values come from EXPO_CONV_TILE / _NT / _SLICES, read once. */
 int expo_conv_tuning(int tile, int nt, int slices);
+
+/* ---- the hand-scheduled critic update (round 6; csrc/critic_step.hip, exposure_amd/critic_direct.py) ------------------
+ * net.py:126-199, 245-251: c_loss = mean(D(fake) - D(real)) + lambda mean(max(||grad_x^ D(x^)|| - 1, 0)^2).  The real,
+ * fake and interpolated images run as ONE batch [real | fake | interpolated] through critics.py:42-98; the kernels
+ * below are the per-row / per-image reductions between its convolutions and GEMMs.  Fixed summation orders.
+ *   expo_critic_head_fwd  hpre float32 [M][hidden] = fc1's pre-activation (critics.py:94-96), M = n_real + n_fake +
+ *                         n_interp rows.  h = lrelu(hpre); logits[m] = h[m] . w2 + b2 (critics.py:97);
+ *                         dh[m] = dlogit[m] w2 slope(h[m]) with dlogit = -inv_n (real), +inv_n (fake), 1 (interpolated:
+ *                         the inner gradient starts from ones, net.py:174-183); scalars[0..1] = mean real / fake logit
+ *   expo_critic_head_bwd  gb1 = sum over the real + fake rows of dh;  gw2 = sum over those rows of dlogit h + sum over
+ *                         the interpolated rows of thpre slope(h) (thpre float32 [n_interp][hidden]: the penalty's
+ *                         tangent in front of fc1's activation);  gb2 = sum of dlogit
+ *   expo_plane_sums       sums[n][c - first] = sum over the pixels of x[n][.][c], first <= c < channels (<= 16 planes):
+ *                         the gradient reaching the per-image values planes_concat broadcast (critics.py:64-76)
+ *   expo_gp_direct        g = u[..., 0:3] + ds (u float32 [n][pixels][u_channels], ds [n][pixels][3]);
+ *                         norm = sqrt(1e-6 + sum g^2), term = max(norm - 1, 0)^2 (net.py:185-187) and
+ *                         v = scale 2 max(norm - 1, 0) / norm g  (the gradient of scale sum(term)) in one launch */
+int expo_critic_head_fwd(const float* hpre, const float* w2, const float* b2, int n_real, int n_fake, int n_interp,
+                         int hidden, float inv_n, float leak, float* logits, float* h, float* dh, float* scalars,
+                         void* stream);
+int expo_critic_head_bwd(const float* dh, const float* h, const float* thpre, int n_real, int n_fake, int n_interp,
+                         int hidden, float inv_n, float leak, float* gb1, float* gw2, float* gb2, void* stream);
+int expo_plane_sums(const float* x, float* sums, int n, size_t pixels_per_image, int channels, int first, void* stream);
+int expo_gp_direct(const float* u, int u_channels, const float* ds, float scale, float* v, float* norm, float* term, int n,
+                   size_t pixels_per_image, void* stream);
 #ifdef __cplusplus
 }
 #endif

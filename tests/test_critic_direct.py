@@ -1,0 +1,301 @@
+"""The hand-scheduled critic update (exposure_amd/critic_direct.py, csrc/critic_step.hip, the mask / bias variants of the
+convolution kernels) -- net.py:126-199, 245-251; critics.py:6-38, 42-98:
+
+* every new kernel against a float64 statement of what it computes;
+* the whole update against the autograd path (``GAN(direct_critic=False)``: loss values, every gradient tensor) and
+  against finite differences of the float64 NumPy oracle (oracle/nets_np.py), eager and replayed from a hipGraph."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from exposure_amd.config import make_cfg
+from exposure_amd.gan import GAN
+
+pytestmark = pytest.mark.gpu
+
+
+def _slope(z, leak=0.2):
+  return torch.where(z > 0, torch.ones_like(z), torch.where(z < 0, torch.full_like(z, leak), torch.full_like(z, 0.5 * (1 + leak))))
+
+
+def _case(n, h, cin, cout, dev, seed):
+  g = torch.Generator(device=dev).manual_seed(seed)
+  x = torch.randn((n, h, h, cin), device=dev, generator=g)
+  w = (torch.randn((cout, cin, 4, 4), device=dev, generator=g) / (16 * cin)**0.5).contiguous(memory_format=torch.channels_last)
+  gy = torch.randn((n, h // 2, h // 2, cout), device=dev, generator=g)
+  return x, w, gy
+
+
+def _ref_dgrad(x_shape, w, gy):
+  n, h, _, cin = x_shape
+  xd = torch.zeros((n, cin, h, h), dtype=torch.float64, requires_grad=True)
+  yd = F.conv2d(xd, w.double().cpu(), None, 2, 1)
+  ref, = torch.autograd.grad(yd, [xd], gy.double().cpu().permute(0, 3, 1, 2))
+  return ref.permute(0, 2, 3, 1)
+
+
+CASES = [(3, 8, 5, 8), (2, 16, 14, 32), (5, 12, 6, 32), (2, 64, 17, 32), (64, 64, 6, 32), (9, 8, 32, 64), (4, 16, 64, 128),
+         (16, 8, 128, 256), (1, 2, 6, 4), (3, 4, 17, 8), (7, 4, 4, 36)]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_data_gradient_with_the_activation_gradient_in_its_epilogue(case, gpu_device):
+  """expo_conv4x4s2_bwd_data_mask == D(dy, w) * slope(z) with z of either sign and exactly 0 (TF's sub-gradient 0.6);
+  6 and 17 input planes take the vector-ALU kernel (conv_bwd_small_kernel), the rest the matrix-core kernel; the plain
+  entry point agrees (no mask) and every element is written."""
+  from exposure_amd import _cabi
+  n, h, cin, cout = case
+  dev = gpu_device
+  x, w, gy = _case(n, h, cin, cout, dev, seed=n + h + cin)
+  z = torch.randn_like(x)
+  z.view(-1)[::7] = 0.0
+  ref = _ref_dgrad(x.shape, w, gy)
+  scale = float(ref.abs().max())
+  dx = torch.full_like(x, float('nan'))
+  _cabi.conv4x4s2_bwd_data(gy, w, dx)
+  assert float((dx.double().cpu() - ref).abs().max()) / scale < 3e-6
+  dm = torch.full_like(x, float('nan'))
+  _cabi.conv4x4s2_bwd_data_mask(gy, w, z, dm, 0.2)
+  assert torch.equal(dm, dx * _slope(z))
+  if cin in (6, 17):  # the same problem through the matrix-core kernel (a forced plan): both kernels must agree
+    _cabi.conv_tuning(0, 1, 1)
+    try:
+      d2 = torch.full_like(x, float('nan'))
+      _cabi.conv4x4s2_bwd_data(gy, w, d2)
+    finally:
+      _cabi.conv_tuning(0, 0, 0)
+    assert float((d2 - dx).abs().max()) / scale < 3e-6
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_forward_with_the_slope_mask_in_place(case, gpu_device):
+  """expo_conv4x4s2_fwd_mask == conv(x, w) * slope(z), into a separate tensor and written over z itself, under every
+  decomposition of the forward kernels."""
+  from exposure_amd import _cabi
+  n, h, cin, cout = case
+  dev = gpu_device
+  x, w, gy = _case(n, h, cin, cout, dev, seed=n + h)
+  z = torch.randn_like(gy)
+  z.view(-1)[::5] = 0.0
+  ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), None, 2, 1).permute(0, 2, 3, 1) * _slope(z).double().cpu()
+  scale = float(ref.abs().max())
+  try:
+    for tile, nt, sl in [(0, 0, 0), (5, 1, 1), (5, 2, 4), (1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0)]:
+      _cabi.conv_tuning(tile, nt, sl)
+      y = torch.full_like(z, float('nan'))
+      _cabi.conv4x4s2_fwd_mask(x, w, z, y, 0.2)
+      assert float((y.double().cpu() - ref).abs().max()) / scale < 2e-6, (case, tile, nt, sl)
+      zz = z.clone()
+      _cabi.conv4x4s2_fwd_mask(x, w, zz, zz, 0.2)
+      assert torch.equal(zz, y), (case, tile, nt, sl)
+  finally:
+    _cabi.conv_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize('case', [(3, 8, 5, 8), (2, 16, 14, 32), (6, 64, 6, 32), (2, 64, 17, 32), (9, 8, 32, 64), (6, 16, 64, 128),
+                                  (16, 8, 128, 256), (7, 4, 4, 36)])
+def test_weight_gradient_with_the_bias_gradient(case, gpu_device):
+  """expo_conv4x4s2_wrw_bias: dw as expo_conv4x4s2_wrw, dbias = the column sums of dy over the first k images (k = 0,
+  part of the batch, all of it), under several splits of the pixel sum; bit-reproducible."""
+  from exposure_amd import _cabi
+  n, h, cin, cout = case
+  dev = gpu_device
+  x, w, gy = _case(n, h, cin, cout, dev, seed=n + h)
+  wd = w.double().cpu().requires_grad_(True)
+  yd = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wd, None, 2, 1)
+  ref, = torch.autograd.grad(yd, [wd], gy.double().cpu().permute(0, 3, 1, 2))
+  scale = float(ref.abs().max())
+  try:
+    for sl, parts in ((0, 0), (1, 1), (2, 3), (4, 0), (4, 7), (3, 2)):
+      _cabi.conv_wrw_tuning(sl, parts)
+      for k in (n, 0, (2 * n) // 3):
+        dw, db = torch.full_like(w, float('nan')), torch.full((cout,), float('nan'), device=dev)
+        _cabi.conv4x4s2_wrw_bias(x, gy, dw, db, k)
+        assert float((dw.double().cpu() - ref).abs().max()) / scale < 1e-5, (case, sl, parts)
+        want = gy[:k].double().sum(dim=(0, 1, 2)).cpu()
+        tol = 1e-5 * float(gy[:k].double().abs().sum(dim=(0, 1, 2)).max()) + 1e-30
+        assert float((db.double().cpu() - want).abs().max()) <= tol, (case, sl, parts, k)
+        dw2, db2 = torch.empty_like(w), torch.empty_like(db)
+        _cabi.conv4x4s2_wrw_bias(x, gy, dw2, db2, k)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+  finally:
+    _cabi.conv_wrw_tuning(0, 0)
+
+
+def test_conv_tuning_rejects_slice_counts_the_kernels_cannot_cut(gpu_device):
+  """3, 5 .. 7 K slices would silently drop K segments (advisor, round 5): rejected at the boundary."""
+  from exposure_amd import _cabi
+  for bad in (3, 5, 6, 7, 12, 17):
+    with pytest.raises(_cabi.ExposureHipError):
+      _cabi.conv_tuning(0, 0, bad)
+  _cabi.conv_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize('rows', [(4, 4, 4), (64, 64, 64), (3, 5, 0), (0, 0, 7)])
+def test_head_kernels(rows, gpu_device):
+  from exposure_amd import _cabi
+  dev = gpu_device
+  nr, nf, ni = rows
+  m, hidden = nr + nf + ni, 128
+  g = torch.Generator(device=dev).manual_seed(m)
+  hpre = torch.randn((m, hidden), device=dev, generator=g)
+  hpre.view(-1)[::11] = 0.0
+  w2, b2 = torch.randn((hidden,), device=dev, generator=g), torch.randn((1,), device=dev, generator=g)
+  inv_n = 1.0 / max(nr, 1)
+  logits, h, dh = torch.empty((m,), device=dev), torch.empty_like(hpre), torch.empty_like(hpre)
+  scalars = torch.zeros((4,), device=dev)
+  _cabi.critic_head_fwd(hpre, w2, b2, nr, nf, ni, inv_n, logits, h, dh, scalars)
+  hd = torch.where(hpre > 0, hpre, 0.2 * hpre).double()
+  assert torch.equal(h, hd.float())
+  want_logits = hd @ w2.double() + b2.double()
+  assert float((logits.double() - want_logits).abs().max()) < 1e-5 * max(1.0, float(want_logits.abs().max()))
+  dl = torch.cat([torch.full((nr,), -inv_n), torch.full((nf,), inv_n), torch.ones(ni)]).to(dev).double()
+  want_dh = dl[:, None] * w2.double()[None, :] * _slope(h).double()
+  assert float((dh.double() - want_dh).abs().max()) < 1e-6 * max(1.0, float(want_dh.abs().max()))
+  if nr:
+    assert abs(float(scalars[0]) - float(want_logits[:nr].mean())) < 1e-5 * max(1.0, float(want_logits.abs().max()))
+  if nf:
+    assert abs(float(scalars[1]) - float(want_logits[nr:nr + nf].mean())) < 1e-5 * max(1.0, float(want_logits.abs().max()))
+  thpre = torch.randn((ni, hidden), device=dev, generator=g)
+  gb1, gw2, gb2 = (torch.full((k,), float('nan'), device=dev) for k in (hidden, hidden, 1))
+  _cabi.critic_head_bwd(dh, h, thpre, nr, nf, ni, inv_n, gb1, gw2, gb2)
+  nl = nr + nf
+  want_gb1 = want_dh[:nl].sum(0)
+  want_gw2 = (dl[:nl, None] * hd[:nl]).sum(0) + (thpre.double() * _slope(h[nl:]).double()).sum(0)
+  assert float((gb1.double() - want_gb1).abs().max()) <= 1e-5 * max(1e-3, float(want_dh[:nl].abs().sum(0).max()) if nl else 1e-3)
+  assert float((gw2.double() - want_gw2).abs().max()) <= 1e-5 * max(1.0, float(want_gw2.abs().max()))
+  assert abs(float(gb2) - float(dl[:nl].sum())) < 1e-6
+
+
+@pytest.mark.parametrize('shape', [(5, 64, 64, 6), (3, 7, 5, 6), (2, 4, 4, 17)])
+def test_plane_sums_and_gp_direct(shape, gpu_device):
+  from exposure_amd import _cabi
+  dev = gpu_device
+  g = torch.Generator(device=dev).manual_seed(shape[1])
+  u = torch.randn(shape, device=dev, generator=g) * 0.02
+  n, c = shape[0], shape[-1]
+  sums = torch.empty((n, c - 3), device=dev)
+  _cabi.plane_sums(u, sums, 3)
+  want = u.double()[..., 3:].sum(dim=(1, 2))
+  assert float((sums.double() - want).abs().max()) <= 1e-5 * float(u.double()[..., 3:].abs().sum(dim=(1, 2)).max())
+  ds = torch.randn(shape[:-1] + (3,), device=dev, generator=g) * 0.02
+  if n > 1:
+    u[1] *= 0.01  # an image whose norm stays below 1: the one-sided penalty and its gradient vanish
+    ds[1] *= 0.01
+  v, norm, term = torch.empty_like(ds), torch.empty((n,), device=dev), torch.empty((n,), device=dev)
+  _cabi.gp_direct(u, ds, 0.37, v, norm, term)
+  gd = (u[..., :3] + ds).double().requires_grad_(True)
+  nm = torch.sqrt(1e-6 + (gd**2).sum(dim=(1, 2, 3)))
+  tm = torch.clamp_min(nm - 1.0, 0.0)**2
+  vd, = torch.autograd.grad(0.37 * tm.sum(), [gd])
+  assert float((norm.double() - nm).abs().max()) < 1e-5 * float(nm.max())
+  assert float((term.double() - tm.detach()).abs().max()) < 1e-4 * max(1e-6, float(tm.max()))
+  assert float((v.double() - vd).abs().max()) <= 1e-4 * max(1e-9, float(vd.abs().max()))
+  if n > 1:
+    assert float(term[1]) == 0.0 and float(v[1].abs().max()) == 0.0
+
+
+def _make_gan(dev, seed, **kw):
+  torch.manual_seed(seed)
+  gan = GAN(make_cfg(), device=dev, **kw)
+  with torch.no_grad():
+    for p in gan.parameters():
+      if p.dim() == 1:
+        p.normal_(0.0, 0.05)
+    gan.critic.fc2.weight.mul_(40.0)  # gradient norm > 1: the one-sided penalty is active
+  return gan
+
+
+@pytest.mark.parametrize('n,dtype', [(8, torch.float32), (5, torch.float16), (64, torch.float16)])
+def test_direct_critic_update_matches_autograd(n, dtype, gpu_device):
+  """Loss values and EVERY gradient tensor of theta_c: the hand-scheduled update against ``critic_losses`` + backward."""
+  from exposure_amd import critic_direct
+  from tests.test_oracle_nets import make_batch
+  dev = gpu_device
+  gan = _make_gan(dev, 3)
+  fake_input, real, _s, _z, _m, alpha = make_batch(n, 17)
+  t = lambda a: torch.from_numpy(a).to(dev)
+  real_t, fake_t, alpha_t = t(real).to(dtype), t(fake_input).to(dtype), t(alpha)
+  assert critic_direct.supported(gan, real_t, fake_t)
+  out = critic_direct.critic_losses_and_grads(gan, real_t, fake_t, alpha_t)
+  got = {name: p.grad.detach().clone() for name, p in gan.critic.named_parameters()}
+  for p in gan.critic.parameters():
+    p.grad = None
+  ref = gan.critic_losses(real_t, fake_t, alpha_t)
+  ref['c_loss'].backward()
+  assert float(ref['gradient_norm']) > 1.0
+  for key in ('c_loss', 'emd', 'gradient_norm', 'gradient_penalty', 'c_average'):
+    a, b = float(out[key]), float(ref[key].detach())
+    assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (key, a, b)
+  for name, p in gan.critic.named_parameters():
+    a, b = got[name], p.grad
+    assert a.shape == b.shape
+    err, scale = float((a - b).abs().max()), float(b.abs().max())
+    assert err <= 2e-4 * scale + 1e-9, (name, err, scale)
+
+
+def test_direct_critic_gradients_against_finite_differences_of_the_oracle(gpu_device):
+  """The gradients the hand-scheduled update hands to Adam, along their own direction, against central differences of
+  the float64 NumPy critic loss (oracle/nets_np.py::critic_losses) -- every variable of the critic."""
+  from exposure_amd import checkpoint, critic_direct
+  from oracle import nets_np as nn_np
+  from tests.test_oracle_nets import make_batch
+  dev = gpu_device
+  gan = _make_gan(dev, 11)
+  n = 8
+  fake_input, real, _s, _z, _m, alpha = make_batch(n, 11)
+  t = lambda a: torch.from_numpy(a).to(dev)
+  d = lambda a: a.astype(np.float64)
+  out = critic_direct.critic_losses_and_grads(gan, t(real), t(fake_input), t(alpha))
+  cfg = dict(nn_np.DEFAULT_CFG)
+  weights = {k: v.astype(np.float64) for k, v in checkpoint.export_tf_dict(gan).items()}
+  rc = nn_np.critic_losses(d(real), d(fake_input), d(alpha), cfg, weights)
+  for key in ('c_loss', 'emd', 'gradient_norm', 'gradient_penalty', 'c_average'):
+    assert abs(float(out[key]) - rc[key]) <= 1e-4 * max(1.0, abs(rc[key])), (key, float(out[key]), rc[key])
+  loss = lambda w: nn_np.critic_losses(d(real), d(fake_input), d(alpha), cfg, w)['c_loss']
+  checked = 0
+  for name, p, kind in checkpoint.tf_name_map(gan):
+    if not name.startswith('critic/'):
+      continue
+    g = checkpoint.to_tf_layout(p.grad, kind).astype(np.float64)
+    gnorm = float(np.sqrt((g**2).sum()))
+    if name.endswith('fully_connected_1/biases'):  # d c_loss / d b2 = sum of dlogit = 0 exactly
+      assert gnorm < 1e-6
+      continue
+    assert gnorm > 0, name
+    w0 = weights[name]
+    s = max(float(np.abs(w0).std()), 0.02)
+    direction = g / gnorm * np.sqrt(g.size)
+    got = float((g * direction).sum())
+    for hstep in (1e-6 * s, 2.5e-7 * s, 6e-8 * s):
+      fd = (loss(dict(weights, **{name: w0 + hstep * direction})) - loss(dict(weights, **{name: w0 - hstep * direction}))) / (2 * hstep)
+      if abs(got - fd) <= 1e-3 * abs(fd):
+        break
+    assert abs(got - fd) <= 1e-3 * abs(fd), (name, got, fd)
+    checked += 1
+  assert checked >= 11
+
+
+def test_direct_critic_step_replayed_from_a_graph_trains_like_the_autograd_step(gpu_device):
+  """Three critic steps (eager warm-up, capture, replay) with the hand-scheduled update == the same three steps through
+  autograd: the weights after Adam agree, and the logit-centre average advances."""
+  from tests.test_oracle_nets import make_batch
+  dev = gpu_device
+  gans = [_make_gan(dev, 5, use_graphs=True, direct_critic=flag) for flag in (True, False)]
+  gans[1].load_state_dict(gans[0].state_dict())
+  t = lambda a: torch.from_numpy(a).to(dev)
+  for step in range(3):
+    fake_input, real, _s, _z, _m, alpha = make_batch(8, 30 + step)
+    outs = [g.critic_step(t(real).half(), t(fake_input).half(), it=1, alpha=t(alpha)) for g in gans]
+    # (identical weights at step 0; afterwards the two runs' weights differ by Adam's response to rounding-level
+    # gradient differences, and c_loss -- fc2 scaled by 40 -- is sensitive to them)
+    tol = 2e-5 if step == 0 else 2e-3
+    assert abs(float(outs[0]['c_loss']) - float(outs[1]['c_loss'])) <= tol * max(1.0, abs(float(outs[1]['c_loss']))), step
+  torch.cuda.synchronize()
+  for (name, a), (_, b) in zip(gans[0].critic.named_parameters(), gans[1].critic.named_parameters()):
+    # Adam normalises the gradient: three steps move every weight by ~3 lr; the two paths' weights stay within a small
+    # fraction of that (sign flips of near-zero gradient elements aside)
+    assert float((a - b).abs().max()) <= 0.2 * 3 * float(gans[0].cfg.lr_c(1)), name
+    assert float((a - b).abs().mean()) <= 0.01 * 3 * float(gans[0].cfg.lr_c(1)), name
+  assert abs(float(gans[0].c_average_biased) - float(gans[1].c_average_biased)) < 1e-5
