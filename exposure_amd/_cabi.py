@@ -57,7 +57,8 @@ SIGNATURES = {
     'expo_conv4x4s2_bwd_data_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_fwd_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_wrw_bias': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    'expo_critic_head_fwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _fp, _vp]),
+    'expo_critic_head_fwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
+    'expo_critic_report': (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _f, _fp, _fp, _vp]),
     'expo_critic_head_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
     'expo_plane_sums': (_i, [_fp, _fp, _i, _sz, _i, _i, _vp]),
     'expo_gp_direct': (_i, [_fp, _i, _fp, _f, _fp, _fp, _fp, _i, _sz, _vp]),
@@ -943,8 +944,8 @@ def conv4x4s2_wrw_bias(x, dy, dw, dbias, bias_images=None):
            'expo_conv4x4s2_wrw_bias')
 
 
-def critic_head_fwd(hpre, w2, b2, n_real, n_fake, n_interp, inv_n, logits, h, dh, scalars, leak=0.2):
-  """expo_critic_head_fwd: fc1 activation, fc2, the rows' upstream gradients and the mean logits of the batched critic pass."""
+def critic_head_fwd(hpre, w2, b2, n_real, n_fake, n_interp, inv_n, logits, h, dh, leak=0.2):
+  """expo_critic_head_fwd: fc1 activation, fc2 and the rows' upstream gradients of the batched critic pass."""
   lib = load()
   m, hidden = hpre.shape
   assert m == n_real + n_fake + n_interp
@@ -953,11 +954,23 @@ def critic_head_fwd(hpre, w2, b2, n_real, n_fake, n_interp, inv_n, logits, h, dh
   assert w2.is_cuda and w2.dtype == torch.float32 and w2.is_contiguous() and w2.numel() == hidden
   assert b2.is_cuda and b2.dtype == torch.float32 and b2.numel() == 1
   _f32(logits, 'logits', (m,))
-  assert scalars.is_cuda and scalars.dtype == torch.float32 and scalars.is_contiguous() and scalars.numel() >= 2
   with torch.cuda.device(hpre.device):
     _check(lib.expo_critic_head_fwd(_ptr(hpre), _ptr(w2), _ptr(b2), int(n_real), int(n_fake), int(n_interp), hidden,
-                                    float(inv_n), float(leak), _ptr(logits), _ptr(h), _ptr(dh), _ptr(scalars), _stream()),
+                                    float(inv_n), float(leak), _ptr(logits), _ptr(h), _ptr(dh), _stream()),
            'expo_critic_head_fwd')
+
+
+def critic_report(logits, norm, term, n_real, n_fake, n_interp, lam, out, ema=None, decay=0.99):
+  """expo_critic_report: out[0..4] = c_loss, emd, mean gradient norm, gradient penalty, c_average; ``ema`` (a device
+  scalar, optional) advances in the same launch."""
+  lib = load()
+  _f32(logits, 'logits', (n_real + n_fake + n_interp,))
+  _f32(norm, 'norm', (n_interp,)), _f32(term, 'term', (n_interp,))
+  assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == 5
+  assert ema is None or (ema.is_cuda and ema.dtype == torch.float32 and ema.numel() == 1)
+  with torch.cuda.device(logits.device):
+    _check(lib.expo_critic_report(_ptr(logits), _ptr(norm), _ptr(term), int(n_real), int(n_fake), int(n_interp), float(lam),
+                                  float(decay), _ptr(out), _ptr(ema), _stream()), 'expo_critic_report')
 
 
 def critic_head_bwd(dh, h, thpre, n_real, n_fake, n_interp, inv_n, gb1, gw2, gb2, leak=0.2):

@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from . import filters as F
-from .nn_ops import conv_bias_lrelu, planes_concat
+from .nn_ops import conv_trunk, planes_concat
 from .util import (STATE_DROPOUT_BEGIN, STATE_REWARD_DIM, STATE_STEP_DIM, STATE_STOPPED_DIM,
                    enrich_image_input, lrelu)
 
@@ -69,8 +69,7 @@ class FeatureExtractor(nn.Module):
     # `centered`: the caller has already subtracted 0.5 (Agent.forward builds the enriched input of both extractors in
     # one launch, nn_ops.planes_concat)
     net = net_nhwc if centered else net_nhwc.float() - 0.5
-    for conv in self.convs:
-      net = conv_bias_lrelu(net, conv.weight, conv.bias)
+    net = conv_trunk(net, self.convs)
     net = net.reshape(net.shape[0], self.output_dim)  # TF reshape order (H,W,C)
     if dropout_mask is None:
       dropout_mask = (torch.rand_like(net) < self.keep_prob).to(net.dtype)

@@ -75,9 +75,10 @@ def _grad_targets(gan):
 
 
 @torch.no_grad()
-def critic_losses_and_grads(gan, real_data, fake_output, alpha):
+def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
   """One evaluation of c_loss and of its gradient with respect to theta_c, written to ``p.grad`` of the critic's
-  parameters.  -> the dict ``GAN.critic_losses`` returns (c_loss, emd, gradient_norm, gradient_penalty, c_average)."""
+  parameters.  -> the dict ``GAN.critic_losses`` returns (c_loss, emd, gradient_norm, gradient_penalty, c_average);
+  ``ema`` (a device scalar) is advanced by 0.01 (c_average - ema) in the reporting launch (net.py:165-168)."""
   cfg, critic = gan.cfg, gan.critic
   dev = real_data.device
   n = real_data.shape[0]
@@ -108,9 +109,7 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha):
   hidden = hpre.shape[1]
   logits = torch.empty((m,), **f32)
   h, dh = torch.empty_like(hpre), torch.empty_like(hpre)
-  scalars = torch.empty((4,), **f32)
-  _cabi.critic_head_fwd(hpre, critic.fc2.weight.reshape(hidden), critic.fc2.bias, n, n, n, inv_n, logits, h, dh, scalars,
-                        LEAK)
+  _cabi.critic_head_fwd(hpre, critic.fc2.weight.reshape(hidden), critic.fc2.bias, n, n, n, inv_n, logits, h, dh, LEAK)
 
   # ---- backward of the three blocks at once (the interpolated block's upstream gradient is 1: the inner gradient) --
   gys = [None] * (len(convs) + 1)  # gys[l]: the gradient in front of layer l's activation (l = 1 .. L)
@@ -152,9 +151,7 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha):
   _cabi.critic_head_bwd(dh, h, thpre, n, n, n, inv_n, grads[id(critic.fc1.bias)],
                         grads[id(critic.fc2.weight)].reshape(hidden), grads[id(critic.fc2.bias)], LEAK)
 
-  # ---- reported values (net.py:188-199) --------------------------------------------------------------------------------
-  mean_real, mean_fake = scalars[0], scalars[1]
-  emd_neg = mean_fake - mean_real
-  gradient_penalty = lam * term.mean()
-  return dict(c_loss=emd_neg + gradient_penalty, emd=-emd_neg, gradient_norm=norm.mean(), gradient_penalty=gradient_penalty,
-              c_average=(mean_fake + mean_real) * 0.5)
+  # ---- reported values (net.py:188-199) and, on one rank, the logit centre's moving average in the same launch ----
+  rep = torch.empty((5,), **f32)
+  _cabi.critic_report(logits, norm, term, n, n, n, lam, rep, ema, 0.99)
+  return dict(c_loss=rep[0], emd=rep[1], gradient_norm=rep[2], gradient_penalty=rep[3], c_average=rep[4])

@@ -18,7 +18,7 @@ from torch import nn
 from torch.autograd.function import once_differentiable
 
 from . import _cabi
-from .nn_ops import conv_bias_lrelu, planes_concat
+from .nn_ops import conv_trunk, planes_concat
 from .util import lrelu
 
 
@@ -118,8 +118,7 @@ class Critic(nn.Module):
     # image channels + state / statistics planes, minus 0.5, as ONE launch on the device (nn_ops.planes_concat);
     # NHWC: the convolutions see channels_last views
     net = planes_concat(images, states, 0.5)
-    for conv in self.convs:
-      net = conv_bias_lrelu(net, conv.weight, conv.bias)
+    net = conv_trunk(net, self.convs)
     net = net.reshape(n, self.flat)
     net = lrelu(self.fc1(net))
     return self.fc2(net)

@@ -7,7 +7,8 @@
 //
 //   expo_critic_head_fwd    fc1's pre-activation [M][hidden] -> h = lrelu(.), logit = h . w2 + b2, the upstream gradient
 //                           of every row's pre-activation (real rows -1/N, fake rows +1/N, interpolated rows 1: the
-//                           inner gradient d D(x^) / d x^ starts from ones, net.py:174-183), mean logits
+//                           inner gradient d D(x^) / d x^ starts from ones, net.py:174-183)
+//   expo_critic_report      the update's reported scalars (net.py:188-199) and the logit centre's moving average (net.py:165-168)
 //   expo_critic_head_bwd    bias / fc2 gradients from the rows of the loss and from the penalty's tangent
 //   expo_plane_sums         per-image sums of the trailing planes of an NHWC tensor (the gradient that reaches the
 //                           statistics planes the critic appends to its input, critics.py:64-76)
@@ -31,35 +32,52 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// One block of 16 waves; wave w takes rows w, w + 16, ...  Row order of the batch: [real | fake | interpolated].
+// 16 waves per block, one row each.  Row order of the batch: [real | fake | interpolated].
 __global__ __launch_bounds__(1024) void critic_head_fwd_kernel(const float* __restrict__ hpre, const float* __restrict__ w2,
                                                                const float* __restrict__ b2, int n_real, int n_fake,
                                                                int n_interp, int hidden, float inv_n, float leak,
                                                                float* __restrict__ logits, float* __restrict__ h,
-                                                               float* __restrict__ dh, float* __restrict__ scalars) {
+                                                               float* __restrict__ dh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rows = n_real + n_fake + n_interp;
-  const float bias = b2[0];
-  for (int m = wave; m < rows; m += 16) {
-    const float dl = m < n_real ? -inv_n : (m < n_real + n_fake ? inv_n : 1.0f);
-    float dot = 0.f;
-    for (int j = lane; j < hidden; j += 64) {
-      const float z = cs_lrelu(hpre[size_t(m) * hidden + j], leak);
-      const float wj = w2[j];
-      h[size_t(m) * hidden + j] = z;
-      dh[size_t(m) * hidden + j] = dl * wj * cs_slope(z, leak);
-      dot = fmaf(z, wj, dot);
-    }
-    dot = wave_sum(dot);
-    if (lane == 0) logits[m] = dot + bias;
+  const int m = blockIdx.x * 16 + wave;
+  if (m >= rows) return;
+  const float dl = m < n_real ? -inv_n : (m < n_real + n_fake ? inv_n : 1.0f);
+  float dot = 0.f;
+  for (int j = lane; j < hidden; j += 64) {
+    const float z = cs_lrelu(hpre[size_t(m) * hidden + j], leak);
+    const float wj = w2[j];
+    h[size_t(m) * hidden + j] = z;
+    dh[size_t(m) * hidden + j] = dl * wj * cs_slope(z, leak);
+    dot = fmaf(z, wj, dot);
   }
-  __syncthreads();  // (logits were written by this block: visible after the barrier)
-  if (threadIdx.x == 0) {
-    float sr = 0.f, sf = 0.f;
-    for (int m = 0; m < n_real; ++m) sr += logits[m];
-    for (int m = 0; m < n_fake; ++m) sf += logits[n_real + m];
-    scalars[0] = n_real > 0 ? sr / float(n_real) : 0.f;  // mean real logit (this rank's rows)
-    scalars[1] = n_fake > 0 ? sf / float(n_fake) : 0.f;  // mean fake logit
+  dot = wave_sum(dot);
+  if (lane == 0) logits[m] = dot + b2[0];
+}
+
+// The reported scalars of a critic update (net.py:188-199) and the moving average of the logit centre (net.py:165-168)
+// in one launch: out = {c_loss, emd, mean gradient norm, gradient penalty, c_average}; ema (nullable) <- ema + (1 - decay)
+// (c_average - ema).  One block; sums in index order per lane, lanes in a fixed tree.
+__global__ __launch_bounds__(64) void critic_report_kernel(const float* __restrict__ logits, const float* __restrict__ norm,
+                                                           const float* __restrict__ term, int n_real, int n_fake,
+                                                           int n_interp, float lambda, float decay, float* __restrict__ out,
+                                                           float* __restrict__ ema) {
+  const int lane = threadIdx.x;
+  float sr = 0.f, sf = 0.f, sn = 0.f, st = 0.f;
+  for (int m = lane; m < n_real; m += 64) sr += logits[m];
+  for (int m = lane; m < n_fake; m += 64) sf += logits[n_real + m];
+  for (int m = lane; m < n_interp; m += 64) { sn += norm[m]; st += term[m]; }
+  sr = wave_sum(sr); sf = wave_sum(sf); sn = wave_sum(sn); st = wave_sum(st);
+  if (lane == 0) {
+    const float mr = n_real > 0 ? sr / float(n_real) : 0.f, mf = n_fake > 0 ? sf / float(n_fake) : 0.f;
+    const float gp = n_interp > 0 ? lambda * st / float(n_interp) : 0.f;
+    const float ca = 0.5f * (mf + mr);
+    out[0] = (mf - mr) + gp;
+    out[1] = mr - mf;
+    out[2] = n_interp > 0 ? sn / float(n_interp) : 0.f;
+    out[3] = gp;
+    out[4] = ca;
+    if (ema) ema[0] = ema[0] + (1.0f - decay) * (ca - ema[0]);
   }
 }
 
@@ -179,14 +197,24 @@ using namespace expo;
 extern "C" {
 
 int expo_critic_head_fwd(const float* hpre, const float* w2, const float* b2, int n_real, int n_fake, int n_interp,
-                         int hidden, float inv_n, float leak, float* logits, float* h, float* dh, float* scalars,
-                         void* stream) {
+                         int hidden, float inv_n, float leak, float* logits, float* h, float* dh, void* stream) {
   if (n_real < 0 || n_fake < 0 || n_interp < 0 || hidden < 1) return fail(EXPO_E_BADARG, "row counts >= 0, hidden >= 1 required");
-  if (n_real + n_fake + n_interp == 0) return EXPO_OK;
-  if (!hpre || !w2 || !b2 || !logits || !h || !dh || !scalars) return fail(EXPO_E_BADARG, "null pointer");
-  hipLaunchKernelGGL(critic_head_fwd_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), hpre, w2, b2, n_real,
-                     n_fake, n_interp, hidden, inv_n, leak, logits, h, dh, scalars);
+  const int rows = n_real + n_fake + n_interp;
+  if (rows == 0) return EXPO_OK;
+  if (!hpre || !w2 || !b2 || !logits || !h || !dh) return fail(EXPO_E_BADARG, "null pointer");
+  hipLaunchKernelGGL(critic_head_fwd_kernel, dim3(unsigned((rows + 15) / 16)), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     hpre, w2, b2, n_real, n_fake, n_interp, hidden, inv_n, leak, logits, h, dh);
   HIP_TRY(hipGetLastError(), "critic_head_fwd launch");
+  return EXPO_OK;
+}
+
+int expo_critic_report(const float* logits, const float* norm, const float* term, int n_real, int n_fake, int n_interp,
+                       float lambda, float decay, float* out, float* ema, void* stream) {
+  if (n_real < 0 || n_fake < 0 || n_interp < 0) return fail(EXPO_E_BADARG, "row counts >= 0 required");
+  if (!logits || !out || (n_interp > 0 && (!norm || !term))) return fail(EXPO_E_BADARG, "null pointer");
+  hipLaunchKernelGGL(critic_report_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), logits, norm, term, n_real,
+                     n_fake, n_interp, lambda, decay, out, ema);
+  HIP_TRY(hipGetLastError(), "critic_report launch");
   return EXPO_OK;
 }
 

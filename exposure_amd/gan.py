@@ -17,7 +17,7 @@ from . import dist as xdist
 from .agent import Agent
 from .critics import Critic
 from .nn_ops import (critic_step_inputs, frozen_parameters, generator_losses_fused, grad_penalty_term,
-                     skip_parameter_gradients)
+                     once_differentiable_convnets, skip_parameter_gradients)
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM, capture_without_gc
 
 
@@ -247,7 +247,9 @@ class GAN(nn.Module):
     self._pending = []
 
   def _generator_body(self, fake_input, z, states, progress, dropout_masks):
-    out = self.generator_losses(fake_input, z, states, progress, 1, dropout_masks)
+    # (this step differentiates its convnets once: each stack of layers runs as one node, nn_ops.conv_trunk)
+    with once_differentiable_convnets():
+      out = self.generator_losses(fake_input, z, states, progress, 1, dropout_masks)
     # the value net's short backward first: its all-reduce then runs under the whole generator backward
     # (v_loss reaches theta_v through old_value only, g_loss through new_value / the critic / the agent: the two
     # backward passes share no graph nodes, so nothing needs to be retained)
@@ -416,8 +418,14 @@ class GAN(nn.Module):
       torch._foreach_clamp_max_(params, float(cfg.clamp_critic))
 
   def _critic_body(self, real_data, fake_output, alpha):
+    ema_done = False
     if self.direct_critic and critic_direct.supported(self, real_data, fake_output):
-      out = critic_direct.critic_losses_and_grads(self, real_data, fake_output, alpha)
+      # on one rank the reporting launch also advances the logit centre's average (with collectives c_average is
+      # averaged over the ranks first, below)
+      ema_done = not self._collectives()
+      if ema_done and (self._c_ema is None or self._c_ema.device != real_data.device):
+        self._c_ema = torch.zeros((), dtype=torch.float32, device=real_data.device)
+      out = critic_direct.critic_losses_and_grads(self, real_data, fake_output, alpha, self._c_ema if ema_done else None)
       self._bucket_ready(self.buckets['c'])  # (a no-op on one rank: the gradients already sit in p.grad)
     else:
       out = self.critic_losses(real_data, fake_output, alpha)
@@ -432,7 +440,8 @@ class GAN(nn.Module):
     ca = out['c_average'].detach().reshape(())
     if self._c_ema is None or self._c_ema.device != ca.device:
       self._c_ema = torch.zeros((), dtype=ca.dtype, device=ca.device)
-    self._c_ema.lerp_(ca, 0.01)  # update_average (net.py:165-168, 267-268): 0.99 * average + 0.01 * c_average
+    if not ema_done:
+      self._c_ema.lerp_(ca, 0.01)  # update_average (net.py:165-168, 267-268): 0.99 * average + 0.01 * c_average
     return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
   def critic_step(self, real_data, fake_output, it=1, alpha=None):

@@ -286,6 +286,94 @@ def conv_bias_lrelu(x, weight, bias, leak=0.2):
   return bias_lrelu(conv2d_nhwc(x, weight), bias, leak)
 
 
+# ---- a whole stack of layers as one node (round 6) ------------------------------------------------------------------
+# The generator step differentiates its convnets ONCE (net.py:222-241; only the critic update's gradient penalty needs the
+# double backward, and that update is hand-scheduled: exposure_amd/critic_direct.py).  A stack `z_l = lrelu(conv(z_{l-1},
+# W_l) + b_l)` as ONE autograd node runs its backward as the critic update does: the activation gradient of layer l - 1 in
+# the EPILOGUE of layer l's data-gradient kernel, the bias gradient out of the weight-gradient launch -- per layer 1 + 2
+# launches (data gradient; weight gradient + its reduce) instead of 5-6 (lrelu backward + bias finish, data gradient,
+# zero fill + MIOpen's split-K weight gradient), and no library kernel.
+_ONCE_DIFFERENTIABLE = False
+
+
+class once_differentiable_convnets:
+  """Context manager: inside, ``conv_trunk`` may run a stack of layers as one once-differentiable node."""
+
+  def __enter__(self):
+    global _ONCE_DIFFERENTIABLE
+    self.prev, _ONCE_DIFFERENTIABLE = _ONCE_DIFFERENTIABLE, True
+
+  def __exit__(self, *exc):
+    global _ONCE_DIFFERENTIABLE
+    _ONCE_DIFFERENTIABLE = self.prev
+
+
+class _ConvTrunk(torch.autograd.Function):
+  """z_L of the stack; backward: input gradient (if wanted) and every (dW_l, db_l) (unless the parameters are frozen /
+  the pass only wants input gradients)."""
+
+  @staticmethod
+  def forward(ctx, x, leak, *wb):
+    ws, bs = wb[0::2], wb[1::2]
+    acts = [x]
+    for w, b in zip(ws, bs):
+      a = acts[-1]
+      z = torch.empty((a.shape[0], a.shape[1] // 2, a.shape[2] // 2, w.shape[0]), dtype=torch.float32, device=a.device)
+      _cabi.conv4x4s2_fwd(a, w, b, z, 1, leak)
+      acts.append(z)
+    ctx.save_for_backward(*acts, *ws)
+    ctx.leak, ctx.layers = leak, len(ws)
+    return acts[-1]
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, gz):
+    n_l = ctx.layers
+    acts, ws = ctx.saved_tensors[:n_l + 1], ctx.saved_tensors[n_l + 1:]
+    want_w = any(ctx.needs_input_grad[2:]) and not _SKIP_PARAM_GRADS
+    gy = torch.empty_like(acts[n_l])
+    _cabi.lrelu_bwd(acts[n_l], gz.contiguous(), gy, ctx.leak)
+    grads = [None] * (2 * n_l)
+    gx = None
+    for l in range(n_l, 0, -1):
+      w = ws[l - 1]
+      if want_w:
+        dw = torch.empty_like(w, memory_format=torch.preserve_format)
+        db = torch.empty((w.shape[0],), dtype=torch.float32, device=w.device)
+        _cabi.conv4x4s2_wrw_bias(acts[l - 1], gy, dw, db)
+        grads[2 * (l - 1)], grads[2 * (l - 1) + 1] = dw, db
+      if l > 1:
+        g = torch.empty_like(acts[l - 1])
+        _cabi.conv4x4s2_bwd_data_mask(gy, w, acts[l - 1], g, ctx.leak)
+        gy = g
+      elif ctx.needs_input_grad[0]:
+        gx = torch.empty_like(acts[0])
+        _cabi.conv4x4s2_bwd_data(gy, w, gx)
+    return (gx, None) + tuple(grads)
+
+
+def conv_trunk(x, convs, leak=0.2):
+  """The stack of ``nn.Conv2d(k=4, s=2, p=1)`` + lrelu layers ``convs`` on NHWC float32 ``x`` (agent.py:21-32,
+  critics.py:13-35): one once-differentiable node inside ``once_differentiable_convnets()`` on a ROCm device (every layer's
+  output width even: the weight-gradient kernel consumes pixels in pairs), layer by layer through ``conv_bias_lrelu``
+  (differentiable to any order) everywhere else."""
+  x = x.contiguous()
+  ok = _ONCE_DIFFERENTIABLE and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+  h, w = x.shape[1], x.shape[2]
+  for conv in convs:
+    ok = ok and _hip_conv(x, conv.weight) and conv.bias is not None and conv.weight.shape[0] % 4 == 0 and \
+        h % 2 == 0 and w % 2 == 0 and (w // 2) % 2 == 0
+    h, w = h // 2, w // 2
+  if not ok:
+    for conv in convs:
+      x = conv_bias_lrelu(x, conv.weight, conv.bias, leak)
+    return x
+  wb = []
+  for conv in convs:
+    wb += [conv.weight.detach(), conv.bias.detach()] if _FROZEN else [conv.weight, conv.bias]
+  return _ConvTrunk.apply(x, leak, *wb)
+
+
 def bias_lrelu(y, bias=None, leak=0.2):
   """``lrelu(y + bias)`` with the channel as the last dimension of ``y`` (float32).  util.py:225-229:
   ``f1*x + f2*|x|``, f1 = (1+leak)/2, f2 = (1-leak)/2, i.e. ``x if x > 0 else leak*x`` (equal to the literal formula

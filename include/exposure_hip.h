@@ -588,7 +588,11 @@ int expo_conv_tuning(int tile, int nt, int slices);
  *   expo_critic_head_fwd  hpre float32 [M][hidden] = fc1's pre-activation (critics.py:94-96), M = n_real + n_fake +
  *                         n_interp rows.  h = lrelu(hpre); logits[m] = h[m] . w2 + b2 (critics.py:97);
  *                         dh[m] = dlogit[m] w2 slope(h[m]) with dlogit = -inv_n (real), +inv_n (fake), 1 (interpolated:
- *                         the inner gradient starts from ones, net.py:174-183); scalars[0..1] = mean real / fake logit
+ *                         the inner gradient starts from ones, net.py:174-183)
+ *   expo_critic_report    out[0..4] = {c_loss = mean fake - mean real + lambda mean term, emd = mean real - mean fake, mean
+ *                         norm, lambda mean term, c_average = (mean fake + mean real) / 2} (net.py:188-199) from the logits
+ *                         [real | fake | interpolated] and the per-image norm / term; ema (nullable, device float) advances
+ *                         as ema += (1 - decay) (c_average - ema) (update_average, net.py:165-168, 267-268)
  *   expo_critic_head_bwd  gb1 = sum over the real + fake rows of dh;  gw2 = sum over those rows of dlogit h + sum over
  *                         the interpolated rows of thpre slope(h) (thpre float32 [n_interp][hidden]: the penalty's
  *                         tangent in front of fc1's activation);  gb2 = sum of dlogit
@@ -598,8 +602,9 @@ int expo_conv_tuning(int tile, int nt, int slices);
  *                         norm = sqrt(1e-6 + sum g^2), term = max(norm - 1, 0)^2 (net.py:185-187) and
  *                         v = scale 2 max(norm - 1, 0) / norm g  (the gradient of scale sum(term)) in one launch */
 int expo_critic_head_fwd(const float* hpre, const float* w2, const float* b2, int n_real, int n_fake, int n_interp,
-                         int hidden, float inv_n, float leak, float* logits, float* h, float* dh, float* scalars,
-                         void* stream);
+                         int hidden, float inv_n, float leak, float* logits, float* h, float* dh, void* stream);
+int expo_critic_report(const float* logits, const float* norm, const float* term, int n_real, int n_fake, int n_interp,
+                       float lambda, float decay, float* out, float* ema, void* stream);
 int expo_critic_head_bwd(const float* dh, const float* h, const float* thpre, int n_real, int n_fake, int n_interp,
                          int hidden, float inv_n, float leak, float* gb1, float* gw2, float* gb2, void* stream);
 int expo_plane_sums(const float* x, float* sums, int n, size_t pixels_per_image, int channels, int first, void* stream);

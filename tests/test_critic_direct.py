@@ -144,8 +144,7 @@ def test_head_kernels(rows, gpu_device):
   w2, b2 = torch.randn((hidden,), device=dev, generator=g), torch.randn((1,), device=dev, generator=g)
   inv_n = 1.0 / max(nr, 1)
   logits, h, dh = torch.empty((m,), device=dev), torch.empty_like(hpre), torch.empty_like(hpre)
-  scalars = torch.zeros((4,), device=dev)
-  _cabi.critic_head_fwd(hpre, w2, b2, nr, nf, ni, inv_n, logits, h, dh, scalars)
+  _cabi.critic_head_fwd(hpre, w2, b2, nr, nf, ni, inv_n, logits, h, dh)
   hd = torch.where(hpre > 0, hpre, 0.2 * hpre).double()
   assert torch.equal(h, hd.float())
   want_logits = hd @ w2.double() + b2.double()
@@ -153,10 +152,15 @@ def test_head_kernels(rows, gpu_device):
   dl = torch.cat([torch.full((nr,), -inv_n), torch.full((nf,), inv_n), torch.ones(ni)]).to(dev).double()
   want_dh = dl[:, None] * w2.double()[None, :] * _slope(h).double()
   assert float((dh.double() - want_dh).abs().max()) < 1e-6 * max(1.0, float(want_dh.abs().max()))
-  if nr:
-    assert abs(float(scalars[0]) - float(want_logits[:nr].mean())) < 1e-5 * max(1.0, float(want_logits.abs().max()))
-  if nf:
-    assert abs(float(scalars[1]) - float(want_logits[nr:nr + nf].mean())) < 1e-5 * max(1.0, float(want_logits.abs().max()))
+  norm, term = torch.rand((ni,), device=dev, generator=g) + 0.5, torch.rand((ni,), device=dev, generator=g)
+  rep, ema = torch.full((5,), float('nan'), device=dev), torch.full((1,), 0.25, device=dev)
+  _cabi.critic_report(logits, norm, term, nr, nf, ni, 10.0, rep, ema, 0.99)
+  mean = lambda v: float(v.double().mean()) if v.numel() else 0.0
+  mr, mf, gp = mean(logits[:nr]), mean(logits[nr:nr + nf]), 10.0 * mean(term)
+  want_rep = [mf - mr + gp, mr - mf, mean(norm), gp, 0.5 * (mf + mr)]
+  for a, b in zip(rep.tolist(), want_rep):
+    assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (rep.tolist(), want_rep)
+  assert abs(float(ema) - (0.25 + 0.01 * (want_rep[4] - 0.25))) < 1e-6
   thpre = torch.randn((ni, hidden), device=dev, generator=g)
   gb1, gw2, gb2 = (torch.full((k,), float('nan'), device=dev) for k in (hidden, hidden, 1))
   _cabi.critic_head_bwd(dh, h, thpre, nr, nf, ni, inv_n, gb1, gw2, gb2)
@@ -294,8 +298,53 @@ def test_direct_critic_step_replayed_from_a_graph_trains_like_the_autograd_step(
     assert abs(float(outs[0]['c_loss']) - float(outs[1]['c_loss'])) <= tol * max(1.0, abs(float(outs[1]['c_loss']))), step
   torch.cuda.synchronize()
   for (name, a), (_, b) in zip(gans[0].critic.named_parameters(), gans[1].critic.named_parameters()):
-    # Adam normalises the gradient: three steps move every weight by ~3 lr; the two paths' weights stay within a small
-    # fraction of that (sign flips of near-zero gradient elements aside)
-    assert float((a - b).abs().max()) <= 0.2 * 3 * float(gans[0].cfg.lr_c(1)), name
-    assert float((a - b).abs().mean()) <= 0.01 * 3 * float(gans[0].cfg.lr_c(1)), name
+    # Adam normalises the gradient: early steps move every weight by ~lr whatever the gradient's size, so an element whose
+    # gradient is rounding-level noise around zero can differ by up to 2 lr per step between the two paths; on average the
+    # weights stay within a small fraction of a step
+    lr = float(gans[0].cfg.lr_c(1))
+    assert float((a - b).abs().max()) <= 2.0 * 3 * lr * 1.01, name
+    assert float((a - b).abs().mean()) <= 0.01 * 3 * lr, name
   assert abs(float(gans[0].c_average_biased) - float(gans[1].c_average_biased)) < 1e-5
+
+
+@pytest.mark.parametrize('cin,size,n,frozen', [(6, 64, 5, False), (14, 64, 4, False), (17, 32, 3, False), (17, 64, 4, True)])
+def test_conv_trunk_node_matches_the_layerwise_path(cin, size, n, frozen, gpu_device):
+  """nn_ops.conv_trunk as ONE once-differentiable node (activation gradients in the data-gradient epilogues, bias
+  gradients out of the weight-gradient launches) against the same stack layer by layer through ``conv_bias_lrelu``:
+  output, input gradient, every weight / bias gradient; frozen parameters receive none."""
+  from exposure_amd import nn_ops
+  dev = gpu_device
+  torch.manual_seed(cin + size)
+  chans = [cin, 32, 64, 128, 256]
+  convs = torch.nn.ModuleList([torch.nn.Conv2d(chans[i], chans[i + 1], 4, 2, 1) for i in range(4)]).to(dev)
+  convs = convs.to(memory_format=torch.channels_last)
+  with torch.no_grad():
+    for c in convs:
+      c.bias.normal_(0.0, 0.1)
+  x0 = torch.randn((n, size, size, cin), device=dev)
+  gz = torch.randn((n, size // 16, size // 16, 256), device=dev)
+  res = []
+  for fused in (True, False):
+    x = x0.clone().requires_grad_(True)
+    for c in convs:
+      c.weight.grad = c.bias.grad = None
+    if fused:
+      with nn_ops.once_differentiable_convnets():
+        if frozen:
+          with nn_ops.frozen_parameters():
+            z = nn_ops.conv_trunk(x, convs)
+        else:
+          z = nn_ops.conv_trunk(x, convs)
+      assert type(z.grad_fn).__name__ == '_ConvTrunkBackward'
+    else:
+      z = x
+      for c in convs:
+        z = nn_ops.conv_bias_lrelu(z, c.weight.detach() if frozen else c.weight, c.bias.detach() if frozen else c.bias)
+    z.backward(gz)
+    res.append([z.detach(), x.grad] + [c.weight.grad for c in convs] + [c.bias.grad for c in convs])
+  for i, (a, b) in enumerate(zip(*res)):
+    if b is None:
+      assert a is None, i
+      continue
+    err, scale = float((a - b).abs().max()), float(b.abs().max())
+    assert err <= 2e-5 * scale + 1e-9, (i, err, scale)
