@@ -259,23 +259,51 @@ def event_pair_overhead_ms(dev, reps=200):
   return max(per_pair - e0.elapsed_time(e1) / reps, 0.0)
 
 
-def rocprof_avg_us(kernel, prefix=None):
-  """Average duration (us) of `kernel` ('bwd_C', ...) in the committed rocprofv3 kernel table of the SAME command
-  (profiles/<round>_final_kernel_stats_chain.csv, newest round first); None when no table lists it."""
+PROFILE_TABLE_OF_SHAPE = {(64, 512, 512, 3): 'chain', (16, 512, 512, 3): 'chain_B', (64, 64, 64, 3): 'chain_A'}
+
+
+def rocprof_avg_us(kernel, shape, dtype, prefix=None):
+  """Average duration (us) of `kernel` ('bwd_C', ...) in the committed rocprofv3 kernel table of the SAME command on the
+  SAME shape and storage dtype (profiles/<round>_final_kernel_stats_chain[_A|_B].csv, newest round first); None when no
+  table exists for this workload or none lists the kernel (a duration measured on another shape would be wrong, not
+  approximate -- like load_traffic)."""
   import csv
   import glob
+  table = PROFILE_TABLE_OF_SHAPE.get(tuple(shape))
+  if table is None:
+    return None
   direction, short = kernel.split('_', 1)
   cls = KERNEL_CLASS.get(short, ('?', '?'))
   wants = ('filter_%s_kernel<%s' % (direction, cls[0]), 'filter_%s_kernelINS_%s' % (direction, cls[1]))
-  for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '%s_final_kernel_stats_chain.csv' % (prefix or 'r*'))),
+  is_dtype = (lambda name: 'f16' in name or 'DF16_' in name or '_Float16' in name) if dtype == 'f16' else \
+      (lambda name: not ('f16' in name or 'DF16_' in name or '_Float16' in name))
+  for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '%s_final_kernel_stats_%s.csv' % (prefix or 'r*', table))),
                      reverse=True):
     try:
+      # whole-batch launches only where the table mixes them with the half-batch launches of the two-stream chain: the
+      # metric shape's table is filtered to grid_y = 64 when it is made (tools/profile_all.sh), the others hold one kind
       for row in csv.reader(l for l in open(path) if not l.startswith('#')):
-        if row and any(w in row[0] for w in wants) and 'IoStream' in row[0] and ('f16' in row[0] or 'DF16_' in row[0]):
-          return {'us': float(row[3]) / 1e3, 'calls': int(row[1]), 'file': os.path.relpath(path, ROOT)}
+        if row and any(w in row[0] for w in wants) and is_dtype(row[0]):
+          return {'us': float(row[3]) / 1e3, 'calls': int(row[1]), 'file': os.path.relpath(path, ROOT),
+                  'shape': 'x'.join(str(v) for v in shape), 'dtype': dtype}
     except (OSError, ValueError, IndexError):
       continue
   return None
+
+
+def committed_train_launches():
+  """Launches per training iteration from the newest committed rocprofv3 table of the training workload
+  (profiles/<round>_final_kernel_stats_train.csv: the timed region's window) -> (count, file) or (None, None)."""
+  import glob
+  import re
+  for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_final_kernel_stats_train.csv')), reverse=True):
+    try:
+      m = re.search(r'= (\d+) per iteration', open(path).readline())
+      if m:
+        return int(m.group(1)), os.path.relpath(path, ROOT)
+    except OSError:
+      continue
+  return None, None
 
 
 def _cpu_chain_rates(name, threads, budget_s=4.0):
@@ -539,9 +567,10 @@ def conv_stack_macs(c_in, size=64, base=32, out_ch=None):
 def train_flops_per_iteration(cfg, n):
   """Analytic GEMM flops (2 x MACs) of ONE training iteration on n images per GPU (net.py:307-365): one generator /
   value step + cfg.citers critic steps.  A layer's forward costs its MACs once; a backward costs them once per wanted
-  gradient (data, weight); the gradient penalty's double backward re-runs every critic layer three more times (the
-  forward-mode pass J v through the data-gradient graph, and its two gradients).  First layers have no data gradient
-  except where the gradient reaches the IMAGE (critic / value nets on generated images, the penalty)."""
+  gradient (data, weight); the gradient penalty's double backward costs every critic layer twice more (the tangent pass
+  t_l = F(t_{l-1}, W_l) through the data-gradient graph and the weight gradient G(t_{l-1}, u_l): critic_direct.py; rounds 3-5
+  counted three, one forward pass of n images per critic step too many -- 7 % of the iteration's total).  First layers have
+  no data gradient except where the gradient reaches the IMAGE (critic / value nets on generated images, the penalty)."""
   trunk = conv_stack_macs(3 + cfg.num_state_dim, out_ch=cfg.feature_extractor_dims // 16)
   crit = conv_stack_macs(3 + 3)
   val = conv_stack_macs(3 + cfg.num_state_dim + 3)
@@ -554,7 +583,7 @@ def train_flops_per_iteration(cfg, n):
   g += 2 * fwd(crit) + dgrad_to_image(crit)  # critic(fake_output) with the image gradient, critic(fake_input) forward only
   g += 2 * fwd(val) + wgrad(val) + dgrad_inner(val) + dgrad_to_image(val)  # old_value (theta_v), new_value (image)
   c = 3 * fwd(crit) + 2 * (wgrad(crit) + dgrad_inner(crit))  # real + fake + interpolated forward; emd backward on 2n
-  c += dgrad_to_image(crit) + 3 * fwd(crit)  # penalty: d D / d x^, then its double backward (three passes per layer)
+  c += dgrad_to_image(crit) + fwd(crit) + wgrad(crit)  # penalty: d D / d x^, then its double backward (two passes per layer)
   return 2.0 * n * (g + cfg.citers * c)
 
 
@@ -629,10 +658,12 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
           'peak': MFMA_FP32_PEAK_TFLOPS,
           'unit': 'TFLOP/s',
           'frac': achieved / MFMA_FP32_PEAK_TFLOPS,
-          'note': 'the nets are fp32 like the reference\'s; forward convolutions (+ bias + lrelu) and the data gradients '
-                  'of the deeper layers run on the in-house implicit-GEMM kernels (csrc/conv_ops.hip, v_mfma_f32_32x32x2_f32: '
-                  '45-80 TFLOP/s inside those kernels), weight gradients on MIOpen; at batch 64 x 64x64 about half of the '
-                  'iteration is convolution kernels, the rest ~900 small launches around them (DESIGN.md 3.10, 3.11)',
+          'note': 'the nets are fp32 like the reference\'s; every convolution primitive (forward + bias + lrelu, data gradient '
+                  'with the activation gradient in its epilogue, weight gradient with the bias sums) runs on the in-house '
+                  'kernels (csrc/conv_ops.hip, v_mfma_f32_32x32x2_f32; 6 / 17-plane data gradients on the vector ALUs); the '
+                  'critic update is a hand-scheduled launch sequence over [real | fake | interpolated] as one batch '
+                  '(exposure_amd/critic_direct.py), the G / V step runs each convnet stack as one autograd node; no MIOpen '
+                  'kernel remains (DESIGN.md 3.12)',
       },
   }
 
@@ -1339,7 +1370,7 @@ def main():
         # and still sits in the 256 MiB Infinity Cache); includes the boundary between two dependent kernels
         'avg_launch_ms_rotating_buffers': b2b,
         # what rocprofv3 --kernel-trace measured for this kernel on the same command (committed table)
-        'rocprof_avg_us': rocprof_avg_us(dom),
+        'rocprof_avg_us': rocprof_avg_us(dom, shape, args.dtype),
         # 12 tensors of this size cycle through a 256 MiB Infinity Cache (MALL): below ~256 MiB per tensor the
         # consumer of a just-written tensor is partly served from it, so `achieved` is an EFFECTIVE bandwidth
         # (FETCH_SIZE/WRITE_SIZE count MALL hits too); `hbm_cold` is the same kernel on 384 MiB tensors
@@ -1376,6 +1407,21 @@ def main():
       pass
     torch.cuda.empty_cache()
     run_legs(result, args, world, rank, dev, dist)
+    # a compact copy where the driver's parser keeps it (`config`): BASELINE configs 2 and 3 / 4 from the same command
+    legs = result.get('legs', {})
+    chain_a, train = legs.get('chain_64x64x64x3', {}), legs.get('train', {})
+    launches, launches_file = committed_train_launches()
+    result['config']['legs'] = {
+        'chain_64x64x64_Mpixels_per_s': chain_a.get('Mpixels_per_s'),
+        'train_ms_per_iteration': train.get('ms_per_iteration'),
+        'train_images_per_s': train.get('images_per_s'),
+        'train_roofline_frac': train.get('roofline', {}).get('frac'),
+        'train_launches_per_iteration': launches,
+        'train_launches_source': launches_file,
+        'capture_drain_verified': train.get('capture_drain_verified'),
+        'allreduce_bus_GBps': legs.get('allreduce', {}).get('bus_GBps'),
+        'errors': {k: v['error'] for k, v in legs.items() if isinstance(v, dict) and 'error' in v} or None,
+    }
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     result['cpu_baseline'] = cpu_baseline()
     try:

@@ -29,6 +29,13 @@ def test_bench_self_launches_two_ranks(workload):
   assert line['scaling'] == 'strong' and line['dry_run'] is True
 
 
+def test_bench_self_launches_eight_ranks_at_config_4_geometry():
+  """BASELINE config 4 (8 ranks, the reference's global batch of 64 split image-wise: 8 images per rank) through the
+  launcher and the gloo rendezvous on the CPU."""
+  line = run_bench('--gpus', '8', '--steps', '2', '--warmup', '1', '--workload', 'train', '--scaling', 'strong')
+  assert line['n_gpus'] == 8 and line['scaling'] == 'strong' and line['dry_run'] is True
+
+
 def test_bench_single_rank_needs_no_launcher():
   line = run_bench('--gpus', '1')
   assert line['n_gpus'] == 1 and line['scaling'] == 'weak'

@@ -46,18 +46,18 @@ def _run_steps(gan, img, real, states, z):
   return g, c
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, n_global=4):
   sys.path.insert(0, ROOT)
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   dist.init_process_group('gloo', rank=rank, world_size=world)
-  torch.set_num_threads(2)
+  torch.set_num_threads(2 if world <= 2 else 1)
   from exposure_amd import dist as xdist
   from exposure_amd.config import make_cfg
   from exposure_amd.gan import GAN
   torch.manual_seed(123)  # identical initial weights on every rank
   gan = GAN(make_cfg(), seed=77)
-  img, real, states, z, _masks, _alpha = _inputs()
+  img, real, states, z, _masks, _alpha = _inputs(n_global)
   sh = xdist.shard  # this rank's images of the global batch (data, not random state)
   _run_steps(gan, sh(img), sh(real), sh(states), sh(z))
   torch.save({'params': [p.detach().clone() for p in gan.parameters()],
@@ -66,19 +66,27 @@ def _worker(rank, world, port, out_dir):
   dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_two_rank_step_matches_single_process(tmp_path):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world,n_global', [(2, 4), (4, 16), (8, 64)])
+def test_ranks_step_matches_single_process(world, n_global, tmp_path):
+  """2, 4 and 8 ranks; the last is BASELINE config 4's geometry in strong scaling -- the reference's global batch of 64
+  split image-wise, 8 images per rank: image shards, GlobalBatchRng rows, armed bucket hooks, local-mean losses averaged
+  by the bucket all-reduce.  Every rank ends bit-identical to the others, and within rounding of ONE process that saw the
+  whole batch."""
   from exposure_amd.config import make_cfg
   from exposure_amd.gan import GAN
   torch.manual_seed(123)
   ref = GAN(make_cfg(), seed=77)
-  _run_steps(ref, *_inputs()[:4])
+  _run_steps(ref, *_inputs(n_global)[:4])
   port = _free_port()
-  mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-  r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
-  r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
-  for a, b in zip(r0['params'], r1['params']):
-    assert torch.equal(a, b)  # ranks stay in lock-step
+  mp.spawn(_worker, args=(world, port, str(tmp_path), n_global), nprocs=world, join=True)
+  ranks = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r)) for r in range(world)]
+  r0 = ranks[0]
+  for other in ranks[1:]:
+    for a, b in zip(r0['params'], other['params']):
+      assert torch.equal(a, b)  # ranks stay in lock-step
+    for a, b in zip(r0['grads'], other['grads']):
+      assert torch.equal(a, b)  # every rank holds the same all-reduced gradient
   # all-reduced mean gradients == full-batch gradients
   for g, p in zip(r0['grads'], ref.parameters()):
     scale = float(p.grad.abs().max()) + 1e-12
