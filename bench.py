@@ -67,10 +67,6 @@ def parse():
   ap.add_argument('--cold-shape', default='256,512,512',
                   help="chain workload: also time the dominant kernel on tensors of this shape (384 MiB each, beyond "
                   "the 256 MiB Infinity Cache) for roofline.hbm_cold; 'none' disables")
-  ap.add_argument('--miopen-find', default='off', choices=['on', 'off'],
-                  help="train workload: MIOpen's benchmark ('find') kernel selection.  Off like the library default "
-                  "(EXPO_MIOPEN_FIND): a find-mode trial kernel faulted inside the 380-test gpu suite (gpurun r03p9), and "
-                  "what it buys varies by box (14.65 vs 16.2 ms per iteration on one, 14.30 vs 14.06 on another)")
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                   help='replay the 17 launches of a step from one hipGraph (auto = on; off: eager C-ABI calls)')
   return ap.parse_args()
@@ -594,7 +590,6 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
   from exposure_amd.gan import GAN
   cfg = make_cfg()
   torch.manual_seed(args.seed)  # identical initial weights on every rank
-  os.environ.setdefault('EXPO_MIOPEN_FIND', '1' if args.miopen_find == 'on' else '0')
   gan = GAN(cfg, device=dev, use_graphs=(args.graph != 'off'), seed=args.seed)
   # weak: cfg.batch_size (64) images per GPU; strong: the reference's global batch of 64 split image-wise
   n = local_shape((cfg.batch_size,), world, args.scaling)[0]
@@ -642,11 +637,6 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
       'batch_per_gpu': n,
       'critic_steps_per_iteration': cfg.citers,
       'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
-      'miopen_find': bool(torch.backends.cudnn.benchmark),
-      # the measured solver rankings the package ships (exposure_amd/miopen_db) or whatever the user set
-      # (MIOpen reads and writes a private per-rank COPY of the shipped files: exposure_amd/__init__.py)
-      'miopen_user_db': ('private copy of %s' % os.path.relpath(os.environ['EXPO_MIOPEN_DB_ACTIVE'], ROOT))
-                        if os.environ.get('EXPO_MIOPEN_DB_ACTIVE') else os.environ.get('MIOPEN_USER_DB_PATH'),
       'capture_drain_verified': getattr(gan, 'capture_drain_verified', None),
       'roofline': {
           'bound': 'mfma_fp32',
@@ -744,8 +734,6 @@ def run_train(args, world, rank, dev, dist):
             'parallelism': 'dp%d image-sharded; flat gradient buckets (theta_g heads / trunks, theta_v, theta_c) '
                            'all-reduced over RCCL from backward hooks' % world,
             'launch': m['launch'],
-            'miopen_find': m['miopen_find'],
-            'miopen_user_db': m['miopen_user_db'],
             'capture_drain_verified': m['capture_drain_verified'],
             'reference_note': 'README.md:43: ~0.30 s/iteration on a GTX 1080 Ti (whole run ~100 min / 20000 it)',
         },

@@ -123,9 +123,11 @@ def load_image(path):
 
 
 def load_agent_weights(agent, state):
-  """Accepts an ``Agent`` state dict or the ``GAN.state_dict()`` that ``python -m exposure_amd.train
-  --save`` writes (keys prefixed 'generator.' / 'critic.' / 'value.'): the generator's entries are
-  picked out and the prefix stripped."""
+  """Accepts an ``Agent`` state dict, a ``GAN.state_dict()`` (keys prefixed 'generator.' / 'critic.' / 'value.') or the
+  ``{'model': GAN.state_dict(), 'optim': ...}`` file that ``python -m exposure_amd.train --save`` writes: the
+  generator's entries are picked out and the prefix stripped."""
+  if 'model' in state and isinstance(state['model'], dict):
+    state = state['model']
   if any(k.startswith('generator.') for k in state):
     state = {k[len('generator.'):]: v for k, v in state.items() if k.startswith('generator.')}
   agent.load_state_dict(state)

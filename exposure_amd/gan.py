@@ -32,15 +32,6 @@ class GAN(nn.Module):
     # path the direct schedule is tested against, and the one every other configuration takes)
     self.direct_critic = bool(direct_critic)
     self._graphs = {}
-    # MIOpen kernel selection: EXPO_MIOPEN_FIND=1 switches on its benchmark ("find") mode, 0 keeps the immediate-mode
-    # heuristic.  (Rounds 1-2 needed find mode: torch's generic double backward of the gradient penalty runs forward
-    # convolutions with batch and channels swapped, for which the heuristic picked a 2 ms kernel.  Those convolutions
-    # are gone -- exposure_amd/nn_ops.py keeps every derivative on the native forward / data / weight kernels.)
-    # Default off: find mode TRIES every applicable solver on each new problem shape, and one of those trial kernels
-    # faulted (GPU memory access fault, process abort) on gfx950 / ROCm 7.2 deep inside the 380-test gpu suite --
-    # reproducible there, never in a fresh process (gpurun r03p8-12).  bench.py --workload train switches it on
-    # (14.7 vs 16.2 ms per iteration).
-    torch.backends.cudnn.benchmark = os.environ.get('EXPO_MIOPEN_FIND', '0') == '1'
     self.generator = Agent(cfg)
     self.critic = Critic(cfg, num_state_dim=0)
     self.value = Critic(cfg, num_state_dim=cfg.num_state_dim)
@@ -134,7 +125,13 @@ class GAN(nn.Module):
         self._c_ema = sd['c_ema'].detach().clone().to(next(self.parameters()).device)
       else:
         self._c_ema.copy_(sd['c_ema'])
-    self.c_average_steps = int(sd.get('c_average_steps', 0))
+      self.c_average_steps = int(sd.get('c_average_steps', 0))
+    else:
+      # no average in the checkpoint: restart it -- the live scalar zeroed IN PLACE (captured steps advance this tensor),
+      # the step count with it (a stale value over (1 - 0.99^1) would be a hundredfold overshoot)
+      if self._c_ema is not None:
+        self._c_ema.zero_()
+      self.c_average_steps = 0
 
   # -- learning rates (config_example.py:134-158; net.py:222-251)
   def set_lrs(self, it, zero_g=False):

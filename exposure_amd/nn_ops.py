@@ -1,23 +1,24 @@
 """Autograd building blocks of the convnets that drive the filter path (``feature_extractor``
 ``/root/reference/agent.py:11-37``, ``cnn`` ``critics.py:6-38``, the FC heads): the stride-2 convolution and the
-``bias + lrelu`` behind every layer.  The GEMM work stays with MIOpen / hipBLASLt (MFMA); this module decides WHICH
-library kernels run and fuses what sits between them.
+``bias + lrelu`` behind every layer.  On a ROCm device every convolution primitive runs on the in-house kernels of
+``csrc/conv_ops.hip`` (f32 matrix cores; since round 6 the weight gradient and the first layers' data gradient too: no
+MIOpen kernel, no zero fill); the FC layers' GEMMs stay with hipBLASLt.  CPU tensors (the tests' float64 runs) and shapes
+the kernels do not take (an odd output width for the weight gradient, an output channel count that is not a multiple
+of 4 for the data gradient, other dtypes) go through ``aten::convolution``.
 
 * :func:`conv2d_nhwc` -- ``ly.conv2d(kernel_size=4, stride=2)`` (SAME) as a family of three autograd Functions that is
   closed under differentiation.  A convolution is bilinear in (input, weight), so every derivative of every order is
-  one of three library calls: forward ``F(x, W)``, data gradient ``D(g, W)`` (a transposed convolution) and weight
+  one of three primitives: forward ``F(x, W)``, data gradient ``D(g, W)`` (a transposed convolution) and weight
   gradient ``G(x, g)``.  torch's generic double backward instead re-expresses the weight gradient of ``D`` as a
   FORWARD convolution with batch and channels swapped -- for the critic's first layer a 6-image batch of 64-channel
-  64x64 inputs under a 32x32 dilated kernel -- which MIOpen runs in 538 us (+ three layout transposes), against
-  17-30 us for its native weight-gradient kernel on the same operands.  The WGAN-GP term (net.py:174-194) takes that
-  path once per critic layer and step: 0.73 ms of a 3.1 ms critic step (gpurun r03p4).
+  64x64 inputs under a 32x32 dilated kernel (538 us + three layout transposes in MIOpen, gpurun r03p4).
+* :func:`conv_trunk` -- a whole stack of layers as ONE once-differentiable node (the generator step); the critic
+  update with its double backward is hand-scheduled (``exposure_amd/critic_direct.py``).
 * :func:`bias_lrelu` -- ``lrelu(y + b)`` (util.py:225-229) in one HIP launch forward and one per backward
   (``expo_bias_lrelu_fwd`` / ``expo_lrelu_bwd``) instead of 2 + 4 element-wise torch launches.
 
 Tensors are NHWC float32 (the reference's layout); convolutions see them as channels_last NCHW views, no copies.
 """
-import os
-
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -73,10 +74,9 @@ def _nhwc(x_nchw):
 
 def _hip_conv(x, w):
   """The in-house implicit-GEMM kernels (csrc/conv_ops.hip) take float32 NHWC tensors on a device and a weight in
-  channels_last memory order ([co][kh][kw][ci]); EXPO_HIP_CONV=0 sends every convolution to MIOpen as before."""
+  channels_last memory order ([co][kh][kw][ci])."""
   return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 4 and
-          tuple(w.shape[2:]) == (4, 4) and w.permute(0, 2, 3, 1).is_contiguous() and
-          os.environ.get('EXPO_HIP_CONV', '1') == '1')
+          tuple(w.shape[2:]) == (4, 4) and w.permute(0, 2, 3, 1).is_contiguous())
 
 
 def _conv_fwd(x, w, bias=None, act=0, leak=0.2):
@@ -113,22 +113,19 @@ class _ConvF(torch.autograd.Function):
 
 
 class _ConvD(torch.autograd.Function):
-  """dx = D(g, W): the data gradient of _ConvF = the transposed convolution of g (NHWC, spatial size doubles).
-  Issued as ``aten.convolution_backward`` with only the input gradient requested -- MIOpen's backward-data kernels,
-  the same call torch's own convolution backward makes (the input operand only carries the shape) -- rather than as
-  a transposed forward convolution: that route picked a kernel that faults on gfx950 / ROCm 7.2 for the 8-image
-  batch of the parity tests when earlier find-mode trials had run in the process (gpurun r03p9)."""
+  """dx = D(g, W): the data gradient of _ConvF = the transposed convolution of g (NHWC, spatial size doubles) --
+  ``expo_conv4x4s2_bwd_data`` (four parity-class GEMMs on the f32 matrix cores; 6 / 17 input planes on the vector ALUs).
+  The fallback is ``aten.convolution_backward`` with only the input gradient requested (the input operand only carries
+  the shape) rather than a transposed forward convolution: that route picked a MIOpen kernel that faults on gfx950 /
+  ROCm 7.2 (gpurun r03p9)."""
 
   @staticmethod
   def forward(ctx, g, w):
     ctx.save_for_backward(g, w)
     n, h, wd, _ = g.shape
-    # (not for the first layers: with 6 / 14 / 17 input planes a 32-wide tile of input channels is mostly padding and
-    # MIOpen's kernel is faster -- 28-45 against 50 us at batch 64, profiles/r05_p3_conv_bwd_wrw.txt)
-    if (_hip_conv(g, w) and w.shape[0] % 4 == 0 and w.shape[1] >= 24 and
-        os.environ.get('EXPO_HIP_CONV_BWD', '1') == '1'):
+    if _hip_conv(g, w) and w.shape[0] % 4 == 0:
       dx = torch.empty((n, 2 * h, 2 * wd, w.shape[1]), dtype=torch.float32, device=g.device)
-      _cabi.conv4x4s2_bwd_data(g, w, dx)  # four parity-class GEMMs on the f32 matrix cores, no zero fill
+      _cabi.conv4x4s2_bwd_data(g, w, dx)  # no zero fill: every element is written
       return dx
     x_like = torch.empty((n, w.shape[1], 2 * h, 2 * wd), dtype=g.dtype, device=g.device,
                          memory_format=torch.channels_last)
@@ -145,19 +142,15 @@ class _ConvD(torch.autograd.Function):
 
 
 class _ConvG(torch.autograd.Function):
-  """dW = G(x, g): the weight gradient of _ConvF (MIOpen's wrw kernel); ``w_like`` only carries shape / layout."""
+  """dW = G(x, g): the weight gradient of _ConvF (``expo_conv4x4s2_wrw``: a fixed summation order, no atomics, no zero
+  fill); ``w_like`` only carries shape / layout."""
 
   @staticmethod
   def forward(ctx, x, g, w_like):
     ctx.save_for_backward(x, g)
-    # EXPO_HIP_CONV_WRW: 0 = MIOpen's kernel for every layer (default), 1 = expo_conv4x4s2_wrw for every layer (a fixed
-    # summation order; MIOpen's split-K kernels add with float atomics), auto = in-house where it measured faster than
-    # MIOpen's zero fill + kernel pair: 24 <= C_in < 128 (19.4 / 19.5 vs 21.3 / 20.4 us, profiles/r05_final_conv_bench.txt).
-    mode = os.environ.get('EXPO_HIP_CONV_WRW', '0')
-    if ((mode == '1' or (mode == 'auto' and 24 <= x.shape[3] < 128)) and _hip_conv(x, w_like) and
-        g.dtype == torch.float32 and g.shape[2] % 2 == 0):
+    if _hip_conv(x, w_like) and g.dtype == torch.float32 and g.shape[2] % 2 == 0:  # (pixels are consumed in pairs)
       dw = torch.empty_like(w_like, memory_format=torch.preserve_format)  # the weight's own (channels_last) layout
-      _cabi.conv4x4s2_wrw(x, g.contiguous(), dw)  # deterministic split over the pixels, no zero fill
+      _cabi.conv4x4s2_wrw(x, g.contiguous(), dw)
       return dw
     return torch.ops.aten.convolution_backward(_nchw(g), _nchw(x), w_like, None, _STRIDE, _PAD, _DIL, False, [0, 0], 1,
                                                [False, True, False])[1]
@@ -276,7 +269,7 @@ class _ConvBiasLrelu(torch.autograd.Function):
 
 def conv_bias_lrelu(x, weight, bias, leak=0.2):
   """``lrelu(ly.conv2d(x, C_out, kernel_size=4, stride=2) + bias)`` for NHWC float32 ``x``: fused where the in-house
-  kernel runs, the ``conv2d_nhwc`` + ``bias_lrelu`` pair elsewhere (CPU, EXPO_HIP_CONV=0, other dtypes)."""
+  kernel runs, the ``conv2d_nhwc`` + ``bias_lrelu`` pair elsewhere (CPU, other dtypes)."""
   assert x.dim() == 4 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and tuple(weight.shape[2:]) == (4, 4)
   x = x.contiguous()
   if _hip_conv(x, weight) and bias is not None:
@@ -443,8 +436,7 @@ class _PlanesConcat(torch.autograd.Function):
 def planes_concat(images, vec, offset=0.5):
   """The input of ``cnn`` / ``feature_extractor``: NHWC ``images`` (3 channels) with the rows of ``vec`` (N, V) appended
   as V constant planes, minus ``offset`` -- critics.py:64-76, agent.py:17-19 + util.py:31-36."""
-  if (images.is_cuda and images.dtype in (torch.float16, torch.float32) and images.shape[-1] == 3 and
-      os.environ.get('EXPO_PLANES_CONCAT', '1') == '1'):
+  if images.is_cuda and images.dtype in (torch.float16, torch.float32) and images.shape[-1] == 3:
     return _PlanesConcat.apply(images, vec, float(offset))
   net = images.float()
   if vec is not None:

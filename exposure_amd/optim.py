@@ -129,7 +129,11 @@ class HipAdam:
       for idx, p in zip(saved['params'], group['params']):
         st = sd['state'].get(idx)
         if st is None:
-          self.state.pop(p, None)
+          # no moments in the checkpoint: ZERO the existing buffers in place (a captured hipGraph keeps updating these
+          # very tensors; popping them would leave the graph on stale moments while an eager step allocates new ones)
+          if p in self.state:
+            for t in self.state[p]:
+              t.zero_()
           continue
         if tuple(st['exp_avg'].shape) != tuple(p.shape):
           raise ValueError('HipAdam.load_state_dict: moment shape %s for a parameter of shape %s' %

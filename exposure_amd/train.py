@@ -2,7 +2,7 @@
 ``train.py:9-14`` / ``GAN.train`` (``net.py:298-403``) on synthetic FiveK-shaped data: the G/V and
 critic alternation with the device-resident replay memory, one hipGraph replay per optimisation
 step.  Dataset loading, TensorBoard, PNG dashboards and checkpoints of the reference are out of scope
-(SURVEY.md section 2); ``--save`` writes a plain ``torch.save`` state dict, ``--save-tf`` a TF-1 checkpoint
+(SURVEY.md section 2); ``--save`` writes weights + optimiser state with ``torch.save`` (``--resume`` reads it), ``--save-tf`` a TF-1 checkpoint
 (``checkpoint.py``, ``tf_bundle.py``).
 
 Note on the numbers it prints: with random-init weights the policy can chain Exposure (x11) and
@@ -27,7 +27,9 @@ def main(argv=None):
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--log-every', type=int, default=10)
   ap.add_argument('--no-graphs', action='store_true')
-  ap.add_argument('--save', default=None)
+  ap.add_argument('--save', default=None, help="torch.save of {'model': state_dict, 'optim': Adam slots, step counters, "
+                  "learning rates and the logit centre's average} -- what the reference's tf.train.Saver keeps (net.py:271)")
+  ap.add_argument('--resume', default=None, help='a file written by --save: weights and optimiser state are restored in place')
   ap.add_argument('--save-tf', default=None, metavar='MODEL_DIR',
                   help="also write MODEL_DIR/model.ckpt-<iters> in TensorFlow's checkpoint format, variable names and "
                   "layouts as the reference's graph declares them (net.py:380-384)")
@@ -43,6 +45,11 @@ def main(argv=None):
   # toy task with the statistics of the real one: dark linear-RAW-like inputs, brighter targets
   memory = ReplayMemory(cfg, SyntheticProvider(dev, gamma=2.2, scale=0.35, dtype=dt, seed=args.seed + 1),
                         SyntheticProvider(dev, gamma=1.2, scale=0.9, dtype=dt, seed=args.seed + 2), seed=args.seed)
+  if args.resume:
+    ckpt = torch.load(args.resume, map_location=dev)
+    gan.load_state_dict(ckpt['model'] if 'model' in ckpt else ckpt)
+    if 'optim' in ckpt:
+      gan.load_optimizer_state_dict(ckpt['optim'])
   t0 = time.time()
   hist = gan.train(memory, max_iter_step=args.iters, log_every=args.log_every)
   torch.cuda.synchronize()
@@ -50,7 +57,7 @@ def main(argv=None):
   print('%d iterations in %.1f s (iteration 0 = 100 warm-up generator steps + 100 critic steps, net.py:314-323)' %
         (len(hist), dt))
   if args.save:
-    torch.save(gan.state_dict(), args.save)
+    torch.save({'model': gan.state_dict(), 'optim': gan.optimizer_state_dict()}, args.save)
   if args.save_tf:
     from . import checkpoint
     print('wrote', checkpoint.save(gan, args.save_tf, args.iters))

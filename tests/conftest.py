@@ -4,11 +4,6 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the test processes' private copy of the shipped MIOpen rankings (exposure_amd/__init__.py) lives with the other
-# temporary files, not in the home directory of whoever runs the suite
-import tempfile
-
-os.environ.setdefault('EXPO_MIOPEN_DB_DIR', os.path.join(tempfile.gettempdir(), 'exposure_amd_miopen_db_%d' % os.getuid()))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 

@@ -28,7 +28,6 @@ python $R/bench.py --workload chain_fused > $OUT/bench_chain_fused.json 2>/dev/n
 python $R/bench.py --workload chain_fused --shape B > $OUT/bench_chain_fused_B.json 2>/dev/null
 python $R/bench.py --workload chain_fused --dtype f32 --shape B > $OUT/bench_chain_fused_f32_B.json 2>/dev/null
 python $R/bench.py --workload train --steps 20 --warmup 3 > $OUT/bench_train.json 2>/dev/null
-python $R/bench.py --workload train --steps 20 --warmup 3 --miopen-find on > $OUT/bench_train_find_on.json 2>/dev/null
 python $R/bench.py --workload train --steps 10 --warmup 3 --graph off > $OUT/bench_train_eager.json 2>/dev/null
 python $R/tools/bench_extra.py > $OUT/bench_extra.json 2>/dev/null
 python $R/tools/r05/conv_bench.py all --reps 20 > $OUT/conv_bench.txt 2>&1  # the in-house convolution kernels against MIOpen, per layer
@@ -53,6 +52,7 @@ python $R/tools/rocpd_stats.py "$(db /tmp/kt_chain_all)" grid_y=32 > $OUT/kernel
 kt cold_all python $R/bench.py --shape $COLD $Q
 python $R/tools/rocpd_stats.py "$(db /tmp/kt_cold_all)" grid_y=256,8 > $OUT/kernel_stats_cold.csv  # whole-batch launches of the per-kernel leg
 python $R/tools/rocpd_stats.py "$(db /tmp/kt_cold_all)" grid_y=32 > $OUT/kernel_stats_cold_tiles.csv  # the chain calls: half-tile launches
+kt chain_A python $R/bench.py --shape A $Q
 kt chain_B python $R/bench.py --shape B $Q
 kt infer_B python $R/bench.py --workload infer --shape B
 kt infer_C python $R/bench.py --workload infer --shape C
