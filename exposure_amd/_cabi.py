@@ -57,6 +57,9 @@ SIGNATURES = {
     'expo_conv4x4s2_bwd_data_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_fwd_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_wrw_bias': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'expo_conv4x4s2_wrw_group': (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                      ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),
+                                      ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_vp), ctypes.POINTER(_sz), _vp]),
     'expo_critic_head_fwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
     'expo_critic_report': (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _f, _fp, _fp, _vp]),
     'expo_critic_head_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
@@ -942,6 +945,34 @@ def conv4x4s2_wrw_bias(x, dy, dw, dbias, bias_images=None):
                                        n, h, wd, cin, cout, ctypes.c_void_p(ws.data_ptr() if ws is not None else 0),
                                        ctypes.c_size_t(ws.numel() if ws is not None else 0), _stream()),
            'expo_conv4x4s2_wrw_bias')
+
+
+def conv4x4s2_wrw_group(items):
+  """The weight and bias gradients of a stack of layers with one reduce launch (expo_conv4x4s2_wrw_group).  ``items``:
+  up to 8 tuples ``(x, dy, dw, dbias or None, bias_images or None)`` as for :func:`conv4x4s2_wrw_bias`."""
+  lib = load()
+  k = len(items)
+  assert 1 <= k <= 8
+  xs, dys, dws, dbs, bis, ns, hs, ws_, cis, cos, wss, wsb, keep = [], [], [], [], [], [], [], [], [], [], [], [], []
+  for x, dy, dw, db, bias_images in items:
+    n, h, wd, cin = x.shape
+    cout = dy.shape[-1]
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    assert dy.dtype == torch.float32 and dy.is_contiguous() and tuple(dy.shape) == (n, h // 2, wd // 2, cout)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (cout, cin, 4, 4) and dw.permute(0, 2, 3, 1).is_contiguous()
+    if db is not None:
+      _f32(db, 'dbias', (cout,))
+    need = int(lib.expo_conv4x4s2_wrw_workspace_bytes(n, h, wd, cin, cout))
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
+    keep.append(ws)
+    xs.append(x.data_ptr()), dys.append(dy.data_ptr()), dws.append(dw.data_ptr()), dbs.append(db.data_ptr() if db is not None else 0)
+    bis.append(n if bias_images is None else int(bias_images)), ns.append(n), hs.append(h), ws_.append(wd), cis.append(cin), cos.append(cout)
+    wss.append(ws.data_ptr() if ws is not None else 0), wsb.append(ws.numel() if ws is not None else 0)
+  vp = lambda v: (_vp * k)(*v)
+  ia = lambda v: (_i * k)(*v)
+  with torch.cuda.device(items[0][0].device):
+    _check(lib.expo_conv4x4s2_wrw_group(k, vp(xs), vp(dys), vp(dws), vp(dbs), ia(bis), ia(ns), ia(hs), ia(ws_), ia(cis), ia(cos),
+                                        vp(wss), (_sz * k)(*wsb), _stream()), 'expo_conv4x4s2_wrw_group')
 
 
 def critic_head_fwd(hpre, w2, b2, n_real, n_fake, n_interp, inv_n, logits, h, dh, leak=0.2):

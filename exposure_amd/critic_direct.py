@@ -145,8 +145,8 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
   thpre = torch.mm(acts[-1][2 * n:].reshape(n, critic.flat), critic.fc1.weight.t())  # (n, hidden)
 
   # ---- gradients: one launch per layer over [loss rows | penalty rows] -----------------------------------------------
-  for l, conv in enumerate(convs, start=1):
-    _cabi.conv4x4s2_wrw_bias(acts[l - 1], gys[l], grads[id(conv.weight)], grads[id(conv.bias)], 2 * n)
+  _cabi.conv4x4s2_wrw_group([(acts[l - 1], gys[l], grads[id(conv.weight)], grads[id(conv.bias)], 2 * n)
+                             for l, conv in enumerate(convs, start=1)])  # (one reduce launch for the four layers)
   torch.mm(dh.t(), flat, out=grads[id(critic.fc1.weight)])
   _cabi.critic_head_bwd(dh, h, thpre, n, n, n, inv_n, grads[id(critic.fc1.bias)],
                         grads[id(critic.fc2.weight)].reshape(hidden), grads[id(critic.fc2.bias)], LEAK)

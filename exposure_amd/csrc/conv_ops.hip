@@ -602,7 +602,9 @@ static FlatPlan bwd_plan(const ConvDims& d, int ni, int forced_s) {
   p.tiles_m = (d.m + 31) / 32;
   p.tiles_n = (d.cin + 32 * ni - 1) / (32 * ni);
   const long tiles = 4L * p.tiles_m * p.tiles_n;
-  const long target = 4096 / ni;
+  // ~4096 waves whatever the tile width: with two channel tiles per wave the third layer at batch 192 ran 54 us on 3072
+  // waves and 43 us on 6144 (tools/r06/conv_sweep.py); the smaller batches are flat between 2048 and 4096
+  const long target = 4096;
   int s = 1;
   while (s < 16 && tiles * s * 2 <= target + target / 2) s *= 2;
   while (s > 4 && (d.cout + (s / 4) - 1) / (s / 4) < 8) s /= 2;
@@ -616,60 +618,90 @@ static FlatPlan bwd_plan(const ConvDims& d, int ni, int forced_s) {
 
 // ---- data gradient of the FIRST layers (6 / 17 input planes: critic, value net) on the vector ALUs ----------------------
 // With Cin = 6 a 32-wide tile of input channels is 81 % padding: the matrix-core kernel above takes 47 us for 0.4 GFLOP.
-// Here a THREAD owns one input pixel of one parity class (ph, pw) -- blockIdx.y, so the taps and the weights are
-// wave-uniform -- and all CIN channels of it: per 4 output channels it loads one 16-byte chunk of dY for each of its 4
-// taps' pixels and issues 16 CIN FMAs whose weight operand is a SCALAR register (the weight index depends on loop
-// counters only: s_load through the scalar cache, no LDS, no vector loads for W).  No padding work: 768 FMAs per thread
-// for Cin = 6 (2.6 us chip-wide at batch 64), 2176 for Cin = 17.
+// Here a BLOCK owns four dY rows' worth of input pixels of one image (input rows 2 a0 .. 2 a0 + 7): it stages the six dY
+// rows a0 - 1 .. a0 + 4 they touch in LDS with coalesced 16-byte loads (pixel stride padded to Cout + 4 floats: the
+// per-pixel 16-byte reads below are conflict-free), and the weights of all four parity classes as [class][tap][co][ci].
+// WAVE = parity class (ph, pw) -- its taps and weights are wave-uniform, read from LDS as broadcasts -- and a lane = a
+// column b and two of the four rows: 2 pixels x CIN accumulators, 4 taps x Cout x CIN FMAs each, every weight read feeding
+// both pixels.  No padding work, no scattered global loads: 0.4 GFLOP for Cin = 6 at batch 64.  (Earlier versions of this
+// round: weights in scalar registers, one s_load per FMA group -- 23 / 84 us, scalar-load latency; four adjacent pixels per
+// thread straight from global memory -- 29 / 58 us, 64 cache lines per wave load.  profiles/r06_experiments.md)
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              const float* __restrict__ zmask, float* __restrict__ dx,
                                                              ConvDims d, float leak) {
-  const int cls = blockIdx.y, ph = cls >> 1, pw = cls & 1;
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  const bool m_ok = m < d.m;
-  const int mm = m_ok ? m : 0;
-  const int n = mm / (d.ho * d.wo), rem = mm - n * (d.ho * d.wo);
-  const int a = rem / d.wo, b = rem - a * d.wo;
-  const __amdgpu_buffer_rsrc_t rg = conv_rsrc(dy, size_t(d.n) * d.ho * d.wo * d.cout);
-  int goff[4];
-  bool gok[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int oh = a + ph - (t >> 1), ow = b + pw - (t & 1);
-    gok[t] = m_ok && unsigned(oh) < unsigned(d.ho) && unsigned(ow) < unsigned(d.wo);
-    goff[t] = ((n * d.ho + oh) * d.wo + ow) * d.cout;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CINP = (CIN + 3) / 4 * 4;  // weight rows padded to whole float4s
+  const int ps = d.cout + 4;               // floats per staged dY pixel
+  const int rowf = (d.wo + 2) * ps;        // a staged row: pixels ow = -1 .. wo (the two outer ones zero)
+  float* const wl = smem;                           // [4 classes][4 taps][cout][CINP]  (first: a statically 16-byte aligned base)
+  float* const gs = smem + 16 * d.cout * CINP;      // [6 rows][wo + 2][ps]
+  const int blocks_per_image = d.ho / 4;
+  const int n = blockIdx.x / blocks_per_image, a0 = (blockIdx.x - n * blocks_per_image) * 4;
+  const int tid = threadIdx.x;
+  // ---- stage: weights (every class), then the six dY rows (rows outside the image and the outer pixels as zeros) ----
+  for (int i = tid; i < 16 * d.cout * CINP; i += 256) {
+    const int c = i % CINP, rest = i / CINP, co = rest % d.cout, ct = rest / d.cout, t = ct & 3, cls = ct >> 2;
+    const int kh = 1 - (cls >> 1) + 2 * (t >> 1), kw = 1 - (cls & 1) + 2 * (t & 1);
+    wl[i] = c < CIN ? w[(size_t(co) * 16 + kh * 4 + kw) * CIN + c] : 0.f;
   }
-  float acc[CIN];
+  const int q4 = d.cout / 4;  // float4 chunks per pixel
+  for (int i = tid; i < 6 * (d.wo + 2) * q4; i += 256) {
+    const int q = i % q4, rest = i / q4, px = rest % (d.wo + 2), r = rest / (d.wo + 2);
+    const int oh = a0 - 1 + r, ow = px - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (unsigned(oh) < unsigned(d.ho) && unsigned(ow) < unsigned(d.wo))
+      v = *reinterpret_cast<const float4*>(dy + (size_t(n * d.ho + oh) * d.wo + ow) * d.cout + 4 * q);
+    *reinterpret_cast<float4*>(gs + r * rowf + px * ps + 4 * q) = v;
+  }
+  __syncthreads();
+  // ---- compute: wave = class, lane = (row pair, column) ------------------------------------------------------------------
+  const int cls = tid >> 6, ph = cls >> 1, pw = cls & 1, lane = tid & 63;
+  const float4* const wc = reinterpret_cast<const float4*>(wl) + size_t(cls) * 4 * d.cout * (CINP / 4);
+  for (int b = lane & 31; b < d.wo; b += 32) {  // (wo = 32 for the 64 x 64 proxies: one pass)
+    const int al = lane >> 5;                   // pixels a0 + al and a0 + al + 2
+    float acc[2][CIN];
 #pragma unroll
-  for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
-  float4 g[4], gn[4];
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) g[t] = buf_load4(rg, goff[t], gok[t]);
-  for (int co = 0; co < d.cout; co += 4) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) gn[t] = buf_load4(rg, goff[t] + co + 4, gok[t] && co + 4 < d.cout);
+      for (int c = 0; c < CIN; ++c) acc[j][c] = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int kh = 1 - ph + 2 * (t >> 1), kw = 1 - pw + 2 * (t & 1);
-      const float gv[4] = {g[t].x, g[t].y, g[t].z, g[t].w};
+      const int th = t >> 1, tw = t & 1;
+      // staged row of pixel j: oh - (a0 - 1) = al + 2 j + ph - th + 1; staged column: ow + 1 = b + pw - tw + 1
+      // (float4 units: rows and pixels are whole float4s, so the reads are single 16-byte LDS operations)
+      const float4* g0 = reinterpret_cast<const float4*>(gs) + ((al + ph - th + 1) * rowf + (b + pw - tw + 1) * ps) / 4;
+      const float4* g1 = g0 + 2 * rowf / 4;
+      const float4* wt = wc + size_t(t) * d.cout * (CINP / 4);
+      for (int co = 0; co < d.cout; co += 4) {
+        const float4 ga = g0[co / 4], gb = g1[co / 4];
+        const float va[4] = {ga.x, ga.y, ga.z, ga.w}, vb[4] = {gb.x, gb.y, gb.z, gb.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* wp = w + (size_t(co + j) * 16 + kh * 4 + kw) * CIN;  // wave-uniform: scalar loads
+        for (int q = 0; q < 4; ++q) {
+          float wv[CINP];
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) acc[c] = fmaf(gv[j], wp[c], acc[c]);
+          for (int c4 = 0; c4 < CINP; c4 += 4) {
+            const float4 v = wt[(co + q) * (CINP / 4) + c4 / 4];  // wave-uniform address: a broadcast read
+            wv[c4] = v.x; wv[c4 + 1] = v.y; wv[c4 + 2] = v.z; wv[c4 + 3] = v.w;
+          }
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) {
+            acc[0][c] = fmaf(va[q], wv[c], acc[0][c]);
+            acc[1][c] = fmaf(vb[q], wv[c], acc[1][c]);
+          }
+        }
       }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) g[t] = gn[t];
-  }
-  if (m_ok) {
-    const size_t o = (size_t(n * d.h + 2 * a + ph) * d.w + 2 * b + pw) * CIN;
+    for (int j = 0; j < 2; ++j) {
+      const int a = a0 + al + 2 * j;
+      const size_t o = (size_t(n * d.h + 2 * a + ph) * d.w + 2 * b + pw) * CIN;
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) {
-      float v = acc[c];
-      if (zmask) v *= lrelu_slope_v(zmask[o + c], leak);
-      dx[o + c] = v;
+      for (int c = 0; c < CIN; ++c) {
+        float v = acc[j][c];
+        if (zmask) v *= lrelu_slope_v(zmask[o + c], leak);
+        dx[o + c] = v;
+      }
     }
   }
 }
@@ -850,6 +882,47 @@ __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __res
   }
 }
 
+// The same sum for SEVERAL layers in one launch (the weight gradients of a whole stack of layers: their main kernels run
+// back to back, one reduce launch finishes them all).  A block finds its layer in the table of first blocks.
+constexpr int kWrwGroupMax = 8;
+struct WrwReduceGroup {
+  const float* ws[kWrwGroupMax];
+  float* dw[kWrwGroupMax];
+  float* dbias[kWrwGroupMax];
+  unsigned dw4[kWrwGroupMax], count4[kWrwGroupMax], stride4[kWrwGroupMax], p[kWrwGroupMax];
+  unsigned first_block[kWrwGroupMax + 1];
+  int layers;
+};
+__global__ __launch_bounds__(256) void conv_wrw_reduce_group_kernel(const WrwReduceGroup g) {
+  __shared__ float4 part[16][16];
+  int l = 0;
+  while (l + 1 < g.layers && blockIdx.x >= g.first_block[l + 1]) ++l;
+  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const size_t i = size_t(blockIdx.x - g.first_block[l]) * 16 + el;
+  const float4* src = reinterpret_cast<const float4*>(g.ws[l]);
+  const size_t count4 = g.count4[l], stride4 = g.stride4[l];
+  const int p = int(g.p[l]);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < count4) {
+    for (int q = grp; q < p; q += 16) {
+      const float4 t = src[size_t(q) * stride4 + i];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+  }
+  part[grp][el] = v;
+  __syncthreads();
+  if (grp == 0 && i < count4) {
+    float4 r = part[0][el];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 t = part[k][el];
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    if (i < g.dw4[l]) reinterpret_cast<float4*>(g.dw[l])[i] = r;
+    else reinterpret_cast<float4*>(g.dbias[l])[i - g.dw4[l]] = r;
+  }
+}
+
 static WrwPlan wrw_plan(const ConvDims& d, int forced_s, int forced_p) {
   WrwPlan p;
   p.tiles_co = (d.cout + 31) / 32;
@@ -945,7 +1018,13 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     int ni = forced_nt;  // column tiles per wave (0: the library's choice)
     // two column tiles per wave (A fragment shared in registers) where that still leaves >= 256 tiles: the third layer,
     // the fourth at batch 128 (17.3 vs 20.0 us, 26.3 vs 31.5 us)
-    if (ni == 0) ni = (long((d.m + 31) / 32) * ((d.cout + 63) / 64) >= 256) ? 2 : 1;
+    if (ni == 0) {
+      const long t2 = long((d.m + 31) / 32) * ((d.cout + 63) / 64), t1 = long((d.m + 31) / 32) * ((d.cout + 31) / 32);
+      ni = t2 >= 256 ? 2 : 1;
+      // blocks that do not divide among the 256 CUs leave half of them a round short: the fourth layer at batch 192 is 384
+      // blocks with two column tiles per wave (48.8 us) and 768 with one (44.4 us)
+      if (ni == 2 && t2 % 256 != 0 && t2 < 1024 && t1 % 256 == 0) ni = 1;
+    }
     if (ni != 1 && ni != 2) ni = 1;
     if (d.cout <= 32) ni = 1;
     const FlatPlan pl = flat_plan(d, ni, forced_s);
@@ -980,10 +1059,21 @@ static int conv_bwd_data_impl(const float* dy, const float* w, const float* zmas
   int ni = conv_tuning().nt.load();  // input-channel tiles per wave (0: the library's choice)
   const int forced_s = conv_tuning().slices.load();
   // the first layers (6 / 17 input planes) on the vector ALUs (conv_bwd_small_kernel), unless a probe forces a plan
-  if (ni == 0 && forced_s == 0 && (cin == 6 || cin == 17) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
-    const dim3 grid(unsigned((d.m + 255) / 256), 4);
-    if (cin == 6) hipLaunchKernelGGL(conv_bwd_small_kernel<6>, grid, dim3(256), 0, s, dy, w, zmask, dx, d, leak);
-    else hipLaunchKernelGGL(conv_bwd_small_kernel<17>, grid, dim3(256), 0, s, dy, w, zmask, dx, d, leak);
+  const size_t small_lds = (size_t(6) * (d.wo + 2) * (cout + 4) + size_t(16) * cout * ((cin + 3) / 4 * 4)) * 4;
+  if (ni == 0 && forced_s == 0 && (cin == 6 || cin == 17) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && d.ho % 4 == 0 &&
+      small_lds <= 160 * 1024) {
+    const dim3 grid(unsigned(d.n * (d.ho / 4)));
+    if (cin == 6) {
+      static const hipError_t attr6 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_small_kernel<6>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)attr6;
+      hipLaunchKernelGGL(conv_bwd_small_kernel<6>, grid, dim3(256), small_lds, s, dy, w, zmask, dx, d, leak);
+    } else {
+      static const hipError_t attr17 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_small_kernel<17>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)attr17;
+      hipLaunchKernelGGL(conv_bwd_small_kernel<17>, grid, dim3(256), small_lds, s, dy, w, zmask, dx, d, leak);
+    }
     HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data (small) launch");
     return EXPO_OK;
   }
@@ -1003,8 +1093,11 @@ static int conv_bwd_data_impl(const float* dy, const float* w, const float* zmas
 // padded to whole float4s)
 static size_t wrw_copy_floats(const ConvDims& d) { return size_t(d.cout) * d.kdim + size_t((d.cout + 3) / 4 * 4); }
 
+// `group` non-null: the reduce launch is DEFERRED -- the layer is appended to the group and expo_conv4x4s2_wrw_group issues
+// one reduce launch for all of them
 static int conv_wrw_impl(const float* x, const float* dy, float* dw, float* dbias, int bias_images, int n, int h, int wd,
-                         int cin, int cout, void* workspace, size_t workspace_bytes, void* stream) {
+                         int cin, int cout, void* workspace, size_t workspace_bytes, void* stream,
+                         WrwReduceGroup* group = nullptr) {
   ConvDims d;
   if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
   if (!dw) return fail(EXPO_E_BADARG, "null pointer");
@@ -1039,6 +1132,13 @@ static int conv_wrw_impl(const float* x, const float* dy, float* dw, float* dbia
   if (pl.p > 1) {
     const size_t dw4 = count / 4, count4 = dbias ? copy / 4 : dw4;
     // (the copies' stride is `copy` floats either way: without a bias gradient the tail of a copy is not read)
+    if (group) {
+      const int l = group->layers++;
+      group->ws[l] = ws; group->dw[l] = dw; group->dbias[l] = dbias;
+      group->dw4[l] = unsigned(dw4); group->count4[l] = unsigned(count4); group->stride4[l] = unsigned(copy / 4);
+      group->p[l] = unsigned(pl.p);
+      return EXPO_OK;
+    }
     hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(unsigned((count4 + 15) / 16)), dim3(256), 0, s,
                        static_cast<const float*>(workspace), dw, dbias, dw4, count4, copy / 4, pl.p);
     HIP_TRY(hipGetLastError(), "conv4x4s2_wrw reduce launch");
@@ -1108,6 +1208,32 @@ int expo_conv4x4s2_wrw_bias(const float* x, const float* dy, float* dw, float* d
                             int wd, int cin, int cout, void* workspace, size_t workspace_bytes, void* stream) {
   if (!dbias) return fail(EXPO_E_BADARG, "null pointer");
   return conv_wrw_impl(x, dy, dw, dbias, bias_images, n, h, wd, cin, cout, workspace, workspace_bytes, stream);
+}
+
+int expo_conv4x4s2_wrw_group(int count, const float* const* x, const float* const* dy, float* const* dw,
+                             float* const* dbias, const int* bias_images, const int* n, const int* h, const int* wd,
+                             const int* cin, const int* cout, void* const* workspace, const size_t* workspace_bytes,
+                             void* stream) {
+  if (count < 0 || count > kWrwGroupMax) return fail(EXPO_E_BADARG, "conv4x4s2_wrw_group: 0 <= count <= 8 layers");
+  if (count == 0) return EXPO_OK;
+  if (!x || !dy || !dw || !dbias || !bias_images || !n || !h || !wd || !cin || !cout || !workspace || !workspace_bytes)
+    return fail(EXPO_E_BADARG, "null pointer");
+  WrwReduceGroup g;
+  g.layers = 0;
+  for (int l = 0; l < count; ++l)
+    if (int rc = conv_wrw_impl(x[l], dy[l], dw[l], dbias[l], bias_images[l], n[l], h[l], wd[l], cin[l], cout[l],
+                               workspace[l], workspace_bytes[l], stream, &g))
+      return rc;
+  if (g.layers == 0) return EXPO_OK;  // every layer fitted one block copy: written in place
+  unsigned blocks = 0;
+  for (int l = 0; l < g.layers; ++l) {
+    g.first_block[l] = blocks;
+    blocks += (g.count4[l] + 15) / 16;
+  }
+  g.first_block[g.layers] = blocks;
+  hipLaunchKernelGGL(conv_wrw_reduce_group_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  HIP_TRY(hipGetLastError(), "conv4x4s2_wrw_group reduce launch");
+  return EXPO_OK;
 }
 
 }  // extern "C"

@@ -328,12 +328,13 @@ class _ConvTrunk(torch.autograd.Function):
     _cabi.lrelu_bwd(acts[n_l], gz.contiguous(), gy, ctx.leak)
     grads = [None] * (2 * n_l)
     gx = None
+    wrw = []  # the layers' weight-gradient launches, finished by ONE reduce launch at the end (expo_conv4x4s2_wrw_group)
     for l in range(n_l, 0, -1):
       w = ws[l - 1]
       if want_w:
         dw = torch.empty_like(w, memory_format=torch.preserve_format)
         db = torch.empty((w.shape[0],), dtype=torch.float32, device=w.device)
-        _cabi.conv4x4s2_wrw_bias(acts[l - 1], gy, dw, db)
+        wrw.append((acts[l - 1], gy, dw, db, None))
         grads[2 * (l - 1)], grads[2 * (l - 1) + 1] = dw, db
       if l > 1:
         g = torch.empty_like(acts[l - 1])
@@ -342,6 +343,8 @@ class _ConvTrunk(torch.autograd.Function):
       elif ctx.needs_input_grad[0]:
         gx = torch.empty_like(acts[0])
         _cabi.conv4x4s2_bwd_data(gy, w, gx)
+    for k in range(0, len(wrw), 8):
+      _cabi.conv4x4s2_wrw_group(wrw[k:k + 8])
     return (gx, None) + tuple(grads)
 
 

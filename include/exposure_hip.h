@@ -571,6 +571,14 @@ int expo_conv4x4s2_fwd_mask(const float* x, const float* w, const float* zmask, 
                             int cout, float leak, void* stream);
 int expo_conv4x4s2_wrw_bias(const float* x, const float* dy, float* dw, float* dbias, int bias_images, int n, int h,
                             int wd, int cin, int cout, void* workspace, size_t workspace_bytes, void* stream);
+/* The weight (and bias) gradients of up to 8 layers -- a whole stack -- with ONE reduce launch for all of them: per layer the
+ * arguments of expo_conv4x4s2_wrw_bias (arrays of `count` entries; dbias[l] may be NULL: no bias gradient for that
+ * layer), each layer with its own workspace of expo_conv4x4s2_wrw_workspace_bytes(...) bytes.  Same results, bit for
+ * bit, as `count` separate calls. */
+int expo_conv4x4s2_wrw_group(int count, const float* const* x, const float* const* dy, float* const* dw,
+                             float* const* dbias, const int* bias_images, const int* n, const int* h, const int* wd,
+                             const int* cin, const int* cout, void* const* workspace, const size_t* workspace_bytes,
+                             void* stream);
 /* Probes and tests: waves per block (1 .. 4) and blocks per tile of the weight-gradient kernel (negative = leave as
  * is, 0 = the library's choice; initial values from EXPO_CONV_WRW_SLICES / EXPO_CONV_PARTS).  Independent of
  * expo_conv_tuning's `slices`. */

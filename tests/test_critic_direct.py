@@ -348,3 +348,23 @@ def test_conv_trunk_node_matches_the_layerwise_path(cin, size, n, frozen, gpu_de
       continue
     err, scale = float((a - b).abs().max()), float(b.abs().max())
     assert err <= 2e-5 * scale + 1e-9, (i, err, scale)
+
+
+def test_grouped_weight_gradients_equal_the_separate_calls(gpu_device):
+  """expo_conv4x4s2_wrw_group (one reduce launch for a stack of layers) == the same layers one call each, bit for bit,
+  including a layer small enough to need no reduce at all and one without a bias gradient."""
+  from exposure_amd import _cabi
+  dev = gpu_device
+  cases = [(6, 64, 6, 32), (6, 32, 32, 64), (6, 16, 64, 128), (6, 8, 128, 256), (1, 4, 4, 8)]
+  items, want = [], []
+  for k, (n, h, cin, cout) in enumerate(cases):
+    x, w, gy = _case(n, h, cin, cout, dev, seed=k)
+    dw, db = torch.full_like(w, float('nan')), (torch.full((cout,), float('nan'), device=dev) if k != 2 else None)
+    items.append((x, gy, dw, db, n - 1 if k == 0 else None))
+    rw, rb = torch.empty_like(w), torch.empty((cout,), device=dev)
+    _cabi.conv4x4s2_wrw_bias(x, gy, rw, rb, n - 1 if k == 0 else None)
+    want.append((rw, rb))
+  _cabi.conv4x4s2_wrw_group(items)
+  for (x, gy, dw, db, _), (rw, rb) in zip(items, want):
+    assert torch.equal(dw, rw)
+    assert db is None or torch.equal(db, rb)
