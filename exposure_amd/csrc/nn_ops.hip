@@ -410,7 +410,7 @@ static inline int grid_for(size_t items) {
 // torch's fused multi-tensor Adam walks chunks of 65 536 elements with one block each: 20-75 blocks for the 1-5 M
 // parameters of one of these networks, 43 us per step on 256 CUs (profiles/r04_final_kernel_stats_train.csv).  Here a
 // block takes 1 024 elements (one float4 per thread), tensors are addressed through a table passed by value, and the
-// step counter lives on the device (read by every block, advanced by the block that finishes last), so the launch is
+// step counter lives on the device (read by every block, advanced by a one-thread launch behind the update), so a step is
 // capturable and replays without host involvement.  Update rule = torch.optim.Adam (no weight decay, no amsgrad):
 //   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 constexpr int kAdamMaxTensors = EXPO_ADAM_MAX_TENSORS;
@@ -434,9 +434,8 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = p - step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, const float* __restrict__ lr, float* __restrict__ step,
-                                                   unsigned* __restrict__ ticket, float b1, float b2, float eps,
-                                                   int advance) {
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, const float* __restrict__ lr, const float* __restrict__ step,
+                                                   float b1, float b2, float eps) {
   int t = 0;
   while (t + 1 < a.count && blockIdx.x >= a.first_block[t + 1]) ++t;  // uniform: scalar compares
   const float st = step[0] + 1.0f;
@@ -467,17 +466,12 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, const float* __re
       v[k] = vv;
     }
   }
-  if (!advance) return;
-  // every block has read step[0] before it takes a ticket (its results depend on the value); the last ticket advances it
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned done = atomicAdd(ticket, 1u);
-    if (done == gridDim.x - 1) {
-      step[0] = st;
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
 }
+
+// t <- t + 1, as a launch of its own BEHIND the update (round 6).  Rounds 4-5 let the last of the update's blocks advance
+// the counter, found through one ticket atomic per block on a single word: ~12 ns each, 1 200 to 6 000 of them per step --
+// 14 of the 19 us of a critic step's update and 72 of the generator's 78 (profiles/r06_experiments.md).
+__global__ void adam_advance_kernel(float* __restrict__ step) { step[0] = step[0] + 1.0f; }
 
 // ---- the input of a convnet: image channels + per-image values broadcast as constant planes, centred ------------------
 // critics.py:64-76 (`tf.concat([images, states planes, statistics planes]) - 0.5` before `cnn`) and agent.py:17-19, 47-53
@@ -487,14 +481,23 @@ template <typename T>
 __global__ __launch_bounds__(256) void planes_concat_kernel(const T* __restrict__ img, const float* __restrict__ vec,
                                                             float* __restrict__ out, size_t total, unsigned hw, unsigned v,
                                                             float offset) {
+  // a PIXEL per thread (round 6; the first version walked elements and paid a 64-bit division for each: 18 us for the
+  // critic update's 192 x 64 x 64 x 6 input): blockIdx.y = image, so the planes' values are block-uniform
   const unsigned C = 3 + v;
-  for (size_t e = size_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += size_t(gridDim.x) * 256) {
-    const size_t pix = e / C;
-    const unsigned c = unsigned(e - pix * C);
-    float val;
-    if (c < 3) val = img ? float(img[pix * 3 + c]) : 0.0f;
-    else val = vec[(pix / hw) * v + (c - 3)];
-    out[e] = val - offset;
+  const unsigned n = blockIdx.y;
+  const float* vn = vec + size_t(n) * v;
+  (void)total;
+  for (unsigned p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) {
+    const size_t pix = size_t(n) * hw + p;
+    float* o = out + pix * C;
+    if (img) {
+      o[0] = float(img[pix * 3 + 0]) - offset;
+      o[1] = float(img[pix * 3 + 1]) - offset;
+      o[2] = float(img[pix * 3 + 2]) - offset;
+    } else {
+      o[0] = o[1] = o[2] = -offset;
+    }
+    for (unsigned c = 0; c < v; ++c) o[3 + c] = vn[c] - offset;
   }
 }
 
@@ -739,16 +742,18 @@ int expo_planes_concat(const void* images, const float* vec, float* out, int n, 
   if (!out || (v > 0 && !vec)) return fail(EXPO_E_BADARG, "null pointer");
   if (dtype != EXPO_F16 && dtype != EXPO_F32) return fail(EXPO_E_BADDTYPE, "dtype must be EXPO_F16 or EXPO_F32");
   if (pixels_per_image > 0xffffffffull) return fail(EXPO_E_BADARG, "image too large");
+  if (n > 65535) return fail(EXPO_E_BADARG, "n > 65535 not supported (grid.y)");
   const size_t total = size_t(n) * pixels_per_image * size_t(3 + v);
-  size_t blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
+  size_t bx = (pixels_per_image + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  const dim3 grid{unsigned(bx), unsigned(n), 1u};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == EXPO_F16)
-    hipLaunchKernelGGL(planes_concat_kernel<_Float16>, dim3(unsigned(blocks)), dim3(256), 0, s, (const _Float16*)images, vec,
-                       out, total, unsigned(pixels_per_image), unsigned(v), offset);
+    hipLaunchKernelGGL(planes_concat_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)images, vec, out, total,
+                       unsigned(pixels_per_image), unsigned(v), offset);
   else
-    hipLaunchKernelGGL(planes_concat_kernel<float>, dim3(unsigned(blocks)), dim3(256), 0, s, (const float*)images, vec, out,
-                       total, unsigned(pixels_per_image), unsigned(v), offset);
+    hipLaunchKernelGGL(planes_concat_kernel<float>, grid, dim3(256), 0, s, (const float*)images, vec, out, total,
+                       unsigned(pixels_per_image), unsigned(v), offset);
   HIP_TRY(hipGetLastError(), "planes_concat launch");
   return EXPO_OK;
 }
@@ -802,11 +807,13 @@ int expo_adam_step(int count, float* const* params, const float* const* grads, f
       a.vec[j] = aligned16(a.p[j]) && aligned16(a.g[j]) && aligned16(a.m[j]) && aligned16(a.v[j]);
     }
     a.first_block[a.count] = blocks;
-    const int advance = base + kAdamMaxTensors >= count;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, a, lr, step, static_cast<unsigned*>(ticket), beta1, beta2,
-                       eps, advance);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, a, lr, step, beta1, beta2, eps);
     HIP_TRY(hipGetLastError(), "adam launch");
   }
+  // every launch above computed with t = step + 1; the counter moves behind them (stream order)
+  (void)ticket;  // (ABI 4-5: the word the blocks took tickets on; still accepted, no longer touched)
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step);
+  HIP_TRY(hipGetLastError(), "adam advance launch");
   return EXPO_OK;
 }
 

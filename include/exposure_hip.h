@@ -479,9 +479,10 @@ int expo_curve_bwd(const void* x, const void* dy, void* dx, const float* params,
  *                                           all four in the same element order (tables of EXPO_ADAM_MAX_TENSORS
  *                                           tensors per launch; more tensors -> more launches)
  *   lr     device float        (a captured launch reads the learning rate of the replay)
- *   step   device float        t - 1 on entry; the launch computes with t = step + 1 and stores t (the block that
- *                              finishes last advances it: capturable, no host involvement)
- *   ticket device uint32, zero before the first call, owned by the optimiser (restored to zero by every call)
+ *   step   device float        t - 1 on entry; the update computes with t = step + 1 and a one-thread launch behind it
+ *                              stores t (capturable, no host involvement; ABI 4-5 let the update's last block do it,
+ *                              found through a ticket atomic per block -- most of the update's time)
+ *   ticket device uint32, owned by the optimiser; accepted for ABI compatibility, not touched since ABI 6
  * Update rule (torch.optim.Adam without weight decay / amsgrad; TF-1's differs only in where epsilon sits:
  * sqrt(v) + eps' with eps' = eps sqrt(1 - beta2^t)):
  *   m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
