@@ -59,9 +59,9 @@ def main():
                                                               ' '.join('%s=%.1f' % kv for kv in res.items())), flush=True)
       if args.what in ('bwd', 'all'):
         res = {}
-        for nt, sl in [(0, 0)] + [(nt, sl) for nt in (1, 2) for sl in (1, 2, 4, 8, 16)]:
-          _cabi.conv_tuning(0, nt, sl)
-          res['n%d s%d' % (nt, sl)] = timeit(lambda: _cabi.conv4x4s2_bwd_data_mask(gy, w, x, dx, 0.2))
+        for tile, nt, sl in [(0, 0, 0)] + [(0, nt, sl) for nt in (1, 2) for sl in (1, 2, 4, 8, 16)] + [(t, 0, 0) for t in (1, 2, 3)]:
+          _cabi.conv_tuning(tile, nt, sl)
+          res['n%d s%d' % (nt, sl) if tile == 0 else 't%d' % tile] = timeit(lambda: _cabi.conv4x4s2_bwd_data_mask(gy, w, x, dx, 0.2))
         _cabi.conv_tuning(0, 0, 0)
         best = min(res, key=res.get)
         print('%s bwd auto %.1f best %s %.1f (%.0f TF) | %s' % (head, res['n0 s0'], best, res[best], gf / res[best] * 1e3,
