@@ -4,11 +4,11 @@
 set -euo pipefail
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/final
-TAG=${1:-r05_final}
-for f in bench_chain bench_chain_1stream bench_chain_A bench_chain_B bench_chain_f32 bench_chain_cold bench_chain_cold_untiled bench_infer_B bench_infer_C bench_chain_fused bench_chain_fused_B bench_chain_fused_f32_B bench_train bench_train_find_on bench_train_eager bench_extra; do
+TAG=${1:-r06_final}
+for f in bench_chain bench_chain_1stream bench_chain_A bench_chain_B bench_chain_f32 bench_chain_cold bench_chain_cold_untiled bench_infer_B bench_infer_C bench_chain_fused bench_chain_fused_B bench_chain_fused_f32_B bench_train bench_train_eager bench_extra; do
   [ -s $SRC/$f.json ] && cp $SRC/$f.json profiles/${TAG}_$f.json
 done
-for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt $SRC/conv_bench.txt; do
+for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt $SRC/conv_bench.txt $SRC/conv_sweep.txt $SRC/step_bench.txt; do
   cp $f profiles/${TAG}_$(basename $f)
 done
 # bench.py quotes, beside its own figure, rocprofv3's duration of the dominant kernel from the table committed WHEN IT
@@ -18,7 +18,7 @@ import json, sys
 sys.path.insert(0, '.')
 import bench
 tag = sys.argv[1]
-for name in ('bench_chain', 'bench_chain_1stream'):
+for name in ('bench_chain', 'bench_chain_1stream', 'bench_chain_A', 'bench_chain_B'):
   path = 'profiles/%s_%s.json' % (tag, name)
   try:
     d = json.load(open(path))
@@ -26,7 +26,9 @@ for name in ('bench_chain', 'bench_chain_1stream'):
     continue
   r = d.get('roofline', {})
   if 'kernel' in r and 'rocprof_avg_us' in r:
-    r['rocprof_avg_us'] = bench.rocprof_avg_us(r['kernel'], prefix=tag.split('_')[0])
+    c = d['config']
+    shape = (c['batch_per_gpu'], c['height'], c['width'], 3)
+    r['rocprof_avg_us'] = bench.rocprof_avg_us(r['kernel'], shape, d['dtype'], prefix=tag.split('_')[0])
     json.dump(d, open(path, 'w'))
 PY
 [ -s $SRC/param_grad_errors.jsonl ] && python tools/r04/param_err_table.py $SRC/param_grad_errors.jsonl > profiles/${TAG}_param_grad_errors.md

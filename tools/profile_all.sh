@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every measured artefact under profiles/ in ONE gpurun call:
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/profile_all.sh'
-# then, back in the container:  tools/collect_profiles.sh r05_final
+# then, back in the container:  tools/collect_profiles.sh r06_final
 # (an 8-GPU lease additionally runs tools/scale_all.sh: the section 8(e) scaling table)
 # rocprofv3 passes: --kernel-trace alone (durations) and one --pmc counter per pass (never combined
 # with sys/runtime tracing); the rocpd databases stay on the GPU box, only CSV summaries come back.
@@ -30,8 +30,10 @@ python $R/bench.py --workload chain_fused --dtype f32 --shape B > $OUT/bench_cha
 python $R/bench.py --workload train --steps 20 --warmup 3 > $OUT/bench_train.json 2>/dev/null
 python $R/bench.py --workload train --steps 10 --warmup 3 --graph off > $OUT/bench_train_eager.json 2>/dev/null
 python $R/tools/bench_extra.py > $OUT/bench_extra.json 2>/dev/null
-python $R/tools/r05/conv_bench.py all --reps 20 > $OUT/conv_bench.txt 2>&1  # the in-house convolution kernels against MIOpen, per layer
-for sz in 96 512 1024; do
+python $R/tools/r05/conv_bench.py all --reps 20 > $OUT/conv_bench.txt 2>&1  # the in-house convolution kernels against MIOpen (its own heuristics: no rankings are shipped any more), per layer
+python $R/tools/r06/conv_sweep.py all 2>/dev/null | grep -v amdgpu.ids > $OUT/conv_sweep.txt  # every decomposition at batch 64 / 192
+python $R/tools/r06/step_bench.py 2>/dev/null | grep "step" > $OUT/step_bench.txt  # critic update hand-scheduled vs autograd, G / V step
+for sz in 24 96 512 1024; do  # (24 MiB = BASELINE config 5's tensors: the ceiling of the per-step chain at 16 x 512 x 512)
   reps=20; [ $sz -ge 512 ] && reps=8
   $R/tools/membench $sz 9 $reps pol > $OUT/membench_${sz}.txt 2>&1
 done
