@@ -392,16 +392,16 @@ class Filter(nn.Module):
     p = self.get_num_filter_parameters()
     return features[:, :p], features[:, p:]
 
-  # Should be implemented in child classes
   def filter_param_regressor(self, features):
+    """filters.py:46-48: every filter class squashes its raw features into its parameter range here."""
     assert False
 
   def pack(self, param):
     """reference-shaped parameter tensor -> (N, P) float32 C-ABI layout."""
     return param.reshape(param.shape[0], self.get_num_filter_parameters())
 
-  # Process the whole image, without masking
   def process(self, img, param):
+    """filters.py:50-53 (the unmasked pixel map): ONE HIP launch for the filter's id (``pixel_filter``)."""
     hsv_mode = int(self.cfg.get('hsv_grad_mode', 0)) if hasattr(self.cfg, 'get') else 0
     return pixel_filter(self.filter_id, img, self.pack(param), hsv_mode)
 
@@ -411,7 +411,6 @@ class Filter(nn.Module):
   def no_high_res(self):
     return False
 
-  # Apply the whole filter with masking
   def apply(self, img, img_features=None, specified_parameter=None, high_res=None):
     """filters.py:62-99 -> (low_res_output, high_res_output or None, debug_info).
 
@@ -434,8 +433,7 @@ class Filter(nn.Module):
       mask_parameters = torch.zeros((1, self.get_num_mask_parameters()), dtype=torch.float32,
                                     device=img.device)
     debug_info = {}
-    # We only debug the first image of this batch
-    if self.debug_info_batched():
+    if self.debug_info_batched():  # (otherwise the first image's parameters only, as in the reference's dict)
       debug_info['filter_parameters'] = filter_parameters
     else:
       debug_info['filter_parameters'] = filter_parameters[0]
