@@ -65,6 +65,7 @@ SIGNATURES = {
     'expo_critic_head_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
     'expo_plane_sums': (_i, [_fp, _fp, _i, _sz, _i, _i, _vp]),
     'expo_gp_direct': (_i, [_fp, _i, _fp, _f, _fp, _fp, _fp, _i, _sz, _vp]),
+    'expo_critic_penalty_tangent': (_i, [_fp, _fp, _fp, _f, _fp, _fp, _fp, _i, _i, _i, _vp]),
     'expo_chain_release': (_i, [_vp]),
     'expo_chain_fwd': (_i, [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i,
                             _vp]),
@@ -1042,6 +1043,20 @@ def gp_direct(u, ds, scale, v, norm, term):
   with torch.cuda.device(u.device):
     _check(lib.expo_gp_direct(_ptr(u), c, _ptr(ds), float(scale), _ptr(v), _ptr(norm), _ptr(term), n,
                               u[0].numel() // c if n else 0, _stream()), 'expo_gp_direct')
+
+
+def critic_penalty_tangent(u, x, stats, scale, t0, norm, term):
+  """expo_critic_penalty_tangent: plane sums, J^T, norm / term / penalty gradient, J v and the tangent's 6-plane input in one
+  launch per batch of interpolated images."""
+  lib = load()
+  n, h, w, c = u.shape
+  assert c == 6 and u.is_cuda and u.dtype == torch.float32 and u.is_contiguous()
+  assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (n, h, w, 3)
+  assert t0.dtype == torch.float32 and t0.is_contiguous() and t0.shape == u.shape
+  _f32(stats, 'stats', (n, 3)), _f32(norm, 'norm', (n,)), _f32(term, 'term', (n,))
+  with torch.cuda.device(u.device):
+    _check(lib.expo_critic_penalty_tangent(_ptr(u), _ptr(x), _ptr(stats), float(scale), _ptr(t0), _ptr(norm), _ptr(term), n, h, w,
+                                           _stream()), 'expo_critic_penalty_tangent')
 
 
 def conv_wrw_tuning(slices=0, parts=0):

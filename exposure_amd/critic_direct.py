@@ -1,5 +1,5 @@
 """The WGAN-GP critic update as a hand-scheduled sequence of HIP launches (``/root/reference/net.py:126-199, 245-251``;
-``critics.py:6-38, 42-98``): no autograd graph, ~45 launches instead of ~150.
+``critics.py:6-38, 42-98``): no autograd graph, 34 launches instead of 161.
 
     c_loss = mean(D(fake) - D(real)) + lambda * mean(max(||grad_x^ D(x^)|| - 1, 0)^2),   x^ = real + alpha (fake - real)
 
@@ -12,10 +12,11 @@ and the rows' upstream gradients dlogit = (-1/n, +1/n, 1) -- the third block is 
   backward       gy_4 = (dh W_fc1) m_4;  gy_{l-1} = D(gy_l, W_l) m_{l-1}  the activation gradient sits in the EPILOGUE of the
                  data-gradient kernel above it (expo_conv4x4s2_bwd_data_mask); the first layer's data gradient only for the
                  interpolated block (6 input planes: conv_bwd_small_kernel on the vector ALUs)
-  penalty        g = u_0[..., :3] + J^T sum(u_0[..., 3:]) (the statistics planes, critics.py:48-76), norm, term and the
-                 penalty's gradient v with respect to g in one launch (expo_gp_direct)
+  penalty        g = u_0[..., :3] + J^T sum(u_0[..., 3:]) (the statistics planes, critics.py:48-76), norm, term, the
+                 penalty's gradient v with respect to g and the tangent's input [v | J v] in ONE launch
+                 (expo_critic_penalty_tangent)
   tangent        the double backward of the penalty is a FORWARD pass of v through the same layers under the same masks:
-                 t_0 = planes(v, J v), t_l = F(t_{l-1}, W_l) m_l -- written IN PLACE over the interpolated block of z_l
+                 t_0 = [v | J v], t_l = F(t_{l-1}, W_l) m_l -- written IN PLACE over the interpolated block of z_l
                  (expo_conv4x4s2_fwd_mask), which nothing reads any more
   weight grads   after that the activation buffers hold [z_{l-1}(real, fake) | t_{l-1}] and the gradient buffers
                  [gy_l(real, fake) | gy_l(interpolated)]: ONE weight-gradient launch per layer over the 3n "images" yields
@@ -125,20 +126,13 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
   u0 = torch.empty((n,) + tuple(acts[0].shape[1:]), **f32)
   _cabi.conv4x4s2_bwd_data(gys[1][2 * n:], convs[0].weight, u0)
 
-  # ---- the penalty on g = d D(x^) / d x^ and its gradient v with respect to g ------------------------------------------------
+  # ---- the penalty on g = d D(x^) / d x^, its gradient v with respect to g, and the tangent's input [v | J v] written over
+  # the interpolated block of the first activation buffer: one launch (plane sums, J^T, norm / term, v, J v, planes) ------
   xi, si = x[2 * n:], stats[2 * n:]
-  gs = torch.empty((n, 3), **f32)
-  _cabi.plane_sums(u0, gs, 3)
-  ds = torch.empty_like(xi)
-  _cabi.critic_stats_bwd(xi, si, gs, ds)
-  v = torch.empty_like(xi)
   norm, term = torch.empty((n,), **f32), torch.empty((n,), **f32)
-  _cabi.gp_direct(u0, ds, lam * inv_n, v, norm, term)
+  _cabi.critic_penalty_tangent(u0, xi, si, lam * inv_n, acts[0][2 * n:], norm, term)
 
   # ---- tangent pass (the double backward), in place over the interpolated block of every activation ----------------
-  jv = torch.empty((n, 3), **f32)
-  _cabi.critic_stats_jvp(xi, si, v, jv)
-  _cabi.planes_concat(v, jv, acts[0][2 * n:], 0.0)
   for l, conv in enumerate(convs, start=1):
     zi = acts[l][2 * n:]
     _cabi.conv4x4s2_fwd_mask(acts[l - 1][2 * n:], conv.weight, zi, zi, LEAK)

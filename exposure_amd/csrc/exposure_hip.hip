@@ -917,6 +917,103 @@ __global__ __launch_bounds__(kThreads) void stats_hvp_kernel(const T* __restrict
   }
 }
 
+// ---- the middle of the hand-scheduled critic update in ONE launch (round 6, exposure_amd/critic_direct.py) --------------
+// Between the first layer's data gradient u (6 planes: image + statistics planes, critics.py:64-76) and the tangent pass of
+// the gradient penalty's double backward (net.py:174-194) sit, per interpolated image: the gradient reaching the
+// statistics (plane sums), J^T of the statistics (stats_bwd), g = u[..., :3] + J^T gs, ||g||, the one-sided term and its
+// gradient v = scale 2 max(||g|| - 1, 0) / ||g|| g (net.py:185-187), J v (stats_jvp) and the tangent's 6-plane input
+// [v | J v broadcast].  Six launches of 5-7 us each as separate kernels; here one block per image walks its pixels three
+// times (u and x stay in L2) with a fixed-order block reduction after each walk.  x is float32 (the critic's input).
+__device__ __forceinline__ void block_sum3(float (&a)[3], float (*part)[3]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = a[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) part[wave][k] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = part[0][k];
+    for (int w = 1; w < 16; ++w) v += part[w][k];
+    a[k] = v;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void critic_penalty_tangent_kernel(const float* __restrict__ u, const float* __restrict__ x,
+                                                                      const float* __restrict__ stats, float scale,
+                                                                      float* __restrict__ t0, float* __restrict__ norm,
+                                                                      float* __restrict__ term, int hw) {
+  __shared__ float part[16][3];
+  const int n = blockIdx.x;
+  const float* un = u + size_t(n) * hw * 6;
+  const float* xn = x + size_t(n) * hw * 3;
+  float* tn = t0 + size_t(n) * hw * 6;
+  const float inv_hw = 1.0f / float(hw), mean = stats[n * 3];
+  // walk 1: the gradient reaching the three statistics = the sums of u's statistics planes
+  float gs[3] = {0.f, 0.f, 0.f};
+  for (int p = threadIdx.x; p < hw; p += 1024) {
+    gs[0] += un[p * 6 + 3];
+    gs[1] += un[p * 6 + 4];
+    gs[2] += un[p * 6 + 5];
+  }
+  block_sum3(gs, part);
+  const float g0 = gs[0] * inv_hw, g1 = gs[1] * 2.0f * inv_hw, g2 = gs[2] * inv_hw;
+  auto grad_at = [&](int p, float (&g)[3], float& lm, SatPix& sp) {  // g = u[:3] + J^T gs at pixel p (stats_bwd_kernel)
+    const float px[3] = {xn[p * 3], xn[p * 3 + 1], xn[p * 3 + 2]};
+    const float l = (px[0] * kLumR + px[1] * kLumG) + px[2] * kLumB + 1e-5f;
+    lm = l - mean;
+    const float dl = fmaf(g1, lm, g0);
+    sp = sat_pix<false>(px);
+    g[0] = un[p * 6 + 0] + fmaf(kLumR, dl, g2 * (sp.fmx * sp.a[0] + sp.fmn * sp.b[0]));
+    g[1] = un[p * 6 + 1] + fmaf(kLumG, dl, g2 * (sp.fmx * sp.a[1] + sp.fmn * sp.b[1]));
+    g[2] = un[p * 6 + 2] + fmaf(kLumB, dl, g2 * (sp.fmx * sp.a[2] + sp.fmn * sp.b[2]));
+  };
+  // walk 2: ||g||^2
+  float sq[3] = {0.f, 0.f, 0.f};
+  for (int p = threadIdx.x; p < hw; p += 1024) {
+    float g[3], lm;
+    SatPix sp;
+    grad_at(p, g, lm, sp);
+    sq[0] = fmaf(g[0], g[0], sq[0]);
+    sq[1] = fmaf(g[1], g[1], sq[1]);
+    sq[2] = fmaf(g[2], g[2], sq[2]);
+  }
+  block_sum3(sq, part);
+  const float nm = sqrtf(1e-6f + ((sq[0] + sq[1]) + sq[2]));
+  const float over = fmaxf(nm - 1.0f, 0.0f);
+  const float coef = scale * 2.0f * over / nm;
+  if (threadIdx.x == 0) {
+    norm[n] = nm;
+    term[n] = over * over;
+  }
+  // walk 3: v = coef g (the tangent's image planes) and J v (stats_jvp_kernel)
+  float jv[3] = {0.f, 0.f, 0.f};
+  for (int p = threadIdx.x; p < hw; p += 1024) {
+    float g[3], lm;
+    SatPix sp;
+    grad_at(p, g, lm, sp);
+    const float v[3] = {g[0] * coef, g[1] * coef, g[2] * coef};
+    tn[p * 6 + 0] = v[0];
+    tn[p * 6 + 1] = v[1];
+    tn[p * 6 + 2] = v[2];
+    const float wv = (v[0] * kLumR + v[1] * kLumG) + v[2] * kLumB;
+    jv[0] += wv;
+    jv[1] = fmaf(lm, wv, jv[1]);
+    jv[2] += sp.fmx * (sp.a[0] * v[0] + sp.a[1] * v[1] + sp.a[2] * v[2]) + sp.fmn * (sp.b[0] * v[0] + sp.b[1] * v[1] + sp.b[2] * v[2]);
+  }
+  block_sum3(jv, part);
+  const float j0 = jv[0] * inv_hw, j1 = jv[1] * 2.0f * inv_hw, j2 = jv[2] * inv_hw;
+  for (int p = threadIdx.x; p < hw; p += 1024) {
+    tn[p * 6 + 3] = j0;
+    tn[p * 6 + 4] = j1;
+    tn[p * 6 + 5] = j2;
+  }
+}
+
 // ------------------------------------------------------------------------------- finish
 // One wave per (image, step): adds the image's bx block records in a fixed order and writes the final
 // per-image values.  Steps of a chain (or the single step of any other entry point) are described by
@@ -2227,6 +2324,18 @@ int expo_critic_stats_jvp(const void* x, const float* stats, const void* v, floa
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == EXPO_F16 ? stats_jvp_t<half_t>(x, stats, v, jv, n, h, w, workspace, workspace_bytes, s)
                            : stats_jvp_t<float>(x, stats, v, jv, n, h, w, workspace, workspace_bytes, s);
+}
+
+int expo_critic_penalty_tangent(const float* u, const float* x, const float* stats, float scale, float* t0, float* norm,
+                                float* term, int n, int h, int w, void* stream) {
+  if (int rc = check_common(n, h, w, EXPO_F32)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!u || !x || !stats || !t0 || !norm || !term) return fail(EXPO_E_BADARG, "null pointer");
+  if (long(h) * w > (1L << 24)) return fail(EXPO_E_BADARG, "critic_penalty_tangent: at most 2^24 pixels per image");
+  hipLaunchKernelGGL(critic_penalty_tangent_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), u, x, stats,
+                     scale, t0, norm, term, h * w);
+  HIP_TRY(hipGetLastError(), "critic_penalty_tangent launch");
+  return EXPO_OK;
 }
 
 int expo_critic_stats_hvp(const void* x, const float* dstats, const float* jv, const void* v, void* out, int n, int h,

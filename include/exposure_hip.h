@@ -609,7 +609,13 @@ int expo_conv_tuning(int tile, int nt, int slices);
  *                         the gradient reaching the per-image values planes_concat broadcast (critics.py:64-76)
  *   expo_gp_direct        g = u[..., 0:3] + ds (u float32 [n][pixels][u_channels], ds [n][pixels][3]);
  *                         norm = sqrt(1e-6 + sum g^2), term = max(norm - 1, 0)^2 (net.py:185-187) and
- *                         v = scale 2 max(norm - 1, 0) / norm g  (the gradient of scale sum(term)) in one launch */
+ *                         v = scale 2 max(norm - 1, 0) / norm g  (the gradient of scale sum(term)) in one launch
+ *   expo_critic_penalty_tangent  everything between the first layer's data gradient and the tangent pass as ONE launch (a
+ *                         block per image): u float32 [n][h w][6] (image + statistics planes), x float32 [n][h w][3] the
+ *                         interpolated images, stats [n][3] their statistics ->  gs = plane sums of u[..., 3:6];
+ *                         g = u[..., 0:3] + J^T gs (expo_critic_stats_bwd);  norm, term as expo_gp_direct;
+ *                         v = scale 2 max(norm - 1, 0) / norm g;  t0 [n][h w][6] = [v | J v broadcast]
+ *                         (expo_critic_stats_jvp + expo_planes_concat with offset 0): the tangent's input */
 int expo_critic_head_fwd(const float* hpre, const float* w2, const float* b2, int n_real, int n_fake, int n_interp,
                          int hidden, float inv_n, float leak, float* logits, float* h, float* dh, void* stream);
 int expo_critic_report(const float* logits, const float* norm, const float* term, int n_real, int n_fake, int n_interp,
@@ -619,6 +625,8 @@ int expo_critic_head_bwd(const float* dh, const float* h, const float* thpre, in
 int expo_plane_sums(const float* x, float* sums, int n, size_t pixels_per_image, int channels, int first, void* stream);
 int expo_gp_direct(const float* u, int u_channels, const float* ds, float scale, float* v, float* norm, float* term, int n,
                    size_t pixels_per_image, void* stream);
+int expo_critic_penalty_tangent(const float* u, const float* x, const float* stats, float scale, float* t0, float* norm,
+                                float* term, int n, int h, int w, void* stream);
 #ifdef __cplusplus
 }
 #endif

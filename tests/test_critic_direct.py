@@ -369,3 +369,37 @@ def test_grouped_weight_gradients_equal_the_separate_calls(gpu_device):
   for (x, gy, dw, db, _), (rw, rb) in zip(items, want):
     assert torch.equal(dw, rw)
     assert db is None or torch.equal(db, rb)
+
+
+@pytest.mark.parametrize('shape', [(5, 64, 64), (3, 7, 5), (2, 2, 2)])
+def test_penalty_tangent_kernel_equals_its_six_launch_composition(shape, gpu_device):
+  """expo_critic_penalty_tangent == plane sums -> expo_critic_stats_bwd -> expo_gp_direct -> expo_critic_stats_jvp ->
+  expo_planes_concat(offset 0): the same norm / term and the same 6-plane tangent input, one image with its norm below 1
+  (no penalty, a zero tangent)."""
+  from exposure_amd import _cabi
+  dev = gpu_device
+  n, h, w = shape
+  g = torch.Generator(device=dev).manual_seed(h)
+  x = torch.rand((n, h, w, 3), device=dev, generator=g) * 1.2 - 0.05
+  u = torch.randn((n, h, w, 6), device=dev, generator=g) * (2.0 / (h * w * 3)**0.5)
+  if n > 1:
+    u[1] *= 0.01
+  stats = torch.empty((n, 3), device=dev)
+  _cabi.critic_stats(x, stats)
+  gs, ds = torch.empty((n, 3), device=dev), torch.empty_like(x)
+  _cabi.plane_sums(u, gs, 3)
+  _cabi.critic_stats_bwd(x, stats, gs, ds)
+  v, norm, term = torch.empty_like(x), torch.empty((n,), device=dev), torch.empty((n,), device=dev)
+  _cabi.gp_direct(u, ds, 0.3, v, norm, term)
+  jv = torch.empty((n, 3), device=dev)
+  _cabi.critic_stats_jvp(x, stats, v, jv)
+  want = torch.empty_like(u)
+  _cabi.planes_concat(v, jv, want, 0.0)
+  t0, norm2, term2 = torch.full_like(u, float('nan')), torch.empty_like(norm), torch.empty_like(term)
+  _cabi.critic_penalty_tangent(u, x, stats, 0.3, t0, norm2, term2)
+  assert float((norm2 - norm).abs().max()) <= 2e-6 * float(norm.max())
+  assert float((term2 - term).abs().max()) <= 1e-5 * max(1e-6, float(term.max()))
+  scale = max(1e-12, float(want.abs().max()))
+  assert float((t0 - want).abs().max()) <= 2e-5 * scale, float((t0 - want).abs().max()) / scale
+  if n > 1:
+    assert float(term2[1]) == 0.0 and float(t0[1].abs().max()) == 0.0
