@@ -26,4 +26,13 @@ produced by running the reference's own NumPy code (``user_study_ui/filters.py``
 ``util.py``) in the build container -- ``tests/golden/make_reference_vectors.py``,
 ``tests/test_reference_vectors.py``.  Everything that lives in TensorFlow (the
 other five filters, every gradient, the tie conventions) stays unpinned.
+
+Since round 6 a COMPOSITION pin covers that TensorFlow side -- TF primitive
+semantics ASSUMED: the bodies of ``process`` / ``filter_param_regressor`` of all
+nine filter classes, the ``util.py`` helpers, ``pdf_sample`` and the selection /
+state / penalty statements of ``agent_generator`` are executed in the build
+container under a NumPy facade for ``tf`` (``tests/golden/make_reference_facade.py``)
+and the restatements here reproduce them to 1e-12 (``tests/test_reference_facade.py``).
+It pins how the primitives are composed, not the primitives: parity stays
+"partial" (DESIGN.md section 7).
 """
