@@ -764,18 +764,20 @@ def generator_losses(fake_logit, fake_input_logit, new_value, old_value, new_sta
 
 
 def gp_inputs(real, fake, alpha, cat_out, interp):
-  """cat_out[:n] = real, cat_out[n:] = fake (float32), interp = real + alpha (fake - real): one launch."""
+  """cat_out[:n] = real, cat_out[n:] = fake (float32), interp = real + alpha (fake - real): one launch.  ``interp`` (and
+  ``alpha``) may be None: conversion + concatenation only."""
   lib = load()
   _img(real, 'real'), _img(fake, 'fake')
   n = real.shape[0]
   assert fake.shape == real.shape and fake.dtype == real.dtype
   m = real[0].numel() if n else 0
   assert cat_out.dtype == torch.float32 and cat_out.is_contiguous() and tuple(cat_out.shape) == (2 * n,) + tuple(real.shape[1:])
-  assert interp.dtype == torch.float32 and interp.is_contiguous() and interp.shape == real.shape
-  assert alpha.is_cuda and alpha.dtype == torch.float32 and alpha.is_contiguous() and alpha.numel() == n
+  if interp is not None:
+    assert interp.dtype == torch.float32 and interp.is_contiguous() and interp.shape == real.shape
+    assert alpha.is_cuda and alpha.dtype == torch.float32 and alpha.is_contiguous() and alpha.numel() == n
   with torch.cuda.device(real.device):
-    _check(lib.expo_gp_inputs(_ptr(real), _ptr(fake), _ptr(alpha), _ptr(cat_out), _ptr(interp), n, m, _dtype_code(real),
-                              _stream()), 'expo_gp_inputs')
+    _check(lib.expo_gp_inputs(_ptr(real), _ptr(fake), _ptr(alpha) if interp is not None else None, _ptr(cat_out), _ptr(interp),
+                              n, m, _dtype_code(real), _stream()), 'expo_gp_inputs')
 
 
 def grad_penalty_fwd(g, norm, term):

@@ -136,13 +136,13 @@ __global__ __launch_bounds__(256) void gp_inputs_kernel(const T* __restrict__ re
                                                         const float* __restrict__ alpha, float* __restrict__ cat_out,
                                                         float* __restrict__ interp, int n, size_t m) {
   const int img = blockIdx.y;
-  const float a = alpha[img];
+  const float a = interp ? alpha[img] : 0.f;  // (interp == NULL: conversion + concatenation only -- the G step's image pairs)
   const size_t base = size_t(img) * m;
   for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < m; i += size_t(gridDim.x) * blockDim.x) {
     const float r = float(real[base + i]), f = float(fake[base + i]);
     cat_out[base + i] = r;
     cat_out[size_t(n) * m + base + i] = f;
-    interp[base + i] = r + a * (f - r);
+    if (interp) interp[base + i] = r + a * (f - r);
   }
 }
 // (2) per image: norm = sqrt(1e-6 + sum g^2), term = max(norm - 1, 0)^2 (net.py:185-187: the one-sided penalty);
@@ -694,7 +694,7 @@ int expo_gp_inputs(const void* real, const void* fake, const float* alpha, float
                    size_t elems_per_image, int dtype, void* stream) {
   if (n < 0) return fail(EXPO_E_BADARG, "n >= 0 required");
   if (n == 0 || elems_per_image == 0) return EXPO_OK;
-  if (!real || !fake || !alpha || !cat_out || !interp) return fail(EXPO_E_BADARG, "null pointer");
+  if (!real || !fake || !cat_out || (interp && !alpha)) return fail(EXPO_E_BADARG, "null pointer");
   if (dtype != EXPO_F16 && dtype != EXPO_F32) return fail(EXPO_E_BADDTYPE, "dtype must be EXPO_F16 or EXPO_F32");
   if (n > 65535) return fail(EXPO_E_BADARG, "n > 65535 not supported (grid.y)");
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -12,7 +12,7 @@ import os
 import torch
 from torch import nn
 
-from . import critic_direct
+from . import critic_direct, generator_direct
 from . import dist as xdist
 from .agent import Agent
 from .critics import Critic
@@ -23,7 +23,8 @@ from .util import STATE_STEP_DIM, STATE_STOPPED_DIM, capture_without_gc
 
 class GAN(nn.Module):
 
-  def __init__(self, cfg, device=None, process_group=None, use_graphs=False, seed=0, direct_critic=True):
+  def __init__(self, cfg, device=None, process_group=None, use_graphs=False, seed=0, direct_critic=True,
+               direct_generator=True):
     super().__init__()
     self.cfg = cfg
     self.use_graphs = bool(use_graphs)
@@ -31,6 +32,9 @@ class GAN(nn.Module):
     # default Wasserstein critic with the gradient penalty on a ROCm device; False keeps every step on autograd (the
     # path the direct schedule is tested against, and the one every other configuration takes)
     self.direct_critic = bool(direct_critic)
+    # likewise the critic / value-net passes of the generator step (exposure_amd/generator_direct.py); the agent itself
+    # stays on autograd
+    self.direct_generator = bool(direct_generator)
     self._graphs = {}
     self.generator = Agent(cfg)
     self.critic = Critic(cfg, num_state_dim=0)
@@ -214,9 +218,17 @@ class GAN(nn.Module):
       bucket.launched = True
       self._pending.append(bucket.all_reduce_mean(self.process_group, async_op=True, force=self.force_collectives))
 
-  def _backward_into(self, loss, names, retain_graph=False):
+  def _backward_into(self, loss, names, retain_graph=False, grad_tensors=None):
     """loss.backward restricted to the named buckets' parameters (the reference's optimize_loss
-    ``variables=`` lists: theta_g sees only g_loss, theta_v only v_loss, theta_c only c_loss)."""
+    ``variables=`` lists: theta_g sees only g_loss, theta_v only v_loss, theta_c only c_loss).  ``loss`` may be a list of
+    tensors with ``grad_tensors`` (the hand-scheduled generator step enters the agent's graph at the retouched image, the
+    surrogate and the penalty with their upstream gradients)."""
+    def run(params):
+      if isinstance(loss, (list, tuple)):
+        torch.autograd.backward(list(loss), grad_tensors=list(grad_tensors), inputs=params, retain_graph=retain_graph)
+      else:
+        loss.backward(inputs=params, retain_graph=retain_graph)
+
     params = []
     if not self._collectives():
       # One rank, nothing to exchange: no flat buffer is needed.  With `.grad = None` autograd hands the optimiser the
@@ -227,13 +239,13 @@ class GAN(nn.Module):
         b = self.buckets[name]
         b.release()
         params += b.params
-      loss.backward(inputs=params, retain_graph=retain_graph)
+      run(params)
       return
     for name in names:
       b = self.buckets[name]
       b.zero()
       params += b.params
-    loss.backward(inputs=params, retain_graph=retain_graph)
+    run(params)
     for name in names:  # a bucket whose hook could not fire (a parameter outside the graph): reduce it now
       self.buckets[name].disarm()
       self._bucket_ready(self.buckets[name])
@@ -244,14 +256,19 @@ class GAN(nn.Module):
     self._pending = []
 
   def _generator_body(self, fake_input, z, states, progress, dropout_masks):
-    # (this step differentiates its convnets once: each stack of layers runs as one node, nn_ops.conv_trunk)
-    with once_differentiable_convnets():
-      out = self.generator_losses(fake_input, z, states, progress, 1, dropout_masks)
-    # the value net's short backward first: its all-reduce then runs under the whole generator backward
-    # (v_loss reaches theta_v through old_value only, g_loss through new_value / the critic / the agent: the two
-    # backward passes share no graph nodes, so nothing needs to be retained)
-    self._backward_into(out['v_loss'], ['v'])
-    self._backward_into(out['g_loss'], ['g_head', 'g_trunk'])
+    if self.direct_generator and generator_direct.supported(self, fake_input, states):
+      # the critic / value-net passes as two hand-scheduled batches of 2n images, their gradients entering the agent's
+      # autograd graph in ONE backward pass (exposure_amd/generator_direct.py)
+      out = generator_direct.generator_step_losses_and_grads(self, fake_input, z, states, progress, dropout_masks)
+    else:
+      # (this step differentiates its convnets once: each stack of layers runs as one node, nn_ops.conv_trunk)
+      with once_differentiable_convnets():
+        out = self.generator_losses(fake_input, z, states, progress, 1, dropout_masks)
+      # the value net's short backward first: its all-reduce then runs under the whole generator backward
+      # (v_loss reaches theta_v through old_value only, g_loss through new_value / the critic / the agent: the two
+      # backward passes share no graph nodes, so nothing needs to be retained)
+      self._backward_into(out['v_loss'], ['v'])
+      self._backward_into(out['g_loss'], ['g_head', 'g_trunk'])
     self._finish_collectives()
     self.opt_g.step()
     self.opt_v.step()

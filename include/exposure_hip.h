@@ -439,7 +439,8 @@ int expo_agent_select_bwd(const float* logits, const int32_t* selected, const fl
  * (ABI 4) The critic step's loss glue (net.py:126-194) -- the callers of the critic around the filter path:
  *   expo_gp_inputs         cat[0:n] = real, cat[n:2n] = fake (float32) and the gradient penalty's interpolation
  *                          interp = real + alpha[n] (fake - real) (net.py:170-172) in one pass; real / fake of `dtype`,
- *                          elems_per_image = H*W*3
+ *                          elems_per_image = H*W*3; interp (and alpha) may be NULL: conversion + concatenation only
+ *                          (the generator step's image pairs, exposure_amd/generator_direct.py)
  *   expo_grad_penalty_fwd  per image: norm = sqrt(1e-6 + sum g^2), term = max(norm - 1, 0)^2 (net.py:185-187; the
  *                          penalty is lambda * mean(term)); g float32 [n][elems_per_image]
  *   expo_grad_penalty_bwd  dg = g * dterm[n] * 2 max(norm - 1, 0) / norm   (the gradient TF takes of that term with

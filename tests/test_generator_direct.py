@@ -1,0 +1,132 @@
+"""The hand-scheduled critic / value-net passes of the generator step (exposure_amd/generator_direct.py) --
+net.py:56-165, 222-241; critics.py:42-98:
+
+* losses, outputs and EVERY gradient tensor of theta_g and theta_v against the autograd step
+  (``GAN(direct_generator=False)``: ``generator_losses`` + one backward per loss), on fp16 and fp32 images, with the
+  gradients landing in fresh tensors and in the flat buckets (the multi-rank layout);
+* the critic's parameters receive nothing (frozen in this step);
+* three optimisation steps replayed from a hipGraph train like the autograd step."""
+import pytest
+import torch
+
+from exposure_amd.config import make_cfg
+from exposure_amd.gan import GAN
+from exposure_amd.nn_ops import once_differentiable_convnets
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_gan(dev, seed, **kw):
+  torch.manual_seed(seed)
+  gan = GAN(make_cfg(), device=dev, **kw)
+  with torch.no_grad():
+    for p in gan.parameters():
+      if p.dim() == 1:
+        p.normal_(0.0, 0.05)
+  return gan
+
+
+def _feed(n, seed, dev, dtype):
+  from tests.test_oracle_nets import make_batch
+  fake_input, _real, states, z, masks, _alpha = make_batch(n, seed)
+  t = lambda a: torch.from_numpy(a).to(dev)
+  return t(fake_input).to(dtype), t(z), t(states), [t(m) for m in masks]
+
+
+def _theta(gan):
+  out = []
+  for bucket in ('g_head', 'g_trunk', 'v'):
+    out += [(bucket, i, p) for i, p in enumerate(gan.buckets[bucket].params)]
+  return out
+
+
+def _clear(gan):
+  for p in gan.parameters():
+    p.grad = None
+
+
+def _autograd_reference(gan, img, z, states, masks, progress):
+  with once_differentiable_convnets():
+    out = gan.generator_losses(img, z, states, progress, 1, masks)
+  gan._backward_into(out['v_loss'], ['v'])
+  gan._backward_into(out['g_loss'], ['g_head', 'g_trunk'])
+  gan._finish_collectives()
+  return out
+
+
+@pytest.mark.parametrize('n,dtype,collectives', [(8, torch.float32, False), (5, torch.float16, False), (64, torch.float16, False),
+                                                 (8, torch.float16, True)])
+def test_direct_generator_step_matches_autograd(n, dtype, collectives, gpu_device):
+  from exposure_amd import generator_direct
+  dev = gpu_device
+  gan = _make_gan(dev, 3)
+  gan.force_collectives = collectives  # True: gradients are written into the flat buckets' views and "all-reduced"
+  img, z, states, masks = _feed(n, 23, dev, dtype)
+  assert generator_direct.supported(gan, img, states)
+  _clear(gan)
+  out = generator_direct.generator_step_losses_and_grads(gan, img, z, states, 0.3, masks)
+  gan._finish_collectives()
+  got = [None if p.grad is None else p.grad.detach().clone() for _, _, p in _theta(gan)]
+  assert all(p.grad is None for p in gan.critic.parameters())
+  _clear(gan)
+  ref = _autograd_reference(gan, img, z, states, masks, 0.3)
+  assert all(p.grad is None for p in gan.critic.parameters())
+  for key in ('g_loss', 'v_loss'):
+    a, b = float(out[key]), float(ref[key].detach())
+    assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (key, a, b)
+  for key in ('fake_output', 'new_states', 'reward', 'q_value', 'fake_logit'):
+    a, b = out[key].detach().float(), ref[key].detach().float()
+    assert a.shape == b.shape, key
+    assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), key
+  checked = 0
+  for (bucket, i, p), a in zip(_theta(gan), got):
+    b = p.grad
+    assert (a is None) == (b is None), (bucket, i)
+    if b is None:
+      continue
+    assert a.shape == b.shape
+    err, scale = float((a - b).abs().max()), float(b.abs().max())
+    # fp16 images: autograd rounds the critic's and the value net's image gradients to fp16 SEPARATELY and adds them in
+    # fp16 (three roundings of 2^-11 per element in front of the agent's backward); the direct step adds in float32 and
+    # rounds once -- the two agree to a few fp16 ulps of the image gradient, not to float32 rounding
+    tol = 2e-4 if dtype == torch.float32 else 5e-3
+    assert err <= tol * scale + 1e-9, (bucket, i, tuple(b.shape), err, scale)
+    checked += 1
+  assert checked >= len(list(gan.value.parameters())) + 8
+
+
+def test_unsupported_configurations_take_the_autograd_step(gpu_device):
+  from exposure_amd import generator_direct
+  dev = gpu_device
+  img, z, states, _ = _feed(4, 5, dev, torch.float16)
+  cfg = make_cfg()
+  cfg.gan = 'ls'
+  torch.manual_seed(0)
+  gan = GAN(cfg, device=dev)
+  assert not generator_direct.supported(gan, img, states)
+  out = gan.generator_step(img, z, states, 0.2, it=3)
+  assert torch.isfinite(out['g_loss'])
+
+
+def test_direct_generator_step_replayed_from_a_graph_trains_like_the_autograd_step(gpu_device):
+  dev = gpu_device
+  gans = [_make_gan(dev, 5, use_graphs=True, direct_generator=flag) for flag in (True, False)]
+  gans[1].load_state_dict(gans[0].state_dict())
+  steps = 3
+  for step in range(steps):
+    img, z, states, masks = _feed(8, 40 + step, dev, torch.float16)
+    outs = [g.generator_step(img, z, states, 0.2, it=4 + step, dropout_masks=masks) for g in gans]
+    tol = 2e-5 if step == 0 else 5e-3
+    for key in ('g_loss', 'v_loss'):
+      a, b = float(outs[0][key]), float(outs[1][key])
+      assert abs(a - b) <= tol * max(1.0, abs(b)), (step, key, a, b)
+  torch.cuda.synchronize()
+  for net, lr in (('generator', float(gans[0].cfg.lr_g(4))), ('value', float(gans[0].cfg.value_lr_mul * gans[0].cfg.lr_g(4)))):
+    for (name, a), (_, b) in zip(getattr(gans[0], net).named_parameters(), getattr(gans[1], net).named_parameters()):
+      # (Adam normalises the gradient: an element whose gradient is rounding-level noise can move by up to lr per step in
+      # either direction; on average the two runs stay within a small fraction of a step)
+      d = (a.detach() - b.detach()).abs()
+      assert float(d.max()) <= 2.0 * steps * lr * 1.01, (net, name)
+      assert float(d.mean()) <= 0.05 * steps * lr, (net, name)
+  for (name, a), (_, b) in zip(gans[0].critic.named_parameters(), gans[1].critic.named_parameters()):
+    assert torch.equal(a, b), name

@@ -47,25 +47,26 @@ def main():
     if direct and '-v' in sys.argv:
       for nm in names:
         print('   ', nm[:110])
-  gan = GAN(make_cfg(), device=dev, use_graphs=True)
   zt, st = t(z), t(states)
-  for _ in range(3):
-    gan.generator_step(fake_t, zt, st, 0.3, it=1)
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(50):
-    gan.generator_step(fake_t, zt, st, 0.3, it=1)
-  torch.cuda.synchronize()
-  ms = (time.perf_counter() - t0) / 50 * 1e3
-  eager = GAN(make_cfg(), device=dev, use_graphs=False)
-  eager.generator_step(fake_t, zt, st, 0.3, it=1)
-  cnt, names = count_launches(lambda: eager.generator_step(fake_t, zt, st, 0.3, it=1))
-  print('G / V step: %.3f ms per replayed step, %d launches (eager count)' % (ms, cnt))
-  if '-g' in sys.argv:
-    import collections
-    for nm, k in collections.Counter(names).most_common(60):
-      print('   %3d %s' % (k, nm[:120]))
-
+  for direct in (True, False):
+    torch.manual_seed(0)
+    gan = GAN(make_cfg(), device=dev, use_graphs=True, direct_generator=direct)
+    for _ in range(3):
+      gan.generator_step(fake_t, zt, st, 0.3, it=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+      gan.generator_step(fake_t, zt, st, 0.3, it=1)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 50 * 1e3
+    eager = GAN(make_cfg(), device=dev, use_graphs=False, direct_generator=direct)
+    eager.generator_step(fake_t, zt, st, 0.3, it=1)
+    cnt, names = count_launches(lambda: eager.generator_step(fake_t, zt, st, 0.3, it=1))
+    print('G / V step direct=%s: %.3f ms per replayed step, %d launches (eager count)' % (direct, ms, cnt))
+    if direct and '-g' in sys.argv:
+      import collections
+      for nm, k in collections.Counter(names).most_common(70):
+        print('   %3d %s' % (k, nm[:120]))
 
 if __name__ == '__main__':
   main()
