@@ -593,24 +593,26 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
   gan = GAN(cfg, device=dev, use_graphs=(args.graph != 'off'), seed=args.seed)
   # weak: cfg.batch_size (64) images per GPU; strong: the reference's global batch of 64 split image-wise
   n = local_shape((cfg.batch_size,), world, args.scaling)[0]
-  from exposure_amd.replay_memory import ReplayMemory, SyntheticProvider
+  from exposure_amd.replay_memory import ReplayMemory, ResidentProvider
   pool_dtype = torch.float16 if args.dtype == 'f16' else torch.float32
-  memory = ReplayMemory(cfg, SyntheticProvider(dev, dtype=pool_dtype, seed=args.seed + 10 * rank + 1),
-                        SyntheticProvider(dev, gamma=1.0, dtype=pool_dtype, seed=args.seed + 10 * rank + 2),
+  # the synthetic RAW / retouched data sets are resident in HBM (4 096 proxies each, generated before the timed region);
+  # batches are views of them and the replay memory's records are gathered straight into the step graphs' inputs
+  memory = ReplayMemory(cfg, ResidentProvider(dev, dtype=pool_dtype, seed=args.seed + 10 * rank + 1),
+                        ResidentProvider(dev, gamma=1.0, dtype=pool_dtype, seed=args.seed + 10 * rank + 2),
                         seed=args.seed + rank)
   # net.py:320-328: the first iteration rolls the generator with lr_g = 0 until terminated
   # trajectories exist for the critic to replay (100 steps in the reference; 8 suffice: 5 steps end one)
   for _ in range(8):
-    feed, feats = memory.get_feed_dict_and_states(n)
+    feed, feats = memory.get_feed_dict_and_states(n, lazy=True)
     out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
     memory.replace_memory(out['fake_output'], out['new_states'], feats, advanced=True)
 
   def iteration(it):
-    feed, feats = memory.get_feed_dict_and_states(n)
+    feed, feats = memory.get_feed_dict_and_states(n, lazy=True)
     out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], progress=it / cfg.max_iter_step, it=it)
     memory.replace_memory(out['fake_output'], out['new_states'], feats, advanced=True)
     for _ in range(cfg.citers):
-      rep = memory.get_replay_feed_dict(n)
+      rep = memory.get_replay_feed_dict(n, lazy=True)
       gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
     return out
 

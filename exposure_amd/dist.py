@@ -61,8 +61,9 @@ class GlobalBatchRng:
     self.gen = torch.Generator(device=self.device)
     self.gen.manual_seed(self.seed)
 
-  def uniform(self, n_local, tail, group=None, device=None):
-    """(n_local, *tail) uniform [0, 1) numbers: this rank's rows of the (n_local * world, *tail) global draw.
+  def uniform(self, n_local, tail, group=None, device=None, lead=None):
+    """(n_local, *tail) uniform [0, 1) numbers: this rank's rows of the (n_local * world, *tail) global draw
+    (``lead``: (lead, n_local, *tail) out of ONE draw of ``lead`` such tensors -- several per-image inputs, one launch).
     ``device``: where the consumer lives.  The generator is created on first use on that device and FOLLOWS the
     module when it moves (``GAN(cfg).cuda()``: drawing on the CPU for inputs on the GPU was a device mismatch); a
     move restarts the stream from the seed, which happens before training, not inside it."""
@@ -72,6 +73,9 @@ class GlobalBatchRng:
     elif self.gen is None:
       self._bind('cpu')
     p, r = world_size(group), rank(group)
+    if lead is not None:
+      full = torch.rand((int(lead), n_local * p) + tuple(tail), generator=self.gen, device=self.device)
+      return full[:, r * n_local:(r + 1) * n_local]
     full = torch.rand((n_local * p,) + tuple(tail), generator=self.gen, device=self.device)
     return full[r * n_local:(r + 1) * n_local]
 

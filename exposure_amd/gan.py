@@ -18,6 +18,7 @@ from .agent import Agent
 from .critics import Critic
 from .nn_ops import (critic_step_inputs, frozen_parameters, generator_losses_fused, grad_penalty_term,
                      once_differentiable_convnets, skip_parameter_gradients)
+from .replay_memory import PoolRows, materialize
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM, capture_without_gc
 
 
@@ -278,17 +279,24 @@ class GAN(nn.Module):
     """The two always-on dropout masks of feature_extractor (agent.py:36), partition-invariant (self.rng)."""
     keep = self.cfg.dropout_keep_prob
     dev = device if device is not None else next(self.parameters()).device
-    return [(self.rng.uniform(n, (self.cfg.feature_extractor_dims,), self.process_group, device=dev) < keep).float()
-            for _ in range(2)]
+    # both masks out of one draw, thresholded into float32 by one launch (were 2 x (rand, <, cast))
+    u = self.rng.uniform(n, (self.cfg.feature_extractor_dims,), self.process_group, device=dev, lead=2)
+    m = torch.empty(u.shape, dtype=torch.float32, device=u.device)
+    torch.lt(u, keep, out=m)
+    return [m[0], m[1]]
 
   def _draw_alpha(self, n):
     """net.py:170-172: alpha ~ U(0, 1) per image for the interpolation of the gradient penalty."""
     return self.rng.uniform(n, (1, 1, 1), self.process_group, device=next(self.parameters()).device)
 
   def generator_step(self, fake_input, z, states, progress, it=1, dropout_masks=None):
-    """opt_g on g_loss w.r.t. theta_g and opt_v on v_loss w.r.t. theta_v (net.py:222-241)."""
+    """opt_g on g_loss w.r.t. theta_g and opt_v on v_loss w.r.t. theta_v (net.py:222-241).  ``fake_input`` / ``states``
+    may be :class:`~exposure_amd.replay_memory.PoolRows` (rows of the replay memory gathered straight into the step
+    graph's inputs)."""
     self.set_lrs(it, zero_g=(it == 0))
     masks = dropout_masks or self._draw_masks(fake_input.shape[0])
+    if not self._replay_steps:
+      fake_input, states = materialize(fake_input), materialize(states)
     if self._replay_steps:
       # (a device scalar filled in place: torch.as_tensor(float, device=...) is a blocking copy from pageable memory --
       # one full drain of the queue per iteration, with the G step's graph launch behind it)
@@ -332,11 +340,11 @@ class GAN(nn.Module):
     entry = self._graphs.get(sig)
     if entry is None:
       self._graphs[sig] = 'warm'
-      return body(*inputs)
+      return body(*[materialize(t) for t in inputs])
     if entry == 'warm':
       # (with a process group the gradient all-reduces are captured too: RCCL collectives are
       # stream-ordered kernels, and the eager first call has already initialised the communicator)
-      static_in = [t.clone() for t in inputs]
+      static_in = [t.materialize() if isinstance(t, PoolRows) else t.clone() for t in inputs]
       # ROOT CAUSE of round 1's "one run in ~15 aborts" (gpurun r02soak, 3 of 28 runs): the eager first call left
       # WorkNCCL entries in ProcessGroupNCCL's watchdog list; they are complete, but the watchdog only reaps its list
       # every ~100 ms.  If it polls (hipEventQuery on the work's end event) AFTER this thread has pulled RCCL's stream
@@ -351,7 +359,7 @@ class GAN(nn.Module):
         warnings.warn('exposure_amd: the NCCL watchdog drain could not be verified (flight recorder off?); steps with '
                       'collectives stay eager (set TORCH_FR_BUFFER_SIZE>0, or EXPO_GRAPH_COLLECTIVES=1)')
         self.use_graphs = self._replay_steps = False
-        return body(*inputs)
+        return body(*[materialize(t) for t in inputs])
       self.capture_drain_verified = verified
       graph = torch.cuda.CUDAGraph()
       # thread_local: RCCL's watchdog thread polls events while this thread captures; under the
@@ -366,12 +374,15 @@ class GAN(nn.Module):
         warnings.warn('hipGraph capture of the %r step failed (%s); continuing with eager launches' % (key, e))
         torch.cuda.synchronize()
         self.use_graphs = self._replay_steps = False
-        return body(*inputs)
+        return body(*[materialize(t) for t in inputs])
       entry = (graph, static_in, static_out)
       self._graphs[sig] = entry
     graph, static_in, static_out = entry
     for dst, src in zip(static_in, inputs):
-      dst.copy_(src)
+      if isinstance(src, PoolRows):
+        src.into(dst)  # gathered straight into the graph's input: one launch instead of gather + copy
+      else:
+        dst.copy_(src)
     graph.replay()
     return static_out
 
@@ -459,9 +470,13 @@ class GAN(nn.Module):
     return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
   def critic_step(self, real_data, fake_output, it=1, alpha=None):
+    """opt_c on c_loss w.r.t. theta_c (net.py:245-251); ``fake_output`` may be
+    :class:`~exposure_amd.replay_memory.PoolRows`."""
     self.set_lrs(it)
     if alpha is None:
       alpha = self._draw_alpha(real_data.shape[0])
+    if not self._replay_steps:
+      real_data, fake_output = materialize(real_data), materialize(fake_output)
     if self._replay_steps:
       out = dict(self._replay('c', self._critic_body, (real_data, fake_output, alpha)))
     else:
@@ -494,12 +509,12 @@ class GAN(nn.Module):
       giters = 100 if it == 0 else cfg.giters  # make sure there are terminating states
       g_out = None
       for _ in range(giters):
-        feed, features = memory.get_feed_dict_and_states(cfg.batch_size)
+        feed, features = memory.get_feed_dict_and_states(cfg.batch_size, lazy=True)
         g_out = self.generator_step(feed['fake_input'], feed['z'], feed['states'], progress, it=it)
         memory.replace_memory(g_out['fake_output'], g_out['new_states'], features, advanced=True)
       c_out = None
       for _ in range(citers):
-        feed = memory.get_replay_feed_dict(cfg.batch_size)
+        feed = memory.get_replay_feed_dict(cfg.batch_size, lazy=True)
         c_out = self.critic_step(feed['real_data'], feed['fake_output'], it=it)
       # the four reported scalars stay on the device (one small launch; the steps' outputs are static graph buffers that
       # the next replay overwrites): the host reads them when it logs and once at the end, not four times per iteration

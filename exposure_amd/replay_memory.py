@@ -25,6 +25,14 @@ eager launches per iteration, 1.8 ms of a 14.2 ms iteration (``tools/r04/memory_
 
 The sequence of random decisions (shuffles, keep draws, noise) is the one of the round-3 implementation, draw for draw:
 ``tests/test_replay_and_loop.py`` runs both side by side and requires identical batches.
+
+Round 6: ~100 of an iteration's 451 launches sat BETWEEN the step graphs (index gathers, the staging copies into the
+graphs' static inputs, the synthetic providers' rand / pow / cast, zero states, row selections: ~6 us each on an idle queue).
+The feed builders can now hand out :class:`PoolRows` -- (pool tensor, device index vector) -- which the step GATHERS
+STRAIGHT INTO its graph's static input (``GAN._replay``: one ``index_select(out=)`` instead of gather + copy);
+``replace_memory`` scatters the whole batch with one index vector (dropped rows go to a trash slot: no row selection), fresh
+records are written in place (``index_fill_`` for the zero states); :class:`ResidentProvider` keeps the synthetic data set
+in HBM and serves batches as views (inputs resident in HBM: nothing to launch).  The host-side decisions are unchanged.
 """
 import numpy as np
 import torch
@@ -50,6 +58,59 @@ class SyntheticProvider:
     feat = torch.arange(self.count, self.count + batch_size, device=self.device, dtype=torch.float32)
     self.count += batch_size
     return x, feat
+
+
+class ResidentProvider:
+  """The synthetic data set of :class:`SyntheticProvider` generated ONCE and kept in HBM (``count`` images: 4 096 proxies of
+  64 x 64 x 3 are 100 MB in fp16 -- MIT-Adobe FiveK itself at this resolution is 123 MB); batches are consecutive VIEWS of
+  it, epoch after epoch (``data_provider.py:59-69`` walks a shuffled epoch the same way; its crop / flip augmentation has no
+  synthetic counterpart).  ``get_next_batch`` launches nothing."""
+
+  def __init__(self, device, size=64, gamma=2.2, scale=1.0, dtype=torch.float32, seed=0, count=4096):
+    self.device, self.size, self.dtype, self.count = device, size, dtype, int(count)
+    src = SyntheticProvider(device, size=size, gamma=gamma, scale=scale, dtype=dtype, seed=seed)
+    parts = [src.get_next_batch(min(256, self.count - at))[0] for at in range(0, self.count, 256)]
+    self.images = torch.cat(parts)
+    self.features = torch.arange(self.count, device=device, dtype=torch.float32)
+    self.at = 0
+
+  def get_next_batch(self, batch_size):
+    assert batch_size <= self.count
+    if self.at + batch_size > self.count:
+      self.at = 0  # next epoch
+    lo = self.at
+    self.at += batch_size
+    return self.images[lo:lo + batch_size], self.features[lo:lo + batch_size]
+
+
+class PoolRows:
+  """Rows ``idx`` (a device int64 vector) of a pool tensor, gathered where they are consumed: ``into(dst)`` writes them
+  straight into a step graph's static input, ``materialize()`` returns them as a tensor.  Valid until the pool is
+  written again (``ReplayMemory`` counts its writes; a stale gather is an error, not a silent wrong batch)."""
+
+  def __init__(self, pool, idx, owner=None):
+    self.pool, self.idx, self.owner = pool, idx, owner
+    self.stamp = owner._writes if owner is not None else None
+    self.shape = (idx.shape[0],) + tuple(pool.shape[1:])
+    self.dtype, self.device = pool.dtype, pool.device
+
+  def _check(self):
+    assert self.owner is None or self.owner._writes == self.stamp, 'PoolRows used after the pool was written'
+
+  def materialize(self):
+    self._check()
+    return self.pool.index_select(0, self.idx)
+
+  def into(self, dst):
+    self._check()
+    assert tuple(dst.shape) == self.shape and dst.dtype == self.dtype and dst.is_contiguous()
+    torch.index_select(self.pool, 0, self.idx, out=dst)
+    return dst
+
+
+def materialize(t):
+  """A tensor for a tensor or a :class:`PoolRows`."""
+  return t.materialize() if isinstance(t, PoolRows) else t
 
 
 class _PinnedRing:
@@ -100,6 +161,7 @@ class ReplayMemory:
     self._h_stopped = np.zeros((0,), dtype=np.float64)  # host mirrors of the two fields the pool reads
     self._h_step = np.zeros((0,), dtype=np.float64)
     self._popped = None  # host (step, stopped) of the batch popped last (replace_memory(advanced=True))
+    self._writes = 0  # device writes to the pool so far (PoolRows validity)
     self.fill_pool()
 
   # -- replay_memory.py:54-63
@@ -126,33 +188,45 @@ class ReplayMemory:
     return self._ft.index_select(0, self._idx(self._order))
 
   # ---- slots
-  def _ensure_capacity(self, like_images, like_states, like_features, need):
+  def _ensure_capacity(self, like_images, state_dim, like_features, need):
+    """Buffers of ``cap`` slots + ONE trash row behind them (the scatter target of rows that are not kept)."""
     if self._img is not None and self._cap >= need:
       return
     cap = max(need, self.target_pool_size + max(int(self.cfg.batch_size), like_images.shape[0]))
-    img = torch.zeros((cap,) + tuple(like_images.shape[1:]), dtype=like_images.dtype, device=self.device)
-    st = torch.zeros((cap,) + tuple(like_states.shape[1:]), dtype=like_states.dtype, device=self.device)
-    ft = torch.zeros((cap,) + tuple(like_features.shape[1:]), dtype=like_features.dtype, device=self.device)
+    img = torch.zeros((cap + 1,) + tuple(like_images.shape[1:]), dtype=like_images.dtype, device=self.device)
+    st = torch.zeros((cap + 1, state_dim), dtype=torch.float32, device=self.device)
+    ft = torch.zeros((cap + 1,) + tuple(like_features.shape[1:]), dtype=like_features.dtype, device=self.device)
     if self._img is not None:  # grow (rare: a caller appending more than one batch)
-      img[:self._cap], st[:self._cap], ft[:self._cap] = self._img, self._st, self._ft
+      img[:self._cap], st[:self._cap], ft[:self._cap] = self._img[:self._cap], self._st[:self._cap], self._ft[:self._cap]
     self._free += list(range(self._cap, cap))
     self._h_stopped = np.concatenate([self._h_stopped, np.zeros(cap - self._cap)])
     self._h_step = np.concatenate([self._h_step, np.zeros(cap - self._cap)])
     self._img, self._st, self._ft, self._cap = img, st, ft, cap
+    self._writes += 1
 
   def _append(self, images, states, features, h_step, h_stopped, rows=None):
-    """Append records (optionally only the rows ``rows`` of the given tensors, a host index array) at the back."""
-    n = images.shape[0] if rows is None else int(len(rows))
+    """Append records at the back: all rows of the given tensors, or only the rows ``rows`` (a host index array) -- the
+    others are scattered to the trash row, so the batch is written with ONE index vector and no row selection.
+    ``states`` None: fresh records (zero states, ``replay_memory.py:54-63``), written as a fill."""
+    total = images.shape[0]
+    n = total if rows is None else int(len(rows))
     if n == 0:
       return
-    self._ensure_capacity(images, states, features, len(self) + n)
+    state_dim = self.cfg.num_state_dim if states is None else states.shape[1]
+    self._ensure_capacity(images, state_dim, features, len(self) + n)
     slots = np.array([self._free.pop() for _ in range(n)], dtype=np.int64)
-    dst = self._idx(slots)
-    if rows is not None and n != images.shape[0]:
-      src = self._idx(rows)
-      images, states, features = images.index_select(0, src), states.index_select(0, src), features.index_select(0, src)
+    if rows is None or n == total:
+      dst = self._idx(slots)
+    else:
+      scatter = np.full((total,), self._cap, dtype=np.int64)  # the trash row
+      scatter[np.asarray(rows)] = slots
+      dst = self._idx(scatter)
+    self._writes += 1
     self._img.index_copy_(0, dst, images.to(self._img.dtype))
-    self._st.index_copy_(0, dst, states.to(self._st.dtype))
+    if states is None:
+      self._st.index_fill_(0, dst, 0.0)
+    else:
+      self._st.index_copy_(0, dst, states.to(self._st.dtype))
     self._ft.index_copy_(0, dst, features.to(self._ft.dtype))
     self._h_step[slots] = h_step
     self._h_stopped[slots] = h_stopped
@@ -165,8 +239,10 @@ class ReplayMemory:
     self._free += gone.tolist()
     self._order = keep
 
-  def _take(self, slots):
+  def _take(self, slots, lazy=False):
     idx = self._idx(slots)
+    if lazy:
+      return PoolRows(self._img, idx, self), PoolRows(self._st, idx, self), PoolRows(self._ft, idx, self)
     return self._img.index_select(0, idx), self._st.index_select(0, idx), self._ft.index_select(0, idx)
 
   def _shuffle(self):
@@ -175,11 +251,12 @@ class ReplayMemory:
 
   # -- replay_memory.py:65-77
   def fill_pool(self):
+    # (the reference appends whole batches and cuts the pool back to its target size: the tail of the last batch is
+    # dropped -- here it is not written in the first place; the provider still advances by a whole batch)
     while len(self) < self.target_pool_size:
       batch, features = self.fake_dataset.get_next_batch(self.cfg.batch_size)
-      self._append(batch, self.get_initial_states(batch.shape[0]), features, 0.0, 0.0)
-    if len(self) > self.target_pool_size:
-      self._drop(slice(0, self.target_pool_size))
+      k = min(batch.shape[0], self.target_pool_size - len(self))
+      self._append(batch[:k], None, features[:k], 0.0, 0.0)
 
   def get_noise(self, batch_size):
     """replay_memory.py:177-185: cfg.z_type 'uniform' (U(0, 1), both shipped configs) or 'normal' (N(0, 1))."""
@@ -190,7 +267,9 @@ class ReplayMemory:
     return self._ring.put(torch.rand((batch_size, self.cfg.z_dim), generator=self.rng))
 
   # -- replay_memory.py:235-252: pop NON-terminated records from the shuffled pool
-  def get_next_fake_batch(self, batch_size):
+  def get_next_fake_batch(self, batch_size, lazy=False):
+    """``lazy``: the batch as :class:`PoolRows` (gathered by its consumer) when one pass over the pool yields it; the
+    rare multi-pass case refills the pool in between and gathers at once, as before."""
     self._shuffle()
     assert batch_size <= len(self)
     got, taken, have = [], [], 0
@@ -207,7 +286,9 @@ class ReplayMemory:
         cut = len(self)
         take = live
       slots = self._order[take]
-      got.append(self._take(slots))  # gathered BEFORE the slots are released (a refill may reuse them)
+      # (an eager gather happens BEFORE the slots are released: a refill may reuse them; a lazy one is only handed out
+      # when no refill follows)
+      got.append(self._take(slots, lazy=lazy and not got and take.size == need))
       taken.append(slots)
       have += take.size
       self._drop(slice(cut, None))
@@ -218,14 +299,14 @@ class ReplayMemory:
     return tuple(torch.cat([g[k] for g in got]) for k in range(3))
 
   # -- replay_memory.py:254-279: terminated records only (with repetition if there are few)
-  def replay_fake_batch(self, batch_size):
+  def replay_fake_batch(self, batch_size, lazy=False):
     self.fill_pool()
     self._shuffle()
     assert batch_size <= len(self)
     done = self._order[self._h_stopped[self._order] > 0]
     assert done.size > 0, 'No terminated states discovered'
     reps = (batch_size + done.size - 1) // done.size
-    return self._take(np.tile(done, reps)[:batch_size])
+    return self._take(np.tile(done, reps)[:batch_size], lazy=lazy)
 
   # -- replay_memory.py:199-209
   def replace_memory(self, images, states, features, advanced=False):
@@ -233,6 +314,7 @@ class ReplayMemory:
     ``get_next_fake_batch`` returned, in the same order -- the host then KNOWS the two fields it needs
     (step + 1; stopped iff step + 1 == cfg.test_steps) and no device read-back happens.  Otherwise they are read from
     ``states`` (one host sync)."""
+    features = materialize(features)  # (rows of the pool itself, popped by get_next_fake_batch: read before any write)
     self._shuffle()
     n = states.shape[0]
     if advanced:
@@ -257,14 +339,16 @@ class ReplayMemory:
                 np.array_equal(st[:, STATE_STEP_DIM], self._h_step[self._order]))
 
   # -- feed-dict builders (replay_memory.py:139-185) as plain dicts of device tensors
-  def get_feed_dict_and_states(self, batch_size):
-    images, states, features = self.get_next_fake_batch(batch_size)
+  def get_feed_dict_and_states(self, batch_size, lazy=False):
+    """``lazy``: ``fake_input`` / ``states`` / the features as :class:`PoolRows` (``GAN.generator_step`` gathers them
+    straight into its graph's inputs; ``replace_memory`` accepts the features as they are)."""
+    images, states, features = self.get_next_fake_batch(batch_size, lazy=lazy)
     real, real_feat = self.real_dataset.get_next_batch(batch_size)
     return dict(fake_input=images, fake_input_feature=features, states=states, real_data=real,
                 real_data_feature=real_feat, z=self.get_noise(batch_size)), features
 
-  def get_replay_feed_dict(self, batch_size):
-    images, _states, features = self.replay_fake_batch(batch_size)
+  def get_replay_feed_dict(self, batch_size, lazy=False):
+    images, _states, features = self.replay_fake_batch(batch_size, lazy=lazy)
     real, real_feat = self.real_dataset.get_next_batch(batch_size)
     return dict(fake_output=images, fake_output_feature=features, real_data=real, real_data_feature=real_feat)
 

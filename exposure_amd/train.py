@@ -18,7 +18,7 @@ import torch
 
 from .config import make_cfg
 from .gan import GAN
-from .replay_memory import ReplayMemory, SyntheticProvider
+from .replay_memory import ReplayMemory, ResidentProvider
 
 
 def main(argv=None):
@@ -43,8 +43,9 @@ def main(argv=None):
   gan = GAN(cfg, device=dev, use_graphs=not args.no_graphs, seed=args.seed)  # (--seed also drives dropout / alpha)
   dt = torch.float32 if args.dtype == 'f32' else torch.float16
   # toy task with the statistics of the real one: dark linear-RAW-like inputs, brighter targets
-  memory = ReplayMemory(cfg, SyntheticProvider(dev, gamma=2.2, scale=0.35, dtype=dt, seed=args.seed + 1),
-                        SyntheticProvider(dev, gamma=1.2, scale=0.9, dtype=dt, seed=args.seed + 2), seed=args.seed)
+  # (both synthetic data sets resident in HBM: 4 096 images each, served as views)
+  memory = ReplayMemory(cfg, ResidentProvider(dev, gamma=2.2, scale=0.35, dtype=dt, seed=args.seed + 1),
+                        ResidentProvider(dev, gamma=1.2, scale=0.9, dtype=dt, seed=args.seed + 2), seed=args.seed)
   if args.resume:
     ckpt = torch.load(args.resume, map_location=dev)
     gan.load_state_dict(ckpt['model'] if 'model' in ckpt else ckpt)

@@ -300,6 +300,39 @@ def test_training_loop_on_gpu(gpu_device):
   assert len(mem) == 32
 
 
+def test_lazy_feeds_train_bit_identically_on_gpu(gpu_device):
+  """PoolRows gathered straight into the step graphs' inputs + views of the HBM-resident data sets (the training loops'
+  feeds since round 6) against the gathered feeds of the same memories: every loss of every step bit-equal, eager and
+  replayed from hipGraphs, and the pools end up identical."""
+  from exposure_amd.replay_memory import ReplayMemory, ResidentProvider
+  dev = gpu_device
+  cfg = make_cfg()
+  cfg.batch_size, cfg.replay_memory_size, cfg.citers = 16, 32, 2
+  for graphs in (False, True):
+    runs = []
+    for lazy in (True, False):
+      torch.manual_seed(0)
+      gan = GAN(cfg, device=dev, use_graphs=graphs, seed=4)
+      mem = ReplayMemory(cfg, ResidentProvider(dev, dtype=torch.float16, seed=1, count=256),
+                         ResidentProvider(dev, gamma=1.0, dtype=torch.float16, seed=2, count=256), seed=0)
+      vals = []
+      for it in range(9):
+        feed, feats = mem.get_feed_dict_and_states(cfg.batch_size, lazy=lazy)
+        g = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], it / 9.0, it=min(it, 1) * it)
+        vals += [g['g_loss'].clone(), g['v_loss'].clone()]
+        mem.replace_memory(g['fake_output'], g['new_states'], feats, advanced=True)
+        if it >= 5:
+          for _ in range(cfg.citers):
+            rep = mem.get_replay_feed_dict(cfg.batch_size, lazy=lazy)
+            c = gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
+            vals.append(c['c_loss'].clone())
+      assert mem.check_host_mirror()
+      runs.append((torch.stack([v.reshape(()) for v in vals]), mem.images, mem.states, mem.features))
+    for a, b in zip(*runs):
+      assert torch.equal(a, b), graphs
+    assert bool(torch.isfinite(runs[0][0]).all())
+
+
 def test_graphed_steps_match_eager(gpu_device):
   """hipGraph replay of the generator / critic step == the eager step (same inputs, masks, alpha)."""
   dev = gpu_device

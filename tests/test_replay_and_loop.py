@@ -112,3 +112,59 @@ def test_training_loop_runs_and_terminates_trajectories():
       hist.append((float(g['g_loss']), float(c['c_loss'])))
   assert all(np.isfinite(v) for pair in hist for v in pair)
   assert cfg.giters == orig_giters
+
+
+def test_lazy_feeds_equal_the_gathered_ones():
+  """``lazy=True`` hands out PoolRows (gathered by the consumer: GAN._replay writes them straight into the step graph's
+  inputs): same seeds, same calls -> the same batches, features and pool contents as the gathered feeds, through pops,
+  replaces with dropped rows (the trash-row scatter) and replays; a PoolRows used after the pool was written is an error."""
+  import pytest
+  from exposure_amd.replay_memory import PoolRows, materialize
+  cfg = make_cfg()
+  cfg.batch_size, cfg.replay_memory_size = 8, 24
+  dev = torch.device('cpu')
+  a = ReplayMemory(cfg, SyntheticProvider(dev, seed=5), SyntheticProvider(dev, gamma=1.0, seed=6), seed=7)
+  b = ReplayMemory(cfg, SyntheticProvider(dev, seed=5), SyntheticProvider(dev, gamma=1.0, seed=6), seed=7)
+  lazies = 0
+  for it in range(30):
+    fa, feat_a = a.get_feed_dict_and_states(8, lazy=True)
+    fb, feat_b = b.get_feed_dict_and_states(8)
+    lazies += isinstance(fa['fake_input'], PoolRows)
+    for k in fb:
+      got = materialize(fa[k])
+      assert got.shape == fb[k].shape and torch.equal(got, fb[k]), (it, k)
+    if isinstance(fa['fake_input'], PoolRows):
+      dst = torch.full(fa['fake_input'].shape, float('nan'))
+      assert fa['fake_input'].into(dst) is dst and torch.equal(dst, fb['fake_input'])
+    st = fb['states'].clone()
+    stopped = ((st[:, 2] + 1 - cfg.test_steps).abs() < 1e-4).float()
+    st[:, 0], st[:, 1], st[:, 2] = stopped, stopped, st[:, 2] + 1
+    st[it % 8, 2] = 9  # over-length: dropped with probability 1 - over_length_keep_prob
+    img = fb['fake_input'] * 0.9
+    a.replace_memory(img, st, feat_a)  # (the features as PoolRows)
+    b.replace_memory(img, st, feat_b)
+    if isinstance(feat_a, PoolRows):
+      with pytest.raises(AssertionError):
+        feat_a.materialize()  # the pool has been written since
+    assert len(a) == len(b) and torch.equal(a.states, b.states) and torch.equal(a.images, b.images)
+    assert torch.equal(a.features, b.features) and a.check_host_mirror()
+    if int((b.states[:, 1] > 0).sum()) > 0:
+      ra, rb = a.get_replay_feed_dict(8, lazy=True), b.get_replay_feed_dict(8)
+      for k in rb:
+        assert torch.equal(materialize(ra[k]), rb[k]), (it, k)
+  assert lazies >= 25
+
+
+def test_resident_provider_serves_views_of_one_data_set():
+  from exposure_amd.replay_memory import ResidentProvider
+  dev = torch.device('cpu')
+  p = ResidentProvider(dev, gamma=2.2, scale=0.5, dtype=torch.float16, seed=3, count=40)
+  ref = SyntheticProvider(dev, gamma=2.2, scale=0.5, dtype=torch.float16, seed=3).get_next_batch(40)[0]
+  assert torch.equal(p.images, ref) and p.images.dtype == torch.float16
+  seen = []
+  for _ in range(5):
+    x, f = p.get_next_batch(16)
+    assert x.shape == (16, 64, 64, 3) and x.data_ptr() >= p.images.data_ptr()  # a view, not a copy
+    assert torch.equal(x, p.images[int(f[0]):int(f[0]) + 16])
+    seen.append(int(f[0]))
+  assert seen == [0, 16, 0, 16, 0]  # 40 images: two whole batches per epoch
