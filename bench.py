@@ -608,13 +608,9 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
     memory.replace_memory(out['fake_output'], out['new_states'], feats, advanced=True)
 
   def iteration(it):
-    feed, feats = memory.get_feed_dict_and_states(n, lazy=True)
-    out = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], progress=it / cfg.max_iter_step, it=it)
-    memory.replace_memory(out['fake_output'], out['new_states'], feats, advanced=True)
-    for _ in range(cfg.citers):
-      rep = memory.get_replay_feed_dict(n, lazy=True)
-      gan.critic_step(rep['real_data'], rep['fake_output'], it=it)
-    return out
+    # one G / V step, its results back into the replay memory, cfg.citers critic steps: planned ahead on the host and
+    # replayed as ONE hipGraph fed by one host-to-device copy (GAN.train_iteration); --graph off: the step-by-step calls
+    return gan.train_iteration(memory, it, progress=it / cfg.max_iter_step, batch_size=n)['g']
 
   trace('pool primed')
   for i in range(warmup):
@@ -638,7 +634,9 @@ def measure_train(args, world, rank, dev, dist, steps, warmup):
       'warmup': warmup,
       'batch_per_gpu': n,
       'critic_steps_per_iteration': cfg.citers,
-      'launch': 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager',
+      'launch': ('one hipGraph replay per iteration, fed by one host-to-device copy of the iteration plan'
+                 if any(k[0] == 'it' for k in gan._graphs) else
+                 'one hipGraph replay per G/V step and per critic step' if gan._replay_steps else 'eager'),
       'capture_drain_verified': getattr(gan, 'capture_drain_verified', None),
       'roofline': {
           'bound': 'mfma_fp32',
@@ -883,7 +881,7 @@ def run_legs(result, args, world, rank, dev, dist):
 
   try:
     leg('chain_64x64x64x3', lambda: measure_shape('A', args, world, rank, dev, dist))
-    leg('train', lambda: measure_train(args, world, rank, dev, dist, steps=10, warmup=3))
+    leg('train', lambda: measure_train(args, world, rank, dev, dist, steps=20, warmup=5))
     if world > 1:
       leg('allreduce', lambda: measure_allreduce(args, world, rank, dev, dist, steps=20, warmup=5))
   finally:

@@ -9,6 +9,7 @@ gradients are all-reduced in flat buckets (``exposure_amd.dist``) before the opt
 """
 import os
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -18,7 +19,7 @@ from .agent import Agent
 from .critics import Critic
 from .nn_ops import (critic_step_inputs, frozen_parameters, generator_losses_fused, grad_penalty_term,
                      once_differentiable_convnets, skip_parameter_gradients)
-from .replay_memory import PoolRows, materialize
+from .replay_memory import HostStaged, PoolRows, materialize
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM, capture_without_gc
 
 
@@ -103,6 +104,7 @@ class GAN(nn.Module):
     }
     self._pending = []
     self._progress = None  # the step's `progress` input as a device scalar (generator_step)
+    self._it_ring = None   # pinned staging buffers of the iteration plans (train_iteration)
     # ExponentialMovingAverage(decay=0.99, zero_debias=True) of c_average (net.py:107-108, 165-168): the biased average
     # lives on the device and is advanced INSIDE the critic step (one in-place lerp, part of the captured graph)
     self._c_ema = None
@@ -328,7 +330,7 @@ class GAN(nn.Module):
     self._graphs.clear()
 
   # ---- hipGraph capture / replay of a whole optimisation step --------------------------------
-  def _replay(self, key, body, inputs):
+  def _replay(self, key, body, inputs, extra_sig=(), rng=False):
     """hipGraph execution of one optimisation step.  Per (step kind, input shapes): the FIRST call
     runs eagerly (it is a normal training step and doubles as the warm-up that lets MIOpen /
     hipBLASLt pick kernels and allocate workspaces), the SECOND call captures ``body`` into one
@@ -336,7 +338,9 @@ class GAN(nn.Module):
     replayed: ~6 000 eager launches (~10 us of host time each) become one graph launch.  Returned
     tensors are the graph's static outputs (valid until the next replay of the same graph)."""
     self._check_heads()
-    sig = (key,) + tuple((tuple(t.shape), t.dtype) for t in inputs)
+    # ``extra_sig``: whatever else the captured launches depend on (buffers the body closes over); ``rng``: the body
+    # draws from self.rng inside the graph (the generator is registered with it: replays continue the eager sequence)
+    sig = (key,) + tuple((tuple(t.shape), t.dtype) for t in inputs) + tuple(extra_sig)
     entry = self._graphs.get(sig)
     if entry is None:
       self._graphs[sig] = 'warm'
@@ -344,7 +348,7 @@ class GAN(nn.Module):
     if entry == 'warm':
       # (with a process group the gradient all-reduces are captured too: RCCL collectives are
       # stream-ordered kernels, and the eager first call has already initialised the communicator)
-      static_in = [t.materialize() if isinstance(t, PoolRows) else t.clone() for t in inputs]
+      static_in = [t.materialize() if isinstance(t, (PoolRows, HostStaged)) else t.clone() for t in inputs]
       # ROOT CAUSE of round 1's "one run in ~15 aborts" (gpurun r02soak, 3 of 28 runs): the eager first call left
       # WorkNCCL entries in ProcessGroupNCCL's watchdog list; they are complete, but the watchdog only reaps its list
       # every ~100 ms.  If it polls (hipEventQuery on the work's end event) AFTER this thread has pulled RCCL's stream
@@ -362,6 +366,8 @@ class GAN(nn.Module):
         return body(*[materialize(t) for t in inputs])
       self.capture_drain_verified = verified
       graph = torch.cuda.CUDAGraph()
+      if rng and self.rng.gen is not None and self.rng.gen.device.type == 'cuda':
+        graph.register_generator_state(self.rng.gen)
       # thread_local: RCCL's watchdog thread polls events while this thread captures; under the
       # default "global" mode such a call from another thread aborts the process
       mode = 'thread_local' if xdist.world_size(self.process_group) > 1 or self.force_collectives else 'global'
@@ -379,8 +385,8 @@ class GAN(nn.Module):
       self._graphs[sig] = entry
     graph, static_in, static_out = entry
     for dst, src in zip(static_in, inputs):
-      if isinstance(src, PoolRows):
-        src.into(dst)  # gathered straight into the graph's input: one launch instead of gather + copy
+      if isinstance(src, (PoolRows, HostStaged)):
+        src.into(dst)  # gathered / copied from pinned memory straight into the graph's input: one launch, not two
       else:
         dst.copy_(src)
     graph.replay()
@@ -495,6 +501,103 @@ class GAN(nn.Module):
       return 0.0
     return self._c_ema / (1.0 - 0.99**self.c_average_steps)
 
+  # -- one regular iteration (net.py:329-365): ONE graph replay fed by ONE host-to-device copy ---------------------------
+  def _iteration_layout(self, memory, n):
+    cfg = self.cfg
+    p = memory.target_pool_size
+    ni = 2 * n + 2 * p + 2 * n * cfg.citers  # int64: G gather / scatter, fresh dst / src, per critic step slots + real rows
+    nf = n * cfg.z_dim + 4                   # float32: z, progress, lr_g, lr_v, lr_c
+    return ni, nf
+
+  def _iteration_body(self, rec):
+    """The captured iteration: ``rec`` is the plan on the device (``ReplayMemory.plan_iteration`` + the iteration's
+    scalars, one uint8 record).  Learning rates and progress are read from it, the pool is gathered from / scattered to with
+    its index vectors, dropout masks and alpha are drawn in the graph (self.rng is registered with it)."""
+    cfg, mem, n = self.cfg, self._it_memory, self._it_n
+    ni, nf = self._iteration_layout(mem, n)
+    p = mem.target_pool_size
+    i64, f32 = rec[:8 * ni].view(torch.int64), rec[8 * ni:8 * ni + 4 * nf].view(torch.float32)
+    at = [0]
+
+    def take(k):
+      v = i64[at[0]:at[0] + k]
+      at[0] += k
+      return v
+
+    g_slots, g_scatter, fresh_dst, fresh_src = take(n), take(n), take(p), take(p)
+    z = f32[:n * cfg.z_dim].view(n, cfg.z_dim)
+    scal = f32[n * cfg.z_dim:]
+    for opt, k in ((self.opt_g, 1), (self.opt_v, 2), (self.opt_c, 3)):
+      for g in opt.param_groups:
+        g['lr'].copy_(scal[k])
+    fake_input, states, feats = mem.planned_generator_batch(g_slots)
+    masks = self._draw_masks(n, device=fake_input.device)
+    g_out = self._generator_body(fake_input, z, states, scal[0], masks)
+    mem.planned_commit(g_scatter, g_out['fake_output'], g_out['new_states'], feats, fresh_dst, fresh_src)
+    c_out = None
+    for _ in range(cfg.citers):
+      real, fake = mem.planned_critic_batch(take(n), take(n))
+      c_out = self._critic_body(real, fake, self._draw_alpha(n))
+    return dict(g=g_out, c=c_out)
+
+  def _iteration_stepwise(self, memory, it, progress, n):
+    cfg = self.cfg
+    feed, features = memory.get_feed_dict_and_states(n, lazy=True)
+    g_out = self.generator_step(feed['fake_input'], feed['z'], feed['states'], progress, it=it)
+    memory.replace_memory(g_out['fake_output'], g_out['new_states'], features, advanced=True)
+    c_out = None
+    for _ in range(cfg.citers):
+      feed = memory.get_replay_feed_dict(n, lazy=True)
+      c_out = self.critic_step(feed['real_data'], feed['fake_output'], it=it)
+    return dict(g=g_out, c=c_out)
+
+  def train_iteration(self, memory, it, progress=None, batch_size=None):
+    """One REGULAR training iteration (net.py:329-365: one generator / value step, its results back into the replay
+    memory, ``cfg.citers`` critic steps on replayed terminated records) -> ``dict(g=<generator_step's outputs>,
+    c=<the last critic_step's>)``.
+
+    With step graphs on and both data sets resident in HBM, nothing the host decides during an iteration depends on what
+    the device computes (the pool's decisions read the host mirror of step / stopped), so the iteration is planned ahead
+    (``ReplayMemory.plan_iteration``: same decisions, same random draws as the step-by-step calls), the plan -- index
+    vectors, selection noise, progress, the three learning rates -- goes to the device as ONE pinned-memory copy, and the
+    whole iteration replays as ONE hipGraph: pool gathers, the G / V step, the scatter of its results and the fresh
+    records, the critic steps with their replayed batches, dropout masks and alpha from the graph-registered generator.
+    Everything else (eager mode, the warm-up iteration 0 and its 100-step phases, providers that stream from the host)
+    takes the step-by-step calls."""
+    cfg = self.cfg
+    n = int(batch_size or cfg.batch_size)
+    progress = float(it) / cfg.max_iter_step if progress is None else float(progress)
+    plan = None
+    if self._replay_steps and it > 0 and int(cfg.giters) == 1 and cfg.citers >= 1:
+      plan = memory.plan_iteration(n, cfg.citers)
+    if plan is None:
+      return self._iteration_stepwise(memory, it, progress, n)
+    dev = memory.device
+    ni, nf = self._iteration_layout(memory, n)
+    # (a ring of its own, four buffers deep: pinning memory is a device-wide synchronisation, not something to do per
+    # iteration; a buffer is rewritten only after the copy that read it has completed)
+    if self._it_ring is None or self._it_ring.device != dev:
+      from .replay_memory import _PinnedRing
+      self._it_ring = _PinnedRing(dev, slots=4)
+    host, key = self._it_ring.take(torch.uint8, 8 * ni + 4 * nf)
+    fields = plan.int64_fields()
+    host[:8 * ni].view(torch.int64).numpy()[:] = np.concatenate([np.asarray(f, dtype=np.int64).ravel() for f in fields])
+    f32 = host[8 * ni:].view(torch.float32).numpy()
+    f32[:n * cfg.z_dim] = plan.z.numpy().ravel()
+    lr_g = cfg.lr_g(it)
+    f32[n * cfg.z_dim:] = (progress, lr_g, cfg.value_lr_mul * lr_g, cfg.lr_c(it))
+    for opt in (self.opt_g, self.opt_v, self.opt_c):
+      for g in opt.param_groups:
+        g.pop('_lr_value', None)  # (set_lrs' note of what the scalar holds: the graph writes it behind its back)
+    if self._c_ema is None or self._c_ema.device != dev:
+      self._c_ema = torch.zeros((), dtype=torch.float32, device=dev)  # (allocated outside any capture)
+    self._it_memory, self._it_n = memory, n
+    extra = (id(memory), memory._img.data_ptr(), memory._st.data_ptr(), memory.fake_dataset.images.data_ptr(),
+             memory.real_dataset.images.data_ptr(), cfg.citers)
+    out = self._replay('it', self._iteration_body, (HostStaged(host, dev, self._it_ring, key),), extra_sig=extra, rng=True)
+    self.c_average_steps += cfg.citers
+    return out
+
   # -- the training loop (net.py:298-403), minus visualisation / checkpoints / TensorBoard
   def train(self, memory, max_iter_step=None, log_every=0, log=print):
     cfg = self.cfg
@@ -507,15 +610,19 @@ class GAN(nn.Module):
       else:
         citers = cfg.citers
       giters = 100 if it == 0 else cfg.giters  # make sure there are terminating states
-      g_out = None
-      for _ in range(giters):
-        feed, features = memory.get_feed_dict_and_states(cfg.batch_size, lazy=True)
-        g_out = self.generator_step(feed['fake_input'], feed['z'], feed['states'], progress, it=it)
-        memory.replace_memory(g_out['fake_output'], g_out['new_states'], features, advanced=True)
-      c_out = None
-      for _ in range(citers):
-        feed = memory.get_replay_feed_dict(cfg.batch_size, lazy=True)
-        c_out = self.critic_step(feed['real_data'], feed['fake_output'], it=it)
+      if giters == 1 and citers == cfg.citers:
+        out = self.train_iteration(memory, it, progress)
+        g_out, c_out = out['g'], out['c']
+      else:
+        g_out = None
+        for _ in range(giters):
+          feed, features = memory.get_feed_dict_and_states(cfg.batch_size, lazy=True)
+          g_out = self.generator_step(feed['fake_input'], feed['z'], feed['states'], progress, it=it)
+          memory.replace_memory(g_out['fake_output'], g_out['new_states'], features, advanced=True)
+        c_out = None
+        for _ in range(citers):
+          feed = memory.get_replay_feed_dict(cfg.batch_size, lazy=True)
+          c_out = self.critic_step(feed['real_data'], feed['fake_output'], it=it)
       # the four reported scalars stay on the device (one small launch; the steps' outputs are static graph buffers that
       # the next replay overwrites): the host reads them when it logs and once at the end, not four times per iteration
       history.append(torch.stack([g_out['g_loss'].reshape(()), g_out['v_loss'].reshape(()), c_out['emd'].reshape(()),

@@ -74,12 +74,17 @@ class ResidentProvider:
     self.features = torch.arange(self.count, device=device, dtype=torch.float32)
     self.at = 0
 
-  def get_next_batch(self, batch_size):
+  def next_rows(self, batch_size):
+    """The first row of the next batch (host only: the batch is ``images[lo:lo + batch_size]``)."""
     assert batch_size <= self.count
     if self.at + batch_size > self.count:
       self.at = 0  # next epoch
     lo = self.at
     self.at += batch_size
+    return lo
+
+  def get_next_batch(self, batch_size):
+    lo = self.next_rows(batch_size)
     return self.images[lo:lo + batch_size], self.features[lo:lo + batch_size]
 
 
@@ -108,9 +113,50 @@ class PoolRows:
     return dst
 
 
+class HostStaged:
+  """A PINNED host tensor on its way to the device: ``into(dst)`` is the one asynchronous copy that puts it into a step
+  graph's static input, ``materialize()`` a fresh device tensor.  ``ring`` / ``key``: the staging ring the buffer came
+  from, told when the copy has been issued (the buffer is reused only after that copy completed)."""
+
+  def __init__(self, host, device, ring=None, key=None):
+    self.host, self.device, self.ring, self.key = host, torch.device(device), ring, key
+    self.shape, self.dtype = tuple(host.shape), host.dtype
+
+  def _issued(self):
+    if self.ring is not None:
+      self.ring.mark(self.key)
+
+  def materialize(self):
+    out = self.host.to(self.device, non_blocking=True)
+    self._issued()
+    return out
+
+  def into(self, dst):
+    assert tuple(dst.shape) == self.shape and dst.dtype == self.dtype
+    dst.copy_(self.host, non_blocking=True)
+    self._issued()
+    return dst
+
+
 def materialize(t):
-  """A tensor for a tensor or a :class:`PoolRows`."""
-  return t.materialize() if isinstance(t, PoolRows) else t
+  """A tensor for a tensor, a :class:`PoolRows` or a :class:`HostStaged`."""
+  return t.materialize() if isinstance(t, (PoolRows, HostStaged)) else t
+
+
+class IterationPlan:
+  """``ReplayMemory.plan_iteration``'s result: host index vectors (int64) and the noise (float32)."""
+
+  def __init__(self, g_slots, z, g_scatter, fresh_dst, fresh_src, c_slots, real_rows):
+    self.g_slots, self.z, self.g_scatter = g_slots, z, g_scatter
+    self.fresh_dst, self.fresh_src, self.c_slots, self.real_rows = fresh_dst, fresh_src, c_slots, real_rows
+
+  def int64_fields(self):
+    """The index vectors in record order: G gather, G scatter, fresh destination / source, then per critic step the
+    replayed slots and the real rows."""
+    out = [self.g_slots, self.g_scatter, self.fresh_dst, self.fresh_src]
+    for a, b in zip(self.c_slots, self.real_rows):
+      out += [a, b]
+    return out
 
 
 class _PinnedRing:
@@ -122,25 +168,37 @@ class _PinnedRing:
     self.cuda = self.device.type == 'cuda'
     self.slots, self.bufs, self.events, self.at = slots, {}, {}, 0
 
+  def take(self, dtype, numel):
+    """A pinned buffer of ``numel`` elements whose last copy (if any) has completed -> (view, key); the caller fills it,
+    issues its copy and calls ``mark(key)``."""
+    key = (dtype, self.at % self.slots)
+    self.at += 1
+    buf = self.bufs.get(key)
+    if buf is None or buf.numel() < numel:
+      buf = torch.empty(max(numel, 256), dtype=dtype)
+      if self.cuda:
+        buf = buf.pin_memory()
+      self.bufs[key] = buf
+    ev = self.events.pop(key, None)
+    if ev is not None:
+      ev.synchronize()
+    return buf[:numel], key
+
+  def mark(self, key):
+    if self.cuda:
+      ev = torch.cuda.Event()
+      ev.record()
+      self.events[key] = ev
+
   def put(self, host_tensor):
     """Device copy of a (small) host tensor; asynchronous on a GPU."""
     if not self.cuda:
       return host_tensor.clone()
-    key = (host_tensor.dtype, self.at % self.slots)
-    self.at += 1
-    buf = self.bufs.get(key)
-    if buf is None or buf.numel() < host_tensor.numel():
-      buf = torch.empty(max(host_tensor.numel(), 256), dtype=host_tensor.dtype).pin_memory()
-      self.bufs[key] = buf
-    ev = self.events.get(key)
-    if ev is not None:
-      ev.synchronize()
-    view = buf[:host_tensor.numel()].view(host_tensor.shape)
+    view, key = self.take(host_tensor.dtype, host_tensor.numel())
+    view = view.view(host_tensor.shape)
     view.copy_(host_tensor)
     out = view.to(self.device, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    self.events[key] = ev
+    self.mark(key)
     return out
 
 
@@ -204,6 +262,22 @@ class ReplayMemory:
     self._img, self._st, self._ft, self._cap = img, st, ft, cap
     self._writes += 1
 
+  def _host_append(self, total, rows, h_step, h_stopped):
+    """The host half of an append: slots for the kept rows (``rows`` None: all ``total``), mirrors, logical order.
+    -> the scatter vector of the ``total`` given rows (a host array: kept rows -> their slots, the others -> the trash row)."""
+    n = total if rows is None else int(len(rows))
+    assert self._img is not None and len(self) + n <= self._cap
+    slots = np.array([self._free.pop() for _ in range(n)], dtype=np.int64)
+    if rows is None or n == total:
+      scatter = slots
+    else:
+      scatter = np.full((total,), self._cap, dtype=np.int64)  # the trash row
+      scatter[np.asarray(rows)] = slots
+    self._h_step[slots] = h_step
+    self._h_stopped[slots] = h_stopped
+    self._order = np.concatenate([self._order, slots])
+    return scatter
+
   def _append(self, images, states, features, h_step, h_stopped, rows=None):
     """Append records at the back: all rows of the given tensors, or only the rows ``rows`` (a host index array) -- the
     others are scattered to the trash row, so the batch is written with ONE index vector and no row selection.
@@ -214,13 +288,7 @@ class ReplayMemory:
       return
     state_dim = self.cfg.num_state_dim if states is None else states.shape[1]
     self._ensure_capacity(images, state_dim, features, len(self) + n)
-    slots = np.array([self._free.pop() for _ in range(n)], dtype=np.int64)
-    if rows is None or n == total:
-      dst = self._idx(slots)
-    else:
-      scatter = np.full((total,), self._cap, dtype=np.int64)  # the trash row
-      scatter[np.asarray(rows)] = slots
-      dst = self._idx(scatter)
+    dst = self._idx(self._host_append(total, rows, h_step, h_stopped))
     self._writes += 1
     self._img.index_copy_(0, dst, images.to(self._img.dtype))
     if states is None:
@@ -228,9 +296,6 @@ class ReplayMemory:
     else:
       self._st.index_copy_(0, dst, states.to(self._st.dtype))
     self._ft.index_copy_(0, dst, features.to(self._ft.dtype))
-    self._h_step[slots] = h_step
-    self._h_stopped[slots] = h_stopped
-    self._order = np.concatenate([self._order, slots])
 
   def _drop(self, positions_kept):
     """Keep the logical positions given (a slice result); the others' slots become free."""
@@ -258,13 +323,16 @@ class ReplayMemory:
       k = min(batch.shape[0], self.target_pool_size - len(self))
       self._append(batch[:k], None, features[:k], 0.0, 0.0)
 
-  def get_noise(self, batch_size):
-    """replay_memory.py:177-185: cfg.z_type 'uniform' (U(0, 1), both shipped configs) or 'normal' (N(0, 1))."""
+  def _host_noise(self, batch_size):
     z_type = getattr(self.cfg, 'z_type', 'uniform')
     if z_type == 'normal':
-      return self._ring.put(torch.randn((batch_size, self.cfg.z_dim), generator=self.rng))
+      return torch.randn((batch_size, self.cfg.z_dim), generator=self.rng)
     assert z_type == 'uniform', 'Unknown noise type: %s' % z_type
-    return self._ring.put(torch.rand((batch_size, self.cfg.z_dim), generator=self.rng))
+    return torch.rand((batch_size, self.cfg.z_dim), generator=self.rng)
+
+  def get_noise(self, batch_size):
+    """replay_memory.py:177-185: cfg.z_type 'uniform' (U(0, 1), both shipped configs) or 'normal' (N(0, 1))."""
+    return self._ring.put(self._host_noise(batch_size))
 
   # -- replay_memory.py:235-252: pop NON-terminated records from the shuffled pool
   def get_next_fake_batch(self, batch_size, lazy=False):
@@ -315,22 +383,108 @@ class ReplayMemory:
     (step + 1; stopped iff step + 1 == cfg.test_steps) and no device read-back happens.  Otherwise they are read from
     ``states`` (one host sync)."""
     features = materialize(features)  # (rows of the pool itself, popped by get_next_fake_batch: read before any write)
+    host = None
+    if not advanced:
+      host = states[:, [STATE_STOPPED_DIM, STATE_STEP_DIM]].detach().to('cpu', torch.float64).numpy()
+    rows, h_step, h_stopped = self._host_replace(states.shape[0], host)
+    self._append(images, states, features, h_step, h_stopped, rows=rows)
+    self.fill_pool()
     self._shuffle()
-    n = states.shape[0]
-    if advanced:
+
+  def _host_replace(self, n, host=None):
+    """The decisions of ``replace_memory`` (replay_memory.py:199-209): shuffle, the records' new (step, stopped) -- from
+    the agent's update rule (``host`` None) or read back -- and the keep draw.  -> (kept rows, their step, their stopped)."""
+    self._shuffle()
+    if host is None:
       assert self._popped is not None and self._popped[0].shape[0] == n, 'advanced=True follows get_next_fake_batch'
       old_step, _old_stopped = self._popped
       h_step = old_step + 1.0
       h_stopped = (np.abs(old_step + 1.0 - float(self.cfg.test_steps)) < 1e-4).astype(np.float64)
     else:
-      host = states[:, [STATE_STOPPED_DIM, STATE_STEP_DIM]].detach().to('cpu', torch.float64).numpy()
       h_stopped, h_step = host[:, 0], host[:, 1]
     keep = torch.from_numpy(h_step < self.cfg.maximum_trajectory_length) | \
         (torch.rand(n, generator=self.rng) < self.cfg.over_length_keep_prob)
     rows = np.nonzero(keep.numpy())[0]
-    self._append(images, states, features, h_step[rows], h_stopped[rows], rows=rows)
-    self.fill_pool()
+    return rows, h_step[rows], h_stopped[rows]
+
+  # ---- one training iteration decided ahead (round 6) ------------------------------------------------------------------
+  def plan_iteration(self, batch_size, citers):
+    """EVERY pool decision of one regular training iteration (net.py:329-365) -- the generator batch's pop, the replace
+    of its results (``advanced``: the host knows the new step / stopped fields without the device), the refill with fresh
+    records, ``citers`` critic replays, the providers' batches, the selection noise -- made NOW, on the host, in exactly
+    the order (and with exactly the random draws) of
+
+        get_feed_dict_and_states -> [G step] -> replace_memory(advanced=True) -> citers x get_replay_feed_dict -> [C step]
+
+    so that the trainer can run the whole iteration as ONE hipGraph replay fed by ONE host-to-device copy of the plan
+    (``GAN.train_iteration``): nothing the host decides depends on what the device computes.  The pool's host state
+    (order, free slots, mirrors) is advanced here; the device writes happen inside the graph.  -> :class:`IterationPlan`,
+    or None (nothing consumed) when the iteration needs the step-by-step path: providers that are not resident in HBM,
+    a pop that would need a refill in the middle, buffers that would have to grow."""
+    fd, rd = self.fake_dataset, self.real_dataset
+    if not (isinstance(fd, ResidentProvider) and isinstance(rd, ResidentProvider)) or self._img is None:
+      return None
+    pool_batch = int(self.cfg.batch_size)
+    if fd.images.dtype != self._img.dtype or max(batch_size, pool_batch) > min(fd.count, rd.count):
+      return None
+    if self._cap < self.target_pool_size + batch_size or len(self) != self.target_pool_size:
+      return None
+    if int(np.count_nonzero(self._h_stopped[self._order] != 1)) < batch_size:
+      return None  # the pop would run the pool dry and refill in the middle (get_next_fake_batch's second pass)
+    trash = self._cap
+    # -- get_feed_dict_and_states: pop, the real batch (drawn like the reference does, unused by the G step), the noise
     self._shuffle()
+    live = np.nonzero(self._h_stopped[self._order] != 1)[0]
+    g_slots = self._order[live[:batch_size]].copy()
+    self._drop(slice(int(live[batch_size - 1]) + 1, None))
+    self._popped = (self._h_step[g_slots].copy(), self._h_stopped[g_slots].copy())
+    rd.next_rows(batch_size)
+    z = self._host_noise(batch_size)
+    # -- replace_memory(advanced=True)
+    rows, h_step, h_stopped = self._host_replace(batch_size)
+    g_scatter = self._host_append(batch_size, rows, h_step, h_stopped) if len(rows) else np.full((batch_size,), trash, np.int64)
+    # -- fill_pool: whole provider batches, of which only the rows that fit are written
+    fresh_dst = np.full((self.target_pool_size,), trash, dtype=np.int64)
+    fresh_src = np.zeros((self.target_pool_size,), dtype=np.int64)
+    at = 0
+    while len(self) < self.target_pool_size:
+      lo = fd.next_rows(pool_batch)
+      k = min(pool_batch, self.target_pool_size - len(self))
+      fresh_dst[at:at + k] = self._host_append(k, None, 0.0, 0.0)
+      fresh_src[at:at + k] = np.arange(lo, lo + k)
+      at += k
+    self._shuffle()
+    # -- citers x get_replay_feed_dict (fill_pool is a no-op: the pool is full)
+    c_slots, real_rows = [], []
+    for _ in range(citers):
+      self._shuffle()
+      done = self._order[self._h_stopped[self._order] > 0]
+      assert done.size > 0, 'No terminated states discovered'
+      reps = (batch_size + done.size - 1) // done.size
+      c_slots.append(np.tile(done, reps)[:batch_size])
+      lo = rd.next_rows(batch_size)
+      real_rows.append(np.arange(lo, lo + batch_size))
+    self._writes += 1
+    return IterationPlan(g_slots, z, g_scatter, fresh_dst, fresh_src, c_slots, real_rows)
+
+  # the device half of a planned iteration: what ``GAN``'s iteration graph executes with the plan's index vectors on the
+  # device (also callable eagerly: tests/test_replay_and_loop.py runs a plan through them on the CPU)
+  def planned_generator_batch(self, g_slots):
+    return self._img.index_select(0, g_slots), self._st.index_select(0, g_slots), self._ft.index_select(0, g_slots)
+
+  def planned_commit(self, g_scatter, fake_output, new_states, features, fresh_dst, fresh_src):
+    """Results of the G step into their slots (dropped rows -> trash row), then the fresh records."""
+    self._img.index_copy_(0, g_scatter, fake_output.to(self._img.dtype))
+    self._st.index_copy_(0, g_scatter, new_states.to(self._st.dtype))
+    self._ft.index_copy_(0, g_scatter, features)
+    fd = self.fake_dataset
+    self._img.index_copy_(0, fresh_dst, fd.images.index_select(0, fresh_src))
+    self._st.index_fill_(0, fresh_dst, 0.0)
+    self._ft.index_copy_(0, fresh_dst, fd.features.index_select(0, fresh_src))
+
+  def planned_critic_batch(self, c_slots, real_rows):
+    """-> (real_data, fake_output) of one critic step."""
+    return self.real_dataset.images.index_select(0, real_rows), self._img.index_select(0, c_slots)
 
   def check_host_mirror(self):
     """Debug / tests: the host mirrors equal the device states (synchronises)."""

@@ -300,6 +300,45 @@ def test_training_loop_on_gpu(gpu_device):
   assert len(mem) == 32
 
 
+def test_iteration_graph_trains_bit_identically_to_the_step_calls(gpu_device):
+  """``GAN.train_iteration``: the whole iteration planned ahead on the host and replayed as ONE hipGraph (pool gathers /
+  scatters, G / V step, five critic steps, masks and alpha from the graph-registered generator, learning rates and
+  progress from the plan record) against the same iterations through generator_step / replace_memory / critic_step:
+  every reported value of every iteration, the weights of all three nets and the pools bit-equal."""
+  from exposure_amd.replay_memory import ReplayMemory, ResidentProvider
+  dev = gpu_device
+  cfg = make_cfg()
+  cfg.batch_size, cfg.replay_memory_size, cfg.citers = 16, 48, 3
+  runs = []
+  for planned in (True, False):
+    torch.manual_seed(0)
+    gan = GAN(cfg, device=dev, use_graphs=True, seed=4)
+    mem = ReplayMemory(cfg, ResidentProvider(dev, dtype=torch.float16, seed=1, count=256),
+                       ResidentProvider(dev, gamma=1.0, dtype=torch.float16, seed=2, count=192), seed=0)
+    for _ in range(7):  # iteration 0's roll-out (net.py:320-328), shortened: terminated records for the critic
+      feed, feats = mem.get_feed_dict_and_states(cfg.batch_size, lazy=True)
+      g = gan.generator_step(feed['fake_input'], feed['z'], feed['states'], 0.0, it=0)
+      mem.replace_memory(g['fake_output'], g['new_states'], feats, advanced=True)
+    vals = []
+    for it in range(1, 8):
+      if planned:
+        out = gan.train_iteration(mem, it)
+      else:
+        out = gan._iteration_stepwise(mem, it, float(it) / cfg.max_iter_step, cfg.batch_size)
+      vals += [out['g'][k].clone().reshape(-1)[:1] for k in ('g_loss', 'v_loss')]
+      vals += [out['c'][k].clone().reshape(-1)[:1] for k in ('c_loss', 'emd', 'gradient_norm', 'c_average')]
+      assert mem.check_host_mirror()
+    if planned:
+      assert any(k[0] == 'it' and isinstance(v, tuple) for k, v in gan._graphs.items()), 'the iteration graph was never captured'
+      assert gan._replay_steps and not any(k[0] == 'c' for k in gan._graphs), 'critic steps ran outside the iteration graph'
+    assert gan.c_average_steps == 7 * cfg.citers
+    runs.append((torch.cat(vals), mem.images, mem.states, mem.features, float(gan.c_average_biased)) +
+                tuple(p.detach().clone() for p in gan.parameters()))
+  assert bool(torch.isfinite(runs[0][0]).all())
+  for i, (a, b) in enumerate(zip(*runs)):
+    assert (a == b) if isinstance(a, float) else torch.equal(a, b), i
+
+
 def test_lazy_feeds_train_bit_identically_on_gpu(gpu_device):
   """PoolRows gathered straight into the step graphs' inputs + views of the HBM-resident data sets (the training loops'
   feeds since round 6) against the gathered feeds of the same memories: every loss of every step bit-equal, eager and

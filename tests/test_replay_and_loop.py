@@ -168,3 +168,56 @@ def test_resident_provider_serves_views_of_one_data_set():
     assert torch.equal(x, p.images[int(f[0]):int(f[0]) + 16])
     seen.append(int(f[0]))
   assert seen == [0, 16, 0, 16, 0]  # 40 images: two whole batches per epoch
+
+
+def test_planned_iteration_equals_the_step_by_step_calls():
+  """``plan_iteration`` (every pool decision of an iteration made ahead, on the host) + its device half against the
+  step-by-step calls on a twin memory: same generator batch, noise, replays, real batches and pool contents, iteration after
+  iteration, including iterations that drop over-length records and refill more than was popped."""
+  from exposure_amd.replay_memory import ResidentProvider
+  cfg = make_cfg()
+  cfg.batch_size, cfg.replay_memory_size = 8, 24
+  dev = torch.device('cpu')
+  mk = lambda: ReplayMemory(cfg, ResidentProvider(dev, seed=5, count=64), ResidentProvider(dev, gamma=1.0, seed=6, count=48), seed=7)
+  a, b = mk(), mk()
+
+  def agent(img, st, it):
+    st = st.clone()
+    stopped = ((st[:, 2] + 1 - cfg.test_steps).abs() < 1e-4).float()
+    st[:, 0], st[:, 1], st[:, 2] = stopped, stopped, st[:, 2] + 1
+    return img * (0.8 + 0.01 * it), st
+
+  planned = replays = 0
+  for it in range(60):
+    # the twin's generator part first: whether terminated records exist afterwards decides if critic steps can follow
+    fb, feat_b = b.get_feed_dict_and_states(8)
+    img_b, st_b = agent(fb['fake_input'], fb['states'], it)
+    b.replace_memory(img_b, st_b, feat_b, advanced=True)
+    citers = 3 if bool((b._h_stopped[b._order] > 0).any()) else 0
+    replays += citers
+    plan = a.plan_iteration(8, citers)
+    if plan is None:  # the same step-by-step calls
+      fa, feat_a = a.get_feed_dict_and_states(8)
+      img, st = agent(fa['fake_input'], fa['states'], it)
+      a.replace_memory(img, st, feat_a, advanced=True)
+      reps_a = [a.get_replay_feed_dict(8) for _ in range(citers)]
+      za, gi, gs, gf = fa['z'], fa['fake_input'], fa['states'], feat_a
+    else:
+      planned += 1
+      t = lambda v: torch.from_numpy(np.ascontiguousarray(v))
+      gi, gs, gf = a.planned_generator_batch(t(plan.g_slots))
+      img, st = agent(gi, gs, it)
+      a.planned_commit(t(plan.g_scatter), img, st, gf, t(plan.fresh_dst), t(plan.fresh_src))
+      reps_a = []
+      for j in range(citers):
+        real, fake = a.planned_critic_batch(t(plan.c_slots[j]), t(plan.real_rows[j]))
+        reps_a.append(dict(real_data=real, fake_output=fake))
+      za = plan.z
+    assert torch.equal(za, fb['z']) and torch.equal(gi, fb['fake_input']) and torch.equal(gs, fb['states'])
+    assert torch.equal(gf, feat_b)
+    for j in range(citers):
+      rb = b.get_replay_feed_dict(8)
+      assert torch.equal(reps_a[j]['real_data'], rb['real_data']) and torch.equal(reps_a[j]['fake_output'], rb['fake_output']), (it, j)
+    assert len(a) == len(b) and torch.equal(a.states, b.states) and torch.equal(a.images, b.images)
+    assert torch.equal(a.features, b.features) and a.check_host_mirror()
+  assert planned >= 40 and replays >= 60
