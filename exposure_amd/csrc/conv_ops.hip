@@ -43,7 +43,22 @@ struct ConvDims {
   int ho, wo;              // h / 2, w / 2
   int kdim;                // 16 cin
   int m;                   // n ho wo
+  int sh_w, sh_hw;         // log2 wo, log2 (ho wo) when both are powers of two, else -1 (pixel index -> (n, oh, ow) by shifts)
 };
+// pixel index m = (n ho + a) wo + b  ->  (n, a, b)
+__device__ __forceinline__ void split_pixel(const ConvDims& d, int m, int& n, int& a, int& b) {
+  if (d.sh_w >= 0) {  // (wave-uniform)
+    n = m >> d.sh_hw;
+    const int rem = m & ((1 << d.sh_hw) - 1);
+    a = rem >> d.sh_w;
+    b = rem & ((1 << d.sh_w) - 1);
+  } else {
+    n = m / (d.ho * d.wo);
+    const int rem = m - n * (d.ho * d.wo);
+    a = rem / d.wo;
+    b = rem - a * d.wo;
+  }
+}
 
 __device__ __forceinline__ float lrelu_v(float v, float leak) { return v > 0.f ? v : v * leak; }
 // d lrelu / d (its argument), read from the OUTPUT z (nn_ops.hip: lrelu keeps sign and zero; TF's sub-gradient at 0)
@@ -96,6 +111,10 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, int elem_o
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int elem_off, bool ok) {
   const uint32_t u = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? elem_off * 4 : kConvOob, 0, 0);
   return __builtin_bit_cast(float, u);
+}
+// (stores likewise: an offset beyond the buffer drops the element -- epilogues without a branch per element)
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, int elem_off, bool ok, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, ok ? elem_off * 4 : kConvOob, 0, 0);
 }
 // A 4-float chunk of an image row: row_off = element offset of the row's start, c = offset inside the row (may be < 0).
 // Cin % 4 == 0 (CIN4): a chunk never straddles a pixel, so it lies inside the row or outside it as a whole -- one
@@ -281,22 +300,34 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_fwd_kernel(const float
           for (int e = 0; e < 16; ++e) acc[i][j][e] += src[((i * NI + j) * 16 + e) * 64 + lane];
     }
   }
+  // (straight-line: slope-mask values through buffer loads issued sixteen at a time, results through buffer stores --
+  // lanes outside the tensor touch nothing; see conv_fwd_flat_kernel)
+  const __amdgpu_buffer_rsrc_t ry = conv_rsrc(y, size_t(d.m) * d.cout);
+  const __amdgpu_buffer_rsrc_t rz = conv_rsrc(zmask ? zmask : y, size_t(d.m) * d.cout);
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn * TN + j * 32 + (lane & 31);
     const float b = (bias && co < d.cout) ? bias[co] : 0.f;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+      float z[16];
+      int off[16];
+      bool ok[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (m < d.m && co < d.cout) {
-          float v = acc[i][j][e] + b;
-          if (act) v = lrelu_v(v, leak);
-          if (zmask) v *= lrelu_slope_v(zmask[size_t(m) * d.cout + co], leak);
-          y[size_t(m) * d.cout + co] = v;
-        }
+        ok[e] = m < d.m && co < d.cout;
+        off[e] = m * d.cout + co;
+        z[e] = buf_load1(rz, off[e], zmask != nullptr && ok[e]);
       }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[i][j][e] + b;
+        if (act) v = lrelu_v(v, leak);
+        if (zmask) v *= lrelu_slope_v(z[e], leak);
+        buf_store1(ry, off[e], ok[e], v);
+      }
+    }
   }
 }
 
@@ -331,9 +362,8 @@ __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __rest
   const int m = tm * 32 + row;  // this lane's A row (output pixel); its B rows (output channels): co[ni]
   const int rr = 4 * d.cin, lim = d.w * d.cin;
   const bool m_ok = m < d.m;
-  const int mm = m_ok ? m : 0;
-  const int n = mm / (d.ho * d.wo), rem = mm - n * (d.ho * d.wo);
-  const int oh = rem / d.wo, ow = rem - oh * d.wo;
+  int n, oh, ow;
+  split_pixel(d, m_ok ? m : 0, n, oh, ow);
   const int img = n * d.h * lim;
   const int ih0 = 2 * oh - 1, c0 = (2 * ow - 1) * d.cin + 4 * half;
   int wrow[NI];
@@ -353,10 +383,6 @@ __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-  auto load_a = [&](int prow, bool row_ok, int off, int seg_end) -> Chunk<CIN4> {
-    // off: this lane's chunk offset inside the kh row (without the lane half's 4, which c0 carries)
-    return row_chunk<CIN4>(rx, prow, c0 + off, lim, row_ok && off + 4 * half < seg_end);
-  };
   auto mma = [&](const float4& a, const float4 (&b)[NI]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -367,76 +393,129 @@ __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __rest
     }
   };
 
+  // ONE software pipeline over all the wave's segments: groups of U chunks of 8 k, the next group's loads in flight while
+  // this group's MFMAs issue -- across segment boundaries too.  (Until round 6 every segment started its own pipeline: a
+  // first layer's wave walks 4 segments of 3 chunks and waited out a full memory latency four times over -- most of its
+  // 35 us at batch 192.)  Loads past a segment's end, and the group past the last one, are masked: they come back as zeros
+  // without touching memory.
+  constexpr int U = (CIN4 && NI == 1) ? 4 : 2;  // (cut-chunk fix-ups / a second column tile double the registers)
   const int g = 4 * pl.s2, per = g / pl.s;
-  for (int seg = sl * per; seg < (sl + 1) * per; ++seg) {
-    const int kh = seg / pl.s2, j = seg - kh * pl.s2;
-    const int r0 = j * pl.rs;
-    const int seg_end = min(r0 + pl.rs, rr);
-    const int ih = ih0 + kh;
+  const int gps = (pl.rs + 8 * U - 1) / (8 * U);  // groups per segment
+  const int total = per * gps;
+  const int usl = __builtin_amdgcn_readfirstlane(sl);
+  // (wave-uniform walk, advanced without divisions) the group to load next: segment (kh, j), group lg inside it
+  int l_kh = (usl * per) / pl.s2, l_j = usl * per - l_kh * pl.s2, l_g = 0, l_t = 0;
+  auto load_group = [&](Chunk<CIN4> (&a)[U], float4 (&b)[U][NI]) {
+    const int r0 = l_j * pl.rs;
+    const int seg_end = l_t < total ? min(r0 + pl.rs, rr) : 0;  // 0: nothing of this group exists
+    const int ih = ih0 + l_kh;
     const bool row_ok = m_ok && unsigned(ih) < unsigned(d.h);
     const int prow = img + ih * lim;
-    auto load_b = [&](int off, float4 (&b)[NI]) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) b[i] = buf_load4(rw, wrow[i] + kh * rr + off, co_ok[i] && off + 4 * half < seg_end);
-    };
-    // chunks of 8 k, U at a time: the next U's loads are in flight while these MFMAs issue (loads past the segment's
-    // end come back as zeros without touching memory, so the pipeline needs no tail case)
-    constexpr int U = (CIN4 && NI == 1) ? 4 : 2;  // (cut-chunk fix-ups / a second column tile double the registers)
-    Chunk<CIN4> ac[U], an[U];
-    float4 bc[U][NI], bn[U][NI];
+    const int base = r0 + l_g * (8 * U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      ac[u] = load_a(prow, row_ok, r0 + 8 * u, seg_end);
-      load_b(r0 + 8 * u, bc[u]);
+      const int off = base + 8 * u;  // this lane's chunk offset inside the kh row (without the lane half's 4: c0 carries it)
+      a[u] = row_chunk<CIN4>(rx, prow, c0 + off, lim, row_ok && off + 4 * half < seg_end);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        b[u][i] = buf_load4(rw, wrow[i] + l_kh * rr + off, co_ok[i] && off + 4 * half < seg_end);
     }
+    ++l_t;
+    if (++l_g == gps) {
+      l_g = 0;
+      if (++l_j == pl.s2) {
+        l_j = 0;
+        ++l_kh;
+      }
+    }
+  };
+  Chunk<CIN4> ac[U], an[U];
+  float4 bc[U][NI], bn[U][NI];
+  load_group(ac, bc);
 #pragma unroll 2
-    for (int r = r0; r < seg_end; r += 8 * U) {
+  for (int t = 0; t < total; ++t) {
+    load_group(an, bn);
+    __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of the MFMAs that hide them
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        an[u] = load_a(prow, row_ok, r + 8 * (U + u), seg_end);
-        load_b(r + 8 * (U + u), bn[u]);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of the MFMAs that hide them
+    for (int u = 0; u < U; ++u) mma(ac[u].get(), bc[u]);
 #pragma unroll
-      for (int u = 0; u < U; ++u) mma(ac[u].get(), bc[u]);
+    for (int u = 0; u < U; ++u) {
+      ac[u] = an[u];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ac[u] = an[u];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) bc[u][i] = bn[u][i];
-      }
+      for (int i = 0; i < NI; ++i) bc[u][i] = bn[u][i];
     }
   }
 
-  // ---- the S partial tiles meet in LDS; wave sl finishes accumulator slots v = sl, sl + S, ... (v = ni 16 + e) ----
-  auto store = [&](int v, float val) {
+  // ---- epilogue.  Straight-line code: bias and slope-mask values come through buffer loads whose out-of-range lanes read
+  // nothing, results leave through buffer stores whose out-of-range lanes write nothing -- the element-wise branches of the
+  // first version closed every `if` with a wait, so a wave walked 16 (32) DEPENDENT load -> store round trips.
+  const __amdgpu_buffer_rsrc_t ry = conv_rsrc(y, size_t(d.m) * d.cout);
+  const __amdgpu_buffer_rsrc_t rz = conv_rsrc(zmask ? zmask : y, size_t(d.m) * d.cout);
+  const __amdgpu_buffer_rsrc_t rb = conv_rsrc(bias ? bias : w, bias ? size_t(d.cout) : 0);
+  float bv[NI];
+  int colv[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    colv[i] = (tn * NI + i) * 32 + (lane & 31);
+    bv[i] = buf_load1(rb, colv[i], bias != nullptr && colv[i] < d.cout);
+  }
+  auto slot_off = [&](int v, bool& ok) -> int {  // accumulator slot v = ni 16 + e of this lane -> element offset in y
     const int i = v >> 4, e = v & 15;
-    const int col = (tn * NI + i) * 32 + (lane & 31);
+    const int col = (tn * NI + (NI == 1 ? 0 : i)) * 32 + (lane & 31);
     const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-    if (mo < d.m && col < d.cout) {
-      if (bias) val += bias[col];
-      if (act) val = lrelu_v(val, leak);
-      if (zmask) val *= lrelu_slope_v(zmask[size_t(mo) * d.cout + col], leak);
-      y[size_t(mo) * d.cout + col] = val;
-    }
+    ok = mo < d.m && col < d.cout;
+    return mo * d.cout + col;
+  };
+  auto finish = [&](float val, int i, float z) -> float {
+    val += bv[NI == 1 ? 0 : i];
+    if (act) val = lrelu_v(val, leak);
+    if (zmask) val *= lrelu_slope_v(z, leak);
+    return val;
   };
   if (pl.s > 1) {
+    // the S partial tiles meet in LDS; wave sl finishes accumulator slots v = sl, sl + S, ... in batches of four
     float* mine = part + sl * (NI * 1024);
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mine[(i * 16 + e) * 64 + lane] = acc[i][e];
     __syncthreads();
-    for (int v = sl; v < NI * 16; v += pl.s) {
-      float val = part[v * 64 + lane];
-      for (int q = 1; q < pl.s; ++q) val += part[q * (NI * 1024) + v * 64 + lane];
-      store(v, val);
+    for (int v0 = sl; v0 < NI * 16; v0 += 4 * pl.s) {
+      float val[4], z[4];
+      int off[4];
+      bool ok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = v0 + j * pl.s;
+        const bool in = v < NI * 16;
+        const int vv = in ? v : 0;
+        off[j] = slot_off(vv, ok[j]);
+        ok[j] = ok[j] && in;
+        z[j] = buf_load1(rz, off[j], zmask != nullptr && ok[j]);
+        float t = part[vv * 64 + lane];
+        for (int q = 1; q < pl.s; ++q) t += part[q * (NI * 1024) + vv * 64 + lane];
+        val[j] = t;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int vv = v0 + j * pl.s < NI * 16 ? v0 + j * pl.s : 0;
+        buf_store1(ry, off[j], ok[j], finish(val[j], vv >> 4, z[j]));
+      }
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
+      float z[16];
+      int off[16];
+      bool ok[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) store(i * 16 + e, acc[i][e]);
+      for (int e = 0; e < 16; ++e) {
+        off[e] = slot_off(i * 16 + e, ok[e]);
+        z[e] = buf_load1(rz, off[e], zmask != nullptr && ok[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) buf_store1(ry, off[e], ok[e], finish(acc[i][e], i, z[e]));
+    }
   }
 }
 
@@ -487,9 +566,8 @@ __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __rest
   const int row = lane & 31, half = lane >> 5;
   const int m = tm * 32 + row;  // this lane's A row (input pixel of the class); its B columns: ci[i]
   const bool m_ok = m < d.m;
-  const int mm = m_ok ? m : 0;
-  const int n = mm / (d.ho * d.wo), rem = mm - n * (d.ho * d.wo);
-  const int a = rem / d.wo, b = rem - a * d.wo;
+  int n, a, b;
+  split_pixel(d, m_ok ? m : 0, n, a, b);
   const __amdgpu_buffer_rsrc_t rg = conv_rsrc(dy, size_t(d.n) * d.ho * d.wo * d.cout);
   const __amdgpu_buffer_rsrc_t rw = conv_rsrc(w, size_t(d.cout) * d.kdim);
   const int wstride = d.kdim;  // floats between two output channels of W
@@ -516,65 +594,77 @@ __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __rest
     }
   };
 
+  // one software pipeline over all the wave's segments (see conv_fwd_flat_kernel): the second layer's data gradient walks
+  // 4 taps x 64 channels = 4 segments of 8 chunks per wave
+  // (two chunks per group for either tile width: 64 registers, 8 waves per SIMD -- the second layer's 6 144 single-tile
+  // waves at batch 192 are 6 per SIMD and run as one round; four chunks per group measured 46.7 against 45.4 us)
+  constexpr int U = 2;
   const int g = 4 * pl.s2, per = g / pl.s;
-  for (int seg = sl * per; seg < (sl + 1) * per; ++seg) {
-    const int t = seg / pl.s2, j = seg - t * pl.s2;
-    const int th = t >> 1, tw = t & 1;
+  const int gps = (pl.rs + 8 * U - 1) / (8 * U);
+  const int total = per * gps;
+  const int usl = __builtin_amdgcn_readfirstlane(sl);
+  int l_tap = (usl * per) / pl.s2, l_j = usl * per - l_tap * pl.s2, l_g = 0, l_t = 0;
+  auto load_group = [&](float4 (&fa)[U], float4 (&fb)[U][NI]) {
+    const int th = l_tap >> 1, tw = l_tap & 1;
     const int oh = a + ph - th, ow = b + pw - tw;
     const int kh = 1 - ph + 2 * th, kw = 1 - pw + 2 * tw;
     const bool pix_ok = m_ok && unsigned(oh) < unsigned(d.ho) && unsigned(ow) < unsigned(d.wo);
     const int abase = ((n * d.ho + oh) * d.wo + ow) * d.cout + 4 * half;        // + co
     const int bbase = (4 * half) * wstride + (kh * 4 + kw) * d.cin;             // + co * wstride + ci
-    const int r0 = j * pl.rs, seg_end = min(r0 + pl.rs, d.cout);
-    auto load_a = [&](int co) -> float4 { return buf_load4(rg, abase + co, pix_ok && co + 4 * half < seg_end); };
-    auto load_b = [&](int co, float4 (&fb)[NI]) {
+    const int r0 = l_j * pl.rs;
+    const int seg_end = l_t < total ? min(r0 + pl.rs, d.cout) : 0;
+    const int base = r0 + l_g * (8 * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int co = base + 8 * u;
       const bool in = co + 4 * half < seg_end;  // (Cout % 4 == 0: the four rows exist together)
+      fa[u] = buf_load4(rg, abase + co, pix_ok && in);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const bool ok = ci_ok[i] && in;
         const int o = bbase + co * wstride + ci[i];
-        fb[i] = make_float4(buf_load1(rw, o, ok), buf_load1(rw, o + wstride, ok), buf_load1(rw, o + 2 * wstride, ok),
-                            buf_load1(rw, o + 3 * wstride, ok));
+        fb[u][i] = make_float4(buf_load1(rw, o, ok), buf_load1(rw, o + wstride, ok), buf_load1(rw, o + 2 * wstride, ok),
+                               buf_load1(rw, o + 3 * wstride, ok));
       }
-    };
-    constexpr int U = NI == 1 ? 4 : 2;
-    float4 ac[U], an[U], bc[U][NI], bn[U][NI];
+    }
+    ++l_t;
+    if (++l_g == gps) {
+      l_g = 0;
+      if (++l_j == pl.s2) {
+        l_j = 0;
+        ++l_tap;
+      }
+    }
+  };
+  float4 ac[U], an[U], bc[U][NI], bn[U][NI];
+  load_group(ac, bc);
+#pragma unroll 2
+  for (int t = 0; t < total; ++t) {
+    load_group(an, bn);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) mma(ac[u], bc[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      ac[u] = load_a(r0 + 8 * u);
-      load_b(r0 + 8 * u, bc[u]);
-    }
-#pragma unroll 2
-    for (int r = r0; r < seg_end; r += 8 * U) {
+      ac[u] = an[u];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        an[u] = load_a(r + 8 * (U + u));
-        load_b(r + 8 * (U + u), bn[u]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) mma(ac[u], bc[u]);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ac[u] = an[u];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) bc[u][i] = bn[u][i];
-      }
+      for (int i = 0; i < NI; ++i) bc[u][i] = bn[u][i];
     }
   }
 
-  // the S partial tiles meet in LDS; wave sl finishes accumulator slots v = sl, sl + S, ... (v = ni 16 + e)
-  auto store = [&](int v, float val) {
+  // ---- epilogue, straight-line like the forward's: the slope mask through buffer loads issued together, the results
+  // through buffer stores (out-of-range lanes touch nothing); pixel -> (n, a, b) by shifts for power-of-two geometry
+  const size_t dx_floats = size_t(d.n) * d.h * d.w * d.cin;
+  const __amdgpu_buffer_rsrc_t rdx = conv_rsrc(dx, dx_floats);
+  const __amdgpu_buffer_rsrc_t rz = conv_rsrc(zmask ? zmask : dx, dx_floats);
+  auto slot_off = [&](int v, bool& ok) -> int {  // accumulator slot v = ni 16 + e of this lane -> element offset in dx
     const int i = v >> 4, e = v & 15;
     const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;  // the pixel of accumulator register e
-    const int c = (tn * NI + i) * 32 + (lane & 31);
-    if (mo < d.m && c < d.cin) {
-      const int no = mo / (d.ho * d.wo), ro = mo - no * (d.ho * d.wo);
-      const int ao = ro / d.wo, bo = ro - ao * d.wo;
-      const size_t o = (size_t(no * d.h + 2 * ao + ph) * d.w + 2 * bo + pw) * d.cin + c;
-      if (zmask) val *= lrelu_slope_v(zmask[o], leak);
-      dx[o] = val;
-    }
+    const int c = (tn * NI + (NI == 1 ? 0 : i)) * 32 + (lane & 31);
+    ok = mo < d.m && c < d.cin;
+    int no, ao, bo;
+    split_pixel(d, ok ? mo : 0, no, ao, bo);
+    return ((no * d.h + 2 * ao + ph) * d.w + 2 * bo + pw) * d.cin + c;
   };
   if (pl.s > 1) {
     float* mine = part + sl * (NI * 1024);
@@ -583,16 +673,41 @@ __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __rest
 #pragma unroll
       for (int e = 0; e < 16; ++e) mine[(i * 16 + e) * 64 + lane] = acc[i][e];
     __syncthreads();
-    for (int v = sl; v < NI * 16; v += pl.s) {
-      float val = part[v * 64 + lane];
-      for (int q = 1; q < pl.s; ++q) val += part[q * (NI * 1024) + v * 64 + lane];
-      store(v, val);
+    for (int v0 = sl; v0 < NI * 16; v0 += 4 * pl.s) {
+      float val[4], z[4];
+      int off[4];
+      bool ok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = v0 + j * pl.s;
+        const bool in = v < NI * 16;
+        const int vv = in ? v : 0;
+        off[j] = slot_off(vv, ok[j]);
+        ok[j] = ok[j] && in;
+        z[j] = buf_load1(rz, off[j], zmask != nullptr && ok[j]);
+        float t = part[vv * 64 + lane];
+        for (int q = 1; q < pl.s; ++q) t += part[q * (NI * 1024) + vv * 64 + lane];
+        val[j] = t;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        buf_store1(rdx, off[j], ok[j], zmask ? val[j] * lrelu_slope_v(z[j], leak) : val[j]);
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
+      float z[16];
+      int off[16];
+      bool ok[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) store(i * 16 + e, acc[i][e]);
+      for (int e = 0; e < 16; ++e) {
+        off[e] = slot_off(i * 16 + e, ok[e]);
+        z[e] = buf_load1(rz, off[e], zmask != nullptr && ok[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        buf_store1(rdx, off[e], ok[e], zmask ? acc[i][e] * lrelu_slope_v(z[e], leak) : acc[i][e]);
+    }
   }
 }
 
@@ -970,6 +1085,11 @@ static int conv_dims(ConvDims* d, int n, int h, int w, int cin, int cout) {
     return fail(EXPO_E_BADARG, "conv4x4s2: a tensor of 2 GB or more is not supported");
   d->n = n; d->h = h; d->w = w; d->cin = cin; d->cout = cout;
   d->ho = h / 2; d->wo = w / 2; d->kdim = 16 * cin; d->m = n * d->ho * d->wo;
+  d->sh_w = d->sh_hw = -1;
+  if ((d->wo & (d->wo - 1)) == 0 && (d->ho & (d->ho - 1)) == 0) {
+    d->sh_w = __builtin_ctz(unsigned(d->wo));
+    d->sh_hw = d->sh_w + __builtin_ctz(unsigned(d->ho));
+  }
   return EXPO_OK;
 }
 
