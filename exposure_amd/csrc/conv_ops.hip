@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
       }
     }
   };
-  constexpr int U = 4;
+  constexpr int U = 4;  // (8 pairs in flight measured no gain: 44.2 vs 43.4 us for the second layer at batch 192)
   float ac[U], an[U];
   Chunk<CIN4> bc[U], bn[U];
   const bool want_bias = db_out != nullptr && tk == 0;
