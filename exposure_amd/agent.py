@@ -183,6 +183,9 @@ class Agent(nn.Module):
     # position in cfg.filters -> C-ABI filter id (they differ when cfg.filters is a subset/reorder)
     self.register_buffer('abi_filter_ids', torch.tensor([f.filter_id for f in self.filters], dtype=torch.int32),
                          persistent=False)
+    # cfg.filters in the C-ABI's own order (both shipped configs): the selected position IS the filter id -- no look-up
+    # (compare, clamp, cast, gather, fill, where: six launches per step)
+    self._abi_identity = [f.filter_id for f in self.filters] == list(range(len(self.filters)))
 
   def pack_heads(self, now=True):
     """Builds the packed storage of the K filter heads (filters.PackedHeads) and, with ``now``, moves the parameters
@@ -416,7 +419,10 @@ def _forward_fused(self, net, z, states, raws, selector_features, is_train, prog
   pdf, entropy, selected, one_hot, surrogate, new_states, pen_base = _AgentSelect.apply(
       logits, z, states, prog.reshape(1).float(), consts, int(is_train))
   params24 = F.heads_regress_select(list(self.filters), raws, selected)
-  abi_ids = torch.where(selected >= 0, self.abi_filter_ids[selected.clamp_min(0).long()], torch.full_like(selected, -1))
+  if self._abi_identity:
+    abi_ids = selected
+  else:
+    abi_ids = torch.where(selected >= 0, self.abi_filter_ids[selected.clamp_min(0).long()], torch.full_like(selected, -1))
   out, overexposure = F.dispatch_filters(net, params24, abi_ids, int(cfg.get('hsv_grad_mode', 0)))
   if cfg.clamp:
     out = torch.clamp(out, 0.0, 5.0)

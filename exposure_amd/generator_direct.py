@@ -88,13 +88,13 @@ class _PairPass:
                           self.dh_unit, LEAK)
 
   def backward(self, dlogit, rows, rows_x, grads=None, rows_w=None):
-    """``dlogit`` (2n,) upstream gradients of the logits; ``rows`` the row range the backward covers (a slice), ``rows_x``
+    """``dlogit`` the upstream gradients of the logits of ``rows``, the row range the backward covers (a slice); ``rows_x``
     the rows (inside it) whose IMAGE gradient is wanted, ``rows_w`` the rows whose weight gradients go to ``grads``
     (id(parameter) -> tensor).  -> d image (float32, rows_x)."""
     net, convs = self.net, list(self.net.convs)
     lo = rows.start
     rel = lambda sl: slice(sl.start - lo, sl.stop - lo)
-    dh = self.dh_unit[rows] * dlogit[rows, None]
+    dh = self.dh_unit[rows] * dlogit[:, None]
     dz = torch.mm(dh, net.fc1.weight)
     top = self.acts[-1][rows]
     gy = torch.empty_like(top)
@@ -121,8 +121,8 @@ class _PairPass:
       dhw = dh[rw]
       torch.mm(dhw.t(), self.flat[rows_w], out=grads[id(net.fc1.weight)])
       torch.sum(dhw, dim=0, out=grads[id(net.fc1.bias)])
-      torch.mv(self.h[rows_w].t(), dlogit[rows_w], out=grads[id(net.fc2.weight)].reshape(self.hidden))
-      torch.sum(dlogit[rows_w], dim=0, keepdim=True, out=grads[id(net.fc2.bias)])
+      torch.mv(self.h[rows_w].t(), dlogit[rw], out=grads[id(net.fc2.weight)].reshape(self.hidden))
+      torch.sum(dlogit[rw], dim=0, keepdim=True, out=grads[id(net.fc2.bias)])
     return d_img
 
 
@@ -172,7 +172,7 @@ def generator_step_losses_and_grads(gan, fake_input, z, states, progress, dropou
     d_img = value.backward(torch.cat([coef[4], coef[1]]), slice(0, 2 * n), B, grads=v_grads, rows_w=A)
     gan._bucket_ready(gan.buckets['v'])
     # the critic (frozen): d g_loss / d fake_logit on the retouched rows only
-    d_img = d_img + critic.backward(torch.cat([coef[0], torch.zeros_like(coef[0])]), A, A)
+    d_img = d_img + critic.backward(coef[0], A, A)
   # ---- the agent: one autograd pass from (retouched image, surrogate, penalty) to theta_g ---------------------------
   tensors = [fake_output, surrogate] + ([penalty] if use_pen else [])
   gtens = [d_img.to(fake_output.dtype), coef[2].reshape(surrogate.shape)] + ([coef[3].reshape(penalty.shape)] if use_pen else [])
