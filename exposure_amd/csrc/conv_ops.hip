@@ -842,17 +842,19 @@ struct WrwPlan {
 // Bias gradient in the same pass (db_out non-null): db[co] = the column sums of dY over the pixel pairs below `bias_pairs`
 // (the critic step batches passes whose bias gradients differ: only the first images' rows count) -- the waves of the
 // tiles with tk = 0 add up the dY values they feed to the matrix cores anyway; one float per block copy and channel.
+// (the body of the kernel: `block` = the block's index among THIS layer's blocks -- blockIdx.x for a launch of its own,
+// blockIdx.x - first_block inside a grouped launch; waves beyond pl.s (a grouped launch has 256 threads per block whatever
+// the layer's plan) own no pixels and take part in the barriers only)
 template <bool CIN4>
-__global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       float* __restrict__ out, size_t out_stride,
-                                                       float* __restrict__ db_out, size_t db_stride, int bias_pairs,
-                                                       ConvDims d, WrwPlan pl) {
-  extern __shared__ __attribute__((aligned(16))) float part[];  // [s][64][64]: slot v = e * 4 + r
-  __shared__ float bpart[4][32];
+__device__ __forceinline__ void conv_wrw_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                              float* __restrict__ out, size_t out_stride, float* __restrict__ db_out,
+                                              size_t db_stride, int bias_pairs, const ConvDims& d, const WrwPlan& pl,
+                                              int block, float* part, float (*bpart)[32]) {
   const int lane = threadIdx.x & 63;
   const int sl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool idle = sl >= pl.s;
   const int tiles = pl.tiles_co * pl.tiles_k;
-  const int tile = blockIdx.x % tiles, pb = blockIdx.x / tiles;
+  const int tile = block % tiles, pb = block / tiles;
   const int tc = tile / pl.tiles_k, tk = tile - tc * pl.tiles_k;
   const int col = lane & 31, half = lane >> 5;
   const int rr = 4 * d.cin, lim = d.w * d.cin;
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
 
   const int wpairs = d.wo / 2, total_pairs = d.m / 2;  // (wo is even: see the host side)
   const int q0 = (pb * pl.s + sl) * pl.pairs_per_wave;
-  const int q1 = min(q0 + pl.pairs_per_wave, total_pairs);
+  const int q1 = idle ? q0 : min(q0 + pl.pairs_per_wave, total_pairs);
   // wave-uniform walk over the pixel pairs (scalar registers), advanced without divisions
   int it_row = q0 / wpairs;  // n ho + oh
   int it_owp = q0 - it_row * wpairs;
@@ -931,7 +933,7 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
   // -> the four tiles' register e is dW[row][k2_0 + 4 (l & 31) .. + 3]: one float4 per lane, 512 contiguous bytes per row
   if (want_bias) {  // (block-uniform) the two pixels of a pair sit in the two lane halves; waves are added in order
     bsum += __shfl_xor(bsum, 32);
-    if (half == 0) bpart[sl][col] = bsum;
+    if (half == 0 && !idle) bpart[sl][col] = bsum;
     __syncthreads();
     if (sl == 0 && half == 0 && co_ok) {
       float v = bpart[0][col];
@@ -946,11 +948,13 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
   };
   if (pl.s > 1) {
     float* mine = part + sl * 4096;
+    if (!idle) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
-      *reinterpret_cast<float4*>(mine + (e * 64 + lane) * 4) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+      for (int e = 0; e < 16; ++e)
+        *reinterpret_cast<float4*>(mine + (e * 64 + lane) * 4) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+    }
     __syncthreads();
-    for (int e = sl; e < 16; e += pl.s) {
+    for (int e = idle ? 16 : sl; e < 16; e += pl.s) {
       float4 v = *reinterpret_cast<const float4*>(part + (e * 64 + lane) * 4);
       for (int q = 1; q < pl.s; ++q) {
         const float4 t = *reinterpret_cast<const float4*>(part + q * 4096 + (e * 64 + lane) * 4);
@@ -958,10 +962,52 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__
       }
       store_row(e, v);
     }
-  } else {
+  } else if (!idle) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) store_row(e, make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]));
   }
+}
+
+template <bool CIN4>
+__global__ __launch_bounds__(256) void conv_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ out, size_t out_stride,
+                                                       float* __restrict__ db_out, size_t db_stride, int bias_pairs,
+                                                       ConvDims d, WrwPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [s][64][64]: slot v = e * 4 + r
+  __shared__ float bpart[4][32];
+  conv_wrw_body<CIN4>(x, dy, out, out_stride, db_out, db_stride, bias_pairs, d, pl, blockIdx.x, part, bpart);
+}
+
+// The weight gradients of a whole STACK of layers as one launch: the four layers' kernels are independent, and launched
+// one after the other each pays its own ramp and tail (17-21 us per launch at batch 64 for 7 us of matrix-core work;
+// ~12 us of a 40 us launch at batch 192).  A block finds its layer in the table of first blocks and runs that layer's body.
+constexpr int kWrwGroupMax = 8;
+struct WrwGroupItem {
+  const float* x;
+  const float* dy;
+  float* out;
+  float* db_out;
+  size_t stride;  // floats between two block copies (of dW and of the bias sums alike)
+  ConvDims d;
+  WrwPlan pl;
+  int bias_pairs, cin4;
+};
+struct WrwGroupArgs {
+  WrwGroupItem it[kWrwGroupMax];
+  unsigned first_block[kWrwGroupMax + 1];
+  int layers;
+};
+__global__ __launch_bounds__(256) void conv_wrw_group_kernel(const WrwGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float part[];
+  __shared__ float bpart[4][32];
+  int l = 0;
+  while (l + 1 < g.layers && blockIdx.x >= g.first_block[l + 1]) ++l;
+  const WrwGroupItem& it = g.it[l];
+  const int block = int(blockIdx.x - g.first_block[l]);
+  if (it.cin4)
+    conv_wrw_body<true>(it.x, it.dy, it.out, it.stride, it.db_out, it.stride, it.bias_pairs, it.d, it.pl, block, part, bpart);
+  else
+    conv_wrw_body<false>(it.x, it.dy, it.out, it.stride, it.db_out, it.stride, it.bias_pairs, it.d, it.pl, block, part, bpart);
 }
 
 // dW = the sum of the P block copies.  A block owns 16 float4 elements; its 16 thread groups each add every 16th copy
@@ -999,7 +1045,6 @@ __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __res
 
 // The same sum for SEVERAL layers in one launch (the weight gradients of a whole stack of layers: their main kernels run
 // back to back, one reduce launch finishes them all).  A block finds its layer in the table of first blocks.
-constexpr int kWrwGroupMax = 8;
 struct WrwReduceGroup {
   const float* ws[kWrwGroupMax];
   float* dw[kWrwGroupMax];
@@ -1217,7 +1262,7 @@ static size_t wrw_copy_floats(const ConvDims& d) { return size_t(d.cout) * d.kdi
 // one reduce launch for all of them
 static int conv_wrw_impl(const float* x, const float* dy, float* dw, float* dbias, int bias_images, int n, int h, int wd,
                          int cin, int cout, void* workspace, size_t workspace_bytes, void* stream,
-                         WrwReduceGroup* group = nullptr) {
+                         WrwReduceGroup* group = nullptr, WrwGroupArgs* main_group = nullptr, size_t* main_lds = nullptr) {
   ConvDims d;
   if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
   if (!dw) return fail(EXPO_E_BADARG, "null pointer");
@@ -1244,11 +1289,20 @@ static int conv_wrw_impl(const float* x, const float* dy, float* dw, float* dbia
   const int bias_pairs = bias_images * d.ho * (d.wo / 2);
   const dim3 grid(unsigned(pl.tiles_co * pl.tiles_k) * pl.p), block(64 * pl.s);
   const size_t lds = pl.s > 1 ? size_t(pl.s) * 16384 : 0;
-  if (d.cin % 4 == 0)
-    hipLaunchKernelGGL(conv_wrw_kernel<true>, grid, block, lds, s, x, dy, out, stride, db_out, stride, bias_pairs, d, pl);
-  else
-    hipLaunchKernelGGL(conv_wrw_kernel<false>, grid, block, lds, s, x, dy, out, stride, db_out, stride, bias_pairs, d, pl);
-  HIP_TRY(hipGetLastError(), "conv4x4s2_wrw launch");
+  if (main_group) {  // the caller launches the stack's main kernels as one grid
+    const int l = main_group->layers++;
+    WrwGroupItem& it = main_group->it[l];
+    it.x = x; it.dy = dy; it.out = out; it.db_out = db_out; it.stride = stride; it.d = d; it.pl = pl;
+    it.bias_pairs = bias_pairs; it.cin4 = d.cin % 4 == 0;
+    main_group->first_block[l + 1] = main_group->first_block[l] + grid.x;
+    if (lds > *main_lds) *main_lds = lds;
+  } else {
+    if (d.cin % 4 == 0)
+      hipLaunchKernelGGL(conv_wrw_kernel<true>, grid, block, lds, s, x, dy, out, stride, db_out, stride, bias_pairs, d, pl);
+    else
+      hipLaunchKernelGGL(conv_wrw_kernel<false>, grid, block, lds, s, x, dy, out, stride, db_out, stride, bias_pairs, d, pl);
+    HIP_TRY(hipGetLastError(), "conv4x4s2_wrw launch");
+  }
   if (pl.p > 1) {
     const size_t dw4 = count / 4, count4 = dbias ? copy / 4 : dw4;
     // (the copies' stride is `copy` floats either way: without a bias gradient the tail of a copy is not read)
@@ -1340,10 +1394,19 @@ int expo_conv4x4s2_wrw_group(int count, const float* const* x, const float* cons
     return fail(EXPO_E_BADARG, "null pointer");
   WrwReduceGroup g;
   g.layers = 0;
+  WrwGroupArgs mg;
+  mg.layers = 0;
+  mg.first_block[0] = 0;
+  size_t lds = 0;
   for (int l = 0; l < count; ++l)
     if (int rc = conv_wrw_impl(x[l], dy[l], dw[l], dbias[l], bias_images[l], n[l], h[l], wd[l], cin[l], cout[l],
-                               workspace[l], workspace_bytes[l], stream, &g))
+                               workspace[l], workspace_bytes[l], stream, &g, &mg, &lds))
       return rc;
+  if (mg.layers > 0) {  // (empty batches were zero-filled by their own calls)
+    hipLaunchKernelGGL(conv_wrw_group_kernel, dim3(mg.first_block[mg.layers]), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), mg);
+    HIP_TRY(hipGetLastError(), "conv4x4s2_wrw_group launch");
+  }
   if (g.layers == 0) return EXPO_OK;  // every layer fitted one block copy: written in place
   unsigned blocks = 0;
   for (int l = 0; l < g.layers; ++l) {
