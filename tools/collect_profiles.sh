@@ -8,7 +8,8 @@ TAG=${1:-r06_final}
 for f in bench_chain bench_chain_1stream bench_chain_A bench_chain_B bench_chain_f32 bench_chain_cold bench_chain_cold_untiled bench_infer_B bench_infer_C bench_chain_fused bench_chain_fused_B bench_chain_fused_f32_B bench_train bench_train_eager bench_extra; do
   [ -s $SRC/$f.json ] && cp $SRC/$f.json profiles/${TAG}_$f.json
 done
-for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt $SRC/conv_bench.txt $SRC/conv_sweep.txt $SRC/step_bench.txt; do
+for f in $SRC/kernel_stats*.csv $SRC/pmc_*.csv $SRC/membench*.txt $SRC/conv_bench.txt $SRC/conv_sweep.txt $SRC/step_bench.txt $SRC/step_trace.txt $SRC/iter_probe.txt $SRC/timeline_train.txt $SRC/pytest_gpu.txt; do
+  [ -s $f ] || continue
   cp $f profiles/${TAG}_$(basename $f)
 done
 # bench.py quotes, beside its own figure, rocprofv3's duration of the dominant kernel from the table committed WHEN IT

@@ -27,12 +27,14 @@ python $R/bench.py --workload infer --shape C > $OUT/bench_infer_C.json 2>/dev/n
 python $R/bench.py --workload chain_fused > $OUT/bench_chain_fused.json 2>/dev/null
 python $R/bench.py --workload chain_fused --shape B > $OUT/bench_chain_fused_B.json 2>/dev/null
 python $R/bench.py --workload chain_fused --dtype f32 --shape B > $OUT/bench_chain_fused_f32_B.json 2>/dev/null
-python $R/bench.py --workload train --steps 20 --warmup 3 > $OUT/bench_train.json 2>/dev/null
+python $R/bench.py --workload train --steps 40 --warmup 6 > $OUT/bench_train.json 2>/dev/null  # (the iteration graph's first replays are slower: six untimed iterations)
 python $R/bench.py --workload train --steps 10 --warmup 3 --graph off > $OUT/bench_train_eager.json 2>/dev/null
+python $R/tools/r06/iter_probe.py 16 2>/dev/null | grep '^it' > $OUT/iter_probe.txt  # host time per iteration, planned or step-by-step
 python $R/tools/bench_extra.py > $OUT/bench_extra.json 2>/dev/null
 python $R/tools/r05/conv_bench.py all --reps 20 > $OUT/conv_bench.txt 2>&1  # the in-house convolution kernels against MIOpen (its own heuristics: no rankings are shipped any more), per layer
 python $R/tools/r06/conv_sweep.py all 2>/dev/null | grep -v amdgpu.ids > $OUT/conv_sweep.txt  # every decomposition at batch 64 / 192
-python $R/tools/r06/step_bench.py 2>/dev/null | grep "step" > $OUT/step_bench.txt  # critic update hand-scheduled vs autograd, G / V step
+python $R/tools/r06/step_bench.py 2>/dev/null | grep "step" > $OUT/step_bench.txt  # critic update and G / V step, hand-scheduled vs autograd
+python $R/tools/r06/step_trace.py gc 2>/dev/null > $OUT/step_trace.txt  # the launches of one eager G / V step and one critic update, in order
 for sz in 24 96 512 1024; do  # (24 MiB = BASELINE config 5's tensors: the ceiling of the per-step chain at 16 x 512 x 512)
   reps=20; [ $sz -ge 512 ] && reps=8
   $R/tools/membench $sz 9 $reps pol > $OUT/membench_${sz}.txt 2>&1
@@ -65,9 +67,10 @@ cp $OUT/kernel_stats_chain.csv $OUT/kernel_stats.csv
 STEPS=10
 for mode in on off; do
   rm -rf /tmp/kt_train_$mode
-  rocprofv3 --kernel-trace -d /tmp/kt_train_$mode -o kt -- python $R/bench.py --workload train --steps $STEPS --warmup 3 --graph $mode > $OUT/bench_train_profiled_$mode.json 2> /tmp/kt_train_$mode.log
+  rocprofv3 --kernel-trace -d /tmp/kt_train_$mode -o kt -- python $R/bench.py --workload train --steps $STEPS --warmup 6 --graph $mode > $OUT/bench_train_profiled_$mode.json 2> /tmp/kt_train_$mode.log
   ms=$(python -c "import json; print(json.load(open('$OUT/bench_train_profiled_$mode.json'))['ms_per_step'] * $STEPS)")
   (cd $R/tools && python rocpd_window_stats.py "$(db /tmp/kt_train_$mode)" $ms $STEPS) > $OUT/kernel_stats_train_graph_$mode.csv
+  [ $mode == on ] && (cd $R/tools && python rocpd_timeline.py "$(db /tmp/kt_train_$mode)" $ms 0) > $OUT/timeline_train.txt  # idle gaps inside the timed region
 done
 cp $OUT/kernel_stats_train_graph_on.csv $OUT/kernel_stats_train.csv
 
