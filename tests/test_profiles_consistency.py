@@ -55,7 +55,7 @@ def test_kernel_tables_list_every_kernel():
   train = open(os.path.join(PROF, '%s_kernel_stats_train.csv' % TAG)).read()
   assert train.startswith('# window')
   per_iteration = int(train.split(' = ')[1].split(' per iteration')[0])
-  assert per_iteration <= 650, per_iteration  # round-5 verdict, item 1: <= 650 (round 5: 1 132; round 6: 451)
+  assert per_iteration <= 350, per_iteration  # round-5 verdict, item 1: <= 650 (round 5: 1 132; round 6: 451 -> 300)
   for frag in ('stats_kernel', 'stats_bwd_kernel', 'bias_lrelu_fwd_kernel', 'lrelu_bwd_kernel', 'dispatch_fwd_kernel',
                'dispatch_bwd_kernel',
                # round 4: the glue of the steps
@@ -64,7 +64,7 @@ def test_kernel_tables_list_every_kernel():
                # round 5: the convnets' convolution on the in-house kernels
                'conv_fwd_flat_kernel', 'conv_fwd_kernel', 'conv_bwd_flat_kernel',
                # round 6: weight gradient + bias sums, first-layer data gradient, the hand-scheduled critic update
-               'conv_wrw_kernel', 'conv_wrw_reduce_group_kernel', 'conv_bwd_small_kernel', 'critic_head_fwd_kernel',
+               'conv_wrw_group_kernel', 'conv_wrw_reduce_group_kernel', 'conv_bwd_small_kernel', 'critic_head_fwd_kernel',
                'critic_head_bwd_kernel', 'critic_penalty_tangent_kernel', 'critic_report_kernel', 'adam_advance_kernel'):
     assert frag in train, frag
   # no library convolution, no zero fill in front of one, no separate activation / bias-gradient launches of the layers
