@@ -731,7 +731,8 @@ static FlatPlan bwd_plan(const ConvDims& d, int ni, int forced_s) {
   return p;
 }
 
-// ---- data gradient of the FIRST layers (6 / 17 input planes: critic, value net) on the vector ALUs ----------------------
+// ---- data gradient of the critic's FIRST layer (6 input planes) on the vector ALUs -------------------------------------
+// (a template over the plane count: the value net's 17 planes ran here too until the matrix-core kernel overtook it)
 // With Cin = 6 a 32-wide tile of input channels is 81 % padding: the matrix-core kernel above takes 47 us for 0.4 GFLOP.
 // Here a BLOCK owns four dY rows' worth of input pixels of one image (input rows 2 a0 .. 2 a0 + 7): it stages the six dY
 // rows a0 - 1 .. a0 + 4 they touch in LDS with coalesced 16-byte loads (pixel stride padded to Cout + 4 floats: the
@@ -1223,22 +1224,17 @@ static int conv_bwd_data_impl(const float* dy, const float* w, const float* zmas
   hipStream_t s = static_cast<hipStream_t>(stream);
   int ni = conv_tuning().nt.load();  // input-channel tiles per wave (0: the library's choice)
   const int forced_s = conv_tuning().slices.load();
-  // the first layers (6 / 17 input planes) on the vector ALUs (conv_bwd_small_kernel), unless a probe forces a plan
+  // the critic's first layer (6 input planes: a 32-wide matrix-core tile would be 81 % padding) on the vector ALUs
+  // (conv_bwd_small_kernel), unless a probe forces a plan.  The value net's 17 planes took that kernel too until the flat
+  // kernel's epilogue stopped serialising its loads (round 6): 37 against 56 us at batch 64, 102 against 149 at batch 192.
   const size_t small_lds = (size_t(6) * (d.wo + 2) * (cout + 4) + size_t(16) * cout * ((cin + 3) / 4 * 4)) * 4;
-  if (ni == 0 && forced_s == 0 && (cin == 6 || cin == 17) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && d.ho % 4 == 0 &&
+  if (ni == 0 && forced_s == 0 && cin == 6 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && d.ho % 4 == 0 &&
       small_lds <= 160 * 1024) {
     const dim3 grid(unsigned(d.n * (d.ho / 4)));
-    if (cin == 6) {
-      static const hipError_t attr6 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_small_kernel<6>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)attr6;
-      hipLaunchKernelGGL(conv_bwd_small_kernel<6>, grid, dim3(256), small_lds, s, dy, w, zmask, dx, d, leak);
-    } else {
-      static const hipError_t attr17 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_small_kernel<17>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)attr17;
-      hipLaunchKernelGGL(conv_bwd_small_kernel<17>, grid, dim3(256), small_lds, s, dy, w, zmask, dx, d, leak);
-    }
+    static const hipError_t attr6 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_small_kernel<6>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr6;
+    hipLaunchKernelGGL(conv_bwd_small_kernel<6>, grid, dim3(256), small_lds, s, dy, w, zmask, dx, d, leak);
     HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data (small) launch");
     return EXPO_OK;
   }

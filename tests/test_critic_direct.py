@@ -42,8 +42,8 @@ CASES = [(3, 8, 5, 8), (2, 16, 14, 32), (5, 12, 6, 32), (2, 64, 17, 32), (64, 64
 @pytest.mark.parametrize('case', CASES)
 def test_data_gradient_with_the_activation_gradient_in_its_epilogue(case, gpu_device):
   """expo_conv4x4s2_bwd_data_mask == D(dy, w) * slope(z) with z of either sign and exactly 0 (TF's sub-gradient 0.6);
-  6 and 17 input planes take the vector-ALU kernel (conv_bwd_small_kernel), the rest the matrix-core kernel; the plain
-  entry point agrees (no mask) and every element is written."""
+  6 input planes take the vector-ALU kernel (conv_bwd_small_kernel), the rest the matrix-core kernel (17 planes since the
+  end of round 6); the plain entry point agrees (no mask) and every element is written."""
   from exposure_amd import _cabi
   n, h, cin, cout = case
   dev = gpu_device
