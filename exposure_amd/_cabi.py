@@ -95,6 +95,7 @@ SIGNATURES = {
     'expo_adam_step': (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                            ctypes.POINTER(_sz), _fp, _fp, _vp, _f, _f, _f, _vp]),
     'expo_gp_inputs': (_i, [_vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
+    'expo_gp_inputs_rows': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
     'expo_grad_penalty_fwd': (_i, [_fp, _fp, _fp, _i, _sz, _vp]),
     'expo_grad_penalty_bwd': (_i, [_fp, _fp, _fp, _fp, _i, _sz, _vp]),
     'expo_curve_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
@@ -763,21 +764,26 @@ def generator_losses(fake_logit, fake_input_logit, new_value, old_value, new_sta
            'expo_generator_losses')
 
 
-def gp_inputs(real, fake, alpha, cat_out, interp):
+def gp_inputs(real, fake, alpha, cat_out, interp, real_rows=None, fake_rows=None):
   """cat_out[:n] = real, cat_out[n:] = fake (float32), interp = real + alpha (fake - real): one launch.  ``interp`` (and
-  ``alpha``) may be None: conversion + concatenation only."""
+  ``alpha``) may be None: conversion + concatenation only.  ``real_rows`` / ``fake_rows`` (device int64 (n,)): the batch's
+  image i is row rows[i] of ``real`` / ``fake`` (a data set, the replay memory's pool) instead of row i."""
   lib = load()
   _img(real, 'real'), _img(fake, 'fake')
-  n = real.shape[0]
-  assert fake.shape == real.shape and fake.dtype == real.dtype
-  m = real[0].numel() if n else 0
+  assert fake.shape[1:] == real.shape[1:] and fake.dtype == real.dtype
+  for rows in (real_rows, fake_rows):
+    assert rows is None or (rows.is_cuda and rows.dtype == torch.int64 and rows.is_contiguous() and rows.dim() == 1)
+  n = real.shape[0] if real_rows is None else real_rows.shape[0]
+  assert n == (fake.shape[0] if fake_rows is None else fake_rows.shape[0])
+  m = real[0].numel() if real.shape[0] else 0
   assert cat_out.dtype == torch.float32 and cat_out.is_contiguous() and tuple(cat_out.shape) == (2 * n,) + tuple(real.shape[1:])
   if interp is not None:
-    assert interp.dtype == torch.float32 and interp.is_contiguous() and interp.shape == real.shape
+    assert interp.dtype == torch.float32 and interp.is_contiguous() and tuple(interp.shape) == (n,) + tuple(real.shape[1:])
     assert alpha.is_cuda and alpha.dtype == torch.float32 and alpha.is_contiguous() and alpha.numel() == n
   with torch.cuda.device(real.device):
-    _check(lib.expo_gp_inputs(_ptr(real), _ptr(fake), _ptr(alpha) if interp is not None else None, _ptr(cat_out), _ptr(interp),
-                              n, m, _dtype_code(real), _stream()), 'expo_gp_inputs')
+    _check(lib.expo_gp_inputs_rows(_ptr(real), _ptr(real_rows), _ptr(fake), _ptr(fake_rows),
+                                   _ptr(alpha) if interp is not None else None, _ptr(cat_out), _ptr(interp),
+                                   n, m, _dtype_code(real), _stream()), 'expo_gp_inputs_rows')
 
 
 def grad_penalty_fwd(g, norm, term):

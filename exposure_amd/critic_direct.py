@@ -32,6 +32,7 @@ bucket when collectives run (means over the LOCAL shard, averaged by the bucket'
 import torch
 
 from . import _cabi
+from .replay_memory import PoolRows
 
 LEAK = 0.2  # util.py:225 lrelu(x, leak=0.2), every layer of critics.py
 
@@ -91,9 +92,16 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
   grads = _grad_targets(gan)
 
   # ---- inputs: [real | fake | interpolated] as float32, statistics planes, - 0.5 ----------------------------------
+  # (PoolRows: the batch's images are rows of a data set / of the replay memory's pool, read in place)
+  real_rows = fake_rows = None
+  if isinstance(real_data, PoolRows):
+    real_data, real_rows = real_data.pool, real_data.idx
+  if isinstance(fake_output, PoolRows):
+    fake_output, fake_rows = fake_output.pool, fake_output.idx
   real_data, fake_output = real_data.contiguous(), fake_output.detach().contiguous()
   x = torch.empty((m,) + tuple(real_data.shape[1:]), **f32)
-  _cabi.gp_inputs(real_data, fake_output, alpha.contiguous().float().reshape(n), x[:2 * n], x[2 * n:])
+  _cabi.gp_inputs(real_data, fake_output, alpha.contiguous().float().reshape(n), x[:2 * n], x[2 * n:],
+                  real_rows=real_rows, fake_rows=fake_rows)
   stats = torch.empty((m, 3), **f32)
   _cabi.critic_stats(x, stats)
   acts = [torch.empty(tuple(x.shape[:-1]) + (6,), **f32)]

@@ -1051,32 +1051,37 @@ struct WrwReduceGroup {
   float* dw[kWrwGroupMax];
   float* dbias[kWrwGroupMax];
   unsigned dw4[kWrwGroupMax], count4[kWrwGroupMax], stride4[kWrwGroupMax], p[kWrwGroupMax];
+  unsigned g_log2[kWrwGroupMax];  // log2 of the thread groups that share the copies of one element (<= 4)
   unsigned first_block[kWrwGroupMax + 1];
   int layers;
 };
 __global__ __launch_bounds__(256) void conv_wrw_reduce_group_kernel(const WrwReduceGroup g) {
-  __shared__ float4 part[16][16];
+  // G = min(16, P) thread groups (a power of two >= P when P < 16), 256 / G elements per block: with 4 copies (the last
+  // layer) the fixed 16 x 16 split left 12 of 16 groups idle and cut 2 MB of dW into 8 192 blocks of 1 KB.  The order of
+  // the sum is the one of conv_wrw_reduce_kernel: group q adds copies q, q + 16, ..., the groups are added in order
+  // (empty groups contribute exact zeros there), so the results are bit-identical.
+  __shared__ float4 part[256];
   int l = 0;
   while (l + 1 < g.layers && blockIdx.x >= g.first_block[l + 1]) ++l;
-  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const size_t i = size_t(blockIdx.x - g.first_block[l]) * 16 + el;
+  const int gl = int(g.g_log2[l]), groups = 1 << gl, per = 256 >> gl;  // groups x per = 256 threads
+  const int el = threadIdx.x & (per - 1), grp = threadIdx.x >> (8 - gl);
+  const size_t i = size_t(blockIdx.x - g.first_block[l]) * per + el;
   const float4* src = reinterpret_cast<const float4*>(g.ws[l]);
   const size_t count4 = g.count4[l], stride4 = g.stride4[l];
   const int p = int(g.p[l]);
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < count4) {
-    for (int q = grp; q < p; q += 16) {
+    for (int q = grp; q < p; q += groups) {
       const float4 t = src[size_t(q) * stride4 + i];
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
   }
-  part[grp][el] = v;
+  part[grp * per + el] = v;
   __syncthreads();
   if (grp == 0 && i < count4) {
-    float4 r = part[0][el];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-      const float4 t = part[k][el];
+    float4 r = part[el];
+    for (int k = 1; k < groups; ++k) {
+      const float4 t = part[k * per + el];
       r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
     }
     if (i < g.dw4[l]) reinterpret_cast<float4*>(g.dw[l])[i] = r;
@@ -1406,8 +1411,12 @@ int expo_conv4x4s2_wrw_group(int count, const float* const* x, const float* cons
   if (g.layers == 0) return EXPO_OK;  // every layer fitted one block copy: written in place
   unsigned blocks = 0;
   for (int l = 0; l < g.layers; ++l) {
+    unsigned gl = 0;
+    while (gl < 4 && (1u << gl) < g.p[l]) ++gl;  // groups = the power of two that holds P copies, at most 16
+    g.g_log2[l] = gl;
+    const unsigned per = 256u >> gl;
     g.first_block[l] = blocks;
-    blocks += (g.count4[l] + 15) / 16;
+    blocks += (g.count4[l] + per - 1) / per;
   }
   g.first_block[g.layers] = blocks;
   hipLaunchKernelGGL(conv_wrw_reduce_group_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g);

@@ -134,12 +134,18 @@ __global__ __launch_bounds__(256) void bias_grad_finish_kernel(const float* __re
 template <typename T>
 __global__ __launch_bounds__(256) void gp_inputs_kernel(const T* __restrict__ real, const T* __restrict__ fake,
                                                         const float* __restrict__ alpha, float* __restrict__ cat_out,
-                                                        float* __restrict__ interp, int n, size_t m) {
+                                                        float* __restrict__ interp, int n, size_t m,
+                                                        const long long* __restrict__ real_rows,
+                                                        const long long* __restrict__ fake_rows) {
+  // real_rows / fake_rows (nullable): image `img` of the batch is row rows[img] of the tensor -- the critic batches of a
+  // planned iteration are read straight out of the resident data set and the replay memory's pool (no gather launches)
   const int img = blockIdx.y;
   const float a = interp ? alpha[img] : 0.f;  // (interp == NULL: conversion + concatenation only -- the G step's image pairs)
   const size_t base = size_t(img) * m;
+  const T* const rsrc = real + size_t(real_rows ? real_rows[img] : img) * m;
+  const T* const fsrc = fake + size_t(fake_rows ? fake_rows[img] : img) * m;
   for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < m; i += size_t(gridDim.x) * blockDim.x) {
-    const float r = float(real[base + i]), f = float(fake[base + i]);
+    const float r = float(rsrc[i]), f = float(fsrc[i]);
     cat_out[base + i] = r;
     cat_out[size_t(n) * m + base + i] = f;
     if (interp) interp[base + i] = r + a * (f - r);
@@ -701,8 +707,9 @@ int expo_agent_select_bwd(const float* logits, const int32_t* selected, const fl
   return EXPO_OK;
 }
 
-int expo_gp_inputs(const void* real, const void* fake, const float* alpha, float* cat_out, float* interp, int n,
-                   size_t elems_per_image, int dtype, void* stream) {
+static int gp_inputs_impl(const void* real, const long long* real_rows, const void* fake, const long long* fake_rows,
+                          const float* alpha, float* cat_out, float* interp, int n, size_t elems_per_image, int dtype,
+                          void* stream) {
   if (n < 0) return fail(EXPO_E_BADARG, "n >= 0 required");
   if (n == 0 || elems_per_image == 0) return EXPO_OK;
   if (!real || !fake || !cat_out || (interp && !alpha)) return fail(EXPO_E_BADARG, "null pointer");
@@ -714,12 +721,24 @@ int expo_gp_inputs(const void* real, const void* fake, const float* alpha, float
   const dim3 grid(unsigned(bx), n), block(256);
   if (dtype == EXPO_F16)
     hipLaunchKernelGGL(gp_inputs_kernel<_Float16>, grid, block, 0, s, (const _Float16*)real, (const _Float16*)fake, alpha,
-                       cat_out, interp, n, elems_per_image);
+                       cat_out, interp, n, elems_per_image, real_rows, fake_rows);
   else
     hipLaunchKernelGGL(gp_inputs_kernel<float>, grid, block, 0, s, (const float*)real, (const float*)fake, alpha, cat_out,
-                       interp, n, elems_per_image);
+                       interp, n, elems_per_image, real_rows, fake_rows);
   HIP_TRY(hipGetLastError(), "gp_inputs launch");
   return EXPO_OK;
+}
+
+int expo_gp_inputs(const void* real, const void* fake, const float* alpha, float* cat_out, float* interp, int n,
+                   size_t elems_per_image, int dtype, void* stream) {
+  return gp_inputs_impl(real, nullptr, fake, nullptr, alpha, cat_out, interp, n, elems_per_image, dtype, stream);
+}
+
+int expo_gp_inputs_rows(const void* real, const int64_t* real_rows, const void* fake, const int64_t* fake_rows,
+                        const float* alpha, float* cat_out, float* interp, int n, size_t elems_per_image, int dtype,
+                        void* stream) {
+  return gp_inputs_impl(real, reinterpret_cast<const long long*>(real_rows), fake,
+                        reinterpret_cast<const long long*>(fake_rows), alpha, cat_out, interp, n, elems_per_image, dtype, stream);
 }
 
 int expo_grad_penalty_fwd(const float* g, float* norm, float* term, int n, size_t elems_per_image, void* stream) {

@@ -459,7 +459,7 @@ class GAN(nn.Module):
       out = critic_direct.critic_losses_and_grads(self, real_data, fake_output, alpha, self._c_ema if ema_done else None)
       self._bucket_ready(self.buckets['c'])  # (a no-op on one rank: the gradients already sit in p.grad)
     else:
-      out = self.critic_losses(real_data, fake_output, alpha)
+      out = self.critic_losses(materialize(real_data), materialize(fake_output), alpha)
       self._backward_into(out['c_loss'], ['c'])
     if self._collectives():
       ca = out['c_average'].clone()
@@ -536,7 +536,9 @@ class GAN(nn.Module):
     mem.planned_commit(g_scatter, g_out['fake_output'], g_out['new_states'], feats, fresh_dst, fresh_src)
     c_out = None
     for _ in range(cfg.citers):
-      real, fake = mem.planned_critic_batch(take(n), take(n))
+      # (rows of the pool / the data set, read in place by the hand-scheduled update's first launch)
+      fake, real = take(n), take(n)
+      real, fake = mem.planned_critic_batch(fake, real, lazy=True)
       c_out = self._critic_body(real, fake, self._draw_alpha(n))
     return dict(g=g_out, c=c_out)
 

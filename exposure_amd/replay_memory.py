@@ -99,6 +99,13 @@ class PoolRows:
     self.shape = (idx.shape[0],) + tuple(pool.shape[1:])
     self.dtype, self.device = pool.dtype, pool.device
 
+  @property
+  def is_cuda(self):
+    return self.pool.is_cuda
+
+  def dim(self):
+    return self.pool.dim()
+
   def _check(self):
     assert self.owner is None or self.owner._writes == self.stamp, 'PoolRows used after the pool was written'
 
@@ -482,8 +489,11 @@ class ReplayMemory:
     self._st.index_fill_(0, fresh_dst, 0.0)
     self._ft.index_copy_(0, fresh_dst, fd.features.index_select(0, fresh_src))
 
-  def planned_critic_batch(self, c_slots, real_rows):
-    """-> (real_data, fake_output) of one critic step."""
+  def planned_critic_batch(self, c_slots, real_rows, lazy=False):
+    """-> (real_data, fake_output) of one critic step; ``lazy``: as :class:`PoolRows` (the hand-scheduled critic update
+    reads the rows straight out of the data set and the pool: ``expo_gp_inputs_rows``)."""
+    if lazy:
+      return PoolRows(self.real_dataset.images, real_rows), PoolRows(self._img, c_slots)
     return self.real_dataset.images.index_select(0, real_rows), self._img.index_select(0, c_slots)
 
   def check_host_mirror(self):

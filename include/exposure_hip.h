@@ -441,6 +441,10 @@ int expo_agent_select_bwd(const float* logits, const int32_t* selected, const fl
  *                          interp = real + alpha[n] (fake - real) (net.py:170-172) in one pass; real / fake of `dtype`,
  *                          elems_per_image = H*W*3; interp (and alpha) may be NULL: conversion + concatenation only
  *                          (the generator step's image pairs, exposure_amd/generator_direct.py)
+ *   expo_gp_inputs_rows    the same with the batch's images named by ROW: image i is row real_rows[i] of `real` / row
+ *                          fake_rows[i] of `fake` (device int64[n]; NULL: row i) -- the replayed records are read straight
+ *                          out of the replay memory's pool and the resident data set (replay_memory.py:168-185 builds
+ *                          that batch on the host), no gather launch in front
  *   expo_grad_penalty_fwd  per image: norm = sqrt(1e-6 + sum g^2), term = max(norm - 1, 0)^2 (net.py:185-187; the
  *                          penalty is lambda * mean(term)); g float32 [n][elems_per_image]
  *   expo_grad_penalty_bwd  dg = g * dterm[n] * 2 max(norm - 1, 0) / norm   (the gradient TF takes of that term with
@@ -449,6 +453,9 @@ int expo_agent_select_bwd(const float* logits, const int32_t* selected, const fl
  */
 int expo_gp_inputs(const void* real, const void* fake, const float* alpha, float* cat_out, float* interp, int n,
                    size_t elems_per_image, int dtype, void* stream);
+int expo_gp_inputs_rows(const void* real, const int64_t* real_rows, const void* fake, const int64_t* fake_rows,
+                        const float* alpha, float* cat_out, float* interp, int n, size_t elems_per_image, int dtype,
+                        void* stream);
 int expo_grad_penalty_fwd(const float* g, float* norm, float* term, int n, size_t elems_per_image, void* stream);
 int expo_grad_penalty_bwd(const float* g, const float* norm, const float* dterm, float* dg, int n,
                           size_t elems_per_image, void* stream);

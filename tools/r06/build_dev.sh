@@ -24,11 +24,11 @@ for u in "${ALL[@]}"; do
     f=("${FLAGS[@]}")
     [ $u == chain_fused ] && f+=(-fno-slp-vectorize -fno-honor-nans)
     [ $u == chain_fused_bwd ] && f+=(-fno-slp-vectorize)
-    /opt/rocm/bin/hipcc "${f[@]}" "${extra[@]}" -c $C/$u.hip -o $O/$u.o 2>/dev/null &
+    /opt/rocm/bin/hipcc "${f[@]}" "${extra[@]}" -c $C/$u.hip -o $O/$u.o 2>$O/$u.log &
     pids+=($!)
   fi
 done
-for p in "${pids[@]}"; do wait $p; done
+for p in "${pids[@]}"; do wait $p || { grep -h -A3 "error" $O/*.log | head -30; exit 1; }; done
 objs=(); for u in "${ALL[@]}"; do objs+=($O/$u.o); done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o $R/exposure_amd/libexposure_hip.so
 echo "dev build done (${units[*]}; ${extra[*]:-no extra flags})"
