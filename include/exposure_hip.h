@@ -507,7 +507,7 @@ int expo_adam_step(int count, float* const* params, const float* const* grads, f
  * agent.py:17-19, 47-53 (`enrich_image_input`, then `net - 0.5` in feature_extractor): dtype conversion,
  * concatenation and subtraction in one launch.
  *   images  device [N][pixels][3] in `dtype` (NULL: zeros -- the adjoint's own adjoint has no image part)
- *   vec     device float32 [N][V] (V may be 0)
+ *   vec     device float32 [N][V] (0 <= V <= 61)
  *   out     device float32 [N][pixels][3 + V] = (c < 3 ? images : vec[n][c - 3]) - offset
  * Linear, so its derivative is slicing / a per-image sum (the host side leaves those to autograd).
  */
