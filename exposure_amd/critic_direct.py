@@ -1,5 +1,5 @@
 """The WGAN-GP critic update as a hand-scheduled sequence of HIP launches (``/root/reference/net.py:126-199, 245-251``;
-``critics.py:6-38, 42-98``): no autograd graph, 34 launches instead of 161.
+``critics.py:6-38, 42-98``): no autograd graph, 29 launches instead of 160.
 
     c_loss = mean(D(fake) - D(real)) + lambda * mean(max(||grad_x^ D(x^)|| - 1, 0)^2),   x^ = real + alpha (fake - real)
 
@@ -21,8 +21,9 @@ and the rows' upstream gradients dlogit = (-1/n, +1/n, 1) -- the third block is 
   weight grads   after that the activation buffers hold [z_{l-1}(real, fake) | t_{l-1}] and the gradient buffers
                  [gy_l(real, fake) | gy_l(interpolated)]: ONE weight-gradient launch per layer over the 3n "images" yields
                  d c_loss / d W_l including the penalty's second-order term, and the bias gradient (column sums over the
-                 first 2n images) comes out of the same launch (expo_conv4x4s2_wrw_bias).  Biases get no gradient from the
-                 penalty: the masks are piecewise constant.
+                 first 2n images) comes out of the same launch (expo_conv4x4s2_wrw_bias); the four layers' launches share
+                 one grid and one reduce (expo_conv4x4s2_wrw_group).  Biases get no gradient from the penalty: the masks are
+                 piecewise constant.
 
 Every quantity equals what ``GAN.critic_losses`` + ``backward`` compute through autograd (tests/test_critic_direct.py holds
 the two against each other and against finite differences of the float64 oracle); the summation orders are fixed, so a step
