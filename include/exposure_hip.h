@@ -593,7 +593,8 @@ int expo_conv4x4s2_wrw_group(int count, const float* const* x, const float* cons
  * expo_conv_tuning's `slices`. */
 int expo_conv_wrw_tuning(int slices, int parts);
 /* Probes and tests: override how the forward / data-gradient kernels decompose a problem (process-wide; negative = leave as is,
- * 0 = the library's own choice).  tile 1-4: an LDS-tiled forward shape, 5: the flat kernel; nt 1 | 2: column tiles per
+ * 0 = the library's own choice).  tile 1-4: an LDS-tiled forward shape, 5: the flat kernel, 6: the
+ * first layers' row-staged kernel where it applies; nt 1 | 2: column tiles per
  * wave; slices 1, 2, 4, 8 or 16: K slices per tile (any other value is rejected: the kernels cut K into 4 S2 segments).
  * The initial values come from EXPO_CONV_TILE / _NT / _SLICES, read once. */
 int expo_conv_tuning(int tile, int nt, int slices);
