@@ -95,6 +95,7 @@ SIGNATURES = {
     'expo_adam_step': (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                            ctypes.POINTER(_sz), _fp, _fp, _vp, _f, _f, _f, _vp]),
     'expo_gp_inputs': (_i, [_vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
+    'expo_net_inputs': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_gp_inputs_rows': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
     'expo_grad_penalty_fwd': (_i, [_fp, _fp, _fp, _i, _sz, _vp]),
     'expo_grad_penalty_bwd': (_i, [_fp, _fp, _fp, _fp, _i, _sz, _vp]),
@@ -784,6 +785,39 @@ def gp_inputs(real, fake, alpha, cat_out, interp, real_rows=None, fake_rows=None
     _check(lib.expo_gp_inputs_rows(_ptr(real), _ptr(real_rows), _ptr(fake), _ptr(fake_rows),
                                    _ptr(alpha) if interp is not None else None, _ptr(cat_out), _ptr(interp),
                                    n, m, _dtype_code(real), _stream()), 'expo_gp_inputs_rows')
+
+
+NET_INPUTS_MAX_PIXELS = 4096  # expo_net_inputs holds an image in LDS
+
+
+def net_inputs(a, b, alpha, planes, stats, x_out=None, x_first=0, vec_a=None, vec_b=None, a_rows=None, b_rows=None,
+               offset=0.5):
+  """expo_net_inputs: planes = concat([a | b (| a + alpha (b - a))] as float32, per-image values, statistics) - offset,
+  stats = the rows' statistics, x_out = the float32 images of rows x_first .. x_first + len(x_out): one launch
+  (critics.py:42-76; net.py:170-172).  ``a_rows`` / ``b_rows`` (device int64 (n,)): image j is row rows[j] of a / b."""
+  lib = load()
+  _img(a, 'a'), _img(b, 'b')
+  assert a.shape[1:] == b.shape[1:] and a.dtype == b.dtype and a.dim() == 4
+  for rows in (a_rows, b_rows):
+    assert rows is None or (rows.is_cuda and rows.dtype == torch.int64 and rows.is_contiguous() and rows.dim() == 1)
+  n = a.shape[0] if a_rows is None else a_rows.shape[0]
+  assert n == (b.shape[0] if b_rows is None else b_rows.shape[0])
+  h, w = int(a.shape[1]), int(a.shape[2])
+  m = (3 if alpha is not None else 2) * n
+  v0 = 0 if vec_a is None else int(vec_a.shape[1])
+  if alpha is not None:
+    assert alpha.is_cuda and alpha.dtype == torch.float32 and alpha.is_contiguous() and alpha.numel() == n
+  if v0:
+    _f32(vec_a, 'vec_a', (n, v0)), _f32(vec_b, 'vec_b', (n, v0))
+  _f32(planes, 'planes', (m, h, w, 6 + v0)), _f32(stats, 'stats', (m, 3))
+  x_count = 0
+  if x_out is not None:
+    x_count = int(x_out.shape[0])
+    _f32(x_out, 'x_out', (x_count, h, w, 3))
+  with torch.cuda.device(a.device):
+    _check(lib.expo_net_inputs(_ptr(a), _ptr(a_rows), _ptr(b), _ptr(b_rows), _ptr(alpha), _ptr(vec_a) if v0 else None,
+                               _ptr(vec_b) if v0 else None, v0, _ptr(planes), _ptr(stats), _ptr(x_out), int(x_first), x_count,
+                               n, h, w, _dtype_code(a), float(offset), _stream()), 'expo_net_inputs')
 
 
 def grad_penalty_fwd(g, norm, term):

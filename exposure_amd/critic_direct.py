@@ -100,13 +100,20 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
   if isinstance(fake_output, PoolRows):
     fake_output, fake_rows = fake_output.pool, fake_output.idx
   real_data, fake_output = real_data.contiguous(), fake_output.detach().contiguous()
-  x = torch.empty((m,) + tuple(real_data.shape[1:]), **f32)
-  _cabi.gp_inputs(real_data, fake_output, alpha.contiguous().float().reshape(n), x[:2 * n], x[2 * n:],
-                  real_rows=real_rows, fake_rows=fake_rows)
+  alpha = alpha.contiguous().float().reshape(n)
   stats = torch.empty((m, 3), **f32)
-  _cabi.critic_stats(x, stats)
-  acts = [torch.empty(tuple(x.shape[:-1]) + (6,), **f32)]
-  _cabi.planes_concat(x, stats, acts[0], 0.5)
+  acts = [torch.empty((m,) + tuple(real_data.shape[1:3]) + (6,), **f32)]
+  if real_data.shape[1] * real_data.shape[2] <= _cabi.NET_INPUTS_MAX_PIXELS:
+    xi = torch.empty((n,) + tuple(real_data.shape[1:]), **f32)  # the interpolated images: the penalty's J^T / J v read them
+    _cabi.net_inputs(real_data, fake_output, alpha, acts[0], stats, x_out=xi, x_first=2 * n, a_rows=real_rows,
+                     b_rows=fake_rows)  # one launch: a block holds its image in LDS
+  else:
+    x = torch.empty((m,) + tuple(real_data.shape[1:]), **f32)
+    xi = x[2 * n:]
+    _cabi.gp_inputs(real_data, fake_output, alpha, x[:2 * n], xi, real_rows=real_rows, fake_rows=fake_rows)
+    _cabi.critic_stats(x, stats)
+    _cabi.planes_concat(x, stats, acts[0], 0.5)
+  si = stats[2 * n:]
 
   # ---- forward ----------------------------------------------------------------------------------------------------------
   for conv in convs:
@@ -137,7 +144,6 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
 
   # ---- the penalty on g = d D(x^) / d x^, its gradient v with respect to g, and the tangent's input [v | J v] written over
   # the interpolated block of the first activation buffer: one launch (plane sums, J^T, norm / term, v, J v, planes) ------
-  xi, si = x[2 * n:], stats[2 * n:]
   norm, term = torch.empty((n,), **f32), torch.empty((n,), **f32)
   _cabi.critic_penalty_tangent(u0, xi, si, lam * inv_n, acts[0][2 * n:], norm, term)
 

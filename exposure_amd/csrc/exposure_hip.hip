@@ -924,6 +924,7 @@ __global__ __launch_bounds__(kThreads) void stats_hvp_kernel(const T* __restrict
 // gradient v = scale 2 max(||g|| - 1, 0) / ||g|| g (net.py:185-187), J v (stats_jvp) and the tangent's 6-plane input
 // [v | J v broadcast].  Six launches of 5-7 us each as separate kernels; here one block per image walks its pixels three
 // times (u and x stay in L2) with a fixed-order block reduction after each walk.  x is float32 (the critic's input).
+template <int WAVES = 16>
 __device__ __forceinline__ void block_sum3(float (&a)[3], float (*part)[3]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -934,10 +935,13 @@ __device__ __forceinline__ void block_sum3(float (&a)[3], float (*part)[3]) {
     if (lane == 0) part[wave][k] = v;
   }
   __syncthreads();
+  // lane w holds wave w's partial; a butterfly leaves the same total (one fixed order) in every lane.  (The first version let
+  // every thread add the 16 partials one after the other: a rolled loop of dependent LDS reads, ~2.5 us per call.)
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float v = part[0][k];
-    for (int w = 1; w < 16; ++w) v += part[w][k];
+    float v = lane < WAVES ? part[lane][k] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     a[k] = v;
   }
   __syncthreads();
@@ -1011,6 +1015,207 @@ __global__ __launch_bounds__(1024) void critic_penalty_tangent_kernel(const floa
     tn[p * 6 + 3] = j0;
     tn[p * 6 + 4] = j1;
     tn[p * 6 + 5] = j2;
+  }
+}
+
+// The same for images of at most 4096 pixels (the 64 x 64 proxies of a training iteration): a thread OWNS four pixels and
+// keeps what the three walks share -- u[..., :3], x, then g -- in registers, so u and x are read once (the three-walk kernel
+// above reads them three times from L2; with one block per image the launch is bound by what ONE CU can stream) and the
+// six planes of the tangent's input leave as 24 contiguous bytes per pixel after the last reduction.
+__global__ __launch_bounds__(1024) void critic_penalty_tangent_reg_kernel(const float* __restrict__ u, const float* __restrict__ x,
+                                                                          const float* __restrict__ stats, float scale,
+                                                                          float* __restrict__ t0, float* __restrict__ norm,
+                                                                          float* __restrict__ term, int hw) {
+  __shared__ float part[16][3];
+  const int n = blockIdx.x;
+  const float* un = u + size_t(n) * hw * 6;
+  const float* xn = x + size_t(n) * hw * 3;
+  float* tn = t0 + size_t(n) * hw * 6;
+  const float inv_hw = 1.0f / float(hw), mean = stats[n * 3];
+  float g[4][3], px[4][3];
+  float gs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = threadIdx.x + 1024 * i;
+    if (p < hw) {
+      const float2 u01 = *reinterpret_cast<const float2*>(un + p * 6), u23 = *reinterpret_cast<const float2*>(un + p * 6 + 2),
+                   u45 = *reinterpret_cast<const float2*>(un + p * 6 + 4);
+      g[i][0] = u01.x, g[i][1] = u01.y, g[i][2] = u23.x;
+      gs[0] += u23.y, gs[1] += u45.x, gs[2] += u45.y;
+      px[i][0] = xn[p * 3], px[i][1] = xn[p * 3 + 1], px[i][2] = xn[p * 3 + 2];
+    }
+  }
+  block_sum3(gs, part);
+  const float g0 = gs[0] * inv_hw, g1 = gs[1] * 2.0f * inv_hw, g2 = gs[2] * inv_hw;
+  float sq[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (threadIdx.x + 1024 * i < hw) {  // g = u[:3] + J^T gs (stats_bwd_kernel)
+      const float l = (px[i][0] * kLumR + px[i][1] * kLumG) + px[i][2] * kLumB + 1e-5f;
+      const float dl = fmaf(g1, l - mean, g0);
+      const SatPix sp = sat_pix<false>(px[i]);
+      g[i][0] += fmaf(kLumR, dl, g2 * (sp.fmx * sp.a[0] + sp.fmn * sp.b[0]));
+      g[i][1] += fmaf(kLumG, dl, g2 * (sp.fmx * sp.a[1] + sp.fmn * sp.b[1]));
+      g[i][2] += fmaf(kLumB, dl, g2 * (sp.fmx * sp.a[2] + sp.fmn * sp.b[2]));
+      sq[0] = fmaf(g[i][0], g[i][0], sq[0]);
+      sq[1] = fmaf(g[i][1], g[i][1], sq[1]);
+      sq[2] = fmaf(g[i][2], g[i][2], sq[2]);
+    }
+  }
+  block_sum3(sq, part);
+  const float nm = sqrtf(1e-6f + ((sq[0] + sq[1]) + sq[2]));
+  const float over = fmaxf(nm - 1.0f, 0.0f);
+  const float coef = scale * 2.0f * over / nm;
+  if (threadIdx.x == 0) {
+    norm[n] = nm;
+    term[n] = over * over;
+  }
+  float jv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (threadIdx.x + 1024 * i < hw) {  // v = coef g and J v (stats_jvp_kernel)
+      g[i][0] *= coef, g[i][1] *= coef, g[i][2] *= coef;
+      const float* v = g[i];
+      const float l = (px[i][0] * kLumR + px[i][1] * kLumG) + px[i][2] * kLumB + 1e-5f;
+      const SatPix sp = sat_pix<false>(px[i]);
+      const float wv = (v[0] * kLumR + v[1] * kLumG) + v[2] * kLumB;
+      jv[0] += wv;
+      jv[1] = fmaf(l - mean, wv, jv[1]);
+      jv[2] += sp.fmx * (sp.a[0] * v[0] + sp.a[1] * v[1] + sp.a[2] * v[2]) + sp.fmn * (sp.b[0] * v[0] + sp.b[1] * v[1] + sp.b[2] * v[2]);
+    }
+  }
+  block_sum3(jv, part);
+  const float j0 = jv[0] * inv_hw, j1 = jv[1] * 2.0f * inv_hw, j2 = jv[2] * inv_hw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = threadIdx.x + 1024 * i;
+    if (p < hw) {
+      *reinterpret_cast<float2*>(tn + p * 6) = make_float2(g[i][0], g[i][1]);
+      *reinterpret_cast<float2*>(tn + p * 6 + 2) = make_float2(g[i][2], j0);
+      *reinterpret_cast<float2*>(tn + p * 6 + 4) = make_float2(j1, j2);
+    }
+  }
+}
+
+// ---- the input side of a hand-scheduled net pass in ONE launch (round 6, exposure_amd/critic_direct.py, generator_direct.py)
+// critics.py:42-76 in front of `cnn`: the batch [a | b (| a + alpha (b - a))] as float32, its statistics {mean luminance,
+// luminance variance, mean saturation} and `concat([images, states planes, statistics planes]) - 0.5`.  As separate launches
+// that was expo_gp_inputs -> expo_critic_stats (streaming pass + finish launch) -> (torch.cat of the states) ->
+// expo_planes_concat: 25 us and four dependent launches for 64 x 64 proxies, of which the statistics' two launches exist only
+// because a block sees part of an image.  Here a block holds its WHOLE image in LDS (<= 4096 pixels = 48 KB): it reads the
+// source rows once (16-byte loads straight from the data set / the replay memory's pool: `rows`), forms the three sums in a
+// fixed order, and writes its share (blockIdx.y of gridDim.y: the loads are cheap, the stores are the traffic) of the
+// (3 + V + 3)-plane tensor with whole-line stores -- and of the float32 image for the rows whose backward needs it
+// (x_first .. x_first + x_count: the interpolated rows of a critic update, the retouched rows of a G / V step).
+constexpr int kNetInputsMaxPixels = 4096;
+struct NetInputsArgs {
+  const void *a, *b;                  // images [.][hw][3] in T
+  const long long *a_rows, *b_rows;   // nullable: image j of the block is row rows[j]
+  const float* alpha;                 // nullable: [n] -> a third block of rows a + alpha (b - a) (net.py:170-172)
+  const float *vec_a, *vec_b;         // nullable: [n][v0] per-image values of the two blocks (the value net's states)
+  float *planes, *stats, *x_out;      // [m][hw][3 + v0 + 3]; [m][3]; nullable [x_count][hw][3]
+  int n, hw, v0, x_first, x_count;
+  float offset;
+  unsigned magic;                     // ceil(2^32 / (3 + v0 + 3)): element -> pixel by a multiply-high (exact below 2^32 / C)
+};
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void net_inputs_kernel(const NetInputsArgs g) {
+  typedef T Vec4 __attribute__((ext_vector_type(4)));
+  __shared__ float px[kNetInputsMaxPixels * 3];
+  __shared__ float part[NT / 64][3];
+  __shared__ float vs[64];
+  const int img = blockIdx.x, blk = img / g.n, j = img - blk * g.n;
+  const int elems = g.hw * 3;
+  const T* pa = static_cast<const T*>(g.a) + size_t(g.a_rows ? g.a_rows[j] : j) * elems;
+  const T* pb = static_cast<const T*>(g.b) + size_t(g.b_rows ? g.b_rows[j] : j) * elems;
+  const bool vec4 = (elems & 3) == 0 && ((uintptr_t(g.a) | uintptr_t(g.b)) & (sizeof(Vec4) - 1)) == 0;
+  // ---- the image, float32, into LDS
+  if (blk == 2) {
+    const float al = g.alpha[j];
+    if (vec4) {
+      for (int e = threadIdx.x * 4; e < elems; e += NT * 4) {
+        const Vec4 r = *reinterpret_cast<const Vec4*>(pa + e), f = *reinterpret_cast<const Vec4*>(pb + e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) px[e + k] = float(r[k]) + al * (float(f[k]) - float(r[k]));
+      }
+    } else {
+      for (int e = threadIdx.x; e < elems; e += NT) px[e] = float(pa[e]) + al * (float(pb[e]) - float(pa[e]));
+    }
+  } else {
+    const T* src = blk ? pb : pa;
+    if (vec4) {
+      for (int e = threadIdx.x * 4; e < elems; e += NT * 4) {
+        const Vec4 r = *reinterpret_cast<const Vec4*>(src + e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) px[e + k] = float(r[k]);
+      }
+    } else {
+      for (int e = threadIdx.x; e < elems; e += NT) px[e] = float(src[e]);
+    }
+  }
+  __syncthreads();
+  // ---- statistics (stats_kernel's arithmetic; finish_kernel's kFinStats): shifted sums, one fixed-order block reduction
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int p = threadIdx.x; p < g.hw; p += NT) {
+    const float* q = px + 3 * p;
+    const float l = ((q[0] * kLumR + q[1] * kLumG) + q[2] * kLumB + 1e-5f) - 0.5f;
+    acc[0] += l;
+    acc[1] = fmaf(l, l, acc[1]);
+    const float c0 = clamp01x(q[0], 0.f, 1.f), c1 = clamp01x(q[1], 0.f, 1.f), c2 = clamp01x(q[2], 0.f, 1.f);
+    const float mx = fmaxf(fmaxf(c0, c1), c2), mn = fminf(fminf(c0, c1), c2);
+    acc[2] = fmaf(mx - mn, fast_rcp(fminf(mx + mn, 2.0f - mx - mn) + 1e-2f), acc[2]);
+  }
+  block_sum3<NT / 64>(acc, part);
+  const float inv_hw = 1.0f / float(g.hw);
+  const float m1 = acc[0] * inv_hw, m2 = acc[1] * inv_hw;
+  const float st[3] = {m1 + 0.5f, m2 - m1 * m1, acc[2] * inv_hw};
+  if (threadIdx.x < 3) {
+    const float s = threadIdx.x == 0 ? st[0] : (threadIdx.x == 1 ? st[1] : st[2]);
+    if (blockIdx.y == 0) g.stats[size_t(img) * 3 + threadIdx.x] = s;
+    vs[g.v0 + threadIdx.x] = s - g.offset;
+  } else if (threadIdx.x >= 64 && threadIdx.x < 64 + unsigned(g.v0)) {
+    const int k = threadIdx.x - 64;
+    vs[k] = (blk ? g.vec_b : g.vec_a)[size_t(j) * g.v0 + k] - g.offset;
+  }
+  __syncthreads();
+  // ---- this block's share of the planes: consecutive output floats, element e -> (pixel, channel)
+  const unsigned C = 3 + g.v0 + 3;
+  const unsigned count = unsigned(g.hw) * C;
+  // (16 bytes per lane and store: the epilogue is store-ISSUE-bound, a dword per lane runs at a third of the rate)
+  const unsigned per = ((count + gridDim.y - 1) / gridDim.y + 255) & ~255u;
+  const unsigned e0 = blockIdx.y * per, e1 = min(count, e0 + per);
+  float* o = g.planes + size_t(img) * count;
+  auto value = [&](unsigned p, unsigned c) { return c < 3 ? px[p * 3 + c] - g.offset : vs[c - 3]; };
+  if ((count & 3) == 0) {
+    for (unsigned e = e0 + threadIdx.x * 4; e < e1; e += NT * 4) {
+      unsigned p = __umulhi(e, g.magic), c = e - p * C;
+      float4 v;
+      v.x = value(p, c);
+      if (++c == C) { c = 0; ++p; }
+      v.y = value(p, c);
+      if (++c == C) { c = 0; ++p; }
+      v.z = value(p, c);
+      if (++c == C) { c = 0; ++p; }
+      v.w = value(p, c);
+      *reinterpret_cast<float4*>(o + e) = v;
+    }
+  } else {
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += NT) {
+      const unsigned p = __umulhi(e, g.magic), c = e - p * C;
+      o[e] = value(p, c);
+    }
+  }
+  // ---- and of the float32 image, for the rows whose backward reads it
+  if (g.x_out && img >= g.x_first && img < g.x_first + g.x_count) {
+    float* xo = g.x_out + size_t(img - g.x_first) * elems;
+    const unsigned xper = ((unsigned(elems) + gridDim.y - 1) / gridDim.y + 255) & ~255u;
+    const unsigned x0 = blockIdx.y * xper, x1 = min(unsigned(elems), x0 + xper);
+    if ((elems & 3) == 0) {
+      for (unsigned e = x0 + threadIdx.x * 4; e < x1; e += NT * 4)
+        *reinterpret_cast<float4*>(xo + e) = *reinterpret_cast<const float4*>(px + e);
+    } else {
+      for (unsigned e = x0 + threadIdx.x; e < x1; e += NT) xo[e] = px[e];
+    }
   }
 }
 
@@ -2332,9 +2537,44 @@ int expo_critic_penalty_tangent(const float* u, const float* x, const float* sta
   if (n == 0) return EXPO_OK;
   if (!u || !x || !stats || !t0 || !norm || !term) return fail(EXPO_E_BADARG, "null pointer");
   if (long(h) * w > (1L << 24)) return fail(EXPO_E_BADARG, "critic_penalty_tangent: at most 2^24 pixels per image");
-  hipLaunchKernelGGL(critic_penalty_tangent_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), u, x, stats,
-                     scale, t0, norm, term, h * w);
+  if (h * w <= 4096 && (reinterpret_cast<uintptr_t>(u) & 7) == 0 && (reinterpret_cast<uintptr_t>(t0) & 7) == 0)
+    hipLaunchKernelGGL(critic_penalty_tangent_reg_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), u, x, stats,
+                       scale, t0, norm, term, h * w);
+  else
+    hipLaunchKernelGGL(critic_penalty_tangent_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), u, x, stats,
+                       scale, t0, norm, term, h * w);
   HIP_TRY(hipGetLastError(), "critic_penalty_tangent launch");
+  return EXPO_OK;
+}
+
+int expo_net_inputs(const void* a, const int64_t* a_rows, const void* b, const int64_t* b_rows, const float* alpha,
+                    const float* vec_a, const float* vec_b, int v0, float* planes, float* stats, float* x_out, int x_first,
+                    int x_count, int n, int h, int w, int dtype, float offset, void* stream) {
+  if (int rc = check_common(n, h, w, dtype)) return rc;
+  if (n == 0) return EXPO_OK;
+  if (!a || !b || !planes || !stats) return fail(EXPO_E_BADARG, "null pointer");
+  if (long(h) * w > kNetInputsMaxPixels) return fail(EXPO_E_BADARG, "net_inputs: at most 4096 pixels per image (the image is held in LDS)");
+  if (v0 < 0 || v0 > 58) return fail(EXPO_E_BADARG, "net_inputs: 0 <= v0 <= 58");
+  if (v0 > 0 && (!vec_a || !vec_b)) return fail(EXPO_E_BADARG, "net_inputs: v0 > 0 needs vec_a and vec_b");
+  if (v0 > 0 && alpha) return fail(EXPO_E_BADARG, "net_inputs: the interpolated block takes no per-image values");
+  const int m = (alpha ? 3 : 2) * n;
+  if (x_out && (x_first < 0 || x_count < 0 || x_first + x_count > m)) return fail(EXPO_E_BADARG, "net_inputs: x rows outside the batch");
+  NetInputsArgs g{a, b, reinterpret_cast<const long long*>(a_rows), reinterpret_cast<const long long*>(b_rows), alpha, vec_a, vec_b,
+                  planes, stats, x_out, n, h * w, v0, x_first, x_out ? x_count : 0, offset,
+                  unsigned((0x100000000ull + (6 + v0) - 1) / (6 + v0))};
+  // blocks per image: ~one block per CU (a CU streams ~25 GB/s whatever runs on it, so the store phase wants every CU busy;
+  // every extra block of an image repeats its loads and sums: 192 images x 1 block 11.2 us, x 2 12.3, x 4 15.6; 128 images with
+  // 17 planes x 1 / 2 / 4: 16.6 / 12.9 / 13.8), at least 4 KB of planes each
+  int parts = (256 + m / 2) / m;
+  const int max_parts = (h * w * (6 + v0) + 1023) / 1024;
+  if (parts > max_parts) parts = max_parts;
+  if (parts > 16) parts = 16;
+  if (parts < 1) parts = 1;
+  const dim3 grid(m, parts);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == EXPO_F16) hipLaunchKernelGGL((net_inputs_kernel<half_t, 1024>), grid, dim3(1024), 0, s, g);
+  else hipLaunchKernelGGL((net_inputs_kernel<float, 1024>), grid, dim3(1024), 0, s, g);
+  HIP_TRY(hipGetLastError(), "net_inputs launch");
   return EXPO_OK;
 }
 

@@ -58,19 +58,29 @@ def supported(gan, fake_input, states):
 class _PairPass:
   """One net on the batch [a | b] (n images each): ``forward()`` -> logits (2n,); ``backward(dlogit, ...)``."""
 
-  def __init__(self, net, img_a, img_b, vec_a=None, vec_b=None):
+  def __init__(self, net, img_a, img_b, vec_a=None, vec_b=None, x_rows=None):
     self.net, self.n = net, img_a.shape[0]
     n, m = self.n, 2 * img_a.shape[0]
     dev = img_a.device
     f32 = dict(dtype=torch.float32, device=dev)
-    self.x = torch.empty((m,) + tuple(img_a.shape[1:]), **f32)
-    _cabi.gp_inputs(img_a.contiguous(), img_b.contiguous(), None, self.x, None)
     self.stats = torch.empty((m, 3), **f32)
-    _cabi.critic_stats(self.x, self.stats)
-    vec = self.stats if vec_a is None else torch.cat([torch.cat([vec_a.float(), vec_b.float()], dim=0), self.stats], dim=1)
-    self.stats_first = 3 + (0 if vec_a is None else vec_a.shape[1])  # first statistics plane of the net's input
-    a0 = torch.empty(tuple(self.x.shape[:-1]) + (3 + vec.shape[1],), **f32)
-    _cabi.planes_concat(self.x, vec.contiguous(), a0, 0.5)
+    v0 = 0 if vec_a is None else vec_a.shape[1]
+    self.stats_first = 3 + v0  # first statistics plane of the net's input
+    a0 = torch.empty((m,) + tuple(img_a.shape[1:3]) + (6 + v0,), **f32)
+    x_rows = slice(0, m) if x_rows is None else x_rows
+    self.x_first = x_rows.start  # self.x: the float32 images of the rows whose image gradient the backward returns
+    if img_a.shape[1] * img_a.shape[2] <= _cabi.NET_INPUTS_MAX_PIXELS:
+      self.x = torch.empty((x_rows.stop - x_rows.start,) + tuple(img_a.shape[1:]), **f32)
+      _cabi.net_inputs(img_a.contiguous(), img_b.contiguous(), None, a0, self.stats, x_out=self.x, x_first=self.x_first,
+                       vec_a=None if vec_a is None else vec_a.float().contiguous(),
+                       vec_b=None if vec_b is None else vec_b.float().contiguous())  # one launch
+    else:
+      x = torch.empty((m,) + tuple(img_a.shape[1:]), **f32)
+      _cabi.gp_inputs(img_a.contiguous(), img_b.contiguous(), None, x, None)
+      _cabi.critic_stats(x, self.stats)
+      vec = self.stats if vec_a is None else torch.cat([torch.cat([vec_a.float(), vec_b.float()], dim=0), self.stats], dim=1)
+      _cabi.planes_concat(x, vec.contiguous(), a0, 0.5)
+      self.x = x[x_rows]
     self.acts = [a0]
     for conv in net.convs:
       a = self.acts[-1]
@@ -111,8 +121,9 @@ class _PairPass:
     _cabi.conv4x4s2_bwd_data(gys[1][rel(rows_x)], convs[0].weight, u0)
     gs = torch.empty((u0.shape[0], 3), dtype=torch.float32, device=u0.device)
     _cabi.plane_sums(u0, gs, self.stats_first)
-    ds = torch.empty_like(self.x[rows_x])
-    _cabi.critic_stats_bwd(self.x[rows_x], self.stats[rows_x], gs, ds)
+    xr = self.x[rows_x.start - self.x_first:rows_x.stop - self.x_first]
+    ds = torch.empty_like(xr)
+    _cabi.critic_stats_bwd(xr, self.stats[rows_x], gs, ds)
     d_img = u0[..., :3] + ds
     if grads is not None:
       rw = rel(rows_w)
@@ -155,8 +166,8 @@ def generator_step_losses_and_grads(gan, fake_input, z, states, progress, dropou
   A, B = slice(0, n), slice(n, 2 * n)
   with torch.no_grad():
     fo = fake_output.detach()
-    critic = _PairPass(gan.critic, fo, fake_input.to(fo.dtype))
-    value = _PairPass(gan.value, fake_input.to(fo.dtype), fo, states, new_states.detach())
+    critic = _PairPass(gan.critic, fo, fake_input.to(fo.dtype), x_rows=A)
+    value = _PairPass(gan.value, fake_input.to(fo.dtype), fo, states, new_states.detach(), x_rows=B)
     losses = torch.empty((2,), **f32)
     reward, q = torch.empty((n,), **f32), torch.empty((n,), **f32)
     coef = torch.empty((5, n), **f32)

@@ -515,6 +515,22 @@ int expo_planes_concat(const void* images, const float* vec, float* out, int n, 
                        int dtype, float offset, void* stream);
 
 /*
+ * The whole input side of a critic / value-net pass as ONE launch (critics.py:42-76 in front of `cnn`; net.py:170-172):
+ * what expo_gp_inputs_rows + expo_critic_stats + expo_planes_concat compute in four, for images of at most 4096 pixels
+ * (a block holds its image in LDS; EXPO_E_BADARG beyond -- the callers then run the separate launches).
+ *   a, b        device [.][H][W][3] in `dtype`; a_rows / b_rows (nullable, int64 [n]): image j of the block is row rows[j]
+ *   alpha       nullable float32 [n]: a third block of rows a + alpha (b - a) (the gradient penalty's interpolation)
+ *   vec_a/_b    nullable float32 [n][v0]: per-image values of the two blocks (the states critics.py:64-70 broadcasts)
+ *   planes      float32 [m][H][W][3 + v0 + 3] = concat(image, values, statistics) - offset,  m = 2 n (3 n with alpha)
+ *   stats       float32 [m][3] = {mean luminance, luminance variance, mean saturation} (critics.py:48-62)
+ *   x_out       nullable float32 [x_count][H][W][3]: the images of rows x_first .. x_first + x_count as float32 (the rows
+ *               whose backward needs them: expo_critic_penalty_tangent, expo_critic_stats_bwd)
+ */
+int expo_net_inputs(const void* a, const int64_t* a_rows, const void* b, const int64_t* b_rows, const float* alpha,
+                    const float* vec_a, const float* vec_b, int v0, float* planes, float* stats, float* x_out, int x_first,
+                    int x_count, int n, int h, int w, int dtype, float offset, void* stream);
+
+/*
  * The generator step's loss glue (net.py:92-160 with cfg.gan == 'w'; util.py:13-16 state columns): per image
  *   stopped = new_states[1], step = new_states[2];  nv = new_value * [step <= max_len];  gate = a + (1 - a) stopped
  *   reward = gate (fake_logit - fake_input_logit) m - penalty;  q = reward + (1 - stopped) gamma nv;  adv = q - old_value

@@ -371,7 +371,7 @@ def test_grouped_weight_gradients_equal_the_separate_calls(gpu_device):
     assert db is None or torch.equal(db, rb)
 
 
-@pytest.mark.parametrize('shape', [(5, 64, 64), (3, 7, 5), (2, 2, 2)])
+@pytest.mark.parametrize('shape', [(5, 64, 64), (3, 7, 5), (2, 2, 2), (2, 80, 72)])  # (> 4096 pixels: the three-walk kernel)
 def test_penalty_tangent_kernel_equals_its_six_launch_composition(shape, gpu_device):
   """expo_critic_penalty_tangent == plane sums -> expo_critic_stats_bwd -> expo_gp_direct -> expo_critic_stats_jvp ->
   expo_planes_concat(offset 0): the same norm / term and the same 6-plane tangent input, one image with its norm below 1
@@ -403,3 +403,52 @@ def test_penalty_tangent_kernel_equals_its_six_launch_composition(shape, gpu_dev
   assert float((t0 - want).abs().max()) <= 2e-5 * scale, float((t0 - want).abs().max()) / scale
   if n > 1:
     assert float(term2[1]) == 0.0 and float(t0[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('shape,v0,interp,rows', [((5, 64, 64), 0, True, True), ((4, 64, 64), 11, False, False),
+                                                    ((3, 7, 5), 0, True, False), ((2, 6, 3), 2, False, True),
+                                                    ((64, 64, 64), 0, True, True), ((1, 1, 1), 0, False, False)])
+def test_net_inputs_equals_its_four_launch_composition(shape, v0, interp, rows, dtype, gpu_device):
+  """expo_net_inputs == expo_gp_inputs_rows -> expo_critic_stats -> cat of the per-image values -> expo_planes_concat: the
+  float32 images of the requested rows and the image planes bit for bit, the statistics (another summation order) to float32
+  rounding of sums of h w terms -- against the float64 formulas of critics.py:48-62 as well."""
+  from exposure_amd import _cabi
+  dev = gpu_device
+  n, h, w = shape
+  g = torch.Generator(device=dev).manual_seed(17 * n + h)
+  pool_a = (torch.rand((n + 3, h, w, 3), device=dev, generator=g) * 1.2 - 0.05).to(dtype)
+  pool_b = (torch.rand((n + 2, h, w, 3), device=dev, generator=g) * 1.2 - 0.05).to(dtype)
+  ra = torch.randperm(n + 3, device=dev, generator=g)[:n].contiguous() if rows else None
+  rb = torch.randperm(n + 2, device=dev, generator=g)[:n].contiguous() if rows else None
+  a, b = (pool_a, pool_b) if rows else (pool_a[:n].contiguous(), pool_b[:n].contiguous())
+  alpha = torch.rand((n,), device=dev, generator=g) if interp else None
+  va = torch.randn((n, v0), device=dev, generator=g) if v0 else None
+  vb = torch.randn((n, v0), device=dev, generator=g) if v0 else None
+  m = (3 if interp else 2) * n
+  # the separate launches
+  x = torch.empty((m, h, w, 3), device=dev)
+  _cabi.gp_inputs(a, b, alpha, x[:2 * n], x[2 * n:] if interp else None, real_rows=ra, fake_rows=rb)
+  stats = torch.empty((m, 3), device=dev)
+  _cabi.critic_stats(x, stats)
+  vec = stats if not v0 else torch.cat([torch.cat([va, vb], dim=0), stats], dim=1).contiguous()
+  want = torch.empty((m, h, w, 6 + v0), device=dev)
+  _cabi.planes_concat(x, vec, want, 0.5)
+  # one launch; the float32 images of the last block and of one row in front of it
+  planes = torch.full_like(want, float('nan'))
+  stats2 = torch.full_like(stats, float('nan'))
+  x_first = m - n - 1 if m > n else 0
+  xo = torch.full((m - x_first, h, w, 3), float('nan'), device=dev)
+  _cabi.net_inputs(a, b, alpha, planes, stats2, x_out=xo, x_first=x_first, vec_a=va, vec_b=vb, a_rows=ra, b_rows=rb)
+  assert torch.equal(xo, x[x_first:])
+  assert torch.equal(planes[..., :3 + v0], want[..., :3 + v0])
+  xd = x.double().cpu().reshape(m, h * w, 3)
+  lum = xd[..., 0] * 0.27 + xd[..., 1] * 0.67 + xd[..., 2] * 0.06 + 1e-5
+  c = xd.clamp(0, 1)
+  mx, mn = c.max(dim=2).values, c.min(dim=2).values
+  sat = (mx - mn) / (torch.minimum(mx + mn, 2.0 - mx - mn) + 1e-2)
+  ref = torch.stack([lum.mean(1), lum.var(1, unbiased=False), sat.mean(1)], dim=1)
+  tol = torch.tensor([2e-6, 2e-6, 4e-6], dtype=torch.float64)
+  assert bool(((stats2.double().cpu() - ref).abs() <= tol).all()), (stats2.double().cpu() - ref).abs().max(0).values
+  assert bool(((stats2 - stats).abs().cpu() <= tol.float()).all())
+  assert torch.equal(planes[..., 3 + v0:], (stats2 - 0.5)[:, None, None, :].expand(m, h, w, 3))

@@ -28,4 +28,14 @@ for m in (64, 128, 192):
       'dz = mm(dh, w)': timeit(lambda: torch.mm(dh, w, out=dz)),
       'dw = mm(dh.t(), flat)': timeit(lambda: torch.mm(dh.t(), flat, out=dw)),
   }
+  # split-K through the library's strided-batch GEMM: S slabs [S][m][128] that the consumer (critic_head_fwd / _bwd) adds
+  for S in (4, 8, 16, 32):
+    k = 4096 // S
+    a3 = flat.view(m, S, k).transpose(0, 1)      # [S][m][k], strides (k, 4096, 1): no copy
+    b3 = w.view(128, S, k).permute(1, 2, 0)      # [S][k][128], strides (k, 1, 4096)
+    slabs = torch.empty((S, m, 128), device=dev)
+    res['bmm S=%d' % S] = timeit(lambda: torch.bmm(a3, b3, out=slabs))
+    if S == 8:
+      err = float((slabs.sum(0) - flat @ w.t()).abs().max())
+      assert err < 1e-2, err
   print('m=%d: ' % m + '  '.join('%s %.1f' % kv for kv in res.items()), flush=True)
