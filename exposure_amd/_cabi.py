@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # never a non-HIP implementation.
 LIB_PATH = os.environ.get('EXPO_HIP_LIB') or os.path.join(_HERE, 'libexposure_hip.so')
 
-EXPO_ABI_VERSION = 6
+EXPO_ABI_VERSION = 7
 EXPO_CURVE_MAX_STEPS = 16
 EXPO_F16, EXPO_F32 = 0, 1
 EXPO_MAX_PARAMS = 24
@@ -60,9 +60,12 @@ SIGNATURES = {
     'expo_conv4x4s2_wrw_group': (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                       ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),
                                       ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_vp), ctypes.POINTER(_sz), _vp]),
-    'expo_critic_head_fwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
+    'expo_critic_head_fwd': (_i, [_fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
     'expo_critic_report': (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _f, _fp, _fp, _vp]),
-    'expo_critic_head_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
+    'expo_critic_head_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
+    'expo_fc_fwd_slabs_count': (_i, [_i, _i]),
+    'expo_fc_fwd_slabs': (_i, [_fp, _fp, _fp, _i, _i, _i, _vp]),
+    'expo_fc_bwd_data_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _f, _vp]),
     'expo_plane_sums': (_i, [_fp, _fp, _i, _sz, _i, _i, _vp]),
     'expo_gp_direct': (_i, [_fp, _i, _fp, _f, _fp, _fp, _fp, _i, _sz, _vp]),
     'expo_critic_penalty_tangent': (_i, [_fp, _fp, _fp, _f, _fp, _fp, _fp, _i, _i, _i, _vp]),
@@ -1018,20 +1021,56 @@ def conv4x4s2_wrw_group(items):
                                         vp(wss), (_sz * k)(*wsb), _stream()), 'expo_conv4x4s2_wrw_group')
 
 
-def critic_head_fwd(hpre, w2, b2, n_real, n_fake, n_interp, inv_n, logits, h, dh, leak=0.2):
-  """expo_critic_head_fwd: fc1 activation, fc2 and the rows' upstream gradients of the batched critic pass."""
+def critic_head_fwd(hpre, w2, b2, n_real, n_fake, n_interp, inv_n, logits, h, dh, leak=0.2, b1=None):
+  """expo_critic_head_fwd: fc1 activation, fc2 and the rows' upstream gradients of the batched critic pass.  ``hpre``
+  (m, hidden) is fc1's pre-activation, or (slabs, m, hidden) partial sums of it (``fc_fwd_slabs``) with fc1's bias ``b1``."""
   lib = load()
-  m, hidden = hpre.shape
+  slabs = 1 if hpre.dim() == 2 else int(hpre.shape[0])
+  m, hidden = hpre.shape[-2:]
   assert m == n_real + n_fake + n_interp
-  for t in (hpre, h, dh):
-    _f32(t, 'hpre / h / dh', (m, hidden))
+  _f32(hpre, 'hpre', (m, hidden) if hpre.dim() == 2 else (slabs, m, hidden))
+  for t in (h, dh):
+    _f32(t, 'h / dh', (m, hidden))
   assert w2.is_cuda and w2.dtype == torch.float32 and w2.is_contiguous() and w2.numel() == hidden
   assert b2.is_cuda and b2.dtype == torch.float32 and b2.numel() == 1
+  if b1 is not None:
+    _f32(b1, 'b1', (hidden,))
   _f32(logits, 'logits', (m,))
   with torch.cuda.device(hpre.device):
-    _check(lib.expo_critic_head_fwd(_ptr(hpre), _ptr(w2), _ptr(b2), int(n_real), int(n_fake), int(n_interp), hidden,
-                                    float(inv_n), float(leak), _ptr(logits), _ptr(h), _ptr(dh), _stream()),
+    _check(lib.expo_critic_head_fwd(_ptr(hpre), _ptr(b1), slabs, _ptr(w2), _ptr(b2), int(n_real), int(n_fake), int(n_interp),
+                                    hidden, float(inv_n), float(leak), _ptr(logits), _ptr(h), _ptr(dh), _stream()),
            'expo_critic_head_fwd')
+
+
+def fc_fwd_slabs_count(m, k):
+  """How many partial sums ``fc_fwd_slabs`` writes for m rows of k features; 0: take the library GEMM."""
+  return int(load().expo_fc_fwd_slabs_count(int(m), int(k)))
+
+
+def fc_fwd_slabs(x, w, slabs):
+  """expo_fc_fwd_slabs: slabs[s] = x[:, K_s] w[:, K_s]^T over the s-th range of features (x (m, k), w (n, k) = nn.Linear's
+  weight, slabs (fc_fwd_slabs_count(m, k), m, n)); sum(slabs, 0) + bias is the layer's pre-activation."""
+  lib = load()
+  m, k = x.shape
+  n = w.shape[0]
+  _f32(x, 'x', (m, k)), _f32(w, 'w', (n, k))
+  _f32(slabs, 'slabs', (fc_fwd_slabs_count(m, k), m, n))
+  with torch.cuda.device(x.device):
+    _check(lib.expo_fc_fwd_slabs(_ptr(x), _ptr(w), _ptr(slabs), m, n, k, _stream()), 'expo_fc_fwd_slabs')
+
+
+def fc_bwd_data_mask(dh, w, z, gy, leak=0.2):
+  """expo_fc_bwd_data_mask: gy = (dh w) * slope(z) -- fc1's data gradient times the activation gradient of the feature map
+  below it (dh (m, j), w (j, c), z / gy any shape of m * c elements)."""
+  lib = load()
+  m, j = dh.shape
+  c = w.shape[1]
+  _f32(dh, 'dh', (m, j)), _f32(w, 'w', (j, c))
+  assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous() and z.numel() == m * c
+  assert gy.is_cuda and gy.dtype == torch.float32 and gy.is_contiguous() and gy.numel() == m * c
+  with torch.cuda.device(dh.device):
+    _check(lib.expo_fc_bwd_data_mask(_ptr(dh), _ptr(w), _ptr(z), _ptr(gy), m, j, c, float(leak), _stream()),
+           'expo_fc_bwd_data_mask')
 
 
 def critic_report(logits, norm, term, n_real, n_fake, n_interp, lam, out, ema=None, decay=0.99):
@@ -1048,18 +1087,21 @@ def critic_report(logits, norm, term, n_real, n_fake, n_interp, lam, out, ema=No
 
 
 def critic_head_bwd(dh, h, thpre, n_real, n_fake, n_interp, inv_n, gb1, gw2, gb2, leak=0.2):
-  """expo_critic_head_bwd: fc1 bias / fc2 weight / fc2 bias gradients of the loss rows and of the penalty's tangent."""
+  """expo_critic_head_bwd: fc1 bias / fc2 weight / fc2 bias gradients of the loss rows and of the penalty's tangent
+  (``thpre`` (n_interp, hidden), or (slabs, n_interp, hidden) partial sums of it)."""
   lib = load()
   m, hidden = h.shape
   assert m == n_real + n_fake + n_interp
   _f32(dh, 'dh', (m, hidden)), _f32(h, 'h', (m, hidden))
+  th_slabs = 1
   if n_interp:
-    _f32(thpre, 'thpre', (n_interp, hidden))
+    th_slabs = 1 if thpre.dim() == 2 else int(thpre.shape[0])
+    _f32(thpre, 'thpre', (n_interp, hidden) if thpre.dim() == 2 else (th_slabs, n_interp, hidden))
   for t, k in ((gb1, hidden), (gw2, hidden), (gb2, 1)):
     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == k
   with torch.cuda.device(h.device):
-    _check(lib.expo_critic_head_bwd(_ptr(dh), _ptr(h), _ptr(thpre), int(n_real), int(n_fake), int(n_interp), hidden,
-                                    float(inv_n), float(leak), _ptr(gb1), _ptr(gw2), _ptr(gb2), _stream()),
+    _check(lib.expo_critic_head_bwd(_ptr(dh), _ptr(h), _ptr(thpre), th_slabs, int(n_real), int(n_fake), int(n_interp),
+                                    hidden, float(inv_n), float(leak), _ptr(gb1), _ptr(gw2), _ptr(gb2), _stream()),
            'expo_critic_head_bwd')
 
 

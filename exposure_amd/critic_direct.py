@@ -60,6 +60,13 @@ def supported(gan, real_data, fake_output):
   return h * w * c.convs[-1].weight.shape[0] == c.flat and c.fc2.weight.shape[0] == 1
 
 
+def fc_split(fc, rows):
+  """expo_fc_fwd_slabs / expo_fc_bwd_data_mask apply to this nn.Linear on `rows` rows."""
+  w = fc.weight
+  return (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.shape[0] % 16 == 0 and w.shape[1] % 128 == 0 and
+          _cabi.fc_fwd_slabs_count(rows, w.shape[1]) > 0)
+
+
 def _grad_targets(gan):
   """Where the gradients go: the bucket's views when collectives run, fresh tensors (handed to the optimiser) otherwise."""
   params = list(gan.critic.parameters())
@@ -122,17 +129,27 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
     _cabi.conv4x4s2_fwd(a, conv.weight, conv.bias, z, 1, LEAK)
     acts.append(z)
   flat = acts[-1].reshape(m, critic.flat)
-  hpre = torch.addmm(critic.fc1.bias, flat, critic.fc1.weight.t())
-  hidden = hpre.shape[1]
+  hidden = critic.fc1.weight.shape[0]
   logits = torch.empty((m,), **f32)
-  h, dh = torch.empty_like(hpre), torch.empty_like(hpre)
-  _cabi.critic_head_fwd(hpre, critic.fc2.weight.reshape(hidden), critic.fc2.bias, n, n, n, inv_n, logits, h, dh, LEAK)
+  h, dh = torch.empty((m, hidden), **f32), torch.empty((m, hidden), **f32)
+  split = fc_split(critic.fc1, m) and fc_split(critic.fc1, n)  # fc1 with its K dimension split: the head kernels add the slabs
+  if split:
+    hpre = torch.empty((_cabi.fc_fwd_slabs_count(m, critic.flat), m, hidden), **f32)
+    _cabi.fc_fwd_slabs(flat, critic.fc1.weight, hpre)
+    _cabi.critic_head_fwd(hpre, critic.fc2.weight.reshape(hidden), critic.fc2.bias, n, n, n, inv_n, logits, h, dh, LEAK,
+                          b1=critic.fc1.bias)
+  else:
+    hpre = torch.addmm(critic.fc1.bias, flat, critic.fc1.weight.t())
+    _cabi.critic_head_fwd(hpre, critic.fc2.weight.reshape(hidden), critic.fc2.bias, n, n, n, inv_n, logits, h, dh, LEAK)
 
   # ---- backward of the three blocks at once (the interpolated block's upstream gradient is 1: the inner gradient) --
   gys = [None] * (len(convs) + 1)  # gys[l]: the gradient in front of layer l's activation (l = 1 .. L)
-  dz = torch.mm(dh, critic.fc1.weight)  # (3n, flat)
   gy = torch.empty_like(acts[-1])
-  _cabi.lrelu_bwd(acts[-1], dz.reshape(acts[-1].shape), gy, LEAK)
+  if split:
+    _cabi.fc_bwd_data_mask(dh, critic.fc1.weight, acts[-1], gy, LEAK)  # (dh W) slope(z_L): GEMM + activation gradient
+  else:
+    dz = torch.mm(dh, critic.fc1.weight)  # (3n, flat)
+    _cabi.lrelu_bwd(acts[-1], dz.reshape(acts[-1].shape), gy, LEAK)
   gys[len(convs)] = gy
   for l in range(len(convs), 1, -1):
     below = acts[l - 1]
@@ -151,7 +168,12 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
   for l, conv in enumerate(convs, start=1):
     zi = acts[l][2 * n:]
     _cabi.conv4x4s2_fwd_mask(acts[l - 1][2 * n:], conv.weight, zi, zi, LEAK)
-  thpre = torch.mm(acts[-1][2 * n:].reshape(n, critic.flat), critic.fc1.weight.t())  # (n, hidden)
+  tflat = acts[-1][2 * n:].reshape(n, critic.flat)
+  if split:
+    thpre = torch.empty((_cabi.fc_fwd_slabs_count(n, critic.flat), n, hidden), **f32)
+    _cabi.fc_fwd_slabs(tflat, critic.fc1.weight, thpre)
+  else:
+    thpre = torch.mm(tflat, critic.fc1.weight.t())  # (n, hidden)
 
   # ---- gradients: one launch per layer over [loss rows | penalty rows] -----------------------------------------------
   _cabi.conv4x4s2_wrw_group([(acts[l - 1], gys[l], grads[id(conv.weight)], grads[id(conv.bias)], 2 * n)

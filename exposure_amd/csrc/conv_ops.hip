@@ -1431,11 +1431,197 @@ static int conv_wrw_impl(const float* x, const float* dy, float* dw, float* dbia
   return EXPO_OK;
 }
 
+// ---- the first FC layer behind the convolutions (critics.py:27-31, agent.py:33-35: `ly.fully_connected(flat, 128)`) -----
+// y = x W^T with x [M][K] (K = 4096 features of a 4 x 4 x 256 map), W [N][K] (N = 128): 0.2 GFLOP at M = 192 that the
+// library runs as one workgroup per 16 x 16 tile walking all of K -- 10 us whatever M is (profiles/r06_experiments.md),
+// 14 calls per training iteration.  Here K is SPLIT: a wave = one 32 x 32 tile over K / (4 S) features (16-byte operand
+// loads like the flat convolution: lane l -> row l & 31, k = 8 c + 4 (l >> 5) ..), the four waves of a block meet in LDS,
+// and the S block partials leave as S slabs [S][M][N] that the consumer -- expo_critic_head_fwd / _bwd, which read the
+// pre-activation exactly once -- adds in slab order together with the bias.  No atomics, a fixed summation order.
+template <int CH>  // CH > 0: the wave's kw = 8 CH features are loaded in ONE burst (a single memory round trip); 0: any kw, pipelined
+__global__ __launch_bounds__(256) void fc_fwd_slabs_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ slabs, int m, int n, int k, int tiles_n,
+                                                           int kw) {
+  __shared__ __attribute__((aligned(16))) float part[4][16][64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int row = lane & 31, half = lane >> 5;
+  const int am = tm * 32 + row, bn = tn * 32 + row;
+  const bool a_ok = am < m, b_ok = bn < n;
+  const int k0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(sl)) * kw + 4 * half;
+  const int aoff = (a_ok ? am : 0) * k + k0, boff = (b_ok ? bn : 0) * k + k0;
+  const __amdgpu_buffer_rsrc_t rx = conv_rsrc(x, size_t(m) * k);
+  const __amdgpu_buffer_rsrc_t rw = conv_rsrc(w, size_t(n) * k);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  auto mma4 = [&](const float4& a, const float4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  };
+  if constexpr (CH > 0) {
+    float4 a[CH], b[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      a[c] = buf_load4(rx, aoff + c * 8, a_ok);
+      b[c] = buf_load4(rw, boff + c * 8, b_ok);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) mma4(a[c], b[c]);  // (the compiler waits chunk by chunk: vmcnt counts down in issue order)
+  } else {
+    constexpr int U = 4;  // chunks of 8 k per group; the next group's loads are in flight under this group's MFMAs
+    const int groups = kw / (8 * U);
+    float4 ac[U], bc[U], an[U], bnx[U];
+    auto load_group = [&](int g, float4 (&a)[U], float4 (&b)[U]) {
+      const bool in = g < groups;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a[u] = buf_load4(rx, aoff + (g * U + u) * 8, a_ok && in);
+        b[u] = buf_load4(rw, boff + (g * U + u) * 8, b_ok && in);
+      }
+    };
+    load_group(0, ac, bc);
+    for (int g = 0; g < groups; ++g) {
+      load_group(g + 1, an, bnx);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) mma4(ac[u], bc[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) ac[u] = an[u], bc[u] = bnx[u];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) part[sl][e][lane] = acc[e];
+  __syncthreads();
+  // wave sl adds accumulator slots 4 sl .. 4 sl + 3 of the four waves (in wave order) and stores them: slot e of lane l is
+  // row (e & 3) + 8 (e >> 2) + 4 (l >> 5), column l & 31 of the tile -- 32 lanes write 128 contiguous bytes
+  const __amdgpu_buffer_rsrc_t ry = conv_rsrc(slabs + size_t(blockIdx.y) * m * n, size_t(m) * n);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = 4 * sl + j;
+    const float v = ((part[0][e][lane] + part[1][e][lane]) + part[2][e][lane]) + part[3][e][lane];
+    const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half, col = tn * 32 + row;
+    buf_store1(ry, mo * n + col, mo < m && col < n, v);
+  }
+}
+
+// Its data gradient with the activation gradient of the layer below in the epilogue (the convolutions' pattern):
+//   gy[m][c] = (sum_j dh[m][j] W[j][c]) slope(z[m][c]),   dh [M][J] (J = 128), W [J][C] (C = 4096), z the top feature map.
+// A wave = one 32 x 32 tile over all of J: A fragments are 16-byte loads of dh rows, B fragments dword loads of W rows (32
+// lanes cover 128 contiguous bytes of row j = 8 c + 4 (l >> 5) + i).  The library's GEMM + the separate lrelu_bwd launch
+// took 10 + 4.4 us at M = 192.
+__global__ __launch_bounds__(256) void fc_bwd_data_mask_kernel(const float* __restrict__ dh, const float* __restrict__ w,
+                                                               const float* __restrict__ z, float* __restrict__ gy, int m,
+                                                               int jdim, int c, int tiles_c, float leak) {
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(sl);
+  const int tm = tile / tiles_c, tc = tile - tm * tiles_c;  // (the four waves of a block: neighbouring column tiles, same dh rows)
+  const int row = lane & 31, half = lane >> 5;
+  const int am = tm * 32 + row, col = tc * 32 + row;
+  const bool a_ok = am < m, c_ok = col < c;
+  const __amdgpu_buffer_rsrc_t ra = conv_rsrc(dh, size_t(m) * jdim);
+  const __amdgpu_buffer_rsrc_t rw = conv_rsrc(w, size_t(jdim) * c);
+  const int aoff = (a_ok ? am : 0) * jdim + 4 * half, boff = 4 * half * c + (c_ok ? col : 0);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  constexpr int U = 2;
+  const int groups = jdim / (8 * U);
+  float4 ac[U], an[U];
+  float bc[U][4], bnx[U][4];
+  auto load_group = [&](int g, float4 (&a)[U], float (&b)[U][4]) {
+    const bool in = g < groups;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ch = g * U + u;
+      a[u] = buf_load4(ra, aoff + ch * 8, a_ok && in);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[u][i] = buf_load1(rw, boff + (ch * 8 + i) * c, c_ok && in);
+    }
+  };
+  load_group(0, ac, bc);
+  for (int g = 0; g < groups; ++g) {
+    load_group(g + 1, an, bnx);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].x, bc[u][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].y, bc[u][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].z, bc[u][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].w, bc[u][3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ac[u] = an[u];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bc[u][i] = bnx[u][i];
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rz = conv_rsrc(z, size_t(m) * c);
+  const __amdgpu_buffer_rsrc_t ry = conv_rsrc(gy, size_t(m) * c);
+  float zv[16];
+  int off[16];
+  bool ok[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int mo = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+    ok[e] = mo < m && c_ok;
+    off[e] = mo * c + col;
+    zv[e] = buf_load1(rz, off[e], ok[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) buf_store1(ry, off[e], ok[e], acc[e] * lrelu_slope_v(zv[e], leak));
+}
+
 }  // namespace expo
 
 using namespace expo;
 
 extern "C" {
+
+int expo_fc_fwd_slabs_count(int m, int k) {
+  if (m <= 0 || k <= 0) return 0;
+  int s = (m + 31) / 32 >= 6 ? 8 : 16;  // ~200 blocks of four waves for 128 columns
+  while (s >= 1 && k % (128 * s) != 0) s >>= 1;  // a wave walks whole groups of 32 features
+  return s;
+}
+
+int expo_fc_fwd_slabs(const float* x, const float* w, float* slabs, int m, int n, int k, void* stream) {
+  if (m < 0 || n <= 0 || k <= 0) return fail(EXPO_E_BADARG, "fc_fwd_slabs: m >= 0, n > 0, k > 0 required");
+  if (m == 0) return EXPO_OK;
+  if (!x || !w || !slabs) return fail(EXPO_E_BADARG, "null pointer");
+  const int s = expo_fc_fwd_slabs_count(m, k);
+  if (s == 0) return fail(EXPO_E_BADARG, "fc_fwd_slabs: k must be a multiple of 128 (whole groups of 32 features per wave)");
+  if (size_t(m) * k >= (1ull << 29) || size_t(n) * k >= (1ull << 29) || size_t(m) * n >= (1ull << 29))
+    return fail(EXPO_E_BADARG, "fc_fwd_slabs: operands of at most 2 GiB");
+  const int tiles_m = (m + 31) / 32, tiles_n = (n + 31) / 32;
+  const int kw = k / (s * 4);
+  const dim3 grid(tiles_m * tiles_n, s);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (kw == 128) hipLaunchKernelGGL(fc_fwd_slabs_kernel<16>, grid, dim3(256), 0, st, x, w, slabs, m, n, k, tiles_n, kw);
+  else if (kw == 64) hipLaunchKernelGGL(fc_fwd_slabs_kernel<8>, grid, dim3(256), 0, st, x, w, slabs, m, n, k, tiles_n, kw);
+  else if (kw == 32) hipLaunchKernelGGL(fc_fwd_slabs_kernel<4>, grid, dim3(256), 0, st, x, w, slabs, m, n, k, tiles_n, kw);
+  else hipLaunchKernelGGL(fc_fwd_slabs_kernel<0>, grid, dim3(256), 0, st, x, w, slabs, m, n, k, tiles_n, kw);
+  HIP_TRY(hipGetLastError(), "fc_fwd_slabs launch");
+  return EXPO_OK;
+}
+
+int expo_fc_bwd_data_mask(const float* dh, const float* w, const float* z, float* gy, int m, int j, int c, float leak,
+                          void* stream) {
+  if (m < 0 || j <= 0 || c <= 0) return fail(EXPO_E_BADARG, "fc_bwd_data_mask: m >= 0, j > 0, c > 0 required");
+  if (m == 0) return EXPO_OK;
+  if (!dh || !w || !z || !gy) return fail(EXPO_E_BADARG, "null pointer");
+  if (j % 16 != 0) return fail(EXPO_E_BADARG, "fc_bwd_data_mask: the hidden width must be a multiple of 16");
+  if (size_t(m) * c >= (1ull << 29) || size_t(j) * c >= (1ull << 29)) return fail(EXPO_E_BADARG, "fc_bwd_data_mask: operands of at most 2 GiB");
+  const int tiles_m = (m + 31) / 32, tiles_c = (c + 31) / 32;
+  if (tiles_c % 4 != 0) return fail(EXPO_E_BADARG, "fc_bwd_data_mask: the feature count must be a multiple of 128");
+  hipLaunchKernelGGL(fc_bwd_data_mask_kernel, dim3(tiles_m * tiles_c / 4), dim3(256), 0, static_cast<hipStream_t>(stream), dh, w, z,
+                     gy, m, j, c, tiles_c, leak);
+  HIP_TRY(hipGetLastError(), "fc_bwd_data_mask launch");
+  return EXPO_OK;
+}
 
 int expo_conv4x4s2_fwd(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cin,
                        int cout, int act, float leak, void* stream) {

@@ -33,19 +33,27 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // 16 waves per block, one row each.  Row order of the batch: [real | fake | interpolated].
-__global__ __launch_bounds__(1024) void critic_head_fwd_kernel(const float* __restrict__ hpre, const float* __restrict__ w2,
+// hpre arrives as `slabs` partial sums [slabs][rows][hidden] (expo_fc_fwd_slabs: fc1 with its K dimension split) that are
+// added here in slab order, then b1 (nullable: already inside a single slab, the library GEMM's addmm).
+__global__ __launch_bounds__(1024) void critic_head_fwd_kernel(const float* __restrict__ hpre, const float* __restrict__ b1,
+                                                               int slabs, const float* __restrict__ w2,
                                                                const float* __restrict__ b2, int n_real, int n_fake,
                                                                int n_interp, int hidden, float inv_n, float leak,
                                                                float* __restrict__ logits, float* __restrict__ h,
                                                                float* __restrict__ dh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rows = n_real + n_fake + n_interp;
-  const int m = blockIdx.x * 16 + wave;
+  const int m = blockIdx.x * 4 + wave;
   if (m >= rows) return;
   const float dl = m < n_real ? -inv_n : (m < n_real + n_fake ? inv_n : 1.0f);
   float dot = 0.f;
+  const size_t slab = size_t(rows) * hidden;
   for (int j = lane; j < hidden; j += 64) {
-    const float z = cs_lrelu(hpre[size_t(m) * hidden + j], leak);
+    float pre = hpre[size_t(m) * hidden + j];
+#pragma unroll 8
+    for (int s = 1; s < slabs; ++s) pre += hpre[s * slab + size_t(m) * hidden + j];
+    if (b1) pre += b1[j];
+    const float z = cs_lrelu(pre, leak);
     const float wj = w2[j];
     h[size_t(m) * hidden + j] = z;
     dh[size_t(m) * hidden + j] = dl * wj * cs_slope(z, leak);
@@ -82,41 +90,52 @@ __global__ __launch_bounds__(64) void critic_report_kernel(const float* __restri
 }
 
 // gb1[j] = sum over the loss rows of dh; gw2[j] = sum over the loss rows of dlogit h + sum over the interpolated rows of
-// thpre slope(h); gb2 = sum of dlogit.  1024 threads = 8 row groups x 128 columns (hidden <= 128 per pass), LDS-reduced in
-// group order.
+// thpre slope(h); gb2 = sum of dlogit.  thpre arrives as `th_slabs` partial sums [th_slabs][n_interp][hidden]
+// (expo_fc_fwd_slabs), added in slab order.  A block = 16 columns x G row groups (G <= 64), the groups' sums added in a
+// fixed tree through LDS (round 6: one block of 8 row groups x 128 columns walked 24 dependent rows and added the groups one
+// after the other -- 9 us for 192 rows).  G is the largest power of two that divides the real block when the real and fake
+// blocks are equally long: group g then holds real row g + i G next to fake row g + i G, whose gradients -w2 s / n and
+// +w2 s' / n cancel EXACTLY where the two slopes agree -- the bias gradient of a unit is often exactly zero, and Adam turns
+// a rounding-level residue there into a full +-lr step.
 __global__ __launch_bounds__(1024) void critic_head_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ h,
-                                                               const float* __restrict__ thpre, int n_real, int n_fake,
-                                                               int n_interp, int hidden, float inv_n, float leak,
-                                                               float* __restrict__ gb1, float* __restrict__ gw2,
+                                                               const float* __restrict__ thpre, int th_slabs, int n_real,
+                                                               int n_fake, int n_interp, int hidden, int groups, float inv_n,
+                                                               float leak, float* __restrict__ gb1, float* __restrict__ gw2,
                                                                float* __restrict__ gb2) {
-  __shared__ float p1[8][128], p2[8][128];
-  const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
+  __shared__ float p1[64][17], p2[64][17];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int n_loss = n_real + n_fake;
-  for (int j0 = 0; j0 < hidden; j0 += 128) {
-    const int j = j0 + col;
-    float s1 = 0.f, s2 = 0.f;
-    if (j < hidden) {
-      for (int m = grp; m < n_loss; m += 8) {
-        const float dl = m < n_real ? -inv_n : inv_n;
-        s1 += dh[size_t(m) * hidden + j];
-        s2 = fmaf(dl, h[size_t(m) * hidden + j], s2);
-      }
-      for (int m = grp; m < n_interp; m += 8)
-        s2 = fmaf(thpre[size_t(m) * hidden + j], cs_slope(h[size_t(n_loss + m) * hidden + j], leak), s2);
+  const int j = blockIdx.x * 16 + col;
+  const size_t slab = size_t(n_interp) * hidden;
+  float s1 = 0.f, s2 = 0.f;
+  if (j < hidden && grp < groups) {
+    for (int m = grp; m < n_loss; m += groups) {
+      const float dl = m < n_real ? -inv_n : inv_n;
+      s1 += dh[size_t(m) * hidden + j];
+      s2 = fmaf(dl, h[size_t(m) * hidden + j], s2);
     }
-    p1[grp][col] = s1;
-    p2[grp][col] = s2;
-    __syncthreads();
-    if (grp == 0 && j < hidden) {
-      float a = p1[0][col], b = p2[0][col];
-#pragma unroll
-      for (int g = 1; g < 8; ++g) { a += p1[g][col]; b += p2[g][col]; }
-      gb1[j] = a;
-      gw2[j] = b;
+    for (int m = grp; m < n_interp; m += groups) {
+      float t = thpre[size_t(m) * hidden + j];
+#pragma unroll 8
+      for (int s = 1; s < th_slabs; ++s) t += thpre[s * slab + size_t(m) * hidden + j];
+      s2 = fmaf(t, cs_slope(h[size_t(n_loss + m) * hidden + j], leak), s2);
+    }
+  }
+  p1[grp][col] = s1;
+  p2[grp][col] = s2;
+  __syncthreads();
+  for (int stride = 32; stride > 0; stride >>= 1) {  // (groups beyond `groups` hold zeros)
+    if (grp < stride) {
+      p1[grp][col] += p1[grp + stride][col];
+      p2[grp][col] += p2[grp + stride][col];
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) gb2[0] = float(n_fake) * inv_n - float(n_real) * inv_n;
+  if (grp == 0 && j < hidden) {
+    gb1[j] = p1[0][col];
+    gw2[j] = p2[0][col];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) gb2[0] = float(n_fake) * inv_n - float(n_real) * inv_n;
 }
 
 // sums[n][c - c0] = sum over the pixels of x[n][p][c], c0 <= c < ct: one block per image, block-reduced in a fixed order
@@ -196,14 +215,15 @@ using namespace expo;
 
 extern "C" {
 
-int expo_critic_head_fwd(const float* hpre, const float* w2, const float* b2, int n_real, int n_fake, int n_interp,
-                         int hidden, float inv_n, float leak, float* logits, float* h, float* dh, void* stream) {
+int expo_critic_head_fwd(const float* hpre, const float* b1, int slabs, const float* w2, const float* b2, int n_real, int n_fake,
+                         int n_interp, int hidden, float inv_n, float leak, float* logits, float* h, float* dh, void* stream) {
   if (n_real < 0 || n_fake < 0 || n_interp < 0 || hidden < 1) return fail(EXPO_E_BADARG, "row counts >= 0, hidden >= 1 required");
+  if (slabs < 1 || slabs > 64) return fail(EXPO_E_BADARG, "critic_head_fwd: 1 <= slabs <= 64");
   const int rows = n_real + n_fake + n_interp;
   if (rows == 0) return EXPO_OK;
   if (!hpre || !w2 || !b2 || !logits || !h || !dh) return fail(EXPO_E_BADARG, "null pointer");
-  hipLaunchKernelGGL(critic_head_fwd_kernel, dim3(unsigned((rows + 15) / 16)), dim3(1024), 0, static_cast<hipStream_t>(stream),
-                     hpre, w2, b2, n_real, n_fake, n_interp, hidden, inv_n, leak, logits, h, dh);
+  hipLaunchKernelGGL(critic_head_fwd_kernel, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     hpre, b1, slabs, w2, b2, n_real, n_fake, n_interp, hidden, inv_n, leak, logits, h, dh);
   HIP_TRY(hipGetLastError(), "critic_head_fwd launch");
   return EXPO_OK;
 }
@@ -218,12 +238,16 @@ int expo_critic_report(const float* logits, const float* norm, const float* term
   return EXPO_OK;
 }
 
-int expo_critic_head_bwd(const float* dh, const float* h, const float* thpre, int n_real, int n_fake, int n_interp,
+int expo_critic_head_bwd(const float* dh, const float* h, const float* thpre, int th_slabs, int n_real, int n_fake, int n_interp,
                          int hidden, float inv_n, float leak, float* gb1, float* gw2, float* gb2, void* stream) {
   if (n_real < 0 || n_fake < 0 || n_interp < 0 || hidden < 1) return fail(EXPO_E_BADARG, "row counts >= 0, hidden >= 1 required");
+  if (th_slabs < 1 || th_slabs > 64) return fail(EXPO_E_BADARG, "critic_head_bwd: 1 <= th_slabs <= 64");
   if (!dh || !h || (n_interp > 0 && !thpre) || !gb1 || !gw2 || !gb2) return fail(EXPO_E_BADARG, "null pointer");
-  hipLaunchKernelGGL(critic_head_bwd_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), dh, h, thpre, n_real,
-                     n_fake, n_interp, hidden, inv_n, leak, gb1, gw2, gb2);
+  int groups = 64;  // row groups per block: see the kernel
+  if (n_real > 0 && n_real == n_fake)
+    while (groups > 1 && n_real % groups != 0) groups >>= 1;
+  hipLaunchKernelGGL(critic_head_bwd_kernel, dim3(unsigned((hidden + 15) / 16)), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     dh, h, thpre, th_slabs, n_real, n_fake, n_interp, hidden, groups, inv_n, leak, gb1, gw2, gb2);
   HIP_TRY(hipGetLastError(), "critic_head_bwd launch");
   return EXPO_OK;
 }

@@ -25,6 +25,7 @@ here.  ``tests/test_generator_direct.py`` holds losses, outputs and every gradie
 import torch
 
 from . import _cabi
+from .critic_direct import fc_split
 from .nn_ops import once_differentiable_convnets
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
 
@@ -88,14 +89,19 @@ class _PairPass:
       _cabi.conv4x4s2_fwd(a, conv.weight, conv.bias, z, 1, LEAK)
       self.acts.append(z)
     self.flat = self.acts[-1].reshape(m, net.flat)
-    hpre = torch.addmm(net.fc1.bias, self.flat, net.fc1.weight.t())
-    self.hidden = hpre.shape[1]
+    self.hidden = net.fc1.weight.shape[0]
     self.logits = torch.empty((m,), **f32)
-    self.h, self.dh_unit = torch.empty_like(hpre), torch.empty_like(hpre)
+    self.h, self.dh_unit = torch.empty((m, self.hidden), **f32), torch.empty((m, self.hidden), **f32)
     # every row as an "interpolated" row: upstream gradient 1, i.e. dh_unit = w2 * slope(h) -- scaled by the rows' real
     # upstream gradients once the loss kernel has produced them
+    self.split = fc_split(net.fc1, m)  # fc1 with its K dimension split: the head kernel adds the slabs
+    if self.split:
+      hpre = torch.empty((_cabi.fc_fwd_slabs_count(m, net.flat), m, self.hidden), **f32)
+      _cabi.fc_fwd_slabs(self.flat, net.fc1.weight, hpre)
+    else:
+      hpre = torch.addmm(net.fc1.bias, self.flat, net.fc1.weight.t())
     _cabi.critic_head_fwd(hpre, net.fc2.weight.reshape(self.hidden), net.fc2.bias, 0, 0, m, 1.0, self.logits, self.h,
-                          self.dh_unit, LEAK)
+                          self.dh_unit, LEAK, b1=net.fc1.bias if self.split else None)
 
   def backward(self, dlogit, rows, rows_x, grads=None, rows_w=None):
     """``dlogit`` the upstream gradients of the logits of ``rows``, the row range the backward covers (a slice); ``rows_x``
@@ -105,10 +111,13 @@ class _PairPass:
     lo = rows.start
     rel = lambda sl: slice(sl.start - lo, sl.stop - lo)
     dh = self.dh_unit[rows] * dlogit[:, None]
-    dz = torch.mm(dh, net.fc1.weight)
     top = self.acts[-1][rows]
     gy = torch.empty_like(top)
-    _cabi.lrelu_bwd(top, dz.reshape(top.shape), gy, LEAK)
+    if self.split:
+      _cabi.fc_bwd_data_mask(dh, net.fc1.weight, top, gy, LEAK)
+    else:
+      dz = torch.mm(dh, net.fc1.weight)
+      _cabi.lrelu_bwd(top, dz.reshape(top.shape), gy, LEAK)
     gys = [None] * (len(convs) + 1)
     gys[len(convs)] = gy
     for l in range(len(convs), 1, -1):

@@ -48,11 +48,12 @@
 extern "C" {
 #endif
 
-#define EXPO_ABI_VERSION 6 /* 2: caller-owned reduction workspace (no float atomics, no fills); 3: derivatives of the
+#define EXPO_ABI_VERSION 7 /* 2: caller-owned reduction workspace (no float atomics, no fills); 3: derivatives of the
                               critic statistics and of the penalty, VignetFilter, bias + lrelu, masked per-image dispatch;
                               4: Tone / Color curves of any cfg.curve_steps (expo_curve_*); 5: the convnets' convolution
                               (expo_conv4x4s2_*); 6: its mask / bias variants, the hand-scheduled critic update's
-                              kernels, expo_build_info */
+                              kernels, expo_build_info; 7: expo_net_inputs, the first FC layer with its K dimension split
+                              (expo_fc_*; expo_critic_head_fwd / _bwd take the partial sums) */
 
 #define EXPO_OK 0
 #define EXPO_E_BADARG (-1)
@@ -619,8 +620,9 @@ int expo_conv_tuning(int tile, int nt, int slices);
  * net.py:126-199, 245-251: c_loss = mean(D(fake) - D(real)) + lambda mean(max(||grad_x^ D(x^)|| - 1, 0)^2).  The real,
  * fake and interpolated images run as ONE batch [real | fake | interpolated] through critics.py:42-98; the kernels
  * below are the per-row / per-image reductions between its convolutions and GEMMs.  Fixed summation orders.
- *   expo_critic_head_fwd  hpre float32 [M][hidden] = fc1's pre-activation (critics.py:94-96), M = n_real + n_fake +
- *                         n_interp rows.  h = lrelu(hpre); logits[m] = h[m] . w2 + b2 (critics.py:97);
+ *   expo_critic_head_fwd  hpre float32 [slabs][M][hidden]: fc1's pre-activation (critics.py:94-96) as `slabs` partial sums
+ *                         (expo_fc_fwd_slabs; 1 = the finished GEMM) added here in slab order, + b1 (nullable: already
+ *                         inside), M = n_real + n_fake + n_interp rows.  h = lrelu(hpre); logits[m] = h[m] . w2 + b2 (critics.py:97);
  *                         dh[m] = dlogit[m] w2 slope(h[m]) with dlogit = -inv_n (real), +inv_n (fake), 1 (interpolated:
  *                         the inner gradient starts from ones, net.py:174-183)
  *   expo_critic_report    out[0..4] = {c_loss = mean fake - mean real + lambda mean term, emd = mean real - mean fake, mean
@@ -628,8 +630,8 @@ int expo_conv_tuning(int tile, int nt, int slices);
  *                         [real | fake | interpolated] and the per-image norm / term; ema (nullable, device float) advances
  *                         as ema += (1 - decay) (c_average - ema) (update_average, net.py:165-168, 267-268)
  *   expo_critic_head_bwd  gb1 = sum over the real + fake rows of dh;  gw2 = sum over those rows of dlogit h + sum over
- *                         the interpolated rows of thpre slope(h) (thpre float32 [n_interp][hidden]: the penalty's
- *                         tangent in front of fc1's activation);  gb2 = sum of dlogit
+ *                         the interpolated rows of thpre slope(h) (thpre float32 [th_slabs][n_interp][hidden]: the penalty's
+ *                         tangent in front of fc1's activation, as partial sums like hpre);  gb2 = sum of dlogit
  *   expo_plane_sums       sums[n][c - first] = sum over the pixels of x[n][.][c], first <= c < channels (<= 16 planes):
  *                         the gradient reaching the per-image values planes_concat broadcast (critics.py:64-76)
  *   expo_gp_direct        g = u[..., 0:3] + ds (u float32 [n][pixels][u_channels], ds [n][pixels][3]);
@@ -641,12 +643,28 @@ int expo_conv_tuning(int tile, int nt, int slices);
  *                         g = u[..., 0:3] + J^T gs (expo_critic_stats_bwd);  norm, term as expo_gp_direct;
  *                         v = scale 2 max(norm - 1, 0) / norm g;  t0 [n][h w][6] = [v | J v broadcast]
  *                         (expo_critic_stats_jvp + expo_planes_concat with offset 0): the tangent's input */
-int expo_critic_head_fwd(const float* hpre, const float* w2, const float* b2, int n_real, int n_fake, int n_interp,
-                         int hidden, float inv_n, float leak, float* logits, float* h, float* dh, void* stream);
+int expo_critic_head_fwd(const float* hpre, const float* b1, int slabs, const float* w2, const float* b2, int n_real, int n_fake,
+                         int n_interp, int hidden, float inv_n, float leak, float* logits, float* h, float* dh, void* stream);
 int expo_critic_report(const float* logits, const float* norm, const float* term, int n_real, int n_fake, int n_interp,
                        float lambda, float decay, float* out, float* ema, void* stream);
-int expo_critic_head_bwd(const float* dh, const float* h, const float* thpre, int n_real, int n_fake, int n_interp,
-                         int hidden, float inv_n, float leak, float* gb1, float* gw2, float* gb2, void* stream);
+int expo_critic_head_bwd(const float* dh, const float* h, const float* thpre, int th_slabs, int n_real, int n_fake,
+                         int n_interp, int hidden, float inv_n, float leak, float* gb1, float* gw2, float* gb2, void* stream);
+
+/* ---- the first FC layer behind a convnet (critics.py:27-31 / agent.py:33-35: ly.fully_connected(flat, 128)) in the
+ * hand-scheduled passes: the library GEMM takes ~10 us for it whatever the batch is (one workgroup per 16 x 16 tile walks
+ * K = 4096), 14 calls per training iteration.
+ *   expo_fc_fwd_slabs_count  S = the number of partial sums expo_fc_fwd_slabs writes for M rows of K features (0: K is not
+ *                         a multiple of 128 -- use the library GEMM)
+ *   expo_fc_fwd_slabs     slabs float32 [S][M][N]: slab s = x[:, K_s] w[:, K_s]^T over the s-th of S ranges of K (x float32
+ *                         [M][K], w float32 [N][K] = nn.Linear's weight).  Their sum in slab order (+ bias) is the
+ *                         pre-activation; expo_critic_head_fwd / _bwd add them while they read it.  Fixed summation order.
+ *   expo_fc_bwd_data_mask gy float32 [M][C] = (dh w) slope(z): the layer's data gradient (dh float32 [M][J], w float32
+ *                         [J][C], J % 16 == 0, C % 128 == 0) times the activation gradient of the feature map z [M][C] below
+ *                         it (util.py:225-229; TF's sub-gradient at 0) -- torch.mm + expo_lrelu_bwd in one launch */
+int expo_fc_fwd_slabs_count(int m, int k);
+int expo_fc_fwd_slabs(const float* x, const float* w, float* slabs, int m, int n, int k, void* stream);
+int expo_fc_bwd_data_mask(const float* dh, const float* w, const float* z, float* gy, int m, int j, int c, float leak,
+                          void* stream);
 int expo_plane_sums(const float* x, float* sums, int n, size_t pixels_per_image, int channels, int first, void* stream);
 int expo_gp_direct(const float* u, int u_channels, const float* ds, float scale, float* v, float* norm, float* term, int n,
                    size_t pixels_per_image, void* stream);

@@ -452,3 +452,51 @@ def test_net_inputs_equals_its_four_launch_composition(shape, v0, interp, rows, 
   assert bool(((stats2.double().cpu() - ref).abs() <= tol).all()), (stats2.double().cpu() - ref).abs().max(0).values
   assert bool(((stats2 - stats).abs().cpu() <= tol.float()).all())
   assert torch.equal(planes[..., 3 + v0:], (stats2 - 0.5)[:, None, None, :].expand(m, h, w, 3))
+
+
+@pytest.mark.parametrize('m,n,k', [(192, 128, 4096), (64, 128, 4096), (128, 128, 4096), (37, 96, 1024), (5, 32, 128), (200, 128, 384)])
+def test_fc_layer_with_its_features_split_and_its_data_gradient(m, n, k, gpu_device):
+  """expo_fc_fwd_slabs: the slabs' sum == x w^T (float64) and the head kernels that consume them equal the head kernels on
+  the finished pre-activation; expo_fc_bwd_data_mask == (dh w) slope(z) (float64)."""
+  from exposure_amd import _cabi
+  dev = gpu_device
+  g = torch.Generator(device=dev).manual_seed(m + k)
+  x = torch.randn((m, k), device=dev, generator=g)
+  w = torch.randn((n, k), device=dev, generator=g) / k**0.5
+  b1 = torch.randn((n,), device=dev, generator=g)
+  s = _cabi.fc_fwd_slabs_count(m, k)
+  assert s >= 1 and k % (128 * s) == 0
+  assert _cabi.fc_fwd_slabs_count(m, 4000) == 0
+  slabs = torch.full((s, m, n), float('nan'), device=dev)
+  _cabi.fc_fwd_slabs(x, w, slabs)
+  want = x.double() @ w.double().t()
+  assert float((slabs.double().sum(0) - want).abs().max()) <= 2e-6 * float(want.abs().max()) * (k / 128)**0.5
+  # the consumers: slabs + b1 against the finished pre-activation
+  hpre = (slabs.double().sum(0) + b1.double()).float()
+  w2, b2 = torch.randn((n,), device=dev, generator=g), torch.randn((1,), device=dev, generator=g)
+  nr = nf = m // 3
+  ni = m - nr - nf
+  outs = []
+  for src, kw in ((hpre, {}), (slabs, dict(b1=b1))):
+    logits, h, dh = torch.empty((m,), device=dev), torch.empty((m, n), device=dev), torch.empty((m, n), device=dev)
+    _cabi.critic_head_fwd(src, w2, b2, nr, nf, ni, 1.0 / max(nr, 1), logits, h, dh, **kw)
+    outs.append((logits, h, dh))
+  for a, b in zip(*outs):
+    assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+  th = torch.randn((s, ni, n), device=dev, generator=g)
+  res = []
+  for src in (th.double().sum(0).float().contiguous(), th):
+    gb1, gw2, gb2 = (torch.full((q,), float('nan'), device=dev) for q in (n, n, 1))
+    _cabi.critic_head_bwd(outs[0][2], outs[0][1], src, nr, nf, ni, 1.0 / max(nr, 1), gb1, gw2, gb2)
+    res.append((gb1, gw2, gb2))
+  for a, b in zip(*res):
+    assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+  # data gradient with the activation gradient of the map below (z with exact zeros and negative values)
+  if n % 16 == 0 and k % 128 == 0:
+    dh = torch.randn((m, n), device=dev, generator=g)
+    z = torch.randn((m, k), device=dev, generator=g)
+    z.view(-1)[::7] = 0.0
+    gy = torch.full((m, k), float('nan'), device=dev)
+    _cabi.fc_bwd_data_mask(dh, w, z, gy)
+    want = (dh.double() @ w.double()) * _slope(z).double()
+    assert float((gy.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) * (n / 16)**0.5
