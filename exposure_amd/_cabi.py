@@ -61,7 +61,7 @@ SIGNATURES = {
                                       ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),
                                       ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_vp), ctypes.POINTER(_sz), _vp]),
     'expo_critic_head_fwd': (_i, [_fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
-    'expo_critic_report': (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _f, _fp, _fp, _vp]),
+    'expo_critic_report': (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
     'expo_critic_head_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _f, _fp, _fp, _fp, _vp]),
     'expo_fc_fwd_slabs_count': (_i, [_i, _i]),
     'expo_fc_fwd_slabs': (_i, [_fp, _fp, _fp, _i, _i, _i, _vp]),
@@ -94,9 +94,9 @@ SIGNATURES = {
     'expo_agent_select_fwd': (_i, [_fp, _fp, _i, _fp, _fp, ctypes.POINTER(_f), _i, _i, _i, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _i, _vp]),
     'expo_agent_select_bwd': (_i, [_fp, _vp, _fp, ctypes.POINTER(_f), _i, _i, _fp, _fp, _fp, _i, _vp]),
     'expo_planes_concat': (_i, [_vp, _fp, _fp, _i, _sz, _i, _i, _f, _vp]),
-    'expo_generator_losses': (_i, [_fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, ctypes.POINTER(_f), _i, _fp, _fp, _fp, _fp, _i, _vp]),
+    'expo_generator_losses': (_i, [_fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, ctypes.POINTER(_f), _i, _fp, _fp, _fp, _fp, _i, _fp, _fp, _vp]),
     'expo_adam_step': (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
-                           ctypes.POINTER(_sz), _fp, _fp, _vp, _f, _f, _f, _vp]),
+                           ctypes.POINTER(_sz), _fp, _fp, _vp, _f, _f, _f, _i, _vp]),
     'expo_gp_inputs': (_i, [_vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
     'expo_net_inputs': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_gp_inputs_rows': (_i, [_vp, _vp, _vp, _vp, _fp, _fp, _fp, _i, _sz, _i, _vp]),
@@ -711,9 +711,11 @@ def agent_select_bwd(logits, selected, progress, consts, state_dim, d_surrogate,
                                      _ptr(d_penalty_base), _ptr(d_logits), n, _stream()), 'expo_agent_select_bwd')
 
 
-def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, ticket, beta1, beta2, eps):
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, ticket, beta1, beta2, eps, step_advanced=False):
   """One Adam update of the listed fp32 tensors (expo_adam_step).  Tensor j of the four lists must share one element
-  order (same sizes and strides, dense); ``lr`` / ``step`` are device floats, ``ticket`` a device int32 (zero)."""
+  order (same sizes and strides, dense); ``lr`` / ``step`` are device floats, ``ticket`` a device int32 (zero).
+  ``step_advanced``: a kernel in front of this update has moved ``step`` already (``critic_report`` / ``generator_losses``
+  with ``adam_step(s)``): the update computes with t = step and launches no advance behind it."""
   lib = load()
   count = len(params)
   assert len(grads) == count and len(exp_avg) == count and len(exp_avg_sq) == count
@@ -731,7 +733,13 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, ticket, beta1, beta2
   numel = (_sz * count)(*[t.numel() for t in params])
   with torch.cuda.device(dev):
     _check(lib.expo_adam_step(count, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, _ptr(lr), _ptr(step),
-                              _ptr(ticket), float(beta1), float(beta2), float(eps), _stream()), 'expo_adam_step')
+                              _ptr(ticket), float(beta1), float(beta2), float(eps), 1 if step_advanced else 0, _stream()),
+           'expo_adam_step')
+
+
+def _step_scalar(t):
+  assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1)
+  return t
 
 
 def planes_concat(images, vec, out, offset):
@@ -751,7 +759,7 @@ def planes_concat(images, vec, out, offset):
 
 
 def generator_losses(fake_logit, fake_input_logit, new_value, old_value, new_states, penalty, surrogate, consts, use_td,
-                     losses, reward, q_value, coef):
+                     losses, reward, q_value, coef, adam_steps=(None, None)):
   """expo_generator_losses: (g_loss, v_loss), reward, q and the five gradient coefficient rows of the G step's loss glue."""
   lib = load()
   n = fake_logit.numel()
@@ -764,7 +772,8 @@ def generator_losses(fake_logit, fake_input_logit, new_value, old_value, new_sta
   with torch.cuda.device(fake_logit.device):
     _check(lib.expo_generator_losses(_ptr(fake_logit), _ptr(fake_input_logit), _ptr(new_value), _ptr(old_value),
                                      _ptr(new_states), int(new_states.shape[1]), _ptr(penalty), _ptr(surrogate), c,
-                                     int(bool(use_td)), _ptr(losses), _ptr(reward), _ptr(q_value), _ptr(coef), n, _stream()),
+                                     int(bool(use_td)), _ptr(losses), _ptr(reward), _ptr(q_value), _ptr(coef), n,
+                                     _ptr(_step_scalar(adam_steps[0])), _ptr(_step_scalar(adam_steps[1])), _stream()),
            'expo_generator_losses')
 
 
@@ -1073,9 +1082,10 @@ def fc_bwd_data_mask(dh, w, z, gy, leak=0.2):
            'expo_fc_bwd_data_mask')
 
 
-def critic_report(logits, norm, term, n_real, n_fake, n_interp, lam, out, ema=None, decay=0.99):
+def critic_report(logits, norm, term, n_real, n_fake, n_interp, lam, out, ema=None, decay=0.99, adam_step=None):
   """expo_critic_report: out[0..4] = c_loss, emd, mean gradient norm, gradient penalty, c_average; ``ema`` (a device
-  scalar, optional) advances in the same launch."""
+  scalar, optional) advances in the same launch, and so does ``adam_step`` (the step counter of the Adam update behind this
+  launch: ``HipAdam.step(advanced=True)``)."""
   lib = load()
   _f32(logits, 'logits', (n_real + n_fake + n_interp,))
   _f32(norm, 'norm', (n_interp,)), _f32(term, 'term', (n_interp,))
@@ -1083,7 +1093,8 @@ def critic_report(logits, norm, term, n_real, n_fake, n_interp, lam, out, ema=No
   assert ema is None or (ema.is_cuda and ema.dtype == torch.float32 and ema.numel() == 1)
   with torch.cuda.device(logits.device):
     _check(lib.expo_critic_report(_ptr(logits), _ptr(norm), _ptr(term), int(n_real), int(n_fake), int(n_interp), float(lam),
-                                  float(decay), _ptr(out), _ptr(ema), _stream()), 'expo_critic_report')
+                                  float(decay), _ptr(out), _ptr(ema), _ptr(_step_scalar(adam_step)), _stream()),
+           'expo_critic_report')
 
 
 def critic_head_bwd(dh, h, thpre, n_real, n_fake, n_interp, inv_n, gb1, gw2, gb2, leak=0.2):

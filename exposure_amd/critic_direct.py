@@ -85,10 +85,11 @@ def _grad_targets(gan):
 
 
 @torch.no_grad()
-def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
+def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None, adam_step=None):
   """One evaluation of c_loss and of its gradient with respect to theta_c, written to ``p.grad`` of the critic's
   parameters.  -> the dict ``GAN.critic_losses`` returns (c_loss, emd, gradient_norm, gradient_penalty, c_average);
-  ``ema`` (a device scalar) is advanced by 0.01 (c_average - ema) in the reporting launch (net.py:165-168)."""
+  ``ema`` (a device scalar) is advanced by 0.01 (c_average - ema) in the reporting launch (net.py:165-168), ``adam_step`` (the
+  step counter of the update the caller runs next, ``HipAdam.step(advanced=True)``) by one."""
   cfg, critic = gan.cfg, gan.critic
   dev = real_data.device
   n = real_data.shape[0]
@@ -184,5 +185,5 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None):
 
   # ---- reported values (net.py:188-199) and, on one rank, the logit centre's moving average in the same launch ----
   rep = torch.empty((5,), **f32)
-  _cabi.critic_report(logits, norm, term, n, n, n, lam, rep, ema, 0.99)
+  _cabi.critic_report(logits, norm, term, n, n, n, lam, rep, ema, 0.99, adam_step=adam_step)
   return dict(c_loss=rep[0], emd=rep[1], gradient_norm=rep[2], gradient_penalty=rep[3], c_average=rep[4])

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(1024) void critic_head_fwd_kernel(const float* __re
 __global__ __launch_bounds__(64) void critic_report_kernel(const float* __restrict__ logits, const float* __restrict__ norm,
                                                            const float* __restrict__ term, int n_real, int n_fake,
                                                            int n_interp, float lambda, float decay, float* __restrict__ out,
-                                                           float* __restrict__ ema) {
+                                                           float* __restrict__ ema, float* __restrict__ adam_step) {
   const int lane = threadIdx.x;
   float sr = 0.f, sf = 0.f, sn = 0.f, st = 0.f;
   for (int m = lane; m < n_real; m += 64) sr += logits[m];
@@ -86,6 +86,7 @@ __global__ __launch_bounds__(64) void critic_report_kernel(const float* __restri
     out[3] = gp;
     out[4] = ca;
     if (ema) ema[0] = ema[0] + (1.0f - decay) * (ca - ema[0]);
+    if (adam_step) adam_step[0] = adam_step[0] + 1.0f;  // (the update behind this launch: expo_adam_step's step_advanced)
   }
 }
 
@@ -229,11 +230,11 @@ int expo_critic_head_fwd(const float* hpre, const float* b1, int slabs, const fl
 }
 
 int expo_critic_report(const float* logits, const float* norm, const float* term, int n_real, int n_fake, int n_interp,
-                       float lambda, float decay, float* out, float* ema, void* stream) {
+                       float lambda, float decay, float* out, float* ema, float* adam_step, void* stream) {
   if (n_real < 0 || n_fake < 0 || n_interp < 0) return fail(EXPO_E_BADARG, "row counts >= 0 required");
   if (!logits || !out || (n_interp > 0 && (!norm || !term))) return fail(EXPO_E_BADARG, "null pointer");
   hipLaunchKernelGGL(critic_report_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), logits, norm, term, n_real,
-                     n_fake, n_interp, lambda, decay, out, ema);
+                     n_fake, n_interp, lambda, decay, out, ema, adam_step);
   HIP_TRY(hipGetLastError(), "critic_report launch");
   return EXPO_OK;
 }

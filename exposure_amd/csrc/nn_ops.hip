@@ -441,10 +441,10 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, const float* __restrict__ lr, const float* __restrict__ step,
-                                                   float b1, float b2, float eps) {
+                                                   float b1, float b2, float eps, float step_add) {
   int t = 0;
   while (t + 1 < a.count && blockIdx.x >= a.first_block[t + 1]) ++t;  // uniform: scalar compares
-  const float st = step[0] + 1.0f;
+  const float st = step[0] + step_add;  // (1: the counter holds the steps taken so far; 0: the caller's previous kernel advanced it)
   const float bc1 = 1.0f - powf(b1, st), bc2 = 1.0f - powf(b2, st);
   const float step_size = lr[0] / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
   const unsigned n = a.n[t];
@@ -536,7 +536,8 @@ __global__ __launch_bounds__(256) void generator_losses_kernel(GLossArgs a, cons
                                                                const float* __restrict__ penalty,
                                                                const float* __restrict__ surrogate, float* __restrict__ losses,
                                                                float* __restrict__ reward_out, float* __restrict__ q_out,
-                                                               float* __restrict__ coef, int n) {
+                                                               float* __restrict__ coef, int n, float* __restrict__ adam_step_a,
+                                                               float* __restrict__ adam_step_b) {
   float gs = 0.f, vs = 0.f;
   const float inv_n = 1.0f / float(n);
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -577,6 +578,10 @@ __global__ __launch_bounds__(256) void generator_losses_kernel(GLossArgs a, cons
   if (threadIdx.x == 0) {
     losses[0] = pg[0] * inv_n;
     losses[1] = pv[0] * inv_n;
+    // (nullable) Adam's step counters of the two optimisers this step's updates belong to: t <- t + 1 here, in front of
+    // the updates, instead of one one-thread launch behind each (expo_adam_step's step_advanced)
+    if (adam_step_a) adam_step_a[0] = adam_step_a[0] + 1.0f;
+    if (adam_step_b) adam_step_b[0] = adam_step_b[0] + 1.0f;
   }
 }
 }  // namespace expo
@@ -793,7 +798,7 @@ int expo_planes_concat(const void* images, const float* vec, float* out, int n, 
 int expo_generator_losses(const float* fake_logit, const float* fake_input_logit, const float* new_value,
                           const float* old_value, const float* new_states, int state_dim, const float* penalty,
                           const float* surrogate, const float* consts, int use_td, float* losses, float* reward, float* q_value,
-                          float* coef, int n, void* stream) {
+                          float* coef, int n, float* adam_step_a, float* adam_step_b, void* stream) {
   if (n <= 0) return fail(EXPO_E_BADARG, "n >= 1 required");
   if (!fake_logit || !fake_input_logit || !new_value || !old_value || !new_states || !surrogate || !consts || !losses ||
       !reward || !q_value || !coef)
@@ -801,14 +806,15 @@ int expo_generator_losses(const float* fake_logit, const float* fake_input_logit
   if (state_dim < 3) return fail(EXPO_E_BADARG, "state rows must hold reward, stopped, step");
   GLossArgs a{consts[0], consts[1], consts[2], consts[3], consts[4], penalty ? 1 : 0, use_td ? 1 : 0, state_dim, 1, 2};
   hipLaunchKernelGGL(generator_losses_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a, fake_logit,
-                     fake_input_logit, new_value, old_value, new_states, penalty, surrogate, losses, reward, q_value, coef, n);
+                     fake_input_logit, new_value, old_value, new_states, penalty, surrogate, losses, reward, q_value, coef, n,
+                     adam_step_a, adam_step_b);
   HIP_TRY(hipGetLastError(), "generator_losses launch");
   return EXPO_OK;
 }
 
 int expo_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const size_t* numel, const float* lr, float* step, void* ticket, float beta1,
-                   float beta2, float eps, void* stream) {
+                   float beta2, float eps, int step_advanced, void* stream) {
   if (count < 0) return fail(EXPO_E_BADARG, "count >= 0 required");
   if (count == 0) return EXPO_OK;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr || !step || !ticket)
@@ -839,13 +845,17 @@ int expo_adam_step(int count, float* const* params, const float* const* grads, f
       a.vec[j] = aligned16(a.p[j]) && aligned16(a.g[j]) && aligned16(a.m[j]) && aligned16(a.v[j]);
     }
     a.first_block[a.count] = blocks;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, a, lr, step, beta1, beta2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, a, lr, step, beta1, beta2, eps, step_advanced ? 0.0f : 1.0f);
     HIP_TRY(hipGetLastError(), "adam launch");
   }
   // every launch above computed with t = step + 1; the counter moves behind them (stream order)
   (void)ticket;  // (ABI 4-5: the word the blocks took tickets on; still accepted, no longer touched)
-  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step);
-  HIP_TRY(hipGetLastError(), "adam advance launch");
+  // (step_advanced: a kernel the caller launched in FRONT of this update -- expo_critic_report, expo_generator_losses -- has
+  // moved the counter already: one launch less per update)
+  if (!step_advanced) {
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step);
+    HIP_TRY(hipGetLastError(), "adam advance launch");
+  }
   return EXPO_OK;
 }
 

@@ -258,12 +258,21 @@ class GAN(nn.Module):
       pend.wait()
     self._pending = []
 
+  @staticmethod
+  def _hip_adam(opt):
+    return hasattr(opt, 'step_counter') and len(opt.param_groups) == 1
+
   def _generator_body(self, fake_input, z, states, progress, dropout_masks):
     if self.direct_generator and generator_direct.supported(self, fake_input, states):
       # the critic / value-net passes as two hand-scheduled batches of 2n images, their gradients entering the agent's
       # autograd graph in ONE backward pass (exposure_amd/generator_direct.py)
-      out = generator_direct.generator_step_losses_and_grads(self, fake_input, z, states, progress, dropout_masks)
+      # (HipAdam: the loss launch advances both step counters, so neither update needs a launch behind it)
+      pre = self._hip_adam(self.opt_g) and self._hip_adam(self.opt_v)
+      out = generator_direct.generator_step_losses_and_grads(
+          self, fake_input, z, states, progress, dropout_masks,
+          adam_steps=(self.opt_g.step_counter(), self.opt_v.step_counter()) if pre else (None, None))
     else:
+      pre = False
       # (this step differentiates its convnets once: each stack of layers runs as one node, nn_ops.conv_trunk)
       with once_differentiable_convnets():
         out = self.generator_losses(fake_input, z, states, progress, 1, dropout_masks)
@@ -273,8 +282,12 @@ class GAN(nn.Module):
       self._backward_into(out['v_loss'], ['v'])
       self._backward_into(out['g_loss'], ['g_head', 'g_trunk'])
     self._finish_collectives()
-    self.opt_g.step()
-    self.opt_v.step()
+    if pre:
+      self.opt_g.step(advanced=True)
+      self.opt_v.step(advanced=True)
+    else:
+      self.opt_g.step()
+      self.opt_v.step()
     return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
   def _draw_masks(self, n, device=None):
@@ -456,9 +469,12 @@ class GAN(nn.Module):
       ema_done = not self._collectives()
       if ema_done and (self._c_ema is None or self._c_ema.device != real_data.device):
         self._c_ema = torch.zeros((), dtype=torch.float32, device=real_data.device)
-      out = critic_direct.critic_losses_and_grads(self, real_data, fake_output, alpha, self._c_ema if ema_done else None)
+      pre = self._hip_adam(self.opt_c)  # the reporting launch advances Adam's step counter as well
+      out = critic_direct.critic_losses_and_grads(self, real_data, fake_output, alpha, self._c_ema if ema_done else None,
+                                                  adam_step=self.opt_c.step_counter() if pre else None)
       self._bucket_ready(self.buckets['c'])  # (a no-op on one rank: the gradients already sit in p.grad)
     else:
+      pre = False
       out = self.critic_losses(materialize(real_data), materialize(fake_output), alpha)
       self._backward_into(out['c_loss'], ['c'])
     if self._collectives():
@@ -466,7 +482,10 @@ class GAN(nn.Module):
       xdist.all_reduce_mean_(ca, self.process_group, force=self.force_collectives)
       out['c_average'] = ca
     self._finish_collectives()
-    self.opt_c.step()
+    if pre:
+      self.opt_c.step(advanced=True)
+    else:
+      self.opt_c.step()
     self.clip_critic_weights()
     ca = out['c_average'].detach().reshape(())
     if self._c_ema is None or self._c_ema.device != ca.device:

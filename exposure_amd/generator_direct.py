@@ -162,9 +162,10 @@ def _grad_targets(gan, module, bucket):
   return out
 
 
-def generator_step_losses_and_grads(gan, fake_input, z, states, progress, dropout_masks):
+def generator_step_losses_and_grads(gan, fake_input, z, states, progress, dropout_masks, adam_steps=(None, None)):
   """Losses of one G / V step and their gradients: theta_v's written to ``p.grad`` by hand, theta_g's through ONE autograd
-  backward over the agent.  -> the dict ``GAN.generator_losses`` returns."""
+  backward over the agent.  -> the dict ``GAN.generator_losses`` returns.  ``adam_steps``: the step counters of the
+  generator's and the value net's optimisers, advanced by the loss launch (``HipAdam.step(advanced=True)`` follows)."""
   cfg = gan.cfg
   n = fake_input.shape[0]
   dev = fake_input.device
@@ -185,7 +186,7 @@ def generator_step_losses_and_grads(gan, fake_input, z, states, progress, dropou
                            new_states.detach().contiguous().float(), penalty.detach().reshape(n).contiguous().float() if use_pen else None,
                            surrogate.detach().reshape(n).contiguous().float(),
                            (cfg.all_reward, cfg.critic_logit_multiplier, cfg.discount_factor, cfg.parameter_lr_mul,
-                            cfg.maximum_trajectory_length), bool(cfg.use_TD), losses, reward, q, coef)
+                            cfg.maximum_trajectory_length), bool(cfg.use_TD), losses, reward, q, coef, adam_steps=adam_steps)
     # the value net: old_value's rows carry d v_loss / d old_value (-> theta_v), new_value's rows d g_loss / d new_value
     # (-> the retouched image); its all-reduce (if any) then runs under the rest of the step
     v_grads = _grad_targets(gan, gan.value, 'v')

@@ -72,8 +72,17 @@ class HipAdam:
                             torch.zeros_like(p, memory_format=torch.preserve_format))
     return st
 
+  def step_counter(self):
+    """The device scalar a kernel in FRONT of ``step(advanced=True)`` advances (``_cabi.critic_report`` /
+    ``generator_losses``): one-group optimisers only."""
+    assert len(self.param_groups) == 1
+    return self.param_groups[0]['_step']
+
   @torch.no_grad()
-  def step(self):
+  def step(self, advanced=False):
+    """``advanced``: the caller's previous launch has moved the step counter (``step_counter()``) already -- the update
+    then needs no one-thread launch behind it.  Every parameter must have a gradient in that case."""
+    assert not advanced or (len(self.param_groups) == 1 and all(p.grad is not None for p in self.params))
     for group in self.param_groups:
       lr = group['lr']
       if not torch.is_tensor(lr):  # a float assigned from outside: move it to the device (not capturable, like torch)
@@ -88,7 +97,7 @@ class HipAdam:
         m, v = self._moments(p)
         ps.append(p), gs.append(g), ms.append(m), vs.append(v)
       _cabi.adam_step(ps, gs, ms, vs, lr, group['_step'], group['_ticket'], group['betas'][0], group['betas'][1],
-                      group['eps'])
+                      group['eps'], step_advanced=advanced)
 
   # -- checkpoint / resume (torch.optim.Optimizer's format)
   def state_dict(self):

@@ -492,6 +492,9 @@ int expo_curve_bwd(const void* x, const void* dy, void* dx, const float* params,
  *                              stores t (capturable, no host involvement; ABI 4-5 let the update's last block do it,
  *                              found through a ticket atomic per block -- most of the update's time)
  *   ticket device uint32, owned by the optimiser; accepted for ABI compatibility, not touched since ABI 6
+ *   step_advanced  (ABI 7) 0: as above.  1: `step` already holds t -- a kernel the caller launched in front of this
+ *                              update moved the counter (expo_critic_report's / expo_generator_losses' adam_step
+ *                              pointers): the update computes with t = step and launches nothing behind it
  * Update rule (torch.optim.Adam without weight decay / amsgrad; TF-1's differs only in where epsilon sits:
  * sqrt(v) + eps' with eps' = eps sqrt(1 - beta2^t)):
  *   m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
@@ -500,7 +503,7 @@ int expo_curve_bwd(const void* x, const void* dy, void* dx, const float* params,
 #define EXPO_ADAM_MAX_TENSORS 64
 int expo_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const size_t* numel, const float* lr, float* step, void* ticket,
-                   float beta1, float beta2, float eps, void* stream);
+                   float beta1, float beta2, float eps, int step_advanced, void* stream);
 
 /*
  * The input tensor of a convnet: image channels + per-image values broadcast as constant planes, minus `offset` --
@@ -544,11 +547,13 @@ int expo_net_inputs(const void* a, const int64_t* a_rows, const void* b, const i
  * coef float32 [5][N] receives d g_loss / d {fake_logit, new_value, surrogate, penalty} and d v_loss / d old_value
  * (stop-gradients of the reference applied: the weight of the surrogate and q inside adv are constants), so the
  * backward pass is coef times the upstream scalar.  One block; N is a minibatch.
+ * adam_step_a / adam_step_b (ABI 7; nullable device floats) += 1: the step counters of the generator's and the value net's
+ * updates behind this launch (expo_adam_step with step_advanced = 1).
  */
 int expo_generator_losses(const float* fake_logit, const float* fake_input_logit, const float* new_value,
                           const float* old_value, const float* new_states, int state_dim, const float* penalty,
                           const float* surrogate, const float* consts, int use_td, float* losses, float* reward,
-                          float* q_value, float* coef, int n, void* stream);
+                          float* q_value, float* coef, int n, float* adam_step_a, float* adam_step_b, void* stream);
 
 /* ---- the convnets' convolution (round 5) ------------------------------------------------------------------------
  * `ly.conv2d(net, C_out, kernel_size=4, stride=2)` (SAME padding; agent.py:21-32, critics.py:13-35) on NHWC float32
@@ -628,7 +633,9 @@ int expo_conv_tuning(int tile, int nt, int slices);
  *   expo_critic_report    out[0..4] = {c_loss = mean fake - mean real + lambda mean term, emd = mean real - mean fake, mean
  *                         norm, lambda mean term, c_average = (mean fake + mean real) / 2} (net.py:188-199) from the logits
  *                         [real | fake | interpolated] and the per-image norm / term; ema (nullable, device float) advances
- *                         as ema += (1 - decay) (c_average - ema) (update_average, net.py:165-168, 267-268)
+ *                         as ema += (1 - decay) (c_average - ema) (update_average, net.py:165-168, 267-268); adam_step
+ *                         (nullable, device float) += 1: the step counter of the update behind this launch
+ *                         (expo_adam_step with step_advanced = 1)
  *   expo_critic_head_bwd  gb1 = sum over the real + fake rows of dh;  gw2 = sum over those rows of dlogit h + sum over
  *                         the interpolated rows of thpre slope(h) (thpre float32 [th_slabs][n_interp][hidden]: the penalty's
  *                         tangent in front of fc1's activation, as partial sums like hpre);  gb2 = sum of dlogit
@@ -646,7 +653,7 @@ int expo_conv_tuning(int tile, int nt, int slices);
 int expo_critic_head_fwd(const float* hpre, const float* b1, int slabs, const float* w2, const float* b2, int n_real, int n_fake,
                          int n_interp, int hidden, float inv_n, float leak, float* logits, float* h, float* dh, void* stream);
 int expo_critic_report(const float* logits, const float* norm, const float* term, int n_real, int n_fake, int n_interp,
-                       float lambda, float decay, float* out, float* ema, void* stream);
+                       float lambda, float decay, float* out, float* ema, float* adam_step, void* stream);
 int expo_critic_head_bwd(const float* dh, const float* h, const float* thpre, int th_slabs, int n_real, int n_fake,
                          int n_interp, int hidden, float inv_n, float leak, float* gb1, float* gw2, float* gb2, void* stream);
 

@@ -184,6 +184,40 @@ def _adam_reference(ps, gs_per_step, lrs, b1, b2, eps):
 
 
 @pytest.mark.gpu
+def test_hip_adam_with_the_step_counter_advanced_in_front_of_the_update(gpu_device):
+  """``HipAdam.step(advanced=True)`` behind a launch that moved the step counter (``critic_report(adam_step=...)``: the
+  hand-scheduled steps save the one-thread launch behind every update) == ``step()``, bit for bit, counters included."""
+  from exposure_amd import _cabi
+  from exposure_amd.optim import HipAdam
+  dev = gpu_device
+  g = torch.Generator(device=dev).manual_seed(3)
+  init = [torch.randn(sz, device=dev, generator=g) for sz in [(5,), (1030,), (32, 6, 4, 4)]]
+  opts = []
+  for _ in range(2):
+    ps = [t.clone().requires_grad_(True) for t in init]
+    opts.append((ps, HipAdam(ps, lr=1e-3, betas=(0.5, 0.9))))
+  logits, norm, term = torch.randn((6,), device=dev, generator=g), torch.ones((2,), device=dev), torch.ones((2,), device=dev)
+  for step in range(4):
+    grads = [torch.randn(t.shape, device=dev, generator=g) for t in init]
+    for k, (ps, opt) in enumerate(opts):
+      for p, gr in zip(ps, grads):
+        p.grad = gr.clone()
+      if k == 0:
+        opt.step()
+      else:
+        _cabi.critic_report(logits, norm, term, 2, 2, 2, 10.0, torch.empty((5,), device=dev), adam_step=opt.step_counter())
+        assert float(opt.step_counter()) == step + 1
+        opt.step(advanced=True)
+    assert float(opts[0][1]._step) == float(opts[1][1]._step) == step + 1
+    for a, b in zip(opts[0][0], opts[1][0]):
+      assert torch.equal(a, b)
+  ps, opt = opts[1]
+  ps[0].grad = None
+  with pytest.raises(AssertionError):
+    opt.step(advanced=True)  # a parameter without a gradient: the caller cannot have advanced the counter for it
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('count', [7, 70])
 def test_hip_adam_matches_the_rule_in_float64(count, gpu_device):
   """expo_adam_step (exposure_amd/optim.py) against torch.optim.Adam's update rule in float64 over six steps with a
