@@ -500,3 +500,28 @@ def test_fc_layer_with_its_features_split_and_its_data_gradient(m, n, k, gpu_dev
     _cabi.fc_bwd_data_mask(dh, w, z, gy)
     want = (dh.double() @ w.double()) * _slope(z).double()
     assert float((gy.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) * (n / 16)**0.5
+
+
+def test_direct_critic_update_on_its_separate_launches(gpu_device, monkeypatch):
+  """Images beyond 4096 pixels, or an FC layer whose width the split kernels do not take, run the update's input side as
+  gp_inputs -> stats -> planes_concat and fc1 through the library GEMM: the same losses and gradients as the fused launches."""
+  from exposure_amd import _cabi, critic_direct
+  from tests.test_oracle_nets import make_batch
+  dev = gpu_device
+  gan = _make_gan(dev, 3)
+  fake_input, real, _s, _z, _m, alpha = make_batch(8, 17)
+  t = lambda a: torch.from_numpy(a).to(dev)
+  real_t, fake_t, alpha_t = t(real).half(), t(fake_input).half(), t(alpha)
+  outs = []
+  for fused in (True, False):
+    if not fused:
+      monkeypatch.setattr(_cabi, 'NET_INPUTS_MAX_PIXELS', 0)
+      monkeypatch.setattr(critic_direct, 'fc_split', lambda fc, rows: False)
+    out = critic_direct.critic_losses_and_grads(gan, real_t, fake_t, alpha_t)
+    outs.append(({k: float(v) for k, v in out.items()},
+                 {name: p.grad.detach().clone() for name, p in gan.critic.named_parameters()}))
+  for key, a in outs[0][0].items():
+    assert abs(a - outs[1][0][key]) <= 2e-5 * max(1.0, abs(a)), key
+  for name, a in outs[0][1].items():
+    b = outs[1][1][name]
+    assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9, name

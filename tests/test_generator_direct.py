@@ -130,3 +130,28 @@ def test_direct_generator_step_replayed_from_a_graph_trains_like_the_autograd_st
       assert float(d.mean()) <= 0.05 * steps * lr, (net, name)
   for (name, a), (_, b) in zip(gans[0].critic.named_parameters(), gans[1].critic.named_parameters()):
     assert torch.equal(a, b), name
+
+
+def test_direct_generator_step_on_its_separate_launches(gpu_device, monkeypatch):
+  """The pair passes with their input side as separate launches and fc1 through the library GEMM (images beyond 4096 pixels,
+  FC widths the split kernels do not take): the same losses and gradients as with the fused launches."""
+  from exposure_amd import _cabi, generator_direct
+  dev = gpu_device
+  gan = _make_gan(dev, 3)
+  img, z, states, masks = _feed(8, 23, dev, torch.float16)
+  res = []
+  for fused in (True, False):
+    if not fused:
+      monkeypatch.setattr(_cabi, 'NET_INPUTS_MAX_PIXELS', 0)
+      monkeypatch.setattr(generator_direct, 'fc_split', lambda fc, rows: False)
+    _clear(gan)
+    out = generator_direct.generator_step_losses_and_grads(gan, img, z, states, 0.3, masks)
+    gan._finish_collectives()
+    res.append((float(out['g_loss']), float(out['v_loss']),
+                [None if p.grad is None else p.grad.detach().clone() for _, _, p in _theta(gan)]))
+  for k in (0, 1):
+    assert abs(res[0][k] - res[1][k]) <= 2e-5 * max(1.0, abs(res[1][k]))
+  for a, b in zip(res[0][2], res[1][2]):
+    assert (a is None) == (b is None)
+    if a is not None:
+      assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9
