@@ -66,6 +66,7 @@ SIGNATURES = {
     'expo_fc_fwd_slabs_count': (_i, [_i, _i]),
     'expo_fc_fwd_slabs': (_i, [_fp, _fp, _fp, _i, _i, _i, _vp]),
     'expo_fc_bwd_data_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _f, _vp]),
+    'expo_fc_wrw': (_i, [_fp, _fp, _fp, _i, _i, _i, _vp]),
     'expo_plane_sums': (_i, [_fp, _fp, _i, _sz, _i, _i, _vp]),
     'expo_gp_direct': (_i, [_fp, _i, _fp, _f, _fp, _fp, _fp, _i, _sz, _vp]),
     'expo_critic_penalty_tangent': (_i, [_fp, _fp, _fp, _f, _fp, _fp, _fp, _i, _i, _i, _vp]),
@@ -1095,6 +1096,16 @@ def critic_report(logits, norm, term, n_real, n_fake, n_interp, lam, out, ema=No
     _check(lib.expo_critic_report(_ptr(logits), _ptr(norm), _ptr(term), int(n_real), int(n_fake), int(n_interp), float(lam),
                                   float(decay), _ptr(out), _ptr(ema), _ptr(_step_scalar(adam_step)), _stream()),
            'expo_critic_report')
+
+
+def fc_wrw(dh, x, dw):
+  """expo_fc_wrw: dw = dh^T x -- the weight gradient of an nn.Linear (dh (m, j), x (m, c), dw (j, c)) over m rows."""
+  lib = load()
+  m, j = dh.shape
+  c = x.shape[1]
+  _f32(dh, 'dh', (m, j)), _f32(x, 'x', (m, c)), _f32(dw, 'dw', (j, c))
+  with torch.cuda.device(dh.device):
+    _check(lib.expo_fc_wrw(_ptr(dh), _ptr(x), _ptr(dw), m, j, c, _stream()), 'expo_fc_wrw')
 
 
 def critic_head_bwd(dh, h, thpre, n_real, n_fake, n_interp, inv_n, gb1, gw2, gb2, leak=0.2):

@@ -179,7 +179,10 @@ def critic_losses_and_grads(gan, real_data, fake_output, alpha, ema=None, adam_s
   # ---- gradients: one launch per layer over [loss rows | penalty rows] -----------------------------------------------
   _cabi.conv4x4s2_wrw_group([(acts[l - 1], gys[l], grads[id(conv.weight)], grads[id(conv.bias)], 2 * n)
                              for l, conv in enumerate(convs, start=1)])  # (one reduce launch for the four layers)
-  torch.mm(dh.t(), flat, out=grads[id(critic.fc1.weight)])
+  if split:
+    _cabi.fc_wrw(dh, flat, grads[id(critic.fc1.weight)])  # dh^T flat: the batch is this GEMM's K dimension
+  else:
+    torch.mm(dh.t(), flat, out=grads[id(critic.fc1.weight)])
   _cabi.critic_head_bwd(dh, h, thpre, n, n, n, inv_n, grads[id(critic.fc1.bias)],
                         grads[id(critic.fc2.weight)].reshape(hidden), grads[id(critic.fc2.bias)], LEAK)
 

@@ -1575,11 +1575,77 @@ __global__ __launch_bounds__(256) void fc_bwd_data_mask_kernel(const float* __re
   for (int e = 0; e < 16; ++e) buf_store1(ry, off[e], ok[e], acc[e] * lrelu_slope_v(zv[e], leak));
 }
 
+// Its weight gradient: dW[j][c] = sum_m dh[m][j] x[m][c] (J = 128 rows of C = 4096): a GEMM whose K dimension is the BATCH
+// (64 .. 192 rows) with a large output -- the library picks 128 x 128 tiles for it at m = 64 (32 workgroups: 13.5 us) and
+// 32 x 128 at m = 192 (9 us).  Here a wave = one 32 x 32 tile of dW over a quarter of the rows; both operands are dword
+// loads of 128 contiguous bytes per row (lane l -> row 2 p + (l >> 5), column l & 31), issued in groups of 16 before their
+// MFMAs; the four waves of a block meet in LDS and are added in wave order.
+__global__ __launch_bounds__(256) void fc_wrw_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                     float* __restrict__ dw, int m, int jdim, int c, int tiles_c, int kw) {
+  __shared__ __attribute__((aligned(16))) float part[4][16][64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int tj = blockIdx.x / tiles_c, tc = blockIdx.x - tj * tiles_c;
+  const int col = lane & 31, half = lane >> 5;
+  const int aj = tj * 32 + col, bc = tc * 32 + col;
+  const bool a_ok = aj < jdim, b_ok = bc < c;
+  const int r0 = __builtin_amdgcn_readfirstlane(sl) * kw + half;  // this lane's first row; it walks every second one
+  const __amdgpu_buffer_rsrc_t ra = conv_rsrc(dh, size_t(m) * jdim);
+  const __amdgpu_buffer_rsrc_t rb = conv_rsrc(x, size_t(m) * c);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  constexpr int U = 8;  // row pairs per group
+  const int groups = (kw / 2 + U - 1) / U;
+  float ac[U], bcur[U], an[U], bnx[U];
+  auto load_group = [&](int g, float (&a)[U], float (&b)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = g * U + u, row = r0 + 2 * p;
+      const bool in = g < groups && 2 * p < kw && row < m;
+      a[u] = buf_load1(ra, row * jdim + aj, a_ok && in);
+      b[u] = buf_load1(rb, row * c + bc, b_ok && in);
+    }
+  };
+  load_group(0, ac, bcur);
+  for (int g = 0; g < groups; ++g) {
+    load_group(g + 1, an, bnx);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bcur[u], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) ac[u] = an[u], bcur[u] = bnx[u];
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) part[sl][e][lane] = acc[e];
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t ry = conv_rsrc(dw, size_t(jdim) * c);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = 4 * sl + q;
+    const float v = ((part[0][e][lane] + part[1][e][lane]) + part[2][e][lane]) + part[3][e][lane];
+    const int jo = tj * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+    buf_store1(ry, jo * c + bc, jo < jdim && b_ok, v);
+  }
+}
+
 }  // namespace expo
 
 using namespace expo;
 
 extern "C" {
+
+int expo_fc_wrw(const float* dh, const float* x, float* dw, int m, int j, int c, void* stream) {
+  if (m < 0 || j <= 0 || c <= 0) return fail(EXPO_E_BADARG, "fc_wrw: m >= 0, j > 0, c > 0 required");
+  if (!dw || (m > 0 && (!dh || !x))) return fail(EXPO_E_BADARG, "null pointer");
+  if (size_t(m) * c >= (1ull << 29) || size_t(j) * c >= (1ull << 29) || size_t(m) * j >= (1ull << 29))
+    return fail(EXPO_E_BADARG, "fc_wrw: operands of at most 2 GiB");
+  const int tiles_j = (j + 31) / 32, tiles_c = (c + 31) / 32;
+  const int kw = ((m + 3) / 4 + 1) & ~1;  // rows per wave: a quarter of the batch, even (m = 0: the tiles are zero-filled)
+  hipLaunchKernelGGL(fc_wrw_kernel, dim3(tiles_j * tiles_c), dim3(256), 0, static_cast<hipStream_t>(stream), dh, x, dw, m, j, c,
+                     tiles_c, kw);
+  HIP_TRY(hipGetLastError(), "fc_wrw launch");
+  return EXPO_OK;
+}
 
 int expo_fc_fwd_slabs_count(int m, int k) {
   if (m <= 0 || k <= 0) return 0;

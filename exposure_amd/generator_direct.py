@@ -139,7 +139,10 @@ class _PairPass:
       _cabi.conv4x4s2_wrw_group([(self.acts[l - 1][rows_w], gys[l][rw], grads[id(conv.weight)], grads[id(conv.bias)], None)
                                  for l, conv in enumerate(convs, start=1)])
       dhw = dh[rw]
-      torch.mm(dhw.t(), self.flat[rows_w], out=grads[id(net.fc1.weight)])
+      if self.split:
+        _cabi.fc_wrw(dhw.contiguous(), self.flat[rows_w], grads[id(net.fc1.weight)])
+      else:
+        torch.mm(dhw.t(), self.flat[rows_w], out=grads[id(net.fc1.weight)])
       torch.sum(dhw, dim=0, out=grads[id(net.fc1.bias)])
       torch.mv(self.h[rows_w].t(), dlogit[rw], out=grads[id(net.fc2.weight)].reshape(self.hidden))
       torch.sum(dlogit[rw], dim=0, keepdim=True, out=grads[id(net.fc2.bias)])

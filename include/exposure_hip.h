@@ -672,6 +672,9 @@ int expo_fc_fwd_slabs_count(int m, int k);
 int expo_fc_fwd_slabs(const float* x, const float* w, float* slabs, int m, int n, int k, void* stream);
 int expo_fc_bwd_data_mask(const float* dh, const float* w, const float* z, float* gy, int m, int j, int c, float leak,
                           void* stream);
+/*   expo_fc_wrw           dw float32 [J][C] = dh^T x (dh float32 [M][J], x float32 [M][C]): the layer's weight gradient over M
+ *                         rows -- a GEMM whose K dimension is the batch; OVERWRITTEN, fixed summation order */
+int expo_fc_wrw(const float* dh, const float* x, float* dw, int m, int j, int c, void* stream);
 int expo_plane_sums(const float* x, float* sums, int n, size_t pixels_per_image, int channels, int first, void* stream);
 int expo_gp_direct(const float* u, int u_channels, const float* ds, float scale, float* v, float* norm, float* term, int n,
                    size_t pixels_per_image, void* stream);

@@ -457,7 +457,7 @@ def test_net_inputs_equals_its_four_launch_composition(shape, v0, interp, rows, 
 @pytest.mark.parametrize('m,n,k', [(192, 128, 4096), (64, 128, 4096), (128, 128, 4096), (37, 96, 1024), (5, 32, 128), (200, 128, 384)])
 def test_fc_layer_with_its_features_split_and_its_data_gradient(m, n, k, gpu_device):
   """expo_fc_fwd_slabs: the slabs' sum == x w^T (float64) and the head kernels that consume them equal the head kernels on
-  the finished pre-activation; expo_fc_bwd_data_mask == (dh w) slope(z) (float64)."""
+  the finished pre-activation; expo_fc_bwd_data_mask == (dh w) slope(z), expo_fc_wrw == dh^T x (float64)."""
   from exposure_amd import _cabi
   dev = gpu_device
   g = torch.Generator(device=dev).manual_seed(m + k)
@@ -500,6 +500,12 @@ def test_fc_layer_with_its_features_split_and_its_data_gradient(m, n, k, gpu_dev
     _cabi.fc_bwd_data_mask(dh, w, z, gy)
     want = (dh.double() @ w.double()) * _slope(z).double()
     assert float((gy.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) * (n / 16)**0.5
+  # weight gradient: the batch is the GEMM's K dimension
+  dh = torch.randn((m, n), device=dev, generator=g)
+  dw = torch.full((n, k), float('nan'), device=dev)
+  _cabi.fc_wrw(dh, x, dw)
+  want = dh.double().t() @ x.double()
+  assert float((dw.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) * max(1.0, m / 16)**0.5
 
 
 def test_direct_critic_update_on_its_separate_launches(gpu_device, monkeypatch):
