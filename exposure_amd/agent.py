@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from . import filters as F
-from .nn_ops import conv_trunk, planes_concat
+from .nn_ops import conv_trunk, conv_trunks, planes_concat
 from .util import (STATE_DROPOUT_BEGIN, STATE_REWARD_DIM, STATE_STEP_DIM, STATE_STOPPED_DIM,
                    enrich_image_input, lrelu)
 
@@ -64,12 +64,16 @@ class FeatureExtractor(nn.Module):
       _xavier_conv(c)
     self.to(memory_format=torch.channels_last)
 
-  def forward(self, net_nhwc, dropout_mask=None, centered=False):
+  def forward(self, net_nhwc, dropout_mask=None, centered=False, trunk_out=None):
     # NHWC end to end (the convolutions see channels_last views: no copy, MIOpen picks its NHWC kernels);
     # `centered`: the caller has already subtracted 0.5 (Agent.forward builds the enriched input of both extractors in
-    # one launch, nn_ops.planes_concat)
-    net = net_nhwc if centered else net_nhwc.float() - 0.5
-    net = conv_trunk(net, self.convs)
+    # one launch, nn_ops.planes_concat); `trunk_out`: the caller has run the convolutions already (Agent.forward runs
+    # both extractors' stacks as one node, nn_ops.conv_trunks)
+    if trunk_out is None:
+      net = net_nhwc if centered else net_nhwc.float() - 0.5
+      net = conv_trunk(net, self.convs)
+    else:
+      net = trunk_out
     net = net.reshape(net.shape[0], self.output_dim)  # TF reshape order (H,W,C)
     if dropout_mask is None:
       dropout_mask = (torch.rand_like(net) < self.keep_prob).to(net.dtype)
@@ -241,7 +245,12 @@ class Agent(nn.Module):
       enriched, centered = planes_concat(net, states, 0.5), True  # float, concat and `- 0.5` of both extractors at once
     else:
       enriched, centered = enrich_image_input(cfg, net.float(), states), False
-    filter_features = self.filter_features(enriched, masks[0], centered=centered)
+    # both extractors read the same input: their stacks as ONE autograd node (the weight gradients of all eight layers then
+    # share one launch, nn_ops.conv_trunks)
+    trunk_f = trunk_s = None
+    if centered:
+      trunk_f, trunk_s = conv_trunks(enriched, [self.filter_features.convs, self.selector_features.convs])
+    filter_features = self.filter_features(enriched, masks[0], centered=centered, trunk_out=trunk_f)
     # Training-time fast path (round 4): the regressors and the one-hot gather of the selected filter's parameters as
     # ONE kernel behind the heads' second FCs (filters.heads_regress_select).  Needs what the dispatch kernels need
     # (8-step curves, masking off) and a device; everything else takes the op-by-op path below.
@@ -261,7 +270,7 @@ class Agent(nn.Module):
     else:
       params, mask_params = self.regress_all(filter_features)  # 8 x reference-shaped, 8 x (N, 6)
 
-    selector_features = self.selector_features(enriched, masks[1], centered=centered)
+    selector_features = self.selector_features(enriched, masks[1], centered=centered, trunk_out=trunk_s)
     if fused_heads and k <= 16 and z.dtype == torch.float32 and states.shape[1] >= 3 + k:
       return self._forward_fused(net, z, states, raws, selector_features, is_train, progress)
     pdf, entropy = self.action_pdf(selector_features)

@@ -348,6 +348,92 @@ class _ConvTrunk(torch.autograd.Function):
     return (gx, None) + tuple(grads)
 
 
+class _ConvTrunks(torch.autograd.Function):
+  """Several stacks of equally many layers on ONE input (the agent's filter and selector extractors, agent.py:47-56): the
+  outputs z_L of every stack.  Backward: the stacks' data gradients stack by stack, and the weight gradients of ALL their
+  layers as one grouped launch (expo_conv4x4s2_wrw_group takes eight layers: two stacks of four share one grid and one
+  reduce launch instead of two of each)."""
+
+  @staticmethod
+  def forward(ctx, x, leak, stacks, *wb):
+    n_l = len(wb) // (2 * stacks)
+    saved, outs = [x], []
+    for s in range(stacks):
+      ws, bs = wb[2 * n_l * s:2 * n_l * (s + 1):2], wb[2 * n_l * s + 1:2 * n_l * (s + 1):2]
+      a = x
+      for w, b in zip(ws, bs):
+        z = torch.empty((a.shape[0], a.shape[1] // 2, a.shape[2] // 2, w.shape[0]), dtype=torch.float32, device=a.device)
+        _cabi.conv4x4s2_fwd(a, w, b, z, 1, leak)
+        saved.append(z)
+        a = z
+      outs.append(a)
+    ctx.save_for_backward(*saved, *wb[0::2])
+    ctx.leak, ctx.layers, ctx.stacks = leak, n_l, stacks
+    return tuple(outs)
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, *gzs):
+    n_l, stacks = ctx.layers, ctx.stacks
+    x = ctx.saved_tensors[0]
+    zs = ctx.saved_tensors[1:1 + n_l * stacks]
+    ws_all = ctx.saved_tensors[1 + n_l * stacks:]
+    grads = [None] * (2 * n_l * stacks)
+    gx = None
+    wrw = []
+    for s in range(stacks):
+      gz = gzs[s]
+      if gz is None:
+        continue
+      acts = (x,) + tuple(zs[n_l * s:n_l * (s + 1)])
+      ws = ws_all[n_l * s:n_l * (s + 1)]
+      want_w = any(ctx.needs_input_grad[3 + 2 * n_l * s:3 + 2 * n_l * (s + 1)]) and not _SKIP_PARAM_GRADS
+      gy = torch.empty_like(acts[n_l])
+      _cabi.lrelu_bwd(acts[n_l], gz.contiguous(), gy, ctx.leak)
+      for l in range(n_l, 0, -1):
+        w = ws[l - 1]
+        if want_w:
+          dw = torch.empty_like(w, memory_format=torch.preserve_format)
+          db = torch.empty((w.shape[0],), dtype=torch.float32, device=w.device)
+          wrw.append((acts[l - 1], gy, dw, db, None))
+          grads[2 * (n_l * s + l - 1)], grads[2 * (n_l * s + l - 1) + 1] = dw, db
+        if l > 1:
+          g = torch.empty_like(acts[l - 1])
+          _cabi.conv4x4s2_bwd_data_mask(gy, w, acts[l - 1], g, ctx.leak)
+          gy = g
+        elif ctx.needs_input_grad[0]:
+          g = torch.empty_like(x)
+          _cabi.conv4x4s2_bwd_data(gy, w, g)
+          gx = g if gx is None else gx + g
+    for k in range(0, len(wrw), 8):
+      _cabi.conv4x4s2_wrw_group(wrw[k:k + 8])
+    return (gx, None, None) + tuple(grads)
+
+
+def _trunk_ok(x, convs):
+  ok = _ONCE_DIFFERENTIABLE and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+  h, w = x.shape[1], x.shape[2]
+  for conv in convs:
+    ok = ok and _hip_conv(x, conv.weight) and conv.bias is not None and conv.weight.shape[0] % 4 == 0 and \
+        h % 2 == 0 and w % 2 == 0 and (w // 2) % 2 == 0
+    h, w = h // 2, w // 2
+  return ok
+
+
+def conv_trunks(x, stacks, leak=0.2):
+  """``[conv_trunk(x, convs) for convs in stacks]`` -- as ONE once-differentiable node when every stack qualifies and they
+  have equally many layers (their weight gradients then share one launch), stack by stack otherwise."""
+  x = x.contiguous()
+  stacks = [list(c) for c in stacks]
+  if len(stacks) < 2 or len({len(c) for c in stacks}) != 1 or not all(_trunk_ok(x, c) for c in stacks):
+    return [conv_trunk(x, c, leak) for c in stacks]
+  wb = []
+  for convs in stacks:
+    for conv in convs:
+      wb += [conv.weight.detach(), conv.bias.detach()] if _FROZEN else [conv.weight, conv.bias]
+  return list(_ConvTrunks.apply(x, leak, len(stacks), *wb))
+
+
 def conv_trunk(x, convs, leak=0.2):
   """The stack of ``nn.Conv2d(k=4, s=2, p=1)`` + lrelu layers ``convs`` on NHWC float32 ``x`` (agent.py:21-32,
   critics.py:13-35): one once-differentiable node inside ``once_differentiable_convnets()`` on a ROCm device (every layer's
