@@ -55,6 +55,8 @@ SIGNATURES = {
     'expo_conv4x4s2_wrw': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_conv_wrw_tuning': (_i, [_i, _i]),
     'expo_conv4x4s2_bwd_data_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
+    'expo_conv4x4s2_fwd_pair': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'expo_conv4x4s2_bwd_data_mask_pair': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_fwd_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_wrw_bias': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_conv4x4s2_wrw_group': (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
@@ -970,6 +972,39 @@ def conv4x4s2_bwd_data_mask(dy, w, zmask, dx, leak=0.2):
   with torch.cuda.device(dy.device):
     _check(lib.expo_conv4x4s2_bwd_data_mask(_ptr(dy), _ptr(w), _ptr(zmask), _ptr(dx), n, h, wd, cin, cout, float(leak),
                                             _stream()), 'expo_conv4x4s2_bwd_data_mask')
+
+
+def conv4x4s2_fwd_pair(a, b, act, leak=0.2):
+  """``conv4x4s2_fwd`` of two problems of one geometry as ONE grid (expo_conv4x4s2_fwd_pair): ``a`` / ``b`` = (x, w, bias, y).
+  Same results as the two calls."""
+  lib = load()
+  (xa, wa, ba, ya), (xb, wb, bb, yb) = a, b
+  n, h, wd, cin, cout = _conv_args(xa.shape, wa)
+  assert _conv_args(xb.shape, wb) == (n, h, wd, cin, cout) and (ba is None) == (bb is None)
+  for x, y, bias in ((xa, ya, ba), (xb, yb, bb)):
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    assert y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (n, h // 2, wd // 2, cout)
+    if bias is not None:
+      _f32(bias, 'bias', (cout,))
+  with torch.cuda.device(xa.device):
+    _check(lib.expo_conv4x4s2_fwd_pair(_ptr(xa), _ptr(wa), _ptr(ba), _ptr(ya), _ptr(xb), _ptr(wb), _ptr(bb), _ptr(yb), n, h, wd,
+                                       cin, cout, int(act), float(leak), _stream()), 'expo_conv4x4s2_fwd_pair')
+
+
+def conv4x4s2_bwd_data_mask_pair(a, b, leak=0.2):
+  """``conv4x4s2_bwd_data_mask`` of two problems of one geometry as ONE grid: ``a`` / ``b`` = (dy, w, zmask, dx)."""
+  lib = load()
+  (dya, wa, za, dxa), (dyb, wb, zb, dxb) = a, b
+  n, h, wd, cin, cout = _conv_args(dxa.shape, wa)
+  assert _conv_args(dxb.shape, wb) == (n, h, wd, cin, cout)
+  for dy, z, dx in ((dya, za, dxa), (dyb, zb, dxb)):
+    assert dy.is_cuda and dy.dtype == torch.float32 and dy.is_contiguous() and tuple(dy.shape) == (n, h // 2, wd // 2, cout)
+    assert dx.dtype == torch.float32 and dx.is_contiguous()
+    assert z.dtype == torch.float32 and z.is_contiguous() and z.shape == dx.shape
+  with torch.cuda.device(dya.device):
+    _check(lib.expo_conv4x4s2_bwd_data_mask_pair(_ptr(dya), _ptr(wa), _ptr(za), _ptr(dxa), _ptr(dyb), _ptr(wb), _ptr(zb), _ptr(dxb),
+                                                 n, h, wd, cin, cout, float(leak), _stream()),
+           'expo_conv4x4s2_bwd_data_mask_pair')
 
 
 def conv4x4s2_fwd_mask(x, w, zmask, y, leak=0.2):

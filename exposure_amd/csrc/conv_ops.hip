@@ -45,6 +45,17 @@ struct ConvDims {
   int m;                   // n ho wo
   int sh_w, sh_hw;         // log2 wo, log2 (ho wo) when both are powers of two, else -1 (pixel index -> (n, oh, ow) by shifts)
 };
+// A PAIR of launches as one grid (gridDim.y = 2): two problems of the same geometry and plan -- the agent's two feature
+// extractors, the critic's and the value net's pair passes of a G / V step -- whose layers are independent and at batch 64 /
+// 128 too small to fill the chip alone.  Blocks with blockIdx.y = 1 take the second problem's pointers.
+struct ConvSecond {
+  const float* x;      // forward: input; data gradient: dY
+  const float* w;
+  const float* bias;   // forward only
+  const float* zmask;
+  float* y;            // forward: output; data gradient: dX
+};
+
 // pixel index m = (n ho + a) wo + b  ->  (n, a, b)
 __device__ __forceinline__ void split_pixel(const ConvDims& d, int m, int& n, int& a, int& b) {
   if (d.sh_w >= 0) {  // (wave-uniform)
@@ -161,7 +172,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_fwd_kernel(const float
                                                                       const float* __restrict__ w,
                                                                       const float* __restrict__ bias,
                                                                       const float* zmask, float* y, ConvDims d,
-                                                                      int act, float leak) {
+                                                                      int act, float leak, ConvSecond sec) {
+  if (blockIdx.y) { x = sec.x; w = sec.w; bias = sec.bias; zmask = sec.zmask; y = sec.y; }  // (the second problem of a pair)
   // zmask (nullable, may alias y): the result is multiplied by the lrelu slope read from zmask at the same position --
   // the tangent pass of the gradient penalty's double backward, t_l = F(t_{l-1}, W_l) * slope(z_l), written over z_l
   constexpr int T = 64 * WM * WN * WK;
@@ -349,7 +361,9 @@ struct FlatPlan {
 template <int NI, bool CIN4>
 __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const float* zmask,
-                                                             float* y, ConvDims d, FlatPlan pl, int act, float leak) {
+                                                             float* y, ConvDims d, FlatPlan pl, int act, float leak,
+                                                             ConvSecond sec) {
+  if (blockIdx.y) { x = sec.x; w = sec.w; bias = sec.bias; zmask = sec.zmask; y = sec.y; }  // (the second problem of a pair)
   // NI = column tiles per WAVE (32 x 32 NI outputs): the A fragment is loaded once and feeds NI MFMAs -- 3 operand
   // loads per 8 MFMAs instead of 2 per 4 for NI = 2
   extern __shared__ __attribute__((aligned(16))) float part[];  // [s][NI][16][64]
@@ -529,7 +543,8 @@ __global__ __launch_bounds__(1024) void conv_fwd_flat_kernel(const float* __rest
 // block instead of one per chunk group.  27.5 -> 14 us for the critic's first layer at batch 192 (0.4 GFLOP per 64 images).
 __global__ __launch_bounds__(512) void conv_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const float* zmask, float* y,
-                                                            ConvDims d, int rows, int act, float leak) {
+                                                            ConvDims d, int rows, int act, float leak, ConvSecond sec) {
+  if (blockIdx.y) { x = sec.x; w = sec.w; bias = sec.bias; zmask = sec.zmask; y = sec.y; }  // (the second problem of a pair)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int cin = d.cin;
   const int lpad = (cin + 3) / 4 * 4;             // zero floats in front of a staged row (>= one pixel, whole float4s)
@@ -641,7 +656,8 @@ static FlatPlan flat_plan(const ConvDims& d, int ni, int forced_s) {
 template <int NI>
 __global__ __launch_bounds__(1024) void conv_bwd_flat_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              const float* __restrict__ zmask, float* __restrict__ dx,
-                                                             ConvDims d, FlatPlan pl, float leak) {
+                                                             ConvDims d, FlatPlan pl, float leak, ConvSecond sec) {
+  if (blockIdx.y) { dy = sec.x; w = sec.w; zmask = sec.zmask; dx = sec.y; }  // (the second problem of a pair)
   // zmask (nullable, the layer BELOW's activation z, shaped like dx): dx *= slope(z) -- the activation gradient of the
   // layer below in this kernel's epilogue instead of a launch of its own
   // NI = input-channel tiles per wave (32 pixels x 32 NI channels): the dY fragment is loaded once for NI MFMAs
@@ -1208,14 +1224,16 @@ static WrwPlan wrw_plan(const ConvDims& d, int forced_s, int forced_p) {
 
 template <int BM, int BN, int WM, int WN, int WK, int BKS>
 static void launch_fwd(const float* x, const float* w, const float* bias, const float* zmask, float* y,
-                       const ConvDims& d, int act, float leak, hipStream_t s) {
+                       const ConvDims& d, int act, float leak, hipStream_t s, const ConvSecond* sec) {
   const int blocks = ((d.m + BM - 1) / BM) * ((d.cout + BN - 1) / BN);
+  const dim3 grid(blocks, sec ? 2 : 1);
+  const ConvSecond s2 = sec ? *sec : ConvSecond{};
   if (d.cin % 4 == 0)
-    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WK, BKS, true>), dim3(blocks), dim3(64 * WM * WN * WK), 0, s, x, w,
-                       bias, zmask, y, d, act, leak);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WK, BKS, true>), grid, dim3(64 * WM * WN * WK), 0, s, x, w,
+                       bias, zmask, y, d, act, leak, s2);
   else
-    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WK, BKS, false>), dim3(blocks), dim3(64 * WM * WN * WK), 0, s, x, w,
-                       bias, zmask, y, d, act, leak);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WK, BKS, false>), grid, dim3(64 * WM * WN * WK), 0, s, x, w,
+                       bias, zmask, y, d, act, leak, s2);
 }
 
 static int conv_dims(ConvDims* d, int n, int h, int w, int cin, int cout) {
@@ -1256,12 +1274,18 @@ static ConvTuning& conv_tuning() {
 }
 
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* zmask, float* y, int n, int h,
-                         int wd, int cin, int cout, int act, float leak, void* stream) {
+                         int wd, int cin, int cout, int act, float leak, void* stream, const ConvSecond* sec = nullptr) {
   ConvDims d;
   if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
   if (n == 0) return EXPO_OK;
   if (!x || !w || !y) return fail(EXPO_E_BADARG, "null pointer");
   if ((reinterpret_cast<uintptr_t>(w) & 15) != 0) return fail(EXPO_E_BADARG, "conv4x4s2: weight must be 16-byte aligned");
+  if (sec && (!sec->x || !sec->w || !sec->y || (reinterpret_cast<uintptr_t>(sec->w) & 15) != 0 ||
+              ((reinterpret_cast<uintptr_t>(sec->x) ^ reinterpret_cast<uintptr_t>(x)) & 15) != 0 || !sec->bias != !bias ||
+              !sec->zmask != !zmask))
+    return fail(EXPO_E_BADARG, "conv4x4s2 pair: the second problem needs the same operands, equally aligned");
+  const dim3 gy2(1, sec ? 2 : 1);
+  const ConvSecond s2 = sec ? *sec : ConvSecond{};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int forced = conv_tuning().tile.load(), forced_nt = conv_tuning().nt.load(), forced_s = conv_tuning().slices.load();
   auto blocks = [&](int bm, int bn) { return ((d.m + bm - 1) / bm) * ((d.cout + bn - 1) / bn); };
@@ -1287,8 +1311,8 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr;
     if (lds <= 160 * 1024) {
-      hipLaunchKernelGGL(conv_fwd_rows_kernel, dim3(unsigned(d.n * (d.ho / rows))), dim3(64 * rows), lds, s, x, w, bias, zmask,
-                         y, d, rows, act, leak);
+      hipLaunchKernelGGL(conv_fwd_rows_kernel, dim3(unsigned(d.n * (d.ho / rows)), gy2.y), dim3(64 * rows), lds, s, x, w, bias,
+                         zmask, y, d, rows, act, leak, s2);
       HIP_TRY(hipGetLastError(), "conv4x4s2_fwd (rows) launch");
       return EXPO_OK;
     }
@@ -1312,7 +1336,8 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     const int nblocks = pl.tiles_m * pl.tiles_n;
     const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
 #define EXPO_FLAT(NI, C4) \
-  hipLaunchKernelGGL((conv_fwd_flat_kernel<NI, C4>), dim3(nblocks), dim3(64 * pl.s), lds, s, x, w, bias, zmask, y, d, pl, act, leak)
+  hipLaunchKernelGGL((conv_fwd_flat_kernel<NI, C4>), dim3(nblocks, gy2.y), dim3(64 * pl.s), lds, s, x, w, bias, zmask, y, d, pl, act, \
+                     leak, s2)
     if (ni == 2) { if (d.cin % 4 == 0) EXPO_FLAT(2, true); else EXPO_FLAT(2, false); }
     else { if (d.cin % 4 == 0) EXPO_FLAT(1, true); else EXPO_FLAT(1, false); }
 #undef EXPO_FLAT
@@ -1320,22 +1345,27 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     return EXPO_OK;
   }
   switch (shape) {
-    case 1: launch_fwd<64, 32, 2, 1, 2, 32>(x, w, bias, zmask, y, d, act, leak, s); break;
-    case 2: launch_fwd<64, 64, 2, 2, 1, 32>(x, w, bias, zmask, y, d, act, leak, s); break;
-    case 3: launch_fwd<32, 64, 1, 2, 2, 32>(x, w, bias, zmask, y, d, act, leak, s); break;
-    default: launch_fwd<32, 32, 1, 1, 4, 16>(x, w, bias, zmask, y, d, act, leak, s); break;
+    case 1: launch_fwd<64, 32, 2, 1, 2, 32>(x, w, bias, zmask, y, d, act, leak, s, sec); break;
+    case 2: launch_fwd<64, 64, 2, 2, 1, 32>(x, w, bias, zmask, y, d, act, leak, s, sec); break;
+    case 3: launch_fwd<32, 64, 1, 2, 2, 32>(x, w, bias, zmask, y, d, act, leak, s, sec); break;
+    default: launch_fwd<32, 32, 1, 1, 4, 16>(x, w, bias, zmask, y, d, act, leak, s, sec); break;
   }
   HIP_TRY(hipGetLastError(), "conv4x4s2_fwd launch");
   return EXPO_OK;
 }
 
 static int conv_bwd_data_impl(const float* dy, const float* w, const float* zmask, float* dx, int n, int h, int wd,
-                              int cin, int cout, float leak, void* stream) {
+                              int cin, int cout, float leak, void* stream, const ConvSecond* sec = nullptr) {
   ConvDims d;
   if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
   if (n == 0) return EXPO_OK;
   if (!dy || !w || !dx) return fail(EXPO_E_BADARG, "null pointer");
   if (cout % 4 != 0) return fail(EXPO_E_BADARG, "conv4x4s2_bwd_data: cout must be a multiple of 4");
+  if (sec && (!sec->x || !sec->w || !sec->y || !sec->zmask != !zmask ||
+              ((reinterpret_cast<uintptr_t>(sec->x) ^ reinterpret_cast<uintptr_t>(dy)) & 15) != 0))
+    return fail(EXPO_E_BADARG, "conv4x4s2_bwd_data pair: the second problem needs the same operands, equally aligned");
+  const unsigned gy2 = sec ? 2 : 1;
+  const ConvSecond s2 = sec ? *sec : ConvSecond{};
   hipStream_t s = static_cast<hipStream_t>(stream);
   int ni = conv_tuning().nt.load();  // input-channel tiles per wave (0: the library's choice)
   const int forced_s = conv_tuning().slices.load();
@@ -1350,6 +1380,8 @@ static int conv_bwd_data_impl(const float* dy, const float* w, const float* zmas
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr6;
     hipLaunchKernelGGL(conv_bwd_small_kernel<6>, grid, dim3(256), small_lds, s, dy, w, zmask, dx, d, leak);
+    if (sec)  // (the vector-ALU kernel takes no pair: two launches)
+      hipLaunchKernelGGL(conv_bwd_small_kernel<6>, grid, dim3(256), small_lds, s, sec->x, sec->w, sec->zmask, sec->y, d, leak);
     HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data (small) launch");
     return EXPO_OK;
   }
@@ -1359,8 +1391,8 @@ static int conv_bwd_data_impl(const float* dy, const float* w, const float* zmas
   const FlatPlan pl = bwd_plan(d, ni, forced_s);
   const int nblocks = 4 * pl.tiles_m * pl.tiles_n;
   const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
-  if (ni == 2) hipLaunchKernelGGL(conv_bwd_flat_kernel<2>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, zmask, dx, d, pl, leak);
-  else hipLaunchKernelGGL(conv_bwd_flat_kernel<1>, dim3(nblocks), dim3(64 * pl.s), lds, s, dy, w, zmask, dx, d, pl, leak);
+  if (ni == 2) hipLaunchKernelGGL(conv_bwd_flat_kernel<2>, dim3(nblocks, gy2), dim3(64 * pl.s), lds, s, dy, w, zmask, dx, d, pl, leak, s2);
+  else hipLaunchKernelGGL(conv_bwd_flat_kernel<1>, dim3(nblocks, gy2), dim3(64 * pl.s), lds, s, dy, w, zmask, dx, d, pl, leak, s2);
   HIP_TRY(hipGetLastError(), "conv4x4s2_bwd_data launch");
   return EXPO_OK;
 }
@@ -1698,6 +1730,21 @@ int expo_conv4x4s2_fwd_mask(const float* x, const float* w, const float* zmask, 
                             int cout, float leak, void* stream) {
   if (!zmask) return fail(EXPO_E_BADARG, "null pointer");
   return conv_fwd_impl(x, w, nullptr, zmask, y, n, h, wd, cin, cout, 0, leak, stream);
+}
+
+int expo_conv4x4s2_fwd_pair(const float* x_a, const float* w_a, const float* bias_a, float* y_a, const float* x_b,
+                            const float* w_b, const float* bias_b, float* y_b, int n, int h, int wd, int cin, int cout, int act,
+                            float leak, void* stream) {
+  const ConvSecond sec{x_b, w_b, bias_b, nullptr, y_b};
+  return conv_fwd_impl(x_a, w_a, bias_a, nullptr, y_a, n, h, wd, cin, cout, act, leak, stream, &sec);
+}
+
+int expo_conv4x4s2_bwd_data_mask_pair(const float* dy_a, const float* w_a, const float* zmask_a, float* dx_a, const float* dy_b,
+                                      const float* w_b, const float* zmask_b, float* dx_b, int n, int h, int wd, int cin,
+                                      int cout, float leak, void* stream) {
+  if (!zmask_a || !zmask_b) return fail(EXPO_E_BADARG, "null pointer");
+  const ConvSecond sec{dy_b, w_b, nullptr, zmask_b, dx_b};
+  return conv_bwd_data_impl(dy_a, w_a, zmask_a, dx_a, n, h, wd, cin, cout, leak, stream, &sec);
 }
 
 int expo_conv_tuning(int tile, int nt, int slices) {

@@ -57,7 +57,8 @@ def supported(gan, fake_input, states):
 
 
 class _PairPass:
-  """One net on the batch [a | b] (n images each): ``forward()`` -> logits (2n,); ``backward(dlogit, ...)``."""
+  """One net on the batch [a | b] (n images each): the constructor builds its input, ``forward_all`` runs the
+  convolutions and the head (-> ``logits`` (2n,)), ``backward(dlogit, ...)`` the explicit backward."""
 
   def __init__(self, net, img_a, img_b, vec_a=None, vec_b=None, x_rows=None):
     self.net, self.n = net, img_a.shape[0]
@@ -83,11 +84,19 @@ class _PairPass:
       _cabi.planes_concat(x, vec.contiguous(), a0, 0.5)
       self.x = x[x_rows]
     self.acts = [a0]
-    for conv in net.convs:
-      a = self.acts[-1]
-      z = torch.empty((m, a.shape[1] // 2, a.shape[2] // 2, conv.weight.shape[0]), **f32)
-      _cabi.conv4x4s2_fwd(a, conv.weight, conv.bias, z, 1, LEAK)
-      self.acts.append(z)
+    self.m = m
+
+  def conv_layer(self, l):
+    """(input, weight, bias, fresh output) of layer l (0-based); the output joins ``acts``."""
+    conv = self.net.convs[l]
+    a = self.acts[l]
+    z = torch.empty((self.m, a.shape[1] // 2, a.shape[2] // 2, conv.weight.shape[0]), dtype=torch.float32, device=a.device)
+    self.acts.append(z)
+    return a, conv.weight, conv.bias, z
+
+  def head(self):
+    net, m = self.net, self.m
+    f32 = dict(dtype=torch.float32, device=self.acts[0].device)
     self.flat = self.acts[-1].reshape(m, net.flat)
     self.hidden = net.fc1.weight.shape[0]
     self.logits = torch.empty((m,), **f32)
@@ -102,6 +111,27 @@ class _PairPass:
       hpre = torch.addmm(net.fc1.bias, self.flat, net.fc1.weight.t())
     _cabi.critic_head_fwd(hpre, net.fc2.weight.reshape(self.hidden), net.fc2.bias, 0, 0, m, 1.0, self.logits, self.h,
                           self.dh_unit, LEAK, b1=net.fc1.bias if self.split else None)
+
+  @staticmethod
+  def forward_all(passes):
+    """The convolutions and heads of the passes: layer by layer, two passes whose layer has ONE geometry (the critic's and
+    the value net's layers 2 .. 4 on 2n images each) as one grid (expo_conv4x4s2_fwd_pair)."""
+    depth = len(passes[0].net.convs)
+    same_depth = all(len(p.net.convs) == depth for p in passes)
+    for l in range(depth if same_depth else 0):
+      items = [p.conv_layer(l) for p in passes]
+      if len(items) == 2 and items[0][0].shape == items[1][0].shape and items[0][1].shape == items[1][1].shape:
+        _cabi.conv4x4s2_fwd_pair(items[0], items[1], 1, LEAK)
+      else:
+        for a, w, b, z in items:
+          _cabi.conv4x4s2_fwd(a, w, b, z, 1, LEAK)
+    if not same_depth:
+      for p in passes:
+        for l in range(len(p.net.convs)):
+          a, w, b, z = p.conv_layer(l)
+          _cabi.conv4x4s2_fwd(a, w, b, z, 1, LEAK)
+    for p in passes:
+      p.head()
 
   def backward(self, dlogit, rows, rows_x, grads=None, rows_w=None):
     """``dlogit`` the upstream gradients of the logits of ``rows``, the row range the backward covers (a slice); ``rows_x``
@@ -181,6 +211,7 @@ def generator_step_losses_and_grads(gan, fake_input, z, states, progress, dropou
     fo = fake_output.detach()
     critic = _PairPass(gan.critic, fo, fake_input.to(fo.dtype), x_rows=A)
     value = _PairPass(gan.value, fake_input.to(fo.dtype), fo, states, new_states.detach(), x_rows=B)
+    _PairPass.forward_all([critic, value])
     losses = torch.empty((2,), **f32)
     reward, q = torch.empty((n,), **f32), torch.empty((n,), **f32)
     coef = torch.empty((5, n), **f32)

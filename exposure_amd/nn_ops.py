@@ -357,19 +357,30 @@ class _ConvTrunks(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, leak, stacks, *wb):
     n_l = len(wb) // (2 * stacks)
-    saved, outs = [x], []
+    ws = [wb[2 * n_l * s:2 * n_l * (s + 1):2] for s in range(stacks)]
+    bs = [wb[2 * n_l * s + 1:2 * n_l * (s + 1):2] for s in range(stacks)]
+    acts = [[x] for _ in range(stacks)]
+    # two stacks of one architecture: layer l of both as ONE grid (expo_conv4x4s2_fwd_pair) -- at batch 64 a layer alone
+    # leaves CUs idle
+    paired = stacks == 2 and all(ws[0][l].shape == ws[1][l].shape for l in range(n_l))
+    for l in range(n_l):
+      zs = []
+      for s in range(stacks):
+        a, w = acts[s][-1], ws[s][l]
+        zs.append(torch.empty((a.shape[0], a.shape[1] // 2, a.shape[2] // 2, w.shape[0]), dtype=torch.float32, device=a.device))
+      if paired:
+        _cabi.conv4x4s2_fwd_pair((acts[0][-1], ws[0][l], bs[0][l], zs[0]), (acts[1][-1], ws[1][l], bs[1][l], zs[1]), 1, leak)
+      else:
+        for s in range(stacks):
+          _cabi.conv4x4s2_fwd(acts[s][-1], ws[s][l], bs[s][l], zs[s], 1, leak)
+      for s in range(stacks):
+        acts[s].append(zs[s])
+    saved = [x]
     for s in range(stacks):
-      ws, bs = wb[2 * n_l * s:2 * n_l * (s + 1):2], wb[2 * n_l * s + 1:2 * n_l * (s + 1):2]
-      a = x
-      for w, b in zip(ws, bs):
-        z = torch.empty((a.shape[0], a.shape[1] // 2, a.shape[2] // 2, w.shape[0]), dtype=torch.float32, device=a.device)
-        _cabi.conv4x4s2_fwd(a, w, b, z, 1, leak)
-        saved.append(z)
-        a = z
-      outs.append(a)
+      saved += acts[s][1:]
     ctx.save_for_backward(*saved, *wb[0::2])
-    ctx.leak, ctx.layers, ctx.stacks = leak, n_l, stacks
-    return tuple(outs)
+    ctx.leak, ctx.layers, ctx.stacks, ctx.paired = leak, n_l, stacks, paired
+    return tuple(acts[s][-1] for s in range(stacks))
 
   @staticmethod
   @once_differentiable
@@ -381,29 +392,37 @@ class _ConvTrunks(torch.autograd.Function):
     grads = [None] * (2 * n_l * stacks)
     gx = None
     wrw = []
-    for s in range(stacks):
-      gz = gzs[s]
-      if gz is None:
-        continue
-      acts = (x,) + tuple(zs[n_l * s:n_l * (s + 1)])
-      ws = ws_all[n_l * s:n_l * (s + 1)]
-      want_w = any(ctx.needs_input_grad[3 + 2 * n_l * s:3 + 2 * n_l * (s + 1)]) and not _SKIP_PARAM_GRADS
-      gy = torch.empty_like(acts[n_l])
-      _cabi.lrelu_bwd(acts[n_l], gz.contiguous(), gy, ctx.leak)
-      for l in range(n_l, 0, -1):
-        w = ws[l - 1]
-        if want_w:
+    live = [s for s in range(stacks) if gzs[s] is not None]
+    acts = {s: (x,) + tuple(zs[n_l * s:n_l * (s + 1)]) for s in live}
+    ws = {s: ws_all[n_l * s:n_l * (s + 1)] for s in live}
+    want_w = {s: any(ctx.needs_input_grad[3 + 2 * n_l * s:3 + 2 * n_l * (s + 1)]) and not _SKIP_PARAM_GRADS for s in live}
+    gy = {}
+    for s in live:
+      gy[s] = torch.empty_like(acts[s][n_l])
+      _cabi.lrelu_bwd(acts[s][n_l], gzs[s].contiguous(), gy[s], ctx.leak)
+    paired = ctx.paired and len(live) == 2
+    for l in range(n_l, 0, -1):
+      for s in live:
+        if want_w[s]:
+          w = ws[s][l - 1]
           dw = torch.empty_like(w, memory_format=torch.preserve_format)
           db = torch.empty((w.shape[0],), dtype=torch.float32, device=w.device)
-          wrw.append((acts[l - 1], gy, dw, db, None))
+          wrw.append((acts[s][l - 1], gy[s], dw, db, None))
           grads[2 * (n_l * s + l - 1)], grads[2 * (n_l * s + l - 1) + 1] = dw, db
-        if l > 1:
-          g = torch.empty_like(acts[l - 1])
-          _cabi.conv4x4s2_bwd_data_mask(gy, w, acts[l - 1], g, ctx.leak)
-          gy = g
-        elif ctx.needs_input_grad[0]:
+      if l > 1:
+        g = {s: torch.empty_like(acts[s][l - 1]) for s in live}
+        if paired:  # the two stacks' data gradients as one grid
+          a, b = live
+          _cabi.conv4x4s2_bwd_data_mask_pair((gy[a], ws[a][l - 1], acts[a][l - 1], g[a]),
+                                             (gy[b], ws[b][l - 1], acts[b][l - 1], g[b]), ctx.leak)
+        else:
+          for s in live:
+            _cabi.conv4x4s2_bwd_data_mask(gy[s], ws[s][l - 1], acts[s][l - 1], g[s], ctx.leak)
+        gy = g
+      elif ctx.needs_input_grad[0]:
+        for s in live:
           g = torch.empty_like(x)
-          _cabi.conv4x4s2_bwd_data(gy, w, g)
+          _cabi.conv4x4s2_bwd_data(gy[s], ws[s][0], g)
           gx = g if gx is None else gx + g
     for k in range(0, len(wrw), 8):
       _cabi.conv4x4s2_wrw_group(wrw[k:k + 8])

@@ -602,6 +602,17 @@ int expo_conv4x4s2_fwd_mask(const float* x, const float* w, const float* zmask, 
                             int cout, float leak, void* stream);
 int expo_conv4x4s2_wrw_bias(const float* x, const float* dy, float* dw, float* dbias, int bias_images, int n, int h,
                             int wd, int cin, int cout, void* workspace, size_t workspace_bytes, void* stream);
+/* (ABI 7) Two problems of ONE geometry as one grid: the forward (bias + activation) and the data gradient (activation
+ * gradient of the layer below in the epilogue) of two independent layers -- the agent's filter and selector extractors read
+ * the same input through different weights (agent.py:47-56), the critic's and the value net's pair passes of a G / V step run
+ * side by side -- at batch 64 / 128, where one of them alone leaves CUs idle.  Same results, bit for bit, as the two
+ * separate calls. */
+int expo_conv4x4s2_fwd_pair(const float* x_a, const float* w_a, const float* bias_a, float* y_a, const float* x_b,
+                            const float* w_b, const float* bias_b, float* y_b, int n, int h, int wd, int cin, int cout, int act,
+                            float leak, void* stream);
+int expo_conv4x4s2_bwd_data_mask_pair(const float* dy_a, const float* w_a, const float* zmask_a, float* dx_a, const float* dy_b,
+                                      const float* w_b, const float* zmask_b, float* dx_b, int n, int h, int wd, int cin,
+                                      int cout, float leak, void* stream);
 /* The weight (and bias) gradients of up to 8 layers -- a whole stack -- with ONE reduce launch for all of them: per layer the
  * arguments of expo_conv4x4s2_wrw_bias (arrays of `count` entries; dbias[l] may be NULL: no bias gradient for that
  * layer), each layer with its own workspace of expo_conv4x4s2_wrw_workspace_bytes(...) bytes.  Same results, bit for

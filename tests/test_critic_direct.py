@@ -531,3 +531,33 @@ def test_direct_critic_update_on_its_separate_launches(gpu_device, monkeypatch):
   for name, a in outs[0][1].items():
     b = outs[1][1][name]
     assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9, name
+
+
+@pytest.mark.parametrize('case', [(64, 64, 14, 32), (8, 64, 17, 32), (64, 32, 32, 64), (128, 16, 64, 128), (64, 8, 128, 256),
+                                  (5, 12, 6, 32), (3, 8, 5, 8)])
+def test_pair_launches_equal_the_two_calls(case, gpu_device):
+  """expo_conv4x4s2_fwd_pair / _bwd_data_mask_pair: two problems of one geometry as one grid (gridDim.y = 2) == the two
+  separate calls, bit for bit -- every forward kernel family (row-staged first layers, LDS-tiled, flat) and the flat data
+  gradient, the same and different inputs."""
+  from exposure_amd import _cabi
+  dev = gpu_device
+  n, h, cin, cout = case
+  xa, wa, gya = _case(n, h, cin, cout, dev, 5)
+  xb, wb, gyb = _case(n, h, cin, cout, dev, 6)
+  g = torch.Generator(device=dev).manual_seed(7)
+  ba, bb = torch.randn((cout,), device=dev, generator=g), torch.randn((cout,), device=dev, generator=g)
+  shape = (n, h // 2, h // 2, cout)
+  for xb_ in (xb, xa):  # (the agent's two extractors read the SAME input)
+    want = [torch.empty(shape, device=dev) for _ in range(2)]
+    _cabi.conv4x4s2_fwd(xa, wa, ba, want[0], 1, 0.2)
+    _cabi.conv4x4s2_fwd(xb_, wb, bb, want[1], 1, 0.2)
+    got = [torch.full(shape, float('nan'), device=dev) for _ in range(2)]
+    _cabi.conv4x4s2_fwd_pair((xa, wa, ba, got[0]), (xb_, wb, bb, got[1]), 1, 0.2)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+  if cout % 4 == 0:
+    want = [torch.empty_like(xa) for _ in range(2)]
+    _cabi.conv4x4s2_bwd_data_mask(gya, wa, xa, want[0], 0.2)
+    _cabi.conv4x4s2_bwd_data_mask(gyb, wb, xb, want[1], 0.2)
+    got = [torch.full_like(xa, float('nan')) for _ in range(2)]
+    _cabi.conv4x4s2_bwd_data_mask_pair((gya, wa, xa, got[0]), (gyb, wb, xb, got[1]), 0.2)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
