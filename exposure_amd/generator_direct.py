@@ -156,19 +156,10 @@ class _PairPass:
       _cabi.conv4x4s2_bwd_data_mask(gys[l], convs[l - 1].weight, below, g, LEAK)
       gys[l - 1] = g
     a0x = self.acts[0][rows_x]
-    w0, first = convs[0].weight, self.stats_first
-    if first > 3:
-      # the planes between the image and the statistics (the value net's 11 state planes) get no gradient here: the first
-      # layer's data gradient over the SIX planes that do -- image + statistics -- runs on the 6-plane kernel (20 against
-      # 37 us for all 17 planes at 64 rows); one tiny concatenation of the weight's input planes in front of it (device-side: an
-      # index tensor built on the host would put a pageable copy into the step's graph)
-      w0 = w0.detach()
-      w0 = torch.cat([w0[:, :3], w0[:, first:first + 3]], dim=1).contiguous(memory_format=torch.channels_last)
-      first = 3
-    u0 = torch.empty(tuple(a0x.shape[:-1]) + (w0.shape[1],), dtype=torch.float32, device=a0x.device)
-    _cabi.conv4x4s2_bwd_data(gys[1][rel(rows_x)], w0, u0)
+    u0 = torch.empty_like(a0x)
+    _cabi.conv4x4s2_bwd_data(gys[1][rel(rows_x)], convs[0].weight, u0)
     gs = torch.empty((u0.shape[0], 3), dtype=torch.float32, device=u0.device)
-    _cabi.plane_sums(u0, gs, first)
+    _cabi.plane_sums(u0, gs, self.stats_first)
     xr = self.x[rows_x.start - self.x_first:rows_x.stop - self.x_first]
     ds = torch.empty_like(xr)
     _cabi.critic_stats_bwd(xr, self.stats[rows_x], gs, ds)
