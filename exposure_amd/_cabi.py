@@ -55,6 +55,8 @@ SIGNATURES = {
     'expo_conv4x4s2_wrw': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'expo_conv_wrw_tuning': (_i, [_i, _i]),
     'expo_conv4x4s2_bwd_data_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
+    'expo_conv4x4s2_fwd_planes': (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'expo_conv4x4s2_fwd_planes_pair': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_fwd_pair': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_bwd_data_mask_pair': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
     'expo_conv4x4s2_fwd_mask': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _vp]),
@@ -972,6 +974,45 @@ def conv4x4s2_bwd_data_mask(dy, w, zmask, dx, leak=0.2):
   with torch.cuda.device(dy.device):
     _check(lib.expo_conv4x4s2_bwd_data_mask(_ptr(dy), _ptr(w), _ptr(zmask), _ptr(dx), n, h, wd, cin, cout, float(leak),
                                             _stream()), 'expo_conv4x4s2_bwd_data_mask')
+
+
+def conv_planes_ok(x_shape, cout):
+  """``conv4x4s2_fwd_planes`` takes this first layer (64-wide NHWC input of 4 .. 20 planes, at most 32 output channels)."""
+  n, h, wd, cin = x_shape
+  return wd == 64 and h % 8 == 0 and 4 <= cin <= 20 and cout <= 32
+
+
+def conv4x4s2_fwd_planes(x, w, bias, y, act, leak=0.2, zmask=None):
+  """``conv4x4s2_fwd`` (or, with ``zmask`` and no bias, ``conv4x4s2_fwd_mask``) of a first layer whose input channels 3 .. are
+  per-image constants (``planes_concat`` / ``net_inputs`` / ``critic_penalty_tangent`` outputs): K = 48 instead of 16 cin
+  (expo_conv4x4s2_fwd_planes).  The caller vouches for the planes being constant."""
+  lib = load()
+  n, h, wd, cin, cout = _conv_args(x.shape, w)
+  assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+  assert y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (n, h // 2, wd // 2, cout)
+  if bias is not None:
+    _f32(bias, 'bias', (cout,))
+  if zmask is not None:
+    assert zmask.dtype == torch.float32 and zmask.is_contiguous() and zmask.shape == y.shape
+  with torch.cuda.device(x.device):
+    _check(lib.expo_conv4x4s2_fwd_planes(_ptr(x), _ptr(w), _ptr(bias), _ptr(zmask), _ptr(y), n, h, wd, cin, cout, int(act),
+                                         float(leak), _stream()), 'expo_conv4x4s2_fwd_planes')
+
+
+def conv4x4s2_fwd_planes_pair(a, b, act, leak=0.2):
+  """``conv4x4s2_fwd_planes`` of two problems of one geometry as ONE grid: ``a`` / ``b`` = (x, w, bias, y)."""
+  lib = load()
+  (xa, wa, ba, ya), (xb, wb, bb, yb) = a, b
+  n, h, wd, cin, cout = _conv_args(xa.shape, wa)
+  assert _conv_args(xb.shape, wb) == (n, h, wd, cin, cout) and (ba is None) == (bb is None)
+  for x, y, bias in ((xa, ya, ba), (xb, yb, bb)):
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    assert y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (n, h // 2, wd // 2, cout)
+    if bias is not None:
+      _f32(bias, 'bias', (cout,))
+  with torch.cuda.device(xa.device):
+    _check(lib.expo_conv4x4s2_fwd_planes_pair(_ptr(xa), _ptr(wa), _ptr(ba), _ptr(ya), _ptr(xb), _ptr(wb), _ptr(bb), _ptr(yb), n, h,
+                                              wd, cin, cout, int(act), float(leak), _stream()), 'expo_conv4x4s2_fwd_planes_pair')
 
 
 def conv4x4s2_fwd_pair(a, b, act, leak=0.2):

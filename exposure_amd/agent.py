@@ -249,7 +249,8 @@ class Agent(nn.Module):
     # share one launch, nn_ops.conv_trunks)
     trunk_f = trunk_s = None
     if centered:
-      trunk_f, trunk_s = conv_trunks(enriched, [self.filter_features.convs, self.selector_features.convs])
+      trunk_f, trunk_s = conv_trunks(enriched, [self.filter_features.convs, self.selector_features.convs],
+                                     const_planes=True)  # (channels 3 ..: the states planes_concat broadcast)
     filter_features = self.filter_features(enriched, masks[0], centered=centered, trunk_out=trunk_f)
     # Training-time fast path (round 4): the regressors and the one-hot gather of the selected filter's parameters as
     # ONE kernel behind the heads' second FCs (filters.heads_regress_select).  Needs what the dispatch kernels need

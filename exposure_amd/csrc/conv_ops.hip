@@ -37,6 +37,7 @@ namespace expo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct __attribute__((packed, aligned(4))) F4U { float v[4]; };  // a 4-float chunk that is only dword-aligned
+struct __attribute__((packed, aligned(4))) F3U { float v[3]; };  // a pixel's three image planes
 
 struct ConvDims {
   int n, h, w, cin, cout;  // h, w: the LARGER spatial size (forward input / data-gradient output), even
@@ -618,6 +619,126 @@ __global__ __launch_bounds__(512) void conv_fwd_rows_kernel(const float* __restr
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     float v = acc[e] + bv;
+    if (act) v = lrelu_v(v, leak);
+    if (zmask) v *= lrelu_slope_v(z[e], leak);
+    buf_store1(ry, off[e], co_ok, v);
+  }
+}
+
+// ---- the same layers when their input comes from expo_planes_concat / expo_net_inputs / expo_critic_penalty_tangent: channels
+// 3 .. C - 1 are PER-IMAGE CONSTANTS (critics.py:64-76, agent.py:17-19: states and statistics broadcast as planes) -----------
+// The convolution is linear: y = conv(image planes, W[..., :3]) + conv(constant planes, W[..., 3:]), and the second term of an
+// output pixel depends only on the image, the channel and on WHICH TAPS fall inside the image -- 3 x 3 border classes
+// (top / inner / bottom row x left / inner / right column; 4 x 4 taps, stride 2, pad 1: the first tap row is outside for
+// oh = 0, the last for oh = ho - 1).  So K shrinks from 16 C (96 / 224 / 272) to 16 x 3 = 48 for EVERY first layer: a block
+// stages three floats per pixel (14.7 KB of LDS instead of 42 - 119 KB: five blocks per CU instead of one for 17 planes),
+// forms U[co][tap] = sum_c W[co][tap][3 + c] v_c once (v read from the image's first pixel), each wave adds the taps valid
+// for its row into T[column class][co] (+ bias), and the epilogue adds T.  A different order of the same sum (float32
+// rounding); the callers ask for it explicitly -- the kernel cannot know that planes are constant.
+__global__ __launch_bounds__(512) void conv_fwd_planes_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const float* zmask, float* y,
+                                                              ConvDims d, int rows, int act, float leak, ConvSecond sec) {
+  if (blockIdx.y) { x = sec.x; w = sec.w; bias = sec.bias; zmask = sec.zmask; y = sec.y; }  // (the second problem of a pair)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cin = d.cin, cv = cin - 3;            // constant planes
+  constexpr int lpad = 4, rpad = 8, rowk = 16, kp = 4 * rowk + 4;  // a kh row of K: 4 pixels x 3 planes, padded to 16
+  const int pitch = lpad + 3 * d.w + rpad;
+  float* const xs = smem;                           // [2 rows + 2][pitch]: the image planes, zero pixels left and right
+  float* const ws = xs + (2 * rows + 2) * pitch;    // [32][kp]: W[co][kh][kw][0..2], every kh row padded with zeros
+  float* const us = ws + 32 * kp;                   // [32][16]: U[co][tap]
+  float* const ts = us + 32 * 16;                   // [rows][3][32]: T[column class][co] of every wave's row
+  float* const vs = ts + rows * 96;                 // [cv]: the constant planes' values
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int blocks_per_image = d.ho / rows;
+  const int n = blockIdx.x / blocks_per_image, oh0 = (blockIdx.x - n * blocks_per_image) * rows;
+  const size_t img = size_t(n) * d.h * d.w * cin;
+  // ---- stage: image planes of the input rows (wave wv: rows wv, wv + rows, ...), weights of the image planes, constants
+  for (int r = wv; r < 2 * rows + 2; r += rows) {
+    const int ih = 2 * oh0 - 1 + r;
+    float* const dst = xs + r * pitch;
+    const bool inside = unsigned(ih) < unsigned(d.h);
+    const float* src = x + img + size_t(inside ? ih : 0) * d.w * cin;
+    for (int p = lane; p < d.w; p += 64) {  // a pixel per lane: its three image planes as one 12-byte load
+      F3U v = {{0.f, 0.f, 0.f}};
+      if (inside) v = *reinterpret_cast<const F3U*>(src + p * cin);
+      dst[lpad + 3 * p] = v.v[0];
+      dst[lpad + 3 * p + 1] = v.v[1];
+      dst[lpad + 3 * p + 2] = v.v[2];
+    }
+    if (lane < lpad) dst[lane] = 0.f;
+    if (lane < rpad) dst[lpad + 3 * d.w + lane] = 0.f;
+  }
+  for (int i = tid; i < 32 * 4 * rowk; i += 64 * rows) {
+    const int co = i / (4 * rowk), rem = i - co * (4 * rowk), kh = rem / rowk, j = rem - kh * rowk;  // j = kw * 3 + c (< 12)
+    const int kw = j / 3, c = j - 3 * kw;
+    ws[co * kp + kh * rowk + j] = (co < d.cout && j < 12) ? w[(size_t(co) * 16 + kh * 4 + kw) * cin + c] : 0.f;
+  }
+  if (tid < cv) vs[tid] = x[img + 3 + tid];
+  __syncthreads();
+  // ---- U[co][tap] = sum_c W[co][tap][3 + c] v_c (one value per thread; 512 threads = 32 x 16)
+  for (int i = tid; i < 512; i += 64 * rows) {
+    const int co = i >> 4, tap = i & 15;
+    float u = 0.f;
+    if (co < d.cout) {
+      const float* wr = w + (size_t(co) * 16 + tap) * cin + 3;
+      for (int c = 0; c < cv; ++c) u = fmaf(wr[c], vs[c], u);
+    }
+    us[i] = u;
+  }
+  __syncthreads();
+  // ---- T[cc][co] of this wave's output row: the taps inside the image for (row class, column class cc), + bias
+  {
+    const int oh = oh0 + wv;
+    const int kh_lo = oh == 0 ? 1 : 0, kh_hi = oh == d.ho - 1 ? 2 : 3;
+    for (int i = lane; i < 96; i += 64) {
+      const int cc = i >> 5, co = i & 31;
+      const int kw_lo = cc == 0 ? 1 : 0, kw_hi = cc == 2 ? 2 : 3;
+      float t = (bias && co < d.cout) ? bias[co] : 0.f;
+      for (int kh = kh_lo; kh <= kh_hi; ++kh)
+        for (int kw = kw_lo; kw <= kw_hi; ++kw) t += us[co * 16 + kh * 4 + kw];
+      ts[wv * 96 + i] = t;
+    }
+  }
+  __syncthreads();
+  // ---- compute: this wave's output row over the image planes (K = 4 x 16)
+  const int ow = lane & 31, half = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float* const abase = xs + (2 * wv) * pitch + lpad + (2 * ow - 1) * 3 + 4 * half;
+  const float* const bbase = ws + ow * kp + 4 * half;
+#pragma unroll
+  for (int kh = 0; kh < 4; ++kh) {
+    const float* ap = abase + kh * pitch;
+    const float* bp = bbase + kh * rowk;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float a0 = ap[8 * q], a1 = ap[8 * q + 1], a2 = ap[8 * q + 2], a3 = ap[8 * q + 3];
+      const float4 b = *reinterpret_cast<const float4*>(bp + 8 * q);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b.w, acc, 0, 0, 0);
+    }
+  }
+  // ---- epilogue: register e = pixel (e & 3) + 8 (e >> 2) + 4 half of the row, lane = channel
+  const __amdgpu_buffer_rsrc_t ry = conv_rsrc(y, size_t(d.m) * d.cout);
+  const __amdgpu_buffer_rsrc_t rz = conv_rsrc(zmask ? zmask : y, size_t(d.m) * d.cout);
+  const int co = lane & 31;
+  const bool co_ok = co < d.cout;
+  const float t0 = ts[wv * 96 + co], t1 = ts[wv * 96 + 32 + co], t2 = ts[wv * 96 + 64 + co];
+  const int m0 = (n * d.ho + oh0 + wv) * d.wo;
+  float z[16];
+  int off[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    off[e] = (m0 + (e & 3) + 8 * (e >> 2) + 4 * half) * d.cout + co;
+    z[e] = buf_load1(rz, off[e], zmask != nullptr && co_ok);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int px = (e & 3) + 8 * (e >> 2) + 4 * half;
+    float v = acc[e] + (px == 0 ? t0 : (px == d.wo - 1 ? t2 : t1));
     if (act) v = lrelu_v(v, leak);
     if (zmask) v *= lrelu_slope_v(z[e], leak);
     buf_store1(ry, off[e], co_ok, v);
@@ -1354,6 +1475,26 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
   return EXPO_OK;
 }
 
+// The first layers on inputs whose channels 3 .. are per-image constants (conv_fwd_planes_kernel); EXPO_E_BADARG for any
+// other geometry -- the callers then take expo_conv4x4s2_fwd.
+static int conv_fwd_planes_impl(const float* x, const float* w, const float* bias, const float* zmask, float* y, int n, int h,
+                                int wd, int cin, int cout, int act, float leak, void* stream, const ConvSecond* sec = nullptr) {
+  ConvDims d;
+  if (int rc = conv_dims(&d, n, h, wd, cin, cout)) return rc;
+  if (d.wo != 32 || cout > 32 || cin < 4 || cin > 20 || d.ho % 4 != 0)
+    return fail(EXPO_E_BADARG, "conv4x4s2_fwd_planes: 64-wide inputs of 4 .. 20 planes, at most 32 output channels");
+  if (n == 0) return EXPO_OK;
+  if (!x || !w || !y || (sec && (!sec->x || !sec->w || !sec->y || !sec->bias != !bias || !sec->zmask != !zmask)))
+    return fail(EXPO_E_BADARG, "null pointer");
+  const int rows = d.ho % 8 == 0 ? 8 : 4;  // (eight: 10.8 us for 14 planes at 64 images; four 11.8, two 15.3)
+  const size_t lds = (size_t(2 * rows + 2) * (4 + 3 * d.w + 8) + size_t(32) * 68 + 512 + size_t(rows) * 96 + 32) * 4;
+  const ConvSecond s2 = sec ? *sec : ConvSecond{};
+  hipLaunchKernelGGL(conv_fwd_planes_kernel, dim3(unsigned(d.n * (d.ho / rows)), sec ? 2 : 1), dim3(64 * rows), lds,
+                     static_cast<hipStream_t>(stream), x, w, bias, zmask, y, d, rows, act, leak, s2);
+  HIP_TRY(hipGetLastError(), "conv4x4s2_fwd_planes launch");
+  return EXPO_OK;
+}
+
 static int conv_bwd_data_impl(const float* dy, const float* w, const float* zmask, float* dx, int n, int h, int wd,
                               int cin, int cout, float leak, void* stream, const ConvSecond* sec = nullptr) {
   ConvDims d;
@@ -1737,6 +1878,18 @@ int expo_conv4x4s2_fwd_pair(const float* x_a, const float* w_a, const float* bia
                             float leak, void* stream) {
   const ConvSecond sec{x_b, w_b, bias_b, nullptr, y_b};
   return conv_fwd_impl(x_a, w_a, bias_a, nullptr, y_a, n, h, wd, cin, cout, act, leak, stream, &sec);
+}
+
+int expo_conv4x4s2_fwd_planes(const float* x, const float* w, const float* bias, const float* zmask, float* y, int n, int h,
+                              int wd, int cin, int cout, int act, float leak, void* stream) {
+  return conv_fwd_planes_impl(x, w, bias, zmask, y, n, h, wd, cin, cout, act, leak, stream);
+}
+
+int expo_conv4x4s2_fwd_planes_pair(const float* x_a, const float* w_a, const float* bias_a, float* y_a, const float* x_b,
+                                   const float* w_b, const float* bias_b, float* y_b, int n, int h, int wd, int cin, int cout,
+                                   int act, float leak, void* stream) {
+  const ConvSecond sec{x_b, w_b, bias_b, nullptr, y_b};
+  return conv_fwd_planes_impl(x_a, w_a, bias_a, nullptr, y_a, n, h, wd, cin, cout, act, leak, stream, &sec);
 }
 
 int expo_conv4x4s2_bwd_data_mask_pair(const float* dy_a, const float* w_a, const float* zmask_a, float* dx_a, const float* dy_b,

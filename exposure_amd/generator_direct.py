@@ -26,7 +26,7 @@ import torch
 
 from . import _cabi
 from .critic_direct import fc_split
-from .nn_ops import once_differentiable_convnets
+from .nn_ops import once_differentiable_convnets, planes_fold
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
 
 LEAK = 0.2
@@ -124,7 +124,9 @@ class _PairPass:
         _cabi.conv4x4s2_fwd_pair(items[0], items[1], 1, LEAK)
       else:
         for a, w, b, z in items:
-          _cabi.conv4x4s2_fwd(a, w, b, z, 1, LEAK)
+          # (first layers: channels 3 .. of expo_net_inputs' output are per-image constants -- folded where that pays)
+          fold = l == 0 and planes_fold(a.shape, w.shape[0])
+          (_cabi.conv4x4s2_fwd_planes if fold else _cabi.conv4x4s2_fwd)(a, w, b, z, 1, LEAK)
     if not same_depth:
       for p in passes:
         for l in range(len(p.net.convs)):

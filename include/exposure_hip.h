@@ -610,6 +610,18 @@ int expo_conv4x4s2_wrw_bias(const float* x, const float* dy, float* dw, float* d
 int expo_conv4x4s2_fwd_pair(const float* x_a, const float* w_a, const float* bias_a, float* y_a, const float* x_b,
                             const float* w_b, const float* bias_b, float* y_b, int n, int h, int wd, int cin, int cout, int act,
                             float leak, void* stream);
+/* (ABI 7) expo_conv4x4s2_fwd (zmask NULL) / expo_conv4x4s2_fwd_mask (zmask given, bias NULL, act 0) of a FIRST layer whose input
+ * comes from expo_planes_concat / expo_net_inputs / expo_critic_penalty_tangent: channels 3 .. cin - 1 of x are per-image
+ * CONSTANTS (the states and statistics critics.py:64-76 / agent.py:17-19 broadcast as planes; the kernel reads their values
+ * from the image's first pixel).  The convolution is linear, so the constant planes contribute one value per image, channel
+ * and border class (which of the 4 x 4 taps fall inside the image): K shrinks from 16 cin to 48.  Same sum in another order
+ * (float32 rounding).  64-wide inputs of 4 .. 20 planes and at most 32 output channels; EXPO_E_BADARG otherwise (take
+ * expo_conv4x4s2_fwd).  The caller vouches for the planes being constant. */
+int expo_conv4x4s2_fwd_planes(const float* x, const float* w, const float* bias, const float* zmask, float* y, int n, int h,
+                              int wd, int cin, int cout, int act, float leak, void* stream);
+int expo_conv4x4s2_fwd_planes_pair(const float* x_a, const float* w_a, const float* bias_a, float* y_a, const float* x_b,
+                                   const float* w_b, const float* bias_b, float* y_b, int n, int h, int wd, int cin, int cout,
+                                   int act, float leak, void* stream);
 int expo_conv4x4s2_bwd_data_mask_pair(const float* dy_a, const float* w_a, const float* zmask_a, float* dx_a, const float* dy_b,
                                       const float* w_b, const float* zmask_b, float* dx_b, int n, int h, int wd, int cin,
                                       int cout, float leak, void* stream);

@@ -561,3 +561,45 @@ def test_pair_launches_equal_the_two_calls(case, gpu_device):
     got = [torch.full_like(xa, float('nan')) for _ in range(2)]
     _cabi.conv4x4s2_bwd_data_mask_pair((gya, wa, xa, got[0]), (gyb, wb, xb, got[1]), 0.2)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+@pytest.mark.parametrize('n,cin,h', [(3, 6, 64), (5, 14, 64), (4, 17, 64), (64, 17, 64), (2, 6, 32), (2, 20, 64)])
+def test_first_layer_with_its_constant_planes_folded(n, cin, h, gpu_device):
+  """expo_conv4x4s2_fwd_planes: a first layer on an input whose channels 3 .. are per-image constants (planes_concat's
+  output) == the float64 convolution of that input -- with bias + lrelu, and as the tangent pass (slope mask, no bias) --
+  and == the pair launch of two such layers; every border class of the 4 x 4 / stride 2 / pad 1 window."""
+  from exposure_amd import _cabi
+  dev = gpu_device
+  w_img = 64
+  g = torch.Generator(device=dev).manual_seed(cin + n)
+  img = torch.rand((n, h, w_img, 3), device=dev, generator=g)
+  vec = torch.randn((n, cin - 3), device=dev, generator=g)
+  x = torch.empty((n, h, w_img, cin), device=dev)
+  _cabi.planes_concat(img, vec, x, 0.5)
+  ws = [(torch.randn((32, cin, 4, 4), device=dev, generator=g) / (16 * cin)**0.5).contiguous(memory_format=torch.channels_last)
+        for _ in range(2)]
+  bs = [torch.randn((32,), device=dev, generator=g) for _ in range(2)]
+  assert _cabi.conv_planes_ok(x.shape, 32) == (h % 8 == 0)
+  if not _cabi.conv_planes_ok(x.shape, 32):
+    return
+  shape = (n, h // 2, w_img // 2, 32)
+  ref = [F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), b.double().cpu(), 2, 1).permute(0, 2, 3, 1)
+         for w, b in zip(ws, bs)]
+  ys = []
+  for w, b, r in zip(ws, bs, ref):
+    y = torch.full(shape, float('nan'), device=dev)
+    _cabi.conv4x4s2_fwd_planes(x, w, b, y, 1, 0.2)
+    want = torch.where(r > 0, r, 0.2 * r)
+    assert float((y.double().cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()) * 4
+    ys.append(y)
+  got = [torch.full(shape, float('nan'), device=dev) for _ in range(2)]
+  _cabi.conv4x4s2_fwd_planes_pair((x, ws[0], bs[0], got[0]), (x, ws[1], bs[1], got[1]), 1, 0.2)
+  assert torch.equal(got[0], ys[0]) and torch.equal(got[1], ys[1])
+  # the tangent pass: no bias, the slope mask of z in the epilogue, in place over z
+  z = torch.randn(shape, device=dev, generator=g)
+  z.view(-1)[::9] = 0.0
+  lin = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), ws[0].double().cpu(), None, 2, 1).permute(0, 2, 3, 1)
+  want = lin * _slope(z).double().cpu()
+  t = z.clone()
+  _cabi.conv4x4s2_fwd_planes(x, ws[0], None, t, 0, 0.2, zmask=t)
+  assert float((t.double().cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()) * 4
