@@ -1,5 +1,5 @@
 """The WGAN-GP critic update as a hand-scheduled sequence of HIP launches (``/root/reference/net.py:126-199, 245-251``;
-``critics.py:6-38, 42-98``): no autograd graph, 29 launches instead of 160.
+``critics.py:6-38, 42-98``): no autograd graph, 24 launches instead of 160.
 
     c_loss = mean(D(fake) - D(real)) + lambda * mean(max(||grad_x^ D(x^)|| - 1, 0)^2),   x^ = real + alpha (fake - real)
 
@@ -8,9 +8,12 @@ The critic is per-sample (no normalisation layers), so the real, the fake and th
 and the rows' upstream gradients dlogit = (-1/n, +1/n, 1) -- the third block is the INNER gradient d D(x^) / d x^, which
 ``tf.gradients`` starts from ones (net.py:174-183) --
 
-  forward        z_1 .. z_4, fc1, fc2                                   4 conv launches (bias + lrelu fused) + 1 GEMM + 1 glue
+  inputs         [real | fake | interpolated] as float32, statistics,   ONE launch (expo_net_inputs: a block holds its image in LDS)
+                 the six planes - 0.5
+  forward        z_1 .. z_4, fc1, fc2                                   4 conv launches (bias + lrelu fused) + fc1 with its K dimension
+                                                                        split (expo_fc_fwd_slabs) + the head kernel that adds the slabs
   backward       gy_4 = (dh W_fc1) m_4;  gy_{l-1} = D(gy_l, W_l) m_{l-1}  the activation gradient sits in the EPILOGUE of the
-                 data-gradient kernel above it (expo_conv4x4s2_bwd_data_mask); the first layer's data gradient only for the
+                 data-gradient kernel above it (expo_fc_bwd_data_mask, expo_conv4x4s2_bwd_data_mask); the first layer's data gradient only for the
                  interpolated block (6 input planes: conv_bwd_small_kernel on the vector ALUs)
   penalty        g = u_0[..., :3] + J^T sum(u_0[..., 3:]) (the statistics planes, critics.py:48-76), norm, term, the
                  penalty's gradient v with respect to g and the tangent's input [v | J v] in ONE launch
@@ -22,8 +25,8 @@ and the rows' upstream gradients dlogit = (-1/n, +1/n, 1) -- the third block is 
                  [gy_l(real, fake) | gy_l(interpolated)]: ONE weight-gradient launch per layer over the 3n "images" yields
                  d c_loss / d W_l including the penalty's second-order term, and the bias gradient (column sums over the
                  first 2n images) comes out of the same launch (expo_conv4x4s2_wrw_bias); the four layers' launches share
-                 one grid and one reduce (expo_conv4x4s2_wrw_group).  Biases get no gradient from the penalty: the masks are
-                 piecewise constant.
+                 one grid and one reduce (expo_conv4x4s2_wrw_group); fc1's is expo_fc_wrw.  Biases get no gradient from the
+                 penalty: the masks are piecewise constant.  The reporting launch also advances Adam's step counter.
 
 Every quantity equals what ``GAN.critic_losses`` + ``backward`` compute through autograd (tests/test_critic_direct.py holds
 the two against each other and against finite differences of the float64 oracle); the summation orders are fixed, so a step

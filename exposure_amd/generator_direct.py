@@ -15,7 +15,9 @@ of the two passes (the value net: ``v_loss`` reaches theta_v through ``old_value
                                               layer; weight / bias gradients from the first block's rows (v_loss), the image
                                               gradient from the second block's (g_loss)
 
-The loss glue is ``expo_generator_losses`` as before (its coefficient rows ARE the rows' upstream gradients).  The image
+The two nets' input sides are one launch each (``expo_net_inputs``), their layers 2 .. 4 run pairwise as one grid
+(``expo_conv4x4s2_fwd_pair``: same geometry, different weights), the value net's 17-plane first layer with its constant planes
+folded (``expo_conv4x4s2_fwd_planes``), fc1 split-K in-house (``expo_fc_*``).  The loss glue is ``expo_generator_losses`` as before (its coefficient rows ARE the rows' upstream gradients).  The image
 gradient of both nets and the coefficients of surrogate / penalty then enter the agent's autograd graph in ONE backward
 pass (``torch.autograd.backward([fake_output, surrogate, penalty], ...)``): theta_g sees exactly d g_loss / d theta_g,
 theta_v exactly d v_loss / d theta_v -- the two losses share no path (q is a constant inside the advantage, the value and
