@@ -1017,7 +1017,7 @@ def conv4x4s2_fwd_planes_pair(a, b, act, leak=0.2):
 
 def conv4x4s2_fwd_pair(a, b, act, leak=0.2):
   """``conv4x4s2_fwd`` of two problems of one geometry as ONE grid (expo_conv4x4s2_fwd_pair): ``a`` / ``b`` = (x, w, bias, y).
-  Same results as the two calls."""
+  Planned for the grid that runs (twice the blocks): the two calls' results up to the order of the K slices' sum."""
   lib = load()
   (xa, wa, ba, ya), (xb, wb, bb, yb) = a, b
   n, h, wd, cin, cout = _conv_args(xa.shape, wa)

@@ -1409,13 +1409,15 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
   const ConvSecond s2 = sec ? *sec : ConvSecond{};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int forced = conv_tuning().tile.load(), forced_nt = conv_tuning().nt.load(), forced_s = conv_tuning().slices.load();
+  const int pair_mul = sec ? 2 : 1;  // a pair is twice the blocks: tile shape and K slices for the grid that actually runs
+  // (the G / V step 1.27 -> 1.25 ms against planning each half as if it ran alone)
   auto blocks = [&](int bm, int bn) { return ((d.m + bm - 1) / bm) * ((d.cout + bn - 1) / bn); };
   int shape = forced;
   // Measured on MI355X (tools/r05/conv_bench.py, profiles/r05_final_conv_bench.txt): the LDS-tiled shapes win where 64 x 64
   // tiles still give every CU a block or two (the second layer; the third at batch 128), the flat decomposition
   // everywhere else (first layers: K is short; deep layers: few rows, long K)
   if (shape == 0 && d.cout > 32 && forced_nt == 0 && forced_s == 0) {
-    const int b64 = blocks(64, 64);
+    const int b64 = blocks(64, 64) * pair_mul;
     if (b64 >= 512) shape = 2;
     else if (b64 >= 256) shape = 3;
   }
@@ -1445,7 +1447,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     // two column tiles per wave (A fragment shared in registers) where that still leaves >= 256 tiles: the third layer,
     // the fourth at batch 128 (17.3 vs 20.0 us, 26.3 vs 31.5 us)
     if (ni == 0) {
-      const long t2 = long((d.m + 31) / 32) * ((d.cout + 63) / 64), t1 = long((d.m + 31) / 32) * ((d.cout + 31) / 32);
+      const long t2 = pair_mul * long((d.m + 31) / 32) * ((d.cout + 63) / 64), t1 = pair_mul * long((d.m + 31) / 32) * ((d.cout + 31) / 32);
       ni = t2 >= 256 ? 2 : 1;
       // blocks that do not divide among the 256 CUs leave half of them a round short: the fourth layer at batch 192 is 384
       // blocks with two column tiles per wave (48.8 us) and 768 with one (44.4 us)
@@ -1453,7 +1455,13 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     }
     if (ni != 1 && ni != 2) ni = 1;
     if (d.cout <= 32) ni = 1;
-    const FlatPlan pl = flat_plan(d, ni, forced_s);
+    FlatPlan pl = flat_plan(d, ni, forced_s);
+    if (pair_mul == 2 && forced_s == 0) {  // K slices as for twice the pixels
+      ConvDims d2 = d;
+      d2.m *= 2;
+      const FlatPlan p2 = flat_plan(d2, ni, 0);
+      pl.s = p2.s; pl.s2 = p2.s2; pl.rs = p2.rs;
+    }
     const int nblocks = pl.tiles_m * pl.tiles_n;
     const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
 #define EXPO_FLAT(NI, C4) \
@@ -1529,7 +1537,13 @@ static int conv_bwd_data_impl(const float* dy, const float* w, const float* zmas
   if (ni == 0) ni = d.cin >= 64 ? 2 : 1;  // (two tiles share the dY fragment: 2-10 % on the deeper layers)
   if (ni != 1 && ni != 2) ni = 1;
   if (d.cin <= 32) ni = 1;
-  const FlatPlan pl = bwd_plan(d, ni, forced_s);
+  FlatPlan pl = bwd_plan(d, ni, forced_s);
+  if (sec && forced_s == 0) {  // a pair: K' slices as for twice the pixels
+    ConvDims d2 = d;
+    d2.m *= 2;
+    const FlatPlan p2 = bwd_plan(d2, ni, 0);
+    pl.s = p2.s; pl.s2 = p2.s2; pl.rs = p2.rs;
+  }
   const int nblocks = 4 * pl.tiles_m * pl.tiles_n;
   const size_t lds = pl.s > 1 ? size_t(pl.s) * ni * 4096 : 0;
   if (ni == 2) hipLaunchKernelGGL(conv_bwd_flat_kernel<2>, dim3(nblocks, gy2), dim3(64 * pl.s), lds, s, dy, w, zmask, dx, d, pl, leak, s2);

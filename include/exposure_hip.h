@@ -605,8 +605,9 @@ int expo_conv4x4s2_wrw_bias(const float* x, const float* dy, float* dw, float* d
 /* (ABI 7) Two problems of ONE geometry as one grid: the forward (bias + activation) and the data gradient (activation
  * gradient of the layer below in the epilogue) of two independent layers -- the agent's filter and selector extractors read
  * the same input through different weights (agent.py:47-56), the critic's and the value net's pair passes of a G / V step run
- * side by side -- at batch 64 / 128, where one of them alone leaves CUs idle.  Same results, bit for bit, as the two
- * separate calls. */
+ * side by side -- at batch 64 / 128, where one of them alone leaves CUs idle.  The decomposition is chosen for the grid that
+ * runs (twice the blocks), so the results equal the two separate calls up to the order in which the K slices are added
+ * (float32 rounding); a pair call is bit-reproducible. */
 int expo_conv4x4s2_fwd_pair(const float* x_a, const float* w_a, const float* bias_a, float* y_a, const float* x_b,
                             const float* w_b, const float* bias_b, float* y_b, int n, int h, int wd, int cin, int cout, int act,
                             float leak, void* stream);

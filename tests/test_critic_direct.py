@@ -537,8 +537,9 @@ def test_direct_critic_update_on_its_separate_launches(gpu_device, monkeypatch):
                                   (5, 12, 6, 32), (3, 8, 5, 8)])
 def test_pair_launches_equal_the_two_calls(case, gpu_device):
   """expo_conv4x4s2_fwd_pair / _bwd_data_mask_pair: two problems of one geometry as one grid (gridDim.y = 2) == the two
-  separate calls, bit for bit -- every forward kernel family (row-staged first layers, LDS-tiled, flat) and the flat data
-  gradient, the same and different inputs."""
+  separate calls up to the order of the K slices' sum (the pair is planned for the grid that runs: twice the blocks), and
+  bit-reproducible -- every forward kernel family (row-staged first layers, LDS-tiled, flat) and the flat data gradient,
+  the same and different inputs."""
   from exposure_amd import _cabi
   dev = gpu_device
   n, h, cin, cout = case
@@ -547,20 +548,32 @@ def test_pair_launches_equal_the_two_calls(case, gpu_device):
   g = torch.Generator(device=dev).manual_seed(7)
   ba, bb = torch.randn((cout,), device=dev, generator=g), torch.randn((cout,), device=dev, generator=g)
   shape = (n, h // 2, h // 2, cout)
+
+  def close(got, want):
+    return float((got - want).abs().max()) <= 4e-6 * float(want.abs().max())
+
   for xb_ in (xb, xa):  # (the agent's two extractors read the SAME input)
     want = [torch.empty(shape, device=dev) for _ in range(2)]
     _cabi.conv4x4s2_fwd(xa, wa, ba, want[0], 1, 0.2)
     _cabi.conv4x4s2_fwd(xb_, wb, bb, want[1], 1, 0.2)
-    got = [torch.full(shape, float('nan'), device=dev) for _ in range(2)]
-    _cabi.conv4x4s2_fwd_pair((xa, wa, ba, got[0]), (xb_, wb, bb, got[1]), 1, 0.2)
-    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    runs = []
+    for _ in range(2):
+      got = [torch.full(shape, float('nan'), device=dev) for _ in range(2)]
+      _cabi.conv4x4s2_fwd_pair((xa, wa, ba, got[0]), (xb_, wb, bb, got[1]), 1, 0.2)
+      assert close(got[0], want[0]) and close(got[1], want[1])
+      runs.append(got)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
   if cout % 4 == 0:
     want = [torch.empty_like(xa) for _ in range(2)]
     _cabi.conv4x4s2_bwd_data_mask(gya, wa, xa, want[0], 0.2)
     _cabi.conv4x4s2_bwd_data_mask(gyb, wb, xb, want[1], 0.2)
-    got = [torch.full_like(xa, float('nan')) for _ in range(2)]
-    _cabi.conv4x4s2_bwd_data_mask_pair((gya, wa, xa, got[0]), (gyb, wb, xb, got[1]), 0.2)
-    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    runs = []
+    for _ in range(2):
+      got = [torch.full_like(xa, float('nan')) for _ in range(2)]
+      _cabi.conv4x4s2_bwd_data_mask_pair((gya, wa, xa, got[0]), (gyb, wb, xb, got[1]), 0.2)
+      assert close(got[0], want[0]) and close(got[1], want[1])
+      runs.append(got)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
 
 
 @pytest.mark.parametrize('n,cin,h', [(3, 6, 64), (5, 14, 64), (4, 17, 64), (64, 17, 64), (2, 6, 32), (2, 20, 64)])

@@ -124,12 +124,17 @@ def test_two_ranks_on_one_gpu_match_one_process(gpu_device, tmp_path, use_graphs
   for a, b in zip(r0['grads'], r1['grads']):
     assert torch.equal(a, b)
   # all-reduced mean gradients == the full-batch gradients of the single process
+  gmax = max(float(ref_g.abs().max()) for ref_g in want['grads'])
   for got, ref_g in zip(r0['grads'], want['grads']):
     scale = float(ref_g.abs().max()) + 1e-12
-    # (fp32 convolutions of 4 and of 8 images, possibly through different MIOpen kernels, and the double backward of the
-    # gradient penalty on top: 1.7e-3 of a tensor's largest gradient seen; a wrong reduction -- sum instead of mean, a
-    # missing shard -- would be off by a factor)
-    assert float((got - ref_g).abs().max()) <= 5e-3 * scale + 1e-8
+    # (fp32 convolutions of 4 and of 8 images through different decompositions, and the double backward of the gradient
+    # penalty on top: 1.7e-3 of a tensor's largest gradient seen; a wrong reduction -- sum instead of mean, a missing shard --
+    # would be off by a factor.  The absolute floor is 2e-5 of the LARGEST gradient in the model: a head whose filter one or
+    # two images selected has gradients of ~1e-6 -- five orders below the model's 7e-2 -- that are one per-image scalar, a sum
+    # over 4 096 pixels with heavy cancellation, times fixed tensors; a rounding-level change of the image gradient moves that
+    # scalar, and with it EVERY tensor of the head by the same factor (seen: 4 % of 2.8e-6 .. 2.2e-5 on all four tensors of
+    # the SaturationPlus head when the paired convolution launches changed their K slicing: tools/r06/dbg_dist.py))
+    assert float((got - ref_g).abs().max()) <= 5e-3 * scale + 2e-5 * gmax
   worst = max(float((a - b).abs().max()) for a, b in zip(r0['params'], want['params']))
   # Adam's steps are ~lr-sized (tests/test_dist_gloo.py); the moments of iteration 1 differ at rounding level
   assert worst < 3e-4, worst
